@@ -1,0 +1,134 @@
+/*
+ * ppocar.h -- C-ABI of the MI355X-native CarEnv hot path (libppocar.so).
+ *
+ * The reference (ProfessorNova/PPO-Car) is pure Python and has no FFI layer; the boundary
+ * this library sits behind is the gymnasium vector-env protocol exactly as train.py uses
+ * it, plus Buffer.calculate_advantages.  Each entry point names the reference interface
+ * it replaces (file:line in the reference tree).  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, int status return: 0 = PC_OK, negative = error
+ *     (pc_strerror).  No exceptions cross the boundary.
+ *   - Array arguments of pc_env_reset/pc_env_step/pc_gae/pc_sample are DEVICE pointers owned
+ *     by the caller (e.g. torch tensors) on the device the handle was created for; they must
+ *     stay alive until the stream has executed the call.  The library owns only its opaque
+ *     handles and the env state inside them.
+ *   - Launches are asynchronous on the caller-supplied hipStream_t (`stream`, NULL = the
+ *     default stream).  The library never synchronises in reset/step/gae/sample.
+ *   - There is NO CPU fallback: every compute entry point needs a gfx950 device and fails
+ *     with PC_ERR_NO_DEVICE / PC_ERR_HIP otherwise.
+ *   - One handle per device; a handle is not thread-safe; different handles are independent.
+ */
+#ifndef PPOCAR_H
+#define PPOCAR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PC_OK 0
+#define PC_ERR_INVALID_ARG (-1)
+#define PC_ERR_IO (-2)          /* track file missing / unreadable (the reference prints and returns None, car_env.py:624-628; here it is a hard error) */
+#define PC_ERR_PARSE (-3)       /* track JSON malformed or schema violated */
+#define PC_ERR_HIP (-4)         /* a HIP runtime call failed */
+#define PC_ERR_UNSUPPORTED (-5) /* e.g. more rays than the kernel menu covers */
+#define PC_ERR_NO_DEVICE (-6)   /* no usable gfx950 device */
+
+#define PC_DTYPE_F32 0 /* float32 state + geometry: the throughput path                                   */
+#define PC_DTYPE_F64 1 /* float64 state + geometry in the reference's operation order: the exact-parity path */
+
+typedef struct pc_track pc_track;
+typedef struct pc_env pc_env;
+
+/* ---- track data: CarEnv.load_track (car_env.py:535-567) + the wall / gate lists that
+ * CarEnv.reset builds (car_env.py:651-676).  Host-side, no GPU needed. ------------------ */
+
+/* Parse a track JSON file (schema written by track_editor.py:50-56,126-127): scales x by
+ * 1280 and y by 720, builds walls = outer segments then inner segments and gates = consecutive
+ * point pairs. */
+int pc_track_load_json(const char* path, pc_track** out);
+/* Same from memory: walls [S][4], gates [G][4] = x1,y1,x2,y2 in pixels. */
+int pc_track_from_arrays(const double* walls, int n_walls, const double* gates, int n_gates, double start_x,
+                         double start_y, double start_angle_deg, pc_track** out);
+/* *n_walls, *n_gates, start[3] = {x, y, angle_deg}; any pointer may be NULL. */
+int pc_track_info(const pc_track* t, int* n_walls, int* n_gates, double* start);
+/* Copy the geometry out (host): walls [S][4], gates [G][4]; either may be NULL. */
+int pc_track_geometry(const pc_track* t, double* walls, double* gates);
+void pc_track_destroy(pc_track* t);
+
+/* ---- the vector environment: gym.vector.AsyncVectorEnv([make_env]*N) (train.py:138-139)
+ * of CarEnv (car_env.py:472-760) wrapped in TransformReward (train.py:65,68). ------------ */
+
+/* number of rays the reference generates for a nominal `num_rays`: len(range(0, 360, 360 // n))
+ * (car_env.py:269) -- 12 -> 12, 16 -> 17, 32 -> 33.  Negative on invalid n. */
+int pc_ray_count(int num_rays_nominal);
+
+/* Create n_envs environments on `device` (HIP ordinal).  `tracks`/`n_tracks`: the track table;
+ * `track_id` (host, [n_envs], may be NULL = all on track 0) picks each env's track -- the
+ * reference allows a different track per env through reset(options=...) (car_env.py:621-628).
+ * Replaces: CarEnv.__init__ (car_env.py:475-533) x N + AsyncVectorEnv construction. */
+int pc_env_create(int device, int64_t n_envs, int num_rays_nominal, const pc_track* const* tracks, int n_tracks,
+                  const uint8_t* track_id, int dtype, pc_env** out);
+void pc_env_destroy(pc_env* e); /* envs.close() (train.py:296) */
+
+int pc_env_obs_dim(const pc_env* e);    /* 6 + R: envs.single_observation_space.shape[0] (train.py:141) as the reference actually produces it */
+int pc_env_num_actions(const pc_env* e); /* 9: envs.single_action_space.n (train.py:142, car_env.py:525) */
+int64_t pc_env_num_envs(const pc_env* e);
+
+/* envs.reset(options={"track_path": p}) (train.py:159; CarEnv.reset car_env.py:605-691):
+ * every env to its track's start state; obs [n_envs][D] float32 (device). */
+int pc_env_reset(pc_env* e, float* obs, void* stream);
+
+/* envs.step(actions) (train.py:185): CarEnv.step (car_env.py:693-760) for every env, reward *
+ * reward_scale (TransformReward, train.py:65,68; computed in float64 then rounded to float32
+ * exactly as `rew_buf[ptr] = rew` does, buffer.py:29), and gymnasium's same-step auto-reset:
+ * an env that terminated or truncated is reset and `obs` holds its reset observation.
+ *   actions     [N] int64, values 0..8 (anything else is treated as 8 = do nothing, car_env.py:721)
+ *   obs         [N][D] float32   -- may point straight into Buffer.obs_buf[t+1]
+ *   reward, terminated, truncated  [N] float32 (flags 0.0 / 1.0, what train.py:191-192 builds)
+ *   gates_passed [N] int32 or NULL -- info["gates_passed"] of the step (before auto-reset)
+ *   final_obs   [N][D] float32 or NULL -- the observation CarEnv.step itself returned
+ *                                         (gymnasium's info["final_observation"] on done envs) */
+int pc_env_step(pc_env* e, const int64_t* actions, double reward_scale, float* obs, float* reward,
+                float* terminated, float* truncated, int32_t* gates_passed, float* final_obs, void* stream);
+
+/* Teacher forcing for parity tests: copy the env state from / to HOST arrays of length n_envs
+ * (any pointer may be NULL).  `rot` is the heading in degrees.  Synchronous.
+ * F32 handles store the heading as a count of 5-degree turns from the track's start angle
+ * (Car.move_car only ever adds +-5.0, car_env.py:440-442), so set_state rounds `rot` to that grid. */
+int pc_env_get_state(pc_env* e, double* px, double* py, double* vx, double* vy, double* rot, int64_t* time_step,
+                     int64_t* next_gate, int64_t* passed);
+int pc_env_set_state(pc_env* e, const double* px, const double* py, const double* vx, const double* vy,
+                     const double* rot, const int64_t* time_step, const int64_t* next_gate, const int64_t* passed);
+
+/* ---- Buffer.calculate_advantages (buffer.py:36-64): GAE(lambda) with separate terminated /
+ * truncated masks, float32, same operation order as the reference's torch expression (bit-exact
+ * with it).  rew, val, term, trunc, adv, ret: [T][N] row-major; last_*: [N].  All device. */
+int pc_gae(int device, const float* rew, const float* val, const float* term, const float* trunc,
+           const float* last_val, const float* last_term, const float* last_trunc, double gamma, double lam,
+           int64_t T, int64_t N, float* adv, float* ret, void* stream);
+
+/* ---- Agent.get_action_and_value's sampling tail (model.py:35-40): for logits [N][A] float32
+ * draw action ~ Categorical(logits) and return log_prob(action) and (optionally) the entropy.
+ * Counter-based RNG (Philox-4x32-10) keyed by (seed, offset): the same (seed, offset, N, A)
+ * gives the same actions on any launch geometry.  actions [N] int64, logprob/entropy [N] float32
+ * (entropy may be NULL).  All device. */
+int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, uint64_t offset, int64_t* actions,
+              float* logprob, float* entropy, void* stream);
+
+const char* pc_strerror(int code);
+/* Last HIP error string seen by this thread (diagnostics for PC_ERR_HIP). */
+const char* pc_last_hip_error(void);
+/* Kernel-launch geometry of the last pc_env_step on this handle (lanes per env, rays per lane,
+ * blocks, threads) -- for bench.py / DESIGN.md; any pointer may be NULL. */
+int pc_env_launch_info(const pc_env* e, int* lanes_per_env, int* rays_per_lane, int* blocks, int* threads);
+/* Override the lanes-per-env choice (power of two 1..64; 0 = automatic).  Tuning knob for bench.py. */
+int pc_env_set_lanes_per_env(pc_env* e, int lanes_per_env);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPOCAR_H */

@@ -1,0 +1,68 @@
+"""ctypes binding of libppocar.so (include/ppocar.h).  The library is the product; there is no
+Python or CPU fallback: if it is missing, importing this module fails loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libppocar.so")
+
+PC_OK = 0
+PC_ERR_INVALID_ARG, PC_ERR_IO, PC_ERR_PARSE, PC_ERR_HIP, PC_ERR_UNSUPPORTED, PC_ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6
+PC_DTYPE_F32, PC_DTYPE_F64 = 0, 1
+DTYPES = {"f32": PC_DTYPE_F32, "float32": PC_DTYPE_F32, "f64": PC_DTYPE_F64, "float64": PC_DTYPE_F64}
+
+
+class PpoCarError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        msg = f"{what}: {lib.pc_strerror(code).decode()} (code {code})"
+        if code == PC_ERR_HIP:
+            msg += f" [{lib.pc_last_hip_error().decode()}]"
+        super().__init__(msg)
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+if not os.path.exists(_LIB_PATH):
+    raise ImportError(
+        f"{_LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C ppo-car_amd/csrc`). There is no CPU fallback for the CarEnv hot path.")
+
+lib = C.CDLL(_LIB_PATH)
+
+_vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
+_sig = {
+    "pc_track_load_json": (_i, [C.c_char_p, C.POINTER(_vp)]),
+    "pc_track_from_arrays": (_i, [_vp, _i, _vp, _i, _d, _d, _d, C.POINTER(_vp)]),
+    "pc_track_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_d)]),
+    "pc_track_geometry": (_i, [_vp, _vp, _vp]),
+    "pc_track_destroy": (None, [_vp]),
+    "pc_ray_count": (_i, [_i]),
+    "pc_env_create": (_i, [_i, _i64, _i, C.POINTER(_vp), _i, _vp, _i, C.POINTER(_vp)]),
+    "pc_env_destroy": (None, [_vp]),
+    "pc_env_obs_dim": (_i, [_vp]),
+    "pc_env_num_actions": (_i, [_vp]),
+    "pc_env_num_envs": (_i64, [_vp]),
+    "pc_env_reset": (_i, [_vp, _vp, _vp]),
+    "pc_env_step": (_i, [_vp, _vp, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pc_env_get_state": (_i, [_vp] * 9),
+    "pc_env_set_state": (_i, [_vp] * 9),
+    "pc_gae": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _i64, _i64, _vp, _vp, _vp]),
+    "pc_sample": (_i, [_i, _vp, _i64, _i, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp]),
+    "pc_strerror": (C.c_char_p, [_i]),
+    "pc_last_hip_error": (C.c_char_p, []),
+    "pc_env_launch_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "pc_env_set_lanes_per_env": (_i, [_vp, _i]),
+}
+for _name, (_res, _args) in _sig.items():
+    _f = getattr(lib, _name)  # AttributeError here = the library does not export what ppocar.h declares
+    _f.restype, _f.argtypes = _res, _args
+
+EXPORTS = tuple(_sig)
+
+
+def check(code, what):
+    if code != PC_OK:
+        raise PpoCarError(code, what)

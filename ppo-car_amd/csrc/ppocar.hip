@@ -1,0 +1,1090 @@
+// ppocar.hip -- HIP kernels (gfx950 / CDNA4) and the C-ABI of libppocar.so.
+//
+// Kernels
+//   env_step_kernel<T, RPL>   K1: the whole CarEnv.step transition (car_env.py:693-760) for one
+//                             vector-env call, with TransformReward and gymnasium's same-step
+//                             auto-reset folded in (train.py:65,68,185).
+//   env_reset_kernel<T>       K2: CarEnv.reset for every env (car_env.py:605-691).
+//   reset_obs_kernel<T>       computes each track's constant reset observation once at create.
+//   gae_kernel                K3: Buffer.calculate_advantages (buffer.py:36-64).
+//   sample_kernel             K4: Categorical(logits).sample / log_prob / entropy (model.py:35-40).
+//
+// Work decomposition of K1: an env is owned by G = 2^lg consecutive lanes of one
+// wavefront ("lanes per env", chosen on the host from n_envs so the chip is filled); lane g of the
+// group sweeps rays g, g+G, g+2G, ... (RPL = rays per lane, a template constant so the per-ray
+// direction / running-minimum live in registers) against all wall segments.  Wall and gate
+// segments are wave-uniform data: they are read with SCALAR loads (s_load_dwordx4 through the
+// scalar cache) straight into SGPRs and enter the VALU as the one free SGPR operand per
+// instruction -- cheaper than an LDS broadcast (no ds_read issue, no staging prologue, no
+// barrier); a wave whose envs sit on different tracks runs the body once per distinct track
+// (waterfall on the track id), so mixed-track batches stay correct.  Per-env reductions (any
+// collision ray < 10 px) are DPP/shuffle butterflies inside the group; there is no LDS, no
+// atomics and no inter-workgroup communication.  No MFMA: this is branchy fp32/fp64 geometry.
+//
+// Numerics
+//   T = double  follows the reference's float64 operation order literally (Ray.cast :166-181,
+//               np.linalg.norm's fused ddot tail, np.radians = x * (pi/180)); the translation unit
+//               is compiled with -ffp-contract=off so nothing is fused behind our back.
+//   T = float   the throughput path: float32 RAY GEOMETRY over a float64 kinematic state.  The
+//               per-env scalar work (thrust, friction, clip, integrate, reward) is a few dozen
+//               float64 operations and stays exactly the reference's; heading is an integer count
+//               of 5-degree turns (Car.move_car only adds +-5.0, :440-442) looked up in a 72-entry
+//               float64 cos/sin table built on the host; ray directions by float32 angle addition
+//               with a per-ray table; ray casts in coordinates RELATIVE to the car, the difference
+//               p1 - pos formed in float64 and then rounded (no pos+dir-pos cancellation,
+//               :169-175), with u = cross(e,a)/cross(e,d) as the distance.  A float32 position
+//               would by itself cost ~1e-4 px at x ~ 1280, i.e. most of the 1e-5 obs tolerance on
+//               grazing rays (measured: DESIGN.md).
+//               Rewards are bit-exact with the reference's float32(r * reward_scaling).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ppocar_internal.h"
+
+// ------------------------------------------------------------------------------------------
+// device-side data
+// ------------------------------------------------------------------------------------------
+struct TrackHdr {        // one per track, read with scalar loads
+    int wall_off, S;     // segs[wall_off .. wall_off+S): the walls
+    int gate_off, G;     // segs[gate_off .. gate_off+G): the reward gates
+    int head_off;        // F32: heading table [72] (cos, sin) of radians(start_rot + 5 j)
+    int start_collides;  // Car.update at reset already hits a wall (car_env.py:686,468-469)
+    int vtx_off, nV;     // F32: the walls again as vertex chains, vtx[vtx_off .. vtx_off+nV)
+    double start_x, start_y, start_rot;
+};
+
+// One wall / gate segment as the reference holds it (Boundary.get_points, car_env.py:74): 32 bytes.
+struct Seg { double x1, y1, x2, y2; };
+
+// F32 wall sweep: the walls as chains of vertices.  Vertex k closes the segment (k-1, k) unless it
+// starts a new chain (brk).  (ex, ey) = p[k-1] - p[k] rounded from float64.  32 bytes = one s_load_dwordx8.
+// Why chains: the reference's hit test 0 < t < 1 (car_env.py:178) is "the two endpoints lie strictly on
+// opposite sides of the ray line".  Evaluated per VERTEX -- one cross product c_k = cross(p_k - pos, dir)
+// shared by the two segments that meet there -- a float32 ray cannot slip between two adjacent walls
+// through the rounding-wide crack that two independently rounded t's leave at their common corner.
+struct Vtx { double x, y; float ex, ey; int brk, pad; };
+
+template <typename T> struct EnvParams {
+    int64_t N;
+    int lg;              // log2(lanes per env)
+    int n_nominal;       // Car num_rays (car_env.py:227)
+    int q;               // n // 4: stride of the collision rays (car_env.py:389)
+    int step_deg;        // 360 // n (car_env.py:269)
+    int R, D;            // actual ray count, obs dim 6 + R
+    double4* __restrict__ pv;               // [N] (px, py, vx, vy): kinematic state, float64 in BOTH modes
+    int4* __restrict__ iv;                  // [N] (rot_k [F32 only], time_step, next_gate, passed)
+    double* __restrict__ rot;               // [N] heading in degrees, F64 only
+    const uint8_t* __restrict__ track_id;   // [N] or nullptr
+    const TrackHdr* __restrict__ hdr;       // [n_tracks]
+    const Seg* __restrict__ segs;           // walls and gates of all tracks
+    const Vtx* __restrict__ vtx;            // F32 only: wall vertex chains of all tracks
+    const double2* __restrict__ headtab;    // F32 only: (cos, sin) of radians(start_rot + 5 j), j < 72, per track
+    const float2* __restrict__ raytab;      // F32 only: [R] (cos, sin) of radians(i * step_deg)
+    const float* __restrict__ reset_obs;    // [n_tracks][D]
+};
+
+#define PC_PI 3.141592653589793238462643383279502884 /* NPY_PI */
+
+__device__ __forceinline__ double d_radians(double deg) { return deg * (PC_PI / 180.0); }  // np.radians
+
+// ---- float64: the reference's own arithmetic --------------------------------------------------
+// Ray.cast (car_env.py:155-184) + np.linalg.norm(pos - pt) (car_env.py:205).  Returns the hit
+// distance, or 1000.0 (Ray.get_distance's `largest_distance`, :198) when there is no hit.
+__device__ __forceinline__ double cast_ref(double x1, double y1, double x2, double y2, double x3, double y3,
+                                           double dx, double dy) {
+    const double x4 = x3 + dx, y4 = y3 + dy;                                  // :169
+    const double den = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4);         // :171
+    if (den == 0) return 1000.0;                                              // :172
+    const double t = ((x1 - x3) * (y3 - y4) - (y1 - y3) * (x3 - x4)) / den;   // :175
+    const double u = -((x1 - x2) * (y1 - y3) - (y1 - y2) * (x1 - x3)) / den;  // :176
+    if (0 < t && t < 1 && u > 0) {                                            // :178
+        const double ptx = x1 + t * (x2 - x1), pty = y1 + t * (y2 - y1);      // :180-181
+        const double d0 = x3 - ptx, d1 = y3 - pty;
+        return sqrt(fma(d1, d1, d0 * d0));  // np.linalg.norm -> cblas_ddot with a fused tail (see oracle)
+    }
+    return 1000.0;
+}
+
+// ---- float32: relative-coordinate cast -----------------------------------------------------------
+// a_k = p_k - pos (formed in float64, then rounded: small near a wall, so nearly exact where it matters),
+// c_k = cross(a_k, dir) = ay_k*dx - ax_k*dy, e = p1 - p2.  With the reference's t, u (car_env.py:171-176):
+//   den = ey*dx - ex*dy = c1 - c2,   t = c1/den,   u = (ey*ax1 - ex*ay1)/den = un/den
+//   0 < t < 1  <=>  c1 and c2 have strictly opposite signs  <=>  c1*c2 < 0
+// and the distance |pos - pt| equals u because |dir| = 1.  den is formed from e directly (not as
+// c1 - c2, which cancels badly for short far segments).  Parallel (den == 0, :172): c1 == c2, no hit.
+// Returns min(best, hit distance): Ray.get_distance's running minimum (:203-207).
+__device__ __forceinline__ float cross_f(float ax, float ay, float dx, float dy) {
+    return __builtin_fmaf(ay, dx, -(ax * dy));
+}
+__device__ __forceinline__ float cast_fast(float best, float c1, float c2, float un, float ex, float ey, float dx,
+                                           float dy) {
+    const float den = __builtin_fmaf(ey, dx, -(ex * dy));
+    const float u = un * __builtin_amdgcn_rcpf(den);
+    const bool better = (c1 * c2 < 0.0f) & (u > 0.0f) & (u < best);
+    return better ? u : best;
+}
+
+template <typename T> struct Math;
+
+template <> struct Math<double> {
+    // heading (cos, sin): computed from the float64 heading as the reference does (:426-427, :584)
+    static __device__ __forceinline__ void heading(const EnvParams<double>&, const TrackHdr&, int, double rot, double& c,
+                                                   double& s) {
+        const double a = d_radians(rot);
+        c = cos(a);
+        s = sin(a);
+    }
+    static __device__ __forceinline__ void ray_dir(const EnvParams<double>& p, int ray, double rot, double, double,
+                                                   double& dx, double& dy) {
+        const double a = d_radians(rot + (double)(ray * p.step_deg));  // Ray.update(x, y, rot + a) :463-466, :153
+        dx = cos(a);
+        dy = sin(a);
+    }
+    // distance of one ray to one segment; (px, py) float64 ray origin
+    static __device__ __forceinline__ double cast(const Seg& sg, double px, double py, double dx, double dy) {
+        return cast_ref(sg.x1, sg.y1, sg.x2, sg.y2, px, py, dx, dy);
+    }
+    static __device__ __forceinline__ float norm_dist(double d) { return (float)(d / 1000.0); }             // :593,:595
+    static __device__ __forceinline__ float norm(double v, double d) { return (float)(v / d); }             // :578-581
+};
+
+template <> struct Math<float> {
+    static __device__ __forceinline__ int mod72(int k) {
+        int m = k % 72;
+        return m < 0 ? m + 72 : m;
+    }
+    // heading from the integer turn count: table of float64 cos/sin built on the host (glibc)
+    static __device__ __forceinline__ void heading(const EnvParams<float>& p, const TrackHdr& h, int k, double, double& c,
+                                                   double& s) {
+        const double2 cs = p.headtab[h.head_off + mod72(k)];
+        c = cs.x;
+        s = cs.y;
+    }
+    static __device__ __forceinline__ void ray_dir(const EnvParams<float>& p, int ray, double, double ch, double sh,
+                                                   float& dx, float& dy) {
+        const float2 cs = p.raytab[ray];  // cos/sin(radians(ray * step)); angle addition in float32
+        const float c = (float)ch, s = (float)sh;
+        dx = __builtin_fmaf(c, cs.x, -(s * cs.y));
+        dy = __builtin_fmaf(s, cs.x, c * cs.y);
+    }
+    static __device__ __forceinline__ float cast(const Seg& sg, double px, double py, float dx, float dy) {
+        const float ax1 = (float)(sg.x1 - px), ay1 = (float)(sg.y1 - py);
+        const float ax2 = (float)(sg.x2 - px), ay2 = (float)(sg.y2 - py);
+        const float ex = (float)(sg.x1 - sg.x2), ey = (float)(sg.y1 - sg.y2);
+        const float un = __builtin_fmaf(ey, ax1, -(ex * ay1));
+        return cast_fast(1000.0f, cross_f(ax1, ay1, dx, dy), cross_f(ax2, ay2, dx, dy), un, ex, ey, dx, dy);
+    }
+    static __device__ __forceinline__ float norm_dist(float d) { return d * 0.001f; }
+    // float64 multiply by the reciprocal, then the float32 cast: equals (float)(v / d) unless v/d sits
+    // within 1e-16 (relative) of a float32 rounding boundary
+    static __device__ __forceinline__ float norm(double v, double d) { return (float)(v * (1.0 / d)); }
+};
+
+// ------------------------------------------------------------------------------------------
+// K1: env step
+// ------------------------------------------------------------------------------------------
+template <typename T, int RPL>
+__device__ __forceinline__ void env_step_body(const EnvParams<T>& p, const int trk, const int64_t e, const int g,
+                                              const int64_t* __restrict__ actions, const double reward_scale,
+                                              float* __restrict__ obs, float* __restrict__ reward,
+                                              float* __restrict__ term_out, float* __restrict__ trunc_out,
+                                              int32_t* __restrict__ gates_passed, float* __restrict__ final_obs) {
+    // trk is the same in every active lane; readfirstlane tells the compiler so, which turns the
+    // header and every wall-segment load below into scalar loads (s_load_dwordx8 into SGPRs)
+    const TrackHdr h = p.hdr[__builtin_amdgcn_readfirstlane(trk)];
+    const int G = 1 << p.lg;
+
+    // ---- state in (coalesced 32/16-byte vectors; the G lanes of an env read the same address)
+    const double4 sv = p.pv[e];
+    const int4 si = p.iv[e];
+    double rot_old = 0.0;
+    if constexpr (sizeof(T) == 8) rot_old = p.rot[e];
+    const int64_t a = actions[e];
+
+    // ---- action translation (car_env.py:698-722): thrust first with the PRE-turn heading, then the turn
+    const bool fwd = (a == 0) | (a == 4) | (a == 5), bwd = (a == 1) | (a == 6) | (a == 7);
+    const bool left = (a == 2) | (a == 4) | (a == 6), right = (a == 3) | (a == 5) | (a == 7);
+    double ch0, sh0;  // heading before the turn
+    Math<T>::heading(p, h, si.x, rot_old, ch0, sh0);
+    double accx = 0.0, accy = 0.0;
+    if (fwd) {  // Car.move_car("forward") :423-430
+        accx = ch0 * 0.8;
+        accy = sh0 * 0.8;
+    } else if (bwd) {  // "backward" :431-438: -force_dir * 0.8
+        accx = -ch0 * 0.8;
+        accy = -sh0 * 0.8;
+    }
+    double rot_new = rot_old;
+    int k_new = si.x;
+    if (left) {  // :440
+        rot_new -= 5.0;
+        k_new -= 1;
+    }
+    if (right) {  // :442
+        rot_new += 5.0;
+        k_new += 1;
+    }
+    const bool turned = left | right;
+    double ch1 = ch0, sh1 = sh0;  // heading after the turn
+    if (turned) Math<T>::heading(p, h, k_new, rot_new, ch1, sh1);
+
+    // ---- Car.update physics (car_env.py:452-461), float64 in both modes
+    double nvx = sv.z + accx, nvy = sv.w + accy;  // :452
+    if (!(fwd | bwd)) {                           // :454 ||acc|| == 0  <=>  no thrust
+        nvx *= 1 - 0.2;                           // :455
+        nvy *= 1 - 0.2;
+    }
+    nvx = nvx < -10.0 ? -10.0 : (nvx > 10.0 ? 10.0 : nvx);  // :457 np.clip per component
+    nvy = nvy < -10.0 ? -10.0 : (nvy > 10.0 ? 10.0 : nvy);
+    const double opx = sv.x, opy = sv.y;
+    const double npx = opx + nvx, npy = opy + nvy;  // :459
+
+    // ---- my rays: directions at the new pose; gate test at the OLD pose for the collision rays
+    T dx[RPL], dy[RPL], best[RPL];
+    bool gate_hit = false;
+    uint64_t colmask = 0;  // which of my ray slots are collision rays
+    const Seg gate = p.segs[h.gate_off + si.z];  // only gate[next] can fire (the oracle does the full scan)
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) {
+        const int ray = g + s * G;
+        const bool valid = ray < p.R;
+        const int rr = valid ? ray : 0;
+        Math<T>::ray_dir(p, rr, rot_new, ch1, sh1, dx[s], dy[s]);
+        if (!valid) {  // den == 0 for every segment -> never hits
+            dx[s] = 0;
+            dy[s] = 0;
+        }
+        best[s] = (T)1000;  // Ray.get_distance :198
+        // Car.check_collision's rays: r in range(0, n, n // 4) (:389) -- nominal n, not R
+        const bool is_col = valid & (ray < p.n_nominal) & (ray % p.q == 0);
+        colmask |= (uint64_t)is_col << s;
+        if (is_col) {  // Car.get_passed_gate (:394-408) uses the rays of the PREVIOUS update
+            T odx = dx[s], ody = dy[s];
+            if (turned) Math<T>::ray_dir(p, rr, rot_old, ch0, sh0, odx, ody);
+            gate_hit |= Math<T>::cast(gate, opx, opy, odx, ody) < (T)10;  // :387,:390
+        }
+    }
+
+    // ---- wall sweep: Car.get_distances (:360-374) -- also serves Car.check_collision (E2)
+    if constexpr (sizeof(T) == 4) {
+        const Vtx* __restrict__ vt = p.vtx + h.vtx_off;
+        Vtx nxt = vt[0];  // wave-uniform -> s_load_dwordx8, operands stay in SGPRs
+        float axp = 0.0f, ayp = 0.0f, cp[RPL];
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) cp[s] = 0.0f;
+        for (int k = 0; k < h.nV; ++k) {
+            const Vtx v = nxt;
+            nxt = vt[k + 1 < h.nV ? k + 1 : k];  // scalar prefetch of the next vertex under this one's VALU work
+            const float ax = (float)(v.x - npx), ay = (float)(v.y - npy);
+            float c[RPL];
+#pragma unroll
+            for (int s = 0; s < RPL; ++s) c[s] = cross_f(ax, ay, dx[s], dy[s]);
+            if (!v.brk) {  // uniform: vertex k closes the segment (k-1, k)
+                const float un = __builtin_fmaf(v.ey, axp, -(v.ex * ayp));
+#pragma unroll
+                for (int s = 0; s < RPL; ++s) best[s] = cast_fast(best[s], cp[s], c[s], un, v.ex, v.ey, dx[s], dy[s]);
+            }
+            axp = ax;
+            ayp = ay;
+#pragma unroll
+            for (int s = 0; s < RPL; ++s) cp[s] = c[s];
+        }
+    } else {
+        const Seg* __restrict__ walls = p.segs + h.wall_off;
+        Seg nxt = walls[0];
+        for (int w = 0; w < h.S; ++w) {
+            const Seg sg = nxt;  // wave-uniform -> s_load_dwordx8
+            nxt = walls[w + 1 < h.S ? w + 1 : w];
+#pragma unroll
+            for (int s = 0; s < RPL; ++s) {
+                const double d = cast_ref(sg.x1, sg.y1, sg.x2, sg.y2, npx, npy, dx[s], dy[s]);
+                if (d < best[s]) best[s] = d;  // :203-207
+            }
+        }
+    }
+    bool wall_hit = false;
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) wall_hit |= ((colmask >> s) & 1) & (best[s] < (T)10);  // :390
+
+    // ---- any() over the env's lanes: xor butterfly inside the 2^lg-lane group
+    int flags = (gate_hit ? 1 : 0) | (wall_hit ? 2 : 0);
+    for (int m = 1; m < G; m <<= 1) flags |= __shfl_xor(flags, m, 64);
+    gate_hit = flags & 1;
+    wall_hit = flags & 2;
+
+    // ---- bookkeeping (car_env.py:694-750), float64 reward exactly as the reference accumulates it
+    double rw = 0.0;
+    if (fwd) rw += 0.01;  // :700,:710,:714
+    int next = si.z, passed = si.w;
+    if (gate_hit) {               // :726 (gate.get_index() == next_gate_index by E1)
+        rw += 1.0;                // :727
+        if (next == h.G - 1) {    // :730 remaining == 0
+            rw += 10.0;           // :732
+            passed += 1;
+            next = 0;             // :734-737
+        } else {
+            passed += 1;          // :740
+            next += 1;            // :741
+        }
+    }
+    const int time = si.y + 1;  // :745
+    const bool destroyed = wall_hit | (h.start_collides != 0);
+    bool term = false, trunc = false;
+    if (destroyed) {  // :746-748
+        term = true;
+        rw -= 3.0;
+    } else if (time >= 1000) {  // :749-750
+        trunc = true;
+    }
+    const bool done = term | trunc;
+
+    // ---- outputs.  Auto-reset (gymnasium 0.29.1 AsyncVectorEnv): a done env returns its reset obs.
+    const float* __restrict__ robs = p.reset_obs + (size_t)trk * p.D;
+    float* __restrict__ orow = obs + (size_t)e * p.D;
+    float* __restrict__ frow = final_obs ? final_obs + (size_t)e * p.D : nullptr;
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) {
+        const int ray = g + s * G;
+        if (ray < p.R) {
+            const float v = Math<T>::norm_dist(best[s]);  // :593
+            orow[6 + ray] = done ? robs[6 + ray] : v;
+            if (frow) frow[6 + ray] = v;
+        }
+    }
+    if (g == 0) {
+        float hd[6];
+        hd[0] = Math<T>::norm(npx, 1280.0);  // :578-581
+        hd[1] = Math<T>::norm(npy, 720.0);
+        hd[2] = Math<T>::norm(nvx, 10.0);
+        hd[3] = Math<T>::norm(nvy, 10.0);
+        hd[4] = (float)ch1;  // :584-588
+        hd[5] = (float)sh1;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            orow[i] = done ? robs[i] : hd[i];
+            if (frow) frow[i] = hd[i];
+        }
+        reward[e] = (float)(rw * reward_scale);  // TransformReward then float32 store (buffer.py:29)
+        term_out[e] = term ? 1.0f : 0.0f;
+        trunc_out[e] = trunc ? 1.0f : 0.0f;
+        if (gates_passed) gates_passed[e] = passed;
+        double4 ov;
+        int4 oi;
+        if (done) {  // CarEnv.reset (:677-686): start pose, zero velocity, counters cleared
+            ov.x = h.start_x; ov.y = h.start_y; ov.z = 0.0; ov.w = 0.0;
+            oi = make_int4(0, 0, 0, 0);
+            if constexpr (sizeof(T) == 8) p.rot[e] = h.start_rot;
+        } else {
+            ov.x = npx; ov.y = npy; ov.z = nvx; ov.w = nvy;
+            oi = make_int4(k_new, time, next, passed);
+            if constexpr (sizeof(T) == 8) p.rot[e] = rot_new;
+        }
+        p.pv[e] = ov;
+        p.iv[e] = oi;
+    }
+}
+
+template <typename T, int RPL>
+__global__ __launch_bounds__(256) void env_step_kernel(const EnvParams<T> p, const int64_t* __restrict__ actions,
+                                                       const double reward_scale, float* __restrict__ obs,
+                                                       float* __restrict__ reward, float* __restrict__ term_out,
+                                                       float* __restrict__ trunc_out, int32_t* __restrict__ gates_passed,
+                                                       float* __restrict__ final_obs) {
+    const int64_t lane = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t e = lane >> p.lg;
+    const int g = (int)(lane & ((1 << p.lg) - 1));
+    if (e >= p.N) return;  // whole env groups leave together (N*G lanes are a multiple of G)
+    if (p.track_id == nullptr) {
+        env_step_body<T, RPL>(p, 0, e, g, actions, reward_scale, obs, reward, term_out, trunc_out, gates_passed, final_obs);
+    } else {
+        // Waterfall: run the body once per distinct track id present in this wavefront so that the track
+        // header / segment loads stay wave-uniform (scalar).  One pass when the wave is uniform.  The loop
+        // is driven by a ballot of the lanes still to do (a plain readfirstlane(mine) is loop-invariant to
+        // the compiler and gets hoisted out of the loop).
+        const int mine = p.track_id[e];
+        uint64_t todo = __ballot(1);
+        while (todo) {
+            const int first = __ffsll((unsigned long long)todo) - 1;
+            const int cur = __builtin_amdgcn_readlane(mine, first);
+            const bool match = mine == cur;
+            if (match)
+                env_step_body<T, RPL>(p, cur, e, g, actions, reward_scale, obs, reward, term_out, trunc_out, gates_passed,
+                                      final_obs);
+            todo &= ~__ballot(match);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: reset, and the per-track reset observation
+// ------------------------------------------------------------------------------------------
+// CarEnv.reset (car_env.py:677-688) for ONE track: Car.reset + Car.update with zero velocity, then
+// _get_obs.  One thread per track; runs once at pc_env_create.  Also reports start_collides.
+template <typename T>
+__global__ void reset_obs_kernel(const EnvParams<T> p, int n_tracks, float* __restrict__ reset_obs,
+                                 int* __restrict__ start_collides) {
+    const int trk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (trk >= n_tracks) return;
+    const TrackHdr h = p.hdr[trk];
+    double nvx = 0.0 + 0.0, nvy = 0.0 + 0.0;  // :452
+    nvx *= 1 - 0.2;                           // :455 friction on zero velocity
+    nvy *= 1 - 0.2;
+    const double npx = h.start_x + nvx, npy = h.start_y + nvy;
+    double ch, sh;
+    Math<T>::heading(p, h, 0, h.start_rot, ch, sh);
+    float* o = reset_obs + (size_t)trk * p.D;
+    o[0] = Math<T>::norm(npx, 1280.0);
+    o[1] = Math<T>::norm(npy, 720.0);
+    o[2] = Math<T>::norm(nvx, 10.0);
+    o[3] = Math<T>::norm(nvy, 10.0);
+    o[4] = (float)ch;
+    o[5] = (float)sh;
+    bool hit = false;
+    for (int ray = 0; ray < p.R; ++ray) {
+        T dx, dy;
+        Math<T>::ray_dir(p, ray, h.start_rot, ch, sh, dx, dy);
+        T best = (T)1000;
+        for (int w = 0; w < h.S; ++w) {
+            const T d = Math<T>::cast(p.segs[h.wall_off + w], npx, npy, dx, dy);
+            if (d < best) best = d;
+        }
+        o[6 + ray] = Math<T>::norm_dist(best);
+        if (ray < p.n_nominal && ray % p.q == 0 && best < (T)10) hit = true;
+    }
+    start_collides[trk] = hit ? 1 : 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void env_reset_kernel(const EnvParams<T> p, float* __restrict__ obs) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.N) return;
+    const int trk = p.track_id ? p.track_id[e] : 0;
+    const TrackHdr h = p.hdr[trk];
+    double4 ov;
+    ov.x = h.start_x; ov.y = h.start_y; ov.z = 0.0; ov.w = 0.0;
+    p.pv[e] = ov;
+    p.iv[e] = make_int4(0, 0, 0, 0);
+    if constexpr (sizeof(T) == 8) p.rot[e] = h.start_rot;
+    if (obs) {
+        const float* r = p.reset_obs + (size_t)trk * p.D;
+        float* o = obs + (size_t)e * p.D;
+        for (int i = 0; i < p.D; ++i) o[i] = r[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: GAE(lambda), buffer.py:36-64.  One lane per env, serial in t (the recurrence), rows
+// coalesced across envs.  Operation order = torch's, one float32 rounding per op (no FMA):
+//   delta    = (rew[t] + (gamma * next_val) * term_mask) - val[t]                       :60
+//   last_gae = delta + (((gamma*lambda) * term_mask) * trunc_mask) * last_gae           :61
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gae_kernel(const float* __restrict__ rew, const float* __restrict__ val,
+                                                  const float* __restrict__ term, const float* __restrict__ trunc,
+                                                  const float* __restrict__ last_val, const float* __restrict__ last_term,
+                                                  const float* __restrict__ last_trunc, const float g, const float gl,
+                                                  const int64_t T, const int64_t N, float* __restrict__ adv,
+                                                  float* __restrict__ ret) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    float next_val = last_val[e];             // :53
+    float tmask = 1.0f - last_term[e];        // :54
+    float trmask = 1.0f - last_trunc[e];      // :55
+    float last_gae = 0.0f;
+    constexpr int U = 8;  // rows in flight per lane: the loads do not depend on the recurrence
+    int64_t t = T - 1;
+    for (; t >= U - 1; t -= U) {
+        float r[U], v[U], tm[U], tr[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int64_t off = (t - j) * N + e;
+            r[j] = rew[off];
+            v[j] = val[off];
+            tm[j] = term[off];
+            tr[j] = trunc[off];
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int64_t off = (t - j) * N + e;
+            float tmp = g * next_val;
+            tmp = tmp * tmask;
+            float delta = r[j] + tmp;
+            delta = delta - v[j];
+            float c = gl * tmask;
+            c = c * trmask;
+            c = c * last_gae;
+            last_gae = delta + c;
+            adv[off] = last_gae;           // :62
+            ret[off] = last_gae + v[j];    // :63
+            next_val = v[j];
+            tmask = 1.0f - tm[j];
+            trmask = 1.0f - tr[j];
+        }
+    }
+    for (; t >= 0; --t) {
+        const int64_t off = t * N + e;
+        const float r = rew[off], v = val[off];
+        float tmp = g * next_val;
+        tmp = tmp * tmask;
+        float delta = r + tmp;
+        delta = delta - v;
+        float c = gl * tmask;
+        c = c * trmask;
+        c = c * last_gae;
+        last_gae = delta + c;
+        adv[off] = last_gae;
+        ret[off] = last_gae + v;
+        next_val = v;
+        tmask = 1.0f - term[off];
+        trmask = 1.0f - trunc[off];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: categorical sample / log_prob / entropy (model.py:35-40), Philox-4x32-10 counter RNG
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1;
+    c[3] = (uint32_t)p0;
+    c[0] = n0;
+    c[2] = n2;
+}
+
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, uint64_t idx) {
+    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1) open, 24 bits
+}
+
+template <int AMAX>
+__global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, const int64_t N, const int A,
+                                                     const uint64_t seed, const uint64_t offset,
+                                                     int64_t* __restrict__ actions, float* __restrict__ logprob,
+                                                     float* __restrict__ entropy) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    float l[AMAX];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < AMAX; ++i) {
+        l[i] = i < A ? logits[e * A + i] : -INFINITY;
+        mx = fmaxf(mx, l[i]);
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < AMAX; ++i) sum += i < A ? expf(l[i] - mx) : 0.0f;
+    const float lse = mx + logf(sum);  // Categorical(logits=...) normalises: logits - logsumexp
+    const float u = philox_uniform(seed, offset, (uint64_t)e);
+    float cum = 0.0f, ent = 0.0f, lp = 0.0f;
+    int act = -1;
+#pragma unroll
+    for (int i = 0; i < AMAX; ++i) {
+        if (i < A) {
+            const float nl = l[i] - lse;
+            const float pr = expf(nl);
+            cum += pr;
+            ent -= pr * fmaxf(nl, -3.4028234663852886e38f);  // torch clamps log-probs at finfo.min
+            if (act < 0 && (u < cum || i == A - 1)) {        // inverse CDF; last bin absorbs rounding
+                act = i;
+                lp = nl;
+            }
+        }
+    }
+    actions[e] = act;
+    logprob[e] = lp;
+    if (entropy) entropy[e] = ent;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_hip_err;
+
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            g_hip_err = std::string(#expr) + ": " + hipGetErrorString(_e);                 \
+            return PC_ERR_HIP;                                                             \
+        }                                                                                  \
+    } while (0)
+
+namespace {
+
+struct DeviceGuard {  // set the handle's device for the call, restore the caller's afterwards
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+        dev_ = dev;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != dev_) (void)hipSetDevice(prev);
+    }
+    int dev_;
+};
+
+constexpr int kMenu[] = {1, 2, 3, 5, 6, 9, 12, 17, 33};  // rays-per-lane instantiations of K1
+
+int pick_rpl(int need) {
+    for (int m : kMenu)
+        if (m >= need) return m;
+    return -1;
+}
+
+}  // namespace
+
+struct pc_env {
+    int device = 0;
+    int dtype = PC_DTYPE_F32;
+    int64_t N = 0;
+    int n_nominal = 12, R = 12, D = 18, n_tracks = 0;
+    int lanes_override = 0;
+    int lg = 0, rpl = 1, blocks = 0;
+    std::vector<TrackHdr> hdr_host;
+    // device buffers
+    double4* pv = nullptr;
+    int4* iv = nullptr;
+    double* rot = nullptr;
+    uint8_t* track_id = nullptr;
+    TrackHdr* hdr = nullptr;
+    Seg* segs = nullptr;
+    Vtx* vtx = nullptr;
+    double2* headtab = nullptr;
+    float2* raytab = nullptr;
+    float* reset_obs = nullptr;
+
+    template <typename T> EnvParams<T> params() const {
+        EnvParams<T> p;
+        p.N = N;
+        p.lg = lg;
+        p.n_nominal = n_nominal;
+        p.q = n_nominal / 4;
+        p.step_deg = 360 / n_nominal;
+        p.R = R;
+        p.D = D;
+        p.pv = pv;
+        p.iv = iv;
+        p.rot = rot;
+        p.track_id = track_id;
+        p.hdr = hdr;
+        p.segs = segs;
+        p.vtx = vtx;
+        p.headtab = headtab;
+        p.raytab = raytab;
+        p.reset_obs = reset_obs;
+        return p;
+    }
+
+    // lanes per env: fill ~4 waves per SIMD (256 CUs x 4 SIMDs x 64 lanes x 4) but never more
+    // lanes than rays, and keep rays-per-lane inside the instantiated menu.
+    int choose_geometry() {
+        int G;
+        if (lanes_override > 0) {
+            G = lanes_override;
+        } else {
+            const int64_t target = 262144;
+            G = 1;
+            while (G < 64 && (int64_t)G * N < target && G < R) G <<= 1;
+        }
+        const int max_rpl = dtype == PC_DTYPE_F64 ? 17 : 33;  // F64 keeps 6 VGPRs per ray slot
+        while (true) {
+            const int need = (R + G - 1) / G;
+            const int m = pick_rpl(need);
+            if (m > 0 && m <= max_rpl) {
+                rpl = m;
+                break;
+            }
+            if (G >= 64) return PC_ERR_UNSUPPORTED;
+            G <<= 1;
+        }
+        lg = 0;
+        while ((1 << lg) < G) ++lg;
+        const int64_t lanes = N << lg;
+        blocks = (int)((lanes + 255) / 256);
+        return PC_OK;
+    }
+};
+
+template <typename T, int RPL>
+static void launch_step(const pc_env* e, const int64_t* actions, double reward_scale, float* obs, float* reward, float* term,
+                        float* trunc, int32_t* gates_passed, float* final_obs, hipStream_t st) {
+    hipLaunchKernelGGL((env_step_kernel<T, RPL>), dim3(e->blocks), dim3(256), 0, st, e->params<T>(), actions, reward_scale, obs,
+                       reward, term, trunc, gates_passed, final_obs);
+}
+
+extern "C" {
+
+const char* pc_strerror(int code) {
+    switch (code) {
+        case PC_OK: return "ok";
+        case PC_ERR_INVALID_ARG: return "invalid argument";
+        case PC_ERR_IO: return "track file not found or unreadable";
+        case PC_ERR_PARSE: return "track JSON malformed or schema violated";
+        case PC_ERR_HIP: return "HIP runtime error";
+        case PC_ERR_UNSUPPORTED: return "unsupported configuration";
+        case PC_ERR_NO_DEVICE: return "no usable gfx950 device";
+        default: return "unknown error";
+    }
+}
+
+const char* pc_last_hip_error(void) { return g_hip_err.c_str(); }
+
+int pc_ray_count(int n) {
+    if (n < 4 || n > 360) return PC_ERR_INVALID_ARG;
+    const int step = 360 / n;
+    return (360 + step - 1) / step;  // len(range(0, 360, 360 // n)), car_env.py:269
+}
+
+int pc_track_load_json(const char* path, pc_track** out) {
+    if (!path || !out) return PC_ERR_INVALID_ARG;
+    std::unique_ptr<pc_track> t(new (std::nothrow) pc_track);
+    if (!t) return PC_ERR_INVALID_ARG;
+    const int rc = pc_internal_parse_track(path, t.get());
+    if (rc != PC_OK) return rc;
+    *out = t.release();
+    return PC_OK;
+}
+
+int pc_track_from_arrays(const double* walls, int n_walls, const double* gates, int n_gates, double start_x, double start_y,
+                         double start_angle_deg, pc_track** out) {
+    if (!walls || !gates || n_walls < 1 || n_gates < 1 || !out) return PC_ERR_INVALID_ARG;
+    pc_track* t = new (std::nothrow) pc_track;
+    if (!t) return PC_ERR_INVALID_ARG;
+    t->walls.assign(walls, walls + 4 * (size_t)n_walls);
+    t->gates.assign(gates, gates + 4 * (size_t)n_gates);
+    t->start_x = start_x;
+    t->start_y = start_y;
+    t->start_rot = start_angle_deg;
+    *out = t;
+    return PC_OK;
+}
+
+int pc_track_info(const pc_track* t, int* n_walls, int* n_gates, double* start) {
+    if (!t) return PC_ERR_INVALID_ARG;
+    if (n_walls) *n_walls = t->n_walls();
+    if (n_gates) *n_gates = t->n_gates();
+    if (start) {
+        start[0] = t->start_x;
+        start[1] = t->start_y;
+        start[2] = t->start_rot;
+    }
+    return PC_OK;
+}
+
+int pc_track_geometry(const pc_track* t, double* walls, double* gates) {
+    if (!t) return PC_ERR_INVALID_ARG;
+    if (walls) memcpy(walls, t->walls.data(), t->walls.size() * sizeof(double));
+    if (gates) memcpy(gates, t->gates.data(), t->gates.size() * sizeof(double));
+    return PC_OK;
+}
+
+void pc_track_destroy(pc_track* t) { delete t; }
+
+void pc_env_destroy(pc_env* e) {
+    if (!e) return;
+    DeviceGuard g(e->device);
+    (void)hipFree(e->pv);
+    (void)hipFree(e->iv);
+    (void)hipFree(e->rot);
+    (void)hipFree(e->track_id);
+    (void)hipFree(e->hdr);
+    (void)hipFree(e->segs);
+    (void)hipFree(e->vtx);
+    (void)hipFree(e->headtab);
+    (void)hipFree(e->raytab);
+    (void)hipFree(e->reset_obs);
+    delete e;
+}
+
+static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8_t* track_id) {
+    const bool f64 = e->dtype == PC_DTYPE_F64;
+    // ---- host images of the track table
+    std::vector<Seg> segs;
+    std::vector<Vtx> vtx;
+    std::vector<double2> headtab;
+    e->hdr_host.resize(e->n_tracks);
+    for (int k = 0; k < e->n_tracks; ++k) {
+        const pc_track* t = tracks[k];
+        TrackHdr& h = e->hdr_host[k];
+        h.S = t->n_walls();
+        h.G = t->n_gates();
+        h.wall_off = (int)segs.size();
+        for (size_t i = 0; i < t->walls.size(); i += 4) segs.push_back(Seg{t->walls[i], t->walls[i + 1], t->walls[i + 2], t->walls[i + 3]});
+        h.gate_off = (int)segs.size();
+        for (size_t i = 0; i < t->gates.size(); i += 4) segs.push_back(Seg{t->gates[i], t->gates[i + 1], t->gates[i + 2], t->gates[i + 3]});
+        // walls as vertex chains: a segment continues the chain iff it starts exactly where the previous ended
+        h.vtx_off = (int)vtx.size();
+        for (int w = 0; w < h.S; ++w) {
+            const Seg& sg = segs[h.wall_off + w];
+            const bool cont = w > 0 && segs[h.wall_off + w - 1].x2 == sg.x1 && segs[h.wall_off + w - 1].y2 == sg.y1;
+            if (!cont) vtx.push_back(Vtx{sg.x1, sg.y1, 0.f, 0.f, 1, 0});
+            vtx.push_back(Vtx{sg.x2, sg.y2, (float)(sg.x1 - sg.x2), (float)(sg.y1 - sg.y2), 0, 0});
+        }
+        h.nV = (int)vtx.size() - h.vtx_off;
+        h.head_off = (int)headtab.size();
+        h.start_collides = 0;
+        h.start_x = t->start_x;
+        h.start_y = t->start_y;
+        h.start_rot = t->start_rot;
+        for (int j = 0; j < 72; ++j) {  // heading grid: start_rot + 5 j degrees, np.radians then libm cos/sin
+            const double a = (t->start_rot + 5.0 * j) * (PC_PI / 180.0);
+            headtab.push_back(make_double2(std::cos(a), std::sin(a)));
+        }
+    }
+    std::vector<float2> raytab(e->R);
+    const int step = 360 / e->n_nominal;
+    for (int i = 0; i < e->R; ++i) {
+        const double a = (double)(i * step) * (PC_PI / 180.0);
+        raytab[i] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    // ---- device buffers
+    const size_t N = (size_t)e->N;
+    HIPCHK(hipMalloc((void**)&e->pv, N * sizeof(double4)));
+    HIPCHK(hipMalloc((void**)&e->iv, N * sizeof(int4)));
+    if (f64) HIPCHK(hipMalloc((void**)&e->rot, N * sizeof(double)));
+    if (track_id) {
+        HIPCHK(hipMalloc((void**)&e->track_id, N));
+        HIPCHK(hipMemcpy(e->track_id, track_id, N, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMalloc((void**)&e->hdr, e->n_tracks * sizeof(TrackHdr)));
+    HIPCHK(hipMemcpy(e->hdr, e->hdr_host.data(), e->n_tracks * sizeof(TrackHdr), hipMemcpyHostToDevice));
+    static_assert(sizeof(Seg) == 32 && sizeof(Vtx) == 32, "segment / vertex records are 32 bytes (one s_load_dwordx8)");
+    HIPCHK(hipMalloc((void**)&e->segs, segs.size() * sizeof(Seg)));
+    HIPCHK(hipMemcpy(e->segs, segs.data(), segs.size() * sizeof(Seg), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&e->vtx, vtx.size() * sizeof(Vtx)));
+    HIPCHK(hipMemcpy(e->vtx, vtx.data(), vtx.size() * sizeof(Vtx), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&e->headtab, headtab.size() * sizeof(double2)));
+    HIPCHK(hipMemcpy(e->headtab, headtab.data(), headtab.size() * sizeof(double2), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&e->raytab, raytab.size() * sizeof(float2)));
+    HIPCHK(hipMemcpy(e->raytab, raytab.data(), raytab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&e->reset_obs, (size_t)e->n_tracks * e->D * sizeof(float)));
+    // ---- per-track reset observation + start_collides, computed on the device by the same arithmetic
+    int* d_sc = nullptr;
+    HIPCHK(hipMalloc((void**)&d_sc, e->n_tracks * sizeof(int)));
+    const int rb = (e->n_tracks + 63) / 64;
+    if (f64)
+        hipLaunchKernelGGL(reset_obs_kernel<double>, dim3(rb), dim3(64), 0, 0, e->params<double>(), e->n_tracks, e->reset_obs, d_sc);
+    else
+        hipLaunchKernelGGL(reset_obs_kernel<float>, dim3(rb), dim3(64), 0, 0, e->params<float>(), e->n_tracks, e->reset_obs, d_sc);
+    HIPCHK(hipGetLastError());
+    std::vector<int> sc(e->n_tracks);
+    HIPCHK(hipMemcpy(sc.data(), d_sc, e->n_tracks * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(d_sc);
+    for (int k = 0; k < e->n_tracks; ++k) e->hdr_host[k].start_collides = sc[k];
+    HIPCHK(hipMemcpy(e->hdr, e->hdr_host.data(), e->n_tracks * sizeof(TrackHdr), hipMemcpyHostToDevice));
+    return PC_OK;
+}
+
+int pc_env_create(int device, int64_t n_envs, int num_rays_nominal, const pc_track* const* tracks, int n_tracks,
+                  const uint8_t* track_id, int dtype, pc_env** out) {
+    if (!out || !tracks || n_tracks < 1 || n_tracks > 256 || n_envs < 1 || (dtype != PC_DTYPE_F32 && dtype != PC_DTYPE_F64))
+        return PC_ERR_INVALID_ARG;
+    if (num_rays_nominal < 4 || num_rays_nominal > 360) return PC_ERR_INVALID_ARG;
+    for (int k = 0; k < n_tracks; ++k)
+        if (!tracks[k] || tracks[k]->n_walls() < 1 || tracks[k]->n_gates() < 1) return PC_ERR_INVALID_ARG;
+    if (track_id)
+        for (int64_t i = 0; i < n_envs; ++i)
+            if (track_id[i] >= n_tracks) return PC_ERR_INVALID_ARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1 || device < 0 || device >= count) return PC_ERR_NO_DEVICE;
+    DeviceGuard guard(device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    pc_env* e = new (std::nothrow) pc_env;
+    if (!e) return PC_ERR_INVALID_ARG;
+    e->device = device;
+    e->dtype = dtype;
+    e->N = n_envs;
+    e->n_nominal = num_rays_nominal;
+    e->R = pc_ray_count(num_rays_nominal);
+    e->D = 6 + e->R;
+    e->n_tracks = n_tracks;
+    int rc = e->choose_geometry();
+    if (rc == PC_OK) rc = env_create_impl(e, tracks, track_id);
+    if (rc != PC_OK) {
+        pc_env_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return PC_OK;
+}
+
+int pc_env_obs_dim(const pc_env* e) { return e ? e->D : PC_ERR_INVALID_ARG; }
+int pc_env_num_actions(const pc_env* e) { return e ? 9 : PC_ERR_INVALID_ARG; }  // spaces.Discrete(9), car_env.py:525
+int64_t pc_env_num_envs(const pc_env* e) { return e ? e->N : PC_ERR_INVALID_ARG; }
+
+int pc_env_set_lanes_per_env(pc_env* e, int lanes) {
+    if (!e || lanes < 0 || lanes > 64 || (lanes & (lanes - 1))) return PC_ERR_INVALID_ARG;
+    const int prev = e->lanes_override;
+    e->lanes_override = lanes;
+    const int rc = e->choose_geometry();
+    if (rc != PC_OK) {
+        e->lanes_override = prev;
+        (void)e->choose_geometry();
+    }
+    return rc;
+}
+
+int pc_env_launch_info(const pc_env* e, int* lanes_per_env, int* rays_per_lane, int* blocks, int* threads) {
+    if (!e) return PC_ERR_INVALID_ARG;
+    if (lanes_per_env) *lanes_per_env = 1 << e->lg;
+    if (rays_per_lane) *rays_per_lane = e->rpl;
+    if (blocks) *blocks = e->blocks;
+    if (threads) *threads = 256;
+    return PC_OK;
+}
+
+int pc_env_reset(pc_env* e, float* obs, void* stream) {
+    if (!e) return PC_ERR_INVALID_ARG;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    const int blocks = (int)((e->N + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (e->dtype == PC_DTYPE_F64)
+        hipLaunchKernelGGL(env_reset_kernel<double>, dim3(blocks), dim3(256), 0, st, e->params<double>(), obs);
+    else
+        hipLaunchKernelGGL(env_reset_kernel<float>, dim3(blocks), dim3(256), 0, st, e->params<float>(), obs);
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_env_step(pc_env* e, const int64_t* actions, double reward_scale, float* obs, float* reward, float* terminated,
+                float* truncated, int32_t* gates_passed, float* final_obs, void* stream) {
+    if (!e || !actions || !obs || !reward || !terminated || !truncated) return PC_ERR_INVALID_ARG;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)stream;
+#define PC_CASE(T, M)                                                                                        \
+    case M:                                                                                                  \
+        launch_step<T, M>(e, actions, reward_scale, obs, reward, terminated, truncated, gates_passed, final_obs, st); \
+        break;
+    if (e->dtype == PC_DTYPE_F64) {
+        switch (e->rpl) {
+            PC_CASE(double, 1) PC_CASE(double, 2) PC_CASE(double, 3) PC_CASE(double, 5) PC_CASE(double, 6)
+            PC_CASE(double, 9) PC_CASE(double, 12) PC_CASE(double, 17)
+            default: return PC_ERR_UNSUPPORTED;
+        }
+    } else {
+        switch (e->rpl) {
+            PC_CASE(float, 1) PC_CASE(float, 2) PC_CASE(float, 3) PC_CASE(float, 5) PC_CASE(float, 6)
+            PC_CASE(float, 9) PC_CASE(float, 12) PC_CASE(float, 17) PC_CASE(float, 33)
+            default: return PC_ERR_UNSUPPORTED;
+        }
+    }
+#undef PC_CASE
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_env_get_state(pc_env* e, double* px, double* py, double* vx, double* vy, double* rot, int64_t* time_step,
+                     int64_t* next_gate, int64_t* passed) {
+    if (!e) return PC_ERR_INVALID_ARG;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    const size_t N = (size_t)e->N;
+    const bool f64 = e->dtype == PC_DTYPE_F64;
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<int4> iv(N);
+    HIPCHK(hipMemcpy(iv.data(), e->iv, N * sizeof(int4), hipMemcpyDeviceToHost));
+    std::vector<double> pv(4 * N);
+    HIPCHK(hipMemcpy(pv.data(), e->pv, 4 * N * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<double> r(N);
+    std::vector<uint8_t> tid(N, 0);
+    if (f64) HIPCHK(hipMemcpy(r.data(), e->rot, N * sizeof(double), hipMemcpyDeviceToHost));
+    if (e->track_id) HIPCHK(hipMemcpy(tid.data(), e->track_id, N, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; ++i) {
+        if (px) px[i] = pv[4 * i];
+        if (py) py[i] = pv[4 * i + 1];
+        if (vx) vx[i] = pv[4 * i + 2];
+        if (vy) vy[i] = pv[4 * i + 3];
+        if (rot) rot[i] = f64 ? r[i] : e->hdr_host[tid[i]].start_rot + 5.0 * iv[i].x;
+        if (time_step) time_step[i] = iv[i].y;
+        if (next_gate) next_gate[i] = iv[i].z;
+        if (passed) passed[i] = iv[i].w;
+    }
+    return PC_OK;
+}
+
+int pc_env_set_state(pc_env* e, const double* px, const double* py, const double* vx, const double* vy, const double* rot,
+                     const int64_t* time_step, const int64_t* next_gate, const int64_t* passed) {
+    if (!e) return PC_ERR_INVALID_ARG;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    const size_t N = (size_t)e->N;
+    const bool f64 = e->dtype == PC_DTYPE_F64;
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<int4> iv(N);
+    HIPCHK(hipMemcpy(iv.data(), e->iv, N * sizeof(int4), hipMemcpyDeviceToHost));
+    std::vector<double> pv(4 * N);
+    HIPCHK(hipMemcpy(pv.data(), e->pv, 4 * N * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> tid(N, 0);
+    if (e->track_id) HIPCHK(hipMemcpy(tid.data(), e->track_id, N, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; ++i) {
+        if (px) pv[4 * i] = px[i];
+        if (py) pv[4 * i + 1] = py[i];
+        if (vx) pv[4 * i + 2] = vx[i];
+        if (vy) pv[4 * i + 3] = vy[i];
+        if (rot && !f64) iv[i].x = (int)std::llround((rot[i] - e->hdr_host[tid[i]].start_rot) / 5.0);
+        if (time_step) iv[i].y = (int)time_step[i];
+        if (next_gate) {
+            if (next_gate[i] < 0 || next_gate[i] >= e->hdr_host[tid[i]].G) return PC_ERR_INVALID_ARG;
+            iv[i].z = (int)next_gate[i];
+        }
+        if (passed) iv[i].w = (int)passed[i];
+    }
+    HIPCHK(hipMemcpy(e->iv, iv.data(), N * sizeof(int4), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->pv, pv.data(), 4 * N * sizeof(double), hipMemcpyHostToDevice));
+    if (f64 && rot) HIPCHK(hipMemcpy(e->rot, rot, N * sizeof(double), hipMemcpyHostToDevice));
+    return PC_OK;
+}
+
+int pc_gae(int device, const float* rew, const float* val, const float* term, const float* trunc, const float* last_val,
+           const float* last_term, const float* last_trunc, double gamma, double lam, int64_t T, int64_t N, float* adv,
+           float* ret, void* stream) {
+    if (!rew || !val || !term || !trunc || !last_val || !last_term || !last_trunc || !adv || !ret || T < 1 || N < 1)
+        return PC_ERR_INVALID_ARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1 || device < 0 || device >= count) return PC_ERR_NO_DEVICE;
+    DeviceGuard guard(device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    const int blocks = (int)((N + 255) / 256);
+    // gamma and gamma*lambda are Python floats that torch casts to float32 at the multiply
+    hipLaunchKernelGGL(gae_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rew, val, term, trunc, last_val, last_term,
+                       last_trunc, (float)gamma, (float)(gamma * lam), T, N, adv, ret);
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, uint64_t offset, int64_t* actions,
+              float* logprob, float* entropy, void* stream) {
+    if (!logits || !actions || !logprob || N < 1 || A < 1) return PC_ERR_INVALID_ARG;
+    if (A > 16) return PC_ERR_UNSUPPORTED;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1 || device < 0 || device >= count) return PC_ERR_NO_DEVICE;
+    DeviceGuard guard(device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    const int blocks = (int)((N + 255) / 256);
+    hipLaunchKernelGGL(sample_kernel<16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, N, A, seed, offset, actions,
+                       logprob, entropy);
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
+
+}  // extern "C"

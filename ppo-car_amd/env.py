@@ -1,0 +1,195 @@
+"""VecCarEnv -- the gymnasium vector-env surface train.py drives (reference train.py:138-142,
+159-164,185,296), backed by the HIP env-step kernel through the C-ABI.  Tensors in, tensors out,
+everything stays on the GPU; no host synchronisation in step()."""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import check, lib
+
+
+class Track:
+    """A loaded track (CarEnv.load_track, car_env.py:535-567).  Host-side only."""
+
+    def __init__(self, path=None, *, walls=None, gates=None, start=None):
+        h = C.c_void_p()
+        if path is not None:
+            # the reference prints "Track file not found" and returns None (car_env.py:624-628);
+            # here a missing / malformed track is a hard error
+            check(lib.pc_track_load_json(os.fsencode(path), C.byref(h)), f"pc_track_load_json({path!r})")
+        else:
+            w = np.ascontiguousarray(walls, np.float64).reshape(-1, 4)
+            g = np.ascontiguousarray(gates, np.float64).reshape(-1, 4)
+            check(lib.pc_track_from_arrays(w.ctypes.data, len(w), g.ctypes.data, len(g), float(start[0]), float(start[1]),
+                                           float(start[2]), C.byref(h)), "pc_track_from_arrays")
+        self._h = h
+        self.path = path
+        s, g_, st = C.c_int(), C.c_int(), (C.c_double * 3)()
+        check(lib.pc_track_info(h, C.byref(s), C.byref(g_), st), "pc_track_info")
+        self.n_walls, self.n_gates = s.value, g_.value
+        self.start_x, self.start_y, self.start_angle = st[0], st[1], st[2]
+
+    def geometry(self):
+        walls = np.zeros((self.n_walls, 4), np.float64)
+        gates = np.zeros((self.n_gates, 4), np.float64)
+        check(lib.pc_track_geometry(self._h, walls.ctypes.data, gates.ctypes.data), "pc_track_geometry")
+        return walls, gates
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.pc_track_destroy(h)
+
+
+def ray_count(num_rays):
+    """len(range(0, 360, 360 // n)) -- car_env.py:269: 12 -> 12, 16 -> 17, 32 -> 33."""
+    r = lib.pc_ray_count(int(num_rays))
+    check(min(r, 0), f"pc_ray_count({num_rays})")
+    return r
+
+
+def _device_index(device):
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError(f"VecCarEnv runs on an AMD GPU only (got device {device}); there is no CPU path")
+    if not torch.cuda.is_available():
+        raise RuntimeError("VecCarEnv needs a GPU: torch.cuda.is_available() is False and there is no CPU fallback")
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
+class VecCarEnv:
+    """n_envs CarEnv instances stepped by one kernel launch.
+
+    Mirrors `gym.vector.AsyncVectorEnv([make_env(...)] * n)` as the reference uses it:
+      reset(options={"track_path": p}) -> (obs[N, D] float32, infos)          train.py:159-164
+      step(actions[N] int64) -> (obs, rewards, terminateds, truncateds, infos)  train.py:185
+        with TransformReward's `r * reward_scaling` (train.py:65,68) and same-step auto-reset
+      close()                                                                   train.py:296
+    `num_rays` is Car's nominal ray count (car_env.py:227); the observation has 6 + R entries with
+    R = len(range(0, 360, 360 // num_rays)) exactly as the reference produces them.
+    tracks: one path / Track, or a list of them with `track_id` [N] picking each env's track.
+    """
+
+    def __init__(self, n_envs, tracks, num_rays=12, reward_scaling=1.0, device="cuda", dtype="f32", track_id=None):
+        self.device = torch.device("cuda", _device_index(device))
+        self.num_envs = int(n_envs)
+        self.num_rays = int(num_rays)
+        self.reward_scaling = float(reward_scaling)
+        self.dtype = dtype
+        self._h = None
+        self._tracks = None
+        self._track_id = None if track_id is None else np.ascontiguousarray(track_id, np.uint8)
+        self._build(tracks)
+
+    # ---- construction ---------------------------------------------------------------------
+    def _build(self, tracks):
+        if isinstance(tracks, (str, os.PathLike, Track)):
+            tracks = [tracks]
+        tr = [t if isinstance(t, Track) else Track(t) for t in tracks]
+        arr = (C.c_void_p * len(tr))(*[t._h for t in tr])
+        h = C.c_void_p()
+        tid = self._track_id
+        if tid is not None and len(tid) != self.num_envs:
+            raise ValueError("track_id must have one entry per env")
+        check(lib.pc_env_create(self.device.index, self.num_envs, self.num_rays, arr, len(tr),
+                                tid.ctypes.data if tid is not None else None, _capi.DTYPES[self.dtype], C.byref(h)),
+              "pc_env_create")
+        self.close()
+        self._h, self._tracks = h, tr
+        self.obs_dim = lib.pc_env_obs_dim(h)
+        self.act_dim = lib.pc_env_num_actions(h)
+        # what train.py:141-142 reads
+        self.single_observation_space_shape = (self.obs_dim,)
+        self.single_action_space_n = self.act_dim
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _new(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    @staticmethod
+    def _ptr(t, dtype, numel, what):
+        if t is None:
+            return None
+        if not (t.is_cuda and t.dtype == dtype and t.is_contiguous() and t.numel() == numel):
+            raise ValueError(f"{what}: need a contiguous {dtype} CUDA tensor with {numel} elements, got "
+                             f"{tuple(t.shape)} {t.dtype} {t.device}")
+        return t.data_ptr()
+
+    # ---- gymnasium-style surface ----------------------------------------------------------------
+    def reset(self, seed=None, options=None, out=None):
+        """seed is accepted and ignored, as in the reference (the env is deterministic, car_env.py:617)."""
+        if options and "track_path" in options:
+            if len(self._tracks) != 1 or self._tracks[0].path != options["track_path"]:
+                self._build(options["track_path"])
+        obs = out if out is not None else self._new(self.num_envs, self.obs_dim)
+        check(lib.pc_env_reset(self._h, self._ptr(obs, torch.float32, self.num_envs * self.obs_dim, "obs"), self._stream()),
+              "pc_env_reset")
+        return obs, {}
+
+    def step(self, actions, out=None, gates_passed=None, final_obs=None):
+        """out = (obs, rewards, terminateds, truncateds) preallocated tensors (e.g. rows of the rollout
+        buffer) or None to allocate.  Flags are float32 0/1, what train.py:191-192 builds."""
+        N, D = self.num_envs, self.obs_dim
+        if actions.dtype != torch.int64 or not actions.is_cuda:
+            actions = actions.to(device=self.device, dtype=torch.int64)
+        actions = actions.contiguous()
+        if out is None:
+            out = (self._new(N, D), self._new(N), self._new(N), self._new(N))
+        obs, rew, term, trunc = out
+        check(lib.pc_env_step(self._h, self._ptr(actions, torch.int64, N, "actions"), self.reward_scaling,
+                              self._ptr(obs, torch.float32, N * D, "obs"), self._ptr(rew, torch.float32, N, "rewards"),
+                              self._ptr(term, torch.float32, N, "terminateds"), self._ptr(trunc, torch.float32, N, "truncateds"),
+                              self._ptr(gates_passed, torch.int32, N, "gates_passed"),
+                              self._ptr(final_obs, torch.float32, N * D, "final_obs"), self._stream()), "pc_env_step")
+        infos = {}
+        if gates_passed is not None:
+            infos["gates_passed"] = gates_passed
+        if final_obs is not None:
+            infos["final_observation"] = final_obs
+        return obs, rew, term, trunc, infos
+
+    def close(self):
+        h, self._h = self._h, None
+        if h:
+            lib.pc_env_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- teacher forcing / introspection (parity tests, bench) -----------------------------------
+    _FIELDS = (("px", np.float64), ("py", np.float64), ("vx", np.float64), ("vy", np.float64), ("rot", np.float64),
+               ("time_step", np.int64), ("next_gate", np.int64), ("passed", np.int64))
+
+    def get_state(self):
+        out = {k: np.zeros(self.num_envs, dt) for k, dt in self._FIELDS}
+        check(lib.pc_env_get_state(self._h, *[out[k].ctypes.data for k, _ in self._FIELDS]), "pc_env_get_state")
+        return out
+
+    def set_state(self, **kw):
+        args = []
+        for k, dt in self._FIELDS:
+            v = kw.pop(k, None)
+            if v is None:
+                args.append(None)
+            else:
+                a = np.ascontiguousarray(np.broadcast_to(np.asarray(v, dt), (self.num_envs,)))
+                args.append(a)
+        if kw:
+            raise TypeError(f"unknown state fields {sorted(kw)}")
+        check(lib.pc_env_set_state(self._h, *[a.ctypes.data if a is not None else None for a in args]), "pc_env_set_state")
+
+    def launch_info(self):
+        v = [C.c_int() for _ in range(4)]
+        check(lib.pc_env_launch_info(self._h, *[C.byref(x) for x in v]), "pc_env_launch_info")
+        return dict(lanes_per_env=v[0].value, rays_per_lane=v[1].value, blocks=v[2].value, threads=v[3].value)
+
+    def set_lanes_per_env(self, lanes):
+        check(lib.pc_env_set_lanes_per_env(self._h, int(lanes)), "pc_env_set_lanes_per_env")

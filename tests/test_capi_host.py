@@ -1,0 +1,152 @@
+"""CPU-side tests of the product library: it loads, exports every symbol include/ppocar.h declares,
+its host logic (track loader, ray count, error codes) matches the reference, and the compute entry
+points refuse to run without a GPU instead of falling back."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import ppo_car_amd as pc
+from ppo_car_amd import _capi
+from conftest import ENV_CONFIGS, GOLDEN, ROOT, TRACKS
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ppocar.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pc_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = C.CDLL(pc.lib_path())
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in ppocar.h but not exported"
+    assert declared == set(_capi.EXPORTS)
+
+
+def test_library_is_in_tree():
+    assert os.path.dirname(pc.lib_path()) == os.path.join(ROOT, "ppo-car_amd")
+
+
+@pytest.mark.parametrize("track,n", ENV_CONFIGS[::3])
+def test_track_loader_matches_reference(track, n):
+    g = np.load(f"{GOLDEN}/env_{track}_n{n}.npz")
+    t = pc.Track(TRACKS[track])
+    walls, gates = t.geometry()
+    assert np.array_equal(walls, g["walls"]) and np.array_equal(gates, g["gates"])   # bit-exact float64
+    assert (t.n_walls, t.n_gates) == ((24, 55) if track == "big_track" else (16, 45))
+    assert np.array_equal([t.start_x, t.start_y, t.start_angle], g["reset_state"][[0, 1, 4]])
+
+
+def test_track_errors(tmp_path):
+    with pytest.raises(pc.PpoCarError) as e:
+        pc.Track(str(tmp_path / "nope.json"))
+    assert e.value.code == _capi.PC_ERR_IO     # reference prints + returns None (car_env.py:626-628); here: hard error
+    bad = tmp_path / "bad.json"
+    bad.write_text('{"outer_track_points": [[0.1, 0.2], [0.3')
+    with pytest.raises(pc.PpoCarError) as e:
+        pc.Track(str(bad))
+    assert e.value.code == _capi.PC_ERR_PARSE
+    missing_key = tmp_path / "nokey.json"
+    missing_key.write_text('{"outer_track_points": [[0,0],[1,1]], "inner_track_points": [[0,0],[1,1]], "reward_gates": [[0,0],[1,1]]}')
+    with pytest.raises(pc.PpoCarError) as e:
+        pc.Track(str(missing_key))
+    assert e.value.code == _capi.PC_ERR_PARSE
+    wrong_shape = tmp_path / "shape.json"
+    wrong_shape.write_text('{"outer_track_points": [[0,0,1],[1,1]], "inner_track_points": [[0,0],[1,1]], '
+                           '"reward_gates": [[0,0],[1,1]], "initial_position": [0.5, 0.5], "initial_angle": 0}')
+    with pytest.raises(pc.PpoCarError):
+        pc.Track(str(wrong_shape))
+
+
+def test_track_json_variants(tmp_path):
+    """whitespace, exponents, negative numbers, extra keys, escaped strings"""
+    p = tmp_path / "t.json"
+    p.write_text('{\n "name": "a \\"quoted\\" one", "outer_track_points": [[1e-1, 2.5E-1], [ 0.3 ,0.4],[0.5,0.6]],\n'
+                 '"inner_track_points": [[0.2,0.2],[0.25,0.3]], "reward_gates": [[0.1,0.1],[0.2,0.2],[0.3,0.3],[0.4,0.4],[0.9,0.9]],'
+                 '"initial_position": [0.5, 0.25], "initial_angle": -12.5, "extra": {"a": [true, false, null]}}')
+    t = pc.Track(str(p))
+    walls, gates = t.geometry()
+    assert t.n_walls == 3 and t.n_gates == 2          # trailing unpaired gate point is dropped, like zip()
+    assert np.array_equal(walls[0], [0.1 * 1280, 0.25 * 720, 0.3 * 1280, 0.4 * 720])
+    assert np.array_equal(walls[2], [0.2 * 1280, 0.2 * 720, 0.25 * 1280, 0.3 * 720])
+    assert np.array_equal(gates[1], [0.3 * 1280, 0.3 * 720, 0.4 * 1280, 0.4 * 720])
+    assert (t.start_x, t.start_y, t.start_angle) == (0.5 * 1280, 0.25 * 720, -12.5)
+
+
+@pytest.mark.parametrize("n", [4, 8, 12, 16, 24, 32, 36, 45, 72, 90, 360])
+def test_ray_count(n):
+    from ppo_car_amd.env import ray_count
+    assert ray_count(n) == len(range(0, 360, 360 // n))
+
+
+def test_ray_count_invalid():
+    from ppo_car_amd.env import ray_count
+    for n in (0, 3, -5, 361):
+        with pytest.raises(pc.PpoCarError):
+            ray_count(n)
+
+
+def test_track_from_arrays_roundtrip():
+    w = np.arange(12, dtype=np.float64).reshape(3, 4)
+    g = np.arange(8, dtype=np.float64).reshape(2, 4) + 100
+    t = pc.Track(walls=w, gates=g, start=(1.0, 2.0, 3.0))
+    ww, gg = t.geometry()
+    assert np.array_equal(ww, w) and np.array_equal(gg, g) and (t.start_x, t.start_y, t.start_angle) == (1.0, 2.0, 3.0)
+
+
+def test_strerror():
+    assert _capi.lib.pc_strerror(0) == b"ok"
+    for c in range(-6, 0):
+        assert len(_capi.lib.pc_strerror(c)) > 3
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_cpu_fallback():
+    with pytest.raises(RuntimeError, match="no CPU"):
+        pc.VecCarEnv(4, TRACKS["big_track"])
+    with pytest.raises(RuntimeError, match="GPU only"):
+        pc.VecCarEnv(4, TRACKS["big_track"], device="cpu")
+    buf = pc.Buffer((18,), 2, 3, torch.device("cpu"))
+    for _ in range(2):
+        buf.store(torch.zeros(3, 18), torch.zeros(3), torch.zeros(3), torch.zeros(3), torch.zeros(3), torch.zeros(3), torch.zeros(3))
+    with pytest.raises(RuntimeError, match="HIP GAE kernel"):
+        buf.calculate_advantages(torch.zeros(1, 3), torch.zeros(1, 3), torch.zeros(1, 3))
+    # the C-ABI itself reports "no device" rather than computing on the host
+    t = pc.Track(TRACKS["big_track"])
+    arr = (C.c_void_p * 1)(t._h)
+    h = C.c_void_p()
+    rc = _capi.lib.pc_env_create(0, 8, 12, arr, 1, None, 0, C.byref(h))
+    assert rc in (_capi.PC_ERR_NO_DEVICE, _capi.PC_ERR_HIP)
+
+
+def test_product_never_touches_the_oracle():
+    """The product tree must not import / link / call anything under oracle/."""
+    pkg = os.path.join(ROOT, "ppo-car_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r"^\s*(import|from)\s+oracle", src, flags=re.M), f
+                assert "liboracle" not in src and "carenv_oracle" not in src, f
+    for f in ("train.py",):
+        p = os.path.join(ROOT, f)
+        if os.path.exists(p):
+            src = open(p).read()
+            assert not re.search(r"^\s*(import|from)\s+oracle", src, flags=re.M), f
+
+
+def test_buffer_store_get_semantics_cpu_storage():
+    """store()/get() are plain tensor plumbing (buffer.py:22-34,66-73) and work on any device."""
+    T, N, D = 3, 4, 5
+    buf = pc.Buffer((D,), T, N, torch.device("cpu"))
+    for t in range(T):
+        buf.store(torch.full((N, D), float(t)), torch.full((N,), 2.0), torch.full((N,), 0.5), torch.zeros(N), torch.zeros(N),
+                  torch.zeros(N), torch.full((N,), -1.0))
+    assert buf.ptr == T
+    obs, act, val, lp = buf.get()
+    assert buf.ptr == 0 and obs.shape == (T, N, D) and act.dtype == torch.float32
+    assert torch.equal(obs[2], torch.full((N, D), 2.0)) and torch.equal(lp, torch.full((T, N), -1.0))
+    with pytest.raises(AssertionError):
+        buf.get()

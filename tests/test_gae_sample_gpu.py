@@ -1,0 +1,134 @@
+"""GPU tests of the GAE(lambda) scan kernel (Buffer.calculate_advantages) and the fused categorical
+sampling kernel (Agent.act)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import ppo_car_amd as pc
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _fill(buf, rew, val, term, trunc):
+    T, N = rew.shape
+    D = buf.obs_buf.shape[-1]
+    for t in range(T):
+        buf.store(torch.zeros(N, D, device="cuda"), torch.zeros(N, device="cuda"), torch.from_numpy(rew[t]).cuda(),
+                  torch.from_numpy(val[t]).cuda(), torch.from_numpy(term[t]).cuda(), torch.from_numpy(trunc[t]).cuda(),
+                  torch.zeros(N, device="cuda"))
+
+
+def test_gae_matches_reference_golden_bit_exact():
+    g = np.load(f"{GOLDEN}/gae_cases.npz")
+    for c in range(int(g["n_cases"])):
+        rew, val = g[f"c{c}_rew"], g[f"c{c}_val"]
+        T, N = rew.shape
+        buf = pc.Buffer((2,), T, N, "cuda", float(g["gamma"]), float(g["lam"]))
+        _fill(buf, rew, val, g[f"c{c}_term"], g[f"c{c}_trunc"])
+        adv, ret = buf.calculate_advantages(torch.from_numpy(g[f"c{c}_last_val"]).cuda(),
+                                            torch.from_numpy(g[f"c{c}_last_term"]).cuda(),
+                                            torch.from_numpy(g[f"c{c}_last_trunc"]).cuda())
+        assert adv.shape == (T, N)
+        assert np.array_equal(adv.cpu().numpy(), g[f"c{c}_adv"]), c      # bit-exact float32
+        assert np.array_equal(ret.cpu().numpy(), g[f"c{c}_ret"]), c
+
+
+@pytest.mark.parametrize("T,N", [(128, 65536), (1024, 4096), (1000, 777), (7, 33)])
+def test_gae_full_sizes_vs_oracle(T, N):
+    """BASELINE sizes ([T,N] = [128,65536] and [1024,4096]) and ragged ones, against the C oracle."""
+    rng = np.random.default_rng(T + N)
+    rew = (rng.standard_normal((T, N)) * 0.3).astype(np.float32)
+    val = rng.standard_normal((T, N)).astype(np.float32)
+    term = (rng.random((T, N)) < 0.015).astype(np.float32)
+    trunc = ((rng.random((T, N)) < 0.002) * (1 - term)).astype(np.float32)
+    lv = rng.standard_normal(N).astype(np.float32)
+    lt = (rng.random(N) < 0.3).astype(np.float32)
+    ltr = ((rng.random(N) < 0.3) * (1 - lt)).astype(np.float32)
+    A, Rt = oracle.gae(rew, val, term, trunc, lv, lt, ltr, 0.99, 0.95)
+    buf = pc.Buffer((1,), T, N, "cuda", 0.99, 0.95)
+    buf.rew_buf.copy_(torch.from_numpy(rew)); buf.val_buf.copy_(torch.from_numpy(val))
+    buf.term_buf.copy_(torch.from_numpy(term)); buf.trunc_buf.copy_(torch.from_numpy(trunc))
+    buf.ptr = T
+    adv, ret = buf.calculate_advantages(torch.from_numpy(lv).cuda().reshape(1, -1), torch.from_numpy(lt).cuda().reshape(1, -1),
+                                        torch.from_numpy(ltr).cuda().reshape(1, -1))
+    assert np.array_equal(adv.cpu().numpy(), A) and np.array_equal(ret.cpu().numpy(), Rt)
+    # property: ret - adv == val exactly as float32 adds (buffer.py:63)
+    assert torch.equal(ret, adv + buf.val_buf)
+
+
+def test_gae_equals_torch_expression_on_gpu():
+    """the reference's own torch loop (buffer.py:51-63) run on the GPU gives the same bits"""
+    T, N = 64, 512
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rew = torch.randn(T, N, device="cuda", generator=g)
+    val = torch.randn(T, N, device="cuda", generator=g)
+    term = (torch.rand(T, N, device="cuda", generator=g) < 0.05).float()
+    trunc = (torch.rand(T, N, device="cuda", generator=g) < 0.02).float() * (1 - term)
+    lv = torch.randn(1, N, device="cuda", generator=g)
+    lt = (torch.rand(1, N, device="cuda", generator=g) < 0.3).float()
+    ltr = torch.zeros(1, N, device="cuda")
+    buf = pc.Buffer((1,), T, N, "cuda", 0.99, 0.95)
+    buf.rew_buf.copy_(rew); buf.val_buf.copy_(val); buf.term_buf.copy_(term); buf.trunc_buf.copy_(trunc)
+    buf.ptr = T
+    adv, ret = buf.calculate_advantages(lv, lt, ltr)
+    ref = torch.zeros_like(rew)
+    last_gae = 0.0
+    for t in reversed(range(T)):
+        nv = lv if t == T - 1 else val[t + 1]
+        tm = 1.0 - lt if t == T - 1 else 1.0 - term[t + 1]
+        trm = 1.0 - ltr if t == T - 1 else 1.0 - trunc[t + 1]
+        delta = rew[t] + 0.99 * nv * tm - val[t]
+        last_gae = delta + 0.99 * 0.95 * tm * trm * last_gae
+        ref[t] = last_gae
+    assert torch.equal(adv, ref.reshape(T, N)) and torch.equal(ret, ref.reshape(T, N) + val)
+
+
+def test_buffer_asserts_like_the_reference():
+    buf = pc.Buffer((3,), 2, 4, "cuda")
+    with pytest.raises(AssertionError, match="Buffer not full"):
+        buf.calculate_advantages(torch.zeros(1, 4), torch.zeros(1, 4), torch.zeros(1, 4))
+
+
+def test_sample_kernel_distribution_logprob_entropy():
+    N, A = 200000, 9
+    g = torch.Generator(device="cuda").manual_seed(1)
+    base = torch.randn(1, A, device="cuda", generator=g) * 1.5
+    logits = base.expand(N, A).contiguous()
+    agent = pc.Agent(23, A).cuda()
+    agent.actor = torch.nn.Identity()       # feed logits straight through
+    agent.critic = torch.nn.Linear(A, 1).cuda()
+    agent.rng_seed = 123
+    a1, lp1, v1 = agent.act(logits)
+    dist = torch.distributions.Categorical(logits=logits)
+    assert a1.dtype == torch.int64 and int(a1.min()) >= 0 and int(a1.max()) < A
+    assert torch.allclose(lp1, dist.log_prob(a1), atol=2e-6)
+    counts = torch.bincount(a1, minlength=A).double().cpu().numpy()
+    p = dist.probs[0].double().cpu().numpy()
+    chi2 = ((counts - N * p) ** 2 / (N * p)).sum()
+    assert chi2 < 40.0            # 8 dof: P(chi2 > 40) ~ 3e-6
+    # a different call counter gives a different draw; the same (seed, offset) the same one
+    a2, _, _ = agent.act(logits)
+    assert (a1 != a2).float().mean() > 0.3
+    agent._rng_offset = 0
+    a3, lp3, _ = agent.act(logits)
+    assert torch.equal(a1, a3) and torch.equal(lp1, lp3)
+
+
+def test_sample_kernel_entropy_and_extreme_logits():
+    from ppo_car_amd._capi import check, lib
+    N, A = 4096, 9
+    g = torch.Generator(device="cuda").manual_seed(2)
+    logits = torch.randn(N, A, device="cuda", generator=g) * 3
+    logits[0] = torch.tensor([100.0] + [-100.0] * 8)          # (near-)deterministic row
+    logits[1] = 0.0                                           # uniform row
+    act = torch.empty(N, dtype=torch.int64, device="cuda")
+    lp = torch.empty(N, device="cuda")
+    ent = torch.empty(N, device="cuda")
+    check(lib.pc_sample(0, logits.data_ptr(), N, A, 9, 0, act.data_ptr(), lp.data_ptr(), ent.data_ptr(),
+                        torch.cuda.current_stream().cuda_stream), "pc_sample")
+    dist = torch.distributions.Categorical(logits=logits)
+    assert torch.allclose(ent, dist.entropy(), atol=5e-6)
+    assert torch.allclose(lp, dist.log_prob(act), atol=5e-6)
+    assert int(act[0]) == 0 and abs(float(ent[1]) - np.log(9)) < 1e-6
