@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: env steps/sec of the whole PPO loop (rollout + GAE + update, the
+`charts/SPS` definition of the reference, train.py:174,292) on big_track.json, "16 rays" (17 actual).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|cfg1|cfg2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE EPOCH of the hot path on one batch of synthetic input: n_steps vector-env steps of
+n_envs envs per GPU (policy forward + sample + env-step kernel + store), the bootstrap value, the GAE
+scan and train_iters x ceil(n_steps/batch_size) clipped-PPO minibatch updates (with the gradient
+all-reduce when N > 1).  Nothing is skipped inside the timed region.  value = all ranks' env steps / the
+slowest rank's time (weak scaling: n_envs per GPU is fixed).
+
+Extra objects on the JSON line:
+  roofline     -- the env-step kernel (K1): algorithmic bytes per launch (176 B per env step
+                  at 16 rays) / its mean duration measured with HIP events on the launch stream inside the
+                  timed epochs; peak = 8 TB/s HBM.  K1 is VALU-bound, so a second, informative
+                  `valu` entry prices the same duration against the fp32 vector peak.
+  cpu_baseline -- the CPU oracle (oracle/, the checker -- never the product) driving the same rollout on the
+                  host cores of this box for a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # the size the BASELINE.json target is quoted on (>= 10 M env steps/s at n_envs = 65536, 16 rays) and the
+    # per-GPU shard of configs[3] (524288 envs on 8 GPUs); n_steps / batch / iters = the reference defaults
+    "target": dict(n_envs=65536, n_steps=1024, num_rays=16, batch_size=512, train_iters=40),
+    # BASELINE.json configs[1]
+    "cfg1": dict(n_envs=4096, n_steps=1024, num_rays=16, batch_size=512, train_iters=40),
+    # BASELINE.json configs[2] (ray-kernel stress: 32 -> 33 rays)
+    "cfg2": dict(n_envs=65536, n_steps=128, num_rays=32, batch_size=512, train_iters=40),
+}
+ALGO_BYTES = {12: 156, 16: 176, 32: 240}      # SURVEY 8(d) / BASELINE.md section 4, per env step
+ALGO_FLOPS = {12: 8200, 16: 11600, 32: 22400}  # ditto, big_track (24 wall segments)
+HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8 TB/s
+VALU_PEAK_TFLOPS = 157.3                       # fp32 vector peak
+
+
+def cpu_baseline(cfg, budget_s=12.0):
+    """Rollout of the same workload on the host: torch-CPU policy forward + the C oracle env on all host
+    cores, bounded sample.  The PPO update is not included (it favours the CPU figure)."""
+    import oracle
+    from ppo_car_amd.model import Agent
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    n_envs = 4096
+    env = oracle.OracleVecEnv(oracle.Track(os.path.join(ROOT, "tracks", "big_track.json")), n_envs,
+                              num_rays=cfg["num_rays"], reward_scaling=0.1, threads=cores)
+    obs = torch.from_numpy(env.reset())
+    agent = Agent(env.D, 9)
+    steps, t0 = 0, time.time()
+    with torch.no_grad():
+        while True:
+            a, lp, _, v = agent.get_action_and_value(obs)
+            o, r, te, tr = env.step(a.numpy())
+            obs = torch.from_numpy(o)
+            steps += 1
+            if time.time() - t0 > budget_s and steps >= 4:
+                break
+    dt = time.time() - t0
+    return {"value": n_envs * steps / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
+            "sample": f"rollout only (torch-CPU policy + C oracle env, {cores} threads), n_envs={n_envs}, {steps} steps, "
+                      f"{cfg['num_rays']} rays, big_track; PPO update not included"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed epochs")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed epochs")
+    ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
+    ap.add_argument("--n-envs", type=int, default=None, help="override envs per GPU")
+    ap.add_argument("--n-steps", type=int, default=None)
+    ap.add_argument("--env-dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-stride", type=int, default=8, help="bracket every k-th env-step launch with HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path for the hot path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ppo_car_amd.ppo import PPOConfig, Trainer
+    wl = dict(WORKLOADS[args.workload])
+    if args.n_envs:
+        wl["n_envs"] = args.n_envs
+    if args.n_steps:
+        wl["n_steps"] = args.n_steps
+    cfg = PPOConfig(track=os.path.join(ROOT, "tracks", "big_track.json"), env_dtype=args.env_dtype, seed=0, **wl)
+    tr = Trainer(cfg, device=dev, rank=rank, world_size=world)
+    tr.profile_stride = 0
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.run_epoch(sync=False)
+    tr.profile_stride = args.event_stride
+    tr.k1_events = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.run_epoch(sync=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    k1_us = float(np.mean([a.elapsed_time(b) for a, b in tr.k1_events]) * 1e3) if tr.k1_events else float("nan")
+    info = tr.envs.launch_info()
+    tr.close()
+
+    if rank == 0:
+        env_steps = cfg.n_envs * cfg.n_steps * args.steps * world
+        nr = cfg.num_rays
+        algo_bytes = ALGO_BYTES.get(nr, 4 * (6 + tr.obs_dim[0] - 6) + 84) * cfg.n_envs
+        achieved = algo_bytes / (k1_us * 1e-6) / 1e9
+        out = {
+            "metric": "env steps/sec (whole node) on big_track.json, 16 rays",
+            "value": env_steps / dt, "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.env_dtype == "f32" else "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: big_track.json, num_rays={nr} ({tr.obs_dim[0] - 6} actual), "
+                                   f"n_envs={cfg.n_envs}/GPU, n_steps={cfg.n_steps}, batch_size={cfg.batch_size}, "
+                                   f"train_iters={cfg.train_iters}; one step = one PPO epoch (rollout + GAE + update)",
+                       "n_envs_total": cfg.n_envs * world, "parallelism": f"env-sharded dp{world}, 1 flat grad all-reduce/minibatch",
+                       "env_kernel": info, "numerics": "float64 kinematic state, float32 ray geometry" if args.env_dtype == "f32"
+                       else "float64 throughout (reference operation order)"},
+            "roofline": {"kernel": "env_step_kernel (K1)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launch_us": k1_us, "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "K1 is fp32-VALU-bound, not HBM-bound (DESIGN.md); see `valu`",
+                         "valu": {"achieved": ALGO_FLOPS.get(nr, 0) * cfg.n_envs / (k1_us * 1e-6) / 1e12,
+                                  "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": ALGO_FLOPS.get(nr, 0) * cfg.n_envs / (k1_us * 1e-6) / 1e12 / VALU_PEAK_TFLOPS}},
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "k1_traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                tf = json.load(open(traffic_file))
+                key = f"{args.env_dtype}_n{nr}_N{cfg.n_envs}"
+                if key in tf:
+                    out["roofline"]["traffic"] = tf[key]["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = tf[key].get("source", "profiles/k1_traffic.json")
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

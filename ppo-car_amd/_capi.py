@@ -3,6 +3,12 @@ Python or CPU fallback: if it is missing, importing this module fails loudly."""
 import ctypes as C
 import os
 
+# torch FIRST: PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7).  Loading it before
+# libppocar.so makes the dynamic linker bind our library to that same HIP runtime, so torch's streams,
+# events and device pointers are valid inside our launches.  The other order would put two HIP runtimes
+# in one process.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libppocar.so")
 
@@ -31,6 +37,19 @@ if not os.path.exists(_LIB_PATH):
         "(or `make -C ppo-car_amd/csrc`). There is no CPU fallback for the CarEnv hot path.")
 
 lib = C.CDLL(_LIB_PATH)
+
+
+def _hip_runtimes():
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({line.split()[-1] for line in f if "libamdhip64" in line})
+    except OSError:
+        return []
+
+
+if len(_hip_runtimes()) > 1:
+    raise ImportError(f"two HIP runtimes are mapped in this process ({_hip_runtimes()}): libppocar.so must share "
+                      "PyTorch's libamdhip64 -- import torch before anything that loads /opt/rocm's copy")
 
 _vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
 _sig = {

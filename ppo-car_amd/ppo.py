@@ -1,0 +1,259 @@
+"""PPO rollout / GAE / clipped-update loop of the reference's train.py (train.py:144-292), GPU-resident.
+
+What changes against the reference is WHERE things run, not WHAT is computed:
+  * the N worker processes + pipes of AsyncVectorEnv are one HIP kernel launch per step (VecCarEnv);
+    actions, observations, rewards and flags never leave the GPU, and the env kernel writes straight
+    into the next rows of the rollout buffer (no per-step host round trip, train.py:185-192);
+  * GAE is the HIP scan kernel behind Buffer.calculate_advantages;
+  * the minibatch indices of one epoch (train.py:225-230) are drawn on the host for all train_iters at
+    once and shipped in one async copy; metrics are accumulated on the device and read once per epoch;
+  * multi-GPU: one process per GPU, envs sharded, parameters identical on every rank, ONE flat-bucket
+    all-reduce (RCCL over xGMI) of all gradients per minibatch between backward and clip_grad_norm_
+    (train.py:259-260), averaged; everything after it is replicated and stays bit-identical across ranks.
+Reference quirks kept on purpose: the minibatch loop runs over range(0, n_steps, batch_size)
+(train.py:228), advantages are normalised per minibatch with the unbiased std (train.py:239),
+the value loss is unclipped (train.py:249), logged sums are divided by train_iters (train.py:286-289).
+"""
+import dataclasses
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .buffer import Buffer
+from .env import VecCarEnv
+from .model import Agent
+
+
+@dataclasses.dataclass
+class PPOConfig:
+    # train.py:72-92 defaults
+    n_envs: int = 16
+    n_epochs: int = 200
+    n_steps: int = 1024
+    batch_size: int = 512
+    train_iters: int = 40
+    gamma: float = 0.99
+    gae_lambda: float = 0.95
+    clip_ratio: float = 0.2
+    ent_coef: float = 0.001
+    vf_coef: float = 0.5
+    learning_rate: float = 3e-4
+    learning_rate_decay: float = 0.99
+    max_grad_norm: float = 1.0
+    reward_scaling: float = 0.1
+    # additions
+    track: str = "tracks/big_track.json"   # replaces the Tk file dialog (train.py:95-111,119)
+    num_rays: int = 12                     # Car(num_rays=...) (car_env.py:227); 16 -> 17 rays, 32 -> 33
+    env_dtype: str = "f32"
+    seed: int = 0
+    full_sweep: bool = False               # opt-in: iterate over all n_steps*n_envs samples per train iter
+    fused_sampler: bool = True             # sampling tail of get_action_and_value as one HIP kernel
+
+
+def flatten_parameters(module):
+    """Re-home all parameters (and their .grad) of `module` in two flat float32 buffers so that the
+    gradient exchange is a single contiguous all-reduce and zero_grad is one memset.
+    Returns (flat_param, flat_grad)."""
+    params = [p for p in module.parameters()]
+    total = sum(p.numel() for p in params)
+    dev, dt = params[0].device, params[0].dtype
+    flat = torch.empty(total, device=dev, dtype=dt)
+    flat_grad = torch.zeros(total, device=dev, dtype=dt)
+    off = 0
+    for p in params:
+        n = p.numel()
+        flat[off:off + n].copy_(p.data.reshape(-1))
+        p.data = flat[off:off + n].view_as(p.data)
+        p.grad = flat_grad[off:off + n].view_as(p.data)
+        off += n
+    return flat, flat_grad
+
+
+class GradExchange:
+    """DDP-style gradient averaging without DDP: one all-reduce of the flat gradient bucket."""
+
+    def __init__(self, flat_grad, world_size):
+        self.flat_grad = flat_grad
+        self.world_size = world_size
+
+    def __call__(self):
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+            self.flat_grad.div_(self.world_size)
+
+
+def ppo_loss(agent, obs, act, old_logprob, adv, ret, clip_ratio, vf_coef, ent_coef):
+    """One minibatch of train.py:233-255.  `adv` is the raw advantage slice; normalisation is here."""
+    _, new_logprobs, entropies, new_values = agent.get_action_and_value(obs, act)
+    ratios = torch.exp(new_logprobs - old_logprob)                                            # :235
+    adv = (adv - adv.mean()) / torch.max(adv.std(), torch.tensor(1e-5, device=adv.device))   # :238-240
+    policy_loss1 = -adv * ratios                                                              # :243
+    policy_loss2 = -adv * torch.clamp(ratios, 1.0 - clip_ratio, 1.0 + clip_ratio)             # :244
+    policy_loss = torch.max(policy_loss1, policy_loss2).mean()                                # :245
+    value_loss = 0.5 * ((new_values.view(-1) - ret) ** 2).mean()                              # :248-249
+    entropy = entropies.mean()                                                                # :252
+    loss = policy_loss + vf_coef * value_loss - ent_coef * entropy                            # :255
+    return loss, policy_loss, value_loss, entropy
+
+
+class PPOLearner:
+    """The update half of train.py (train.py:216-269): optimizer, scheduler, minibatch index draws,
+    clipped-PPO minibatch steps with the flat-bucket gradient exchange.  Pure torch: runs on any device
+    (the multi-rank path is tested on CPU with gloo); the env and the GAE scan live in Trainer."""
+
+    def __init__(self, agent, cfg: PPOConfig, device, rank=0, world_size=1):
+        self.agent, self.cfg, self.device, self.rank, self.world_size = agent, cfg, torch.device(device), rank, world_size
+        self.flat_param, self.flat_grad = flatten_parameters(agent)
+        if world_size > 1:
+            import torch.distributed as dist
+            dist.broadcast(self.flat_param, src=0)       # every rank starts from rank 0's parameters
+        self.exchange = GradExchange(self.flat_grad, world_size)
+        self.optimizer = torch.optim.Adam(agent.parameters(), lr=cfg.learning_rate, eps=1e-5)            # train.py:146
+        self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=1, gamma=cfg.learning_rate_decay)  # :147
+        self._np_rng = np.random.default_rng(cfg.seed * 7919 + rank)
+        self.n_minibatches = len(range(0, cfg.n_steps, cfg.batch_size))     # train.py:228
+        idx = torch.empty(cfg.train_iters, self.n_minibatches * cfg.batch_size, dtype=torch.int64)
+        self._idx_host = idx.pin_memory() if self.device.type == "cuda" else idx
+        self.metrics = torch.zeros(4, device=self.device)
+
+    def draw_indices(self, M):
+        """train.py:225-230: per train iter a fresh shuffle of all M = n_steps*n_envs indices, of which only
+        the first n_minibatches*batch_size are ever used -- i.e. a uniform sample without replacement.  Drawn
+        on the host (the reference shuffles on the host too) for all iters at once, one async copy."""
+        cfg = self.cfg
+        K = min(self.n_minibatches * cfg.batch_size, M)   # a slice past the end of the shuffled array is just shorter
+        host = self._idx_host.numpy()
+        for i in range(cfg.train_iters):
+            host[i, :K] = self._np_rng.permutation(M) if K == M else self._np_rng.choice(M, size=K, replace=False)
+        return self._idx_host.to(self.device, non_blocking=True)[:, :K]
+
+    def minibatch_step(self, obs, act, logprob, adv, ret):
+        cfg = self.cfg
+        loss, pl, vl, ent = ppo_loss(self.agent, obs, act, logprob, adv, ret, cfg.clip_ratio, cfg.vf_coef, cfg.ent_coef)
+        self.flat_grad.zero_()                                                           # train.py:258
+        loss.backward()                                                                  # :259
+        self.exchange()                                # the one all-reduce per minibatch
+        nn.utils.clip_grad_norm_(self.agent.parameters(), cfg.max_grad_norm)             # :260
+        self.optimizer.step()                                                            # :261
+        with torch.no_grad():
+            self.metrics += torch.stack([pl.detach(), vl.detach(), ent.detach(), loss.detach()])   # :263-266
+
+    def update(self, obs, act, logprob, adv, ret):
+        """obs [M, D], the rest [M] (the flattened trajectories of train.py:209-214)."""
+        cfg = self.cfg
+        self.metrics.zero_()
+        B = cfg.batch_size
+        M = obs.shape[0]
+        if cfg.full_sweep:
+            n_mb = M // B
+            idx_all = torch.stack([torch.randperm(M, device=self.device)[:n_mb * B] for _ in range(cfg.train_iters)])
+        else:
+            n_mb = self.n_minibatches
+            idx_all = self.draw_indices(M)
+        for it in range(cfg.train_iters):                                                # :223
+            for mb in range(n_mb):                                                       # :228
+                idx = idx_all[it, mb * B:(mb + 1) * B]
+                if idx.numel() == 0:
+                    continue
+                self.minibatch_step(obs[idx], act[idx], logprob[idx], adv[idx], ret[idx])
+        self.scheduler.step()                                                            # :269
+
+
+class Trainer:
+    def __init__(self, cfg: PPOConfig, device="cuda", rank=0, world_size=1):
+        self.cfg, self.rank, self.world_size = cfg, rank, world_size
+        self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        torch.manual_seed(cfg.seed)  # identical initial parameters on every rank (then broadcast anyway)
+        self.envs = VecCarEnv(cfg.n_envs, cfg.track, num_rays=cfg.num_rays, reward_scaling=cfg.reward_scaling,
+                              device=self.device, dtype=cfg.env_dtype)
+        self.obs_dim = (self.envs.obs_dim,)          # train.py:141
+        self.act_dim = self.envs.act_dim             # train.py:142
+        self.agent = Agent(self.obs_dim[0], self.act_dim).to(self.device)   # train.py:145
+        self.agent.rng_seed = cfg.seed * 1000003 + rank
+        self.learner = PPOLearner(self.agent, cfg, self.device, rank, world_size)
+        self.optimizer, self.scheduler = self.learner.optimizer, self.learner.scheduler
+        self.buffer = Buffer(self.obs_dim, cfg.n_steps, cfg.n_envs, self.device, cfg.gamma, cfg.gae_lambda)   # :152
+        N = cfg.n_envs
+        self.next_obs = torch.empty(N, *self.obs_dim, device=self.device)
+        self.next_term = torch.zeros(N, device=self.device)      # train.py:165-166
+        self.next_trunc = torch.zeros(N, device=self.device)
+        self.actions = torch.empty(N, dtype=torch.int64, device=self.device)
+        self.envs.reset(options={"track_path": cfg.track}, out=self.next_obs)   # train.py:159
+        self.global_step_idx = 0
+        self.epoch = 0
+        self.start_time = time.time()
+        self.profile_stride = 0      # bench.py: bracket every k-th env-step launch with events on the launch stream
+        self.k1_events = []
+
+    # ---- train.py:173-195 ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def rollout(self):
+        cfg, buf, envs, agent = self.cfg, self.buffer, self.envs, self.agent
+        T = cfg.n_steps
+        buf.obs_buf[0].copy_(self.next_obs)
+        buf.term_buf[0].copy_(self.next_term)       # flags that preceded obs 0 (train.py:176-177)
+        buf.trunc_buf[0].copy_(self.next_trunc)
+        for t in range(T):
+            obs = buf.obs_buf[t]
+            if cfg.fused_sampler:
+                _, _, values = agent.act(obs, out_action=self.actions, out_logprob=buf.logprob_buf[t])
+                actions = self.actions
+            else:
+                actions, logprobs, _, values = agent.get_action_and_value(obs)   # train.py:181
+                buf.logprob_buf[t].copy_(logprobs)
+            buf.val_buf[t].copy_(values.view(-1))
+            buf.act_buf[t].copy_(actions)            # stored as float32 like the reference (buffer.py:13)
+            last = t == T - 1
+            out = (self.next_obs if last else buf.obs_buf[t + 1], buf.rew_buf[t],
+                   self.next_term if last else buf.term_buf[t + 1], self.next_trunc if last else buf.trunc_buf[t + 1])
+            if self.profile_stride and t % self.profile_stride == 0:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                envs.step(actions, out=out)
+                e1.record()
+                self.k1_events.append((e0, e1))
+            else:
+                envs.step(actions, out=out)          # train.py:185 -- zero-copy into the buffer rows
+        buf.ptr = T
+        self.global_step_idx += cfg.n_envs * T * self.world_size   # train.py:174, whole job
+
+    # ---- train.py:197-269 ---------------------------------------------------------------------------
+    def update(self):
+        buf, agent = self.buffer, self.agent
+        with torch.no_grad():
+            next_values = agent.get_value(self.next_obs).reshape(1, -1)                          # train.py:200
+            adv, ret = buf.calculate_advantages(next_values, self.next_term.reshape(1, -1),
+                                                self.next_trunc.reshape(1, -1))                   # :203
+        obs, act, _val, logprob = buf.get()                                                      # :206
+        self.learner.update(obs.view(-1, *self.obs_dim), act.view(-1), logprob.view(-1), adv.view(-1), ret.view(-1))
+
+    def run_epoch(self, sync=True):
+        """One epoch = rollout + update.  Returns the reference's scalars (train.py:286-292) when sync."""
+        self.rollout()
+        with torch.no_grad():
+            rew_mean = self.buffer.rew_buf.mean()
+        self.update()
+        self.epoch += 1
+        if not sync:
+            return None
+        m = (self.learner.metrics / self.cfg.train_iters).tolist()   # divided by train_iters, not by #minibatches
+        avg_reward = float(rew_mean) / self.cfg.reward_scaling       # train.py:272-274
+        if self.world_size > 1:
+            import torch.distributed as dist
+            t = torch.tensor(m + [avg_reward], device=self.device)
+            dist.all_reduce(t)
+            t /= self.world_size
+            *m, avg_reward = t.tolist()
+        elapsed = time.time() - self.start_time
+        return {"losses/policy_loss": m[0], "losses/value_loss": m[1], "losses/entropy": m[2], "losses/total_loss": m[3],
+                "charts/avg_reward": avg_reward, "charts/learning_rate": self.optimizer.param_groups[0]["lr"],
+                "charts/SPS": self.global_step_idx / max(elapsed, 1e-9), "global_step": self.global_step_idx,
+                "elapsed": elapsed}
+
+    def close(self):
+        self.envs.close()
