@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--n-envs", type=int, default=None, help="override envs per GPU")
     ap.add_argument("--n-steps", type=int, default=None)
     ap.add_argument("--env-dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--policy", default="fused", choices=["fused", "sample", "torch"], help="rollout policy-step implementation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--event-stride", type=int, default=8, help="bracket every k-th env-step launch with HIP events")
     args = ap.parse_args()
@@ -109,7 +110,7 @@ def main():
         wl["n_envs"] = args.n_envs
     if args.n_steps:
         wl["n_steps"] = args.n_steps
-    cfg = PPOConfig(track=os.path.join(ROOT, "tracks", "big_track.json"), env_dtype=args.env_dtype, seed=0, **wl)
+    cfg = PPOConfig(track=os.path.join(ROOT, "tracks", "big_track.json"), env_dtype=args.env_dtype, seed=0, policy=args.policy, **wl)
     tr = Trainer(cfg, device=dev, rank=rank, world_size=world)
     tr.profile_stride = 0
 
@@ -122,6 +123,7 @@ def main():
         tr.run_epoch(sync=False)
     tr.profile_stride = args.event_stride
     tr.k1_events = []
+    tr.phase_events = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -134,6 +136,8 @@ def main():
         dt = float(t)
     k1_us = float(np.mean([a.elapsed_time(b) for a, b in tr.k1_events]) * 1e3) if tr.k1_events else float("nan")
     info = tr.envs.launch_info()
+    split = {"rollout_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in tr.phase_events])),
+             "gae_update_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in tr.phase_events]))}
     tr.close()
 
     if rank == 0:
@@ -150,7 +154,7 @@ def main():
                                    f"n_envs={cfg.n_envs}/GPU, n_steps={cfg.n_steps}, batch_size={cfg.batch_size}, "
                                    f"train_iters={cfg.train_iters}; one step = one PPO epoch (rollout + GAE + update)",
                        "n_envs_total": cfg.n_envs * world, "parallelism": f"env-sharded dp{world}, 1 flat grad all-reduce/minibatch",
-                       "env_kernel": info, "numerics": "float64 kinematic state, float32 ray geometry" if args.env_dtype == "f32"
+                       "env_kernel": info, "policy_step": args.policy, "epoch_split": split, "numerics": "float64 kinematic state, float32 ray geometry" if args.env_dtype == "f32"
                        else "float64 throughout (reference operation order)"},
             "roofline": {"kernel": "env_step_kernel (K1)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -48,8 +48,10 @@ class Buffer:
         f = lambda t: t.detach().to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
         lv, lt, ltr = f(last_vals), f(last_terminateds), f(last_truncateds)
         assert lv.numel() == N and lt.numel() == N and ltr.numel() == N
-        adv = torch.empty_like(self.rew_buf)
-        ret = torch.empty_like(self.rew_buf)
+        if getattr(self, "adv_buf", None) is None:   # allocated once: HIP-graph consumers keep their addresses
+            self.adv_buf = torch.empty_like(self.rew_buf)
+            self.ret_buf = torch.empty_like(self.rew_buf)
+        adv, ret = self.adv_buf, self.ret_buf
         stream = torch.cuda.current_stream(self.device).cuda_stream
         check(lib.pc_gae(self.device.index if self.device.index is not None else torch.cuda.current_device(),
                          self.rew_buf.data_ptr(), self.val_buf.data_ptr(), self.term_buf.data_ptr(), self.trunc_buf.data_ptr(),

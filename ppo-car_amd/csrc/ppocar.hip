@@ -612,6 +612,154 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
 }
 
 // ------------------------------------------------------------------------------------------
+// K5: fused policy step -- Agent.get_action_and_value(x) in the rollout (model.py:34-41, train.py:181):
+//   actor  Linear(D,256) - ReLU - Linear(256,A)    critic  Linear(D,256) - ReLU - Linear(256,1)
+//   action ~ Categorical(logits), log_prob(action), value
+// in ONE launch.  GEMM-shaped, so it runs on the matrix cores: v_mfma_f32_16x16x4_f32 (fp32 in, fp32
+// accumulate, bit-for-bit an fmaf chain -- no reduced precision).  Orientation: rows = hidden units,
+// columns = envs.  A wave owns 64 envs (4 column tiles of 16).  Per hidden tile of 16 units (32 tiles:
+// 16 actor + 16 critic):
+//   layer 1   acc[16 hid x 16 env] = b1 + W1[16 x K] * X^T[K x 16]      K = 4*KS >= D, KS MFMAs per tile
+//   ReLU      in registers
+//   layer 2   out[16 x 16 env] += W2cat^T[16 x 4] * acc                  4 MFMAs: accumulator register `reg`
+//             of lane l holds hidden row 4*(l>>4)+reg of env column l&15, which is exactly the B-operand
+//             slot (k = l>>4, j = l&15) of the next MFMA -- the hidden layer never leaves the registers.
+// W2cat has the A actor columns and the critic in column A (rows 0..255 actor, 256..511 critic).  The
+// weights sit in LDS (W1 rows padded to an odd stride: conflict-free ds_read_b32), each A operand read once
+// per 4 MFMAs (the 4 env tiles), which also gives every MFMA three independent ones between it and its
+// dependent successor.  The [16 x 64] output goes through LDS so that lane = env for the softmax / Philox
+// draw; outputs are written coalesced.
+// ------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int KS>
+__global__ __launch_bounds__(256) void policy_kernel(const float* __restrict__ obs, const int64_t N, const int D, const int A,
+                                                     const float* __restrict__ aW1, const float* __restrict__ ab1,
+                                                     const float* __restrict__ aW2, const float* __restrict__ ab2,
+                                                     const float* __restrict__ cW1, const float* __restrict__ cb1,
+                                                     const float* __restrict__ cW2, const float* __restrict__ cb2,
+                                                     const uint64_t seed, const uint64_t offset,
+                                                     const uint64_t* __restrict__ offset_dev, int64_t* __restrict__ action,
+                                                     float* __restrict__ action_f, float* __restrict__ logprob,
+                                                     float* __restrict__ value, float* __restrict__ logits_out) {
+    constexpr int HID = 256, NT = 2 * HID / 16;  // 32 hidden tiles
+    constexpr int LD1 = 4 * KS + 1;              // odd row stride: lanes 0..15 hit 16 different banks
+    constexpr int LDO = 17;
+    extern __shared__ float lds[];
+    float* sW1 = lds;                        // [512][LD1]
+    float* sB1 = sW1 + 2 * HID * LD1;        // [512]
+    float* sW2 = sB1 + 2 * HID;              // [NT][4][64]  A operands of layer 2, lane-ordered
+    float* sB2 = sW2 + NT * 4 * 64;          // [16]
+    float* sOut = sB2 + 16;                  // [4 waves][64 envs][LDO]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lc = lane & 15, lk = lane >> 4;
+
+    // ---- stage the weights (once per workgroup; the grid is persistent)
+    for (int i = tid; i < 2 * HID * 4 * KS; i += 256) {
+        const int r = i / (4 * KS), c = i - r * (4 * KS);
+        float v = 0.0f;
+        if (c < D) v = r < HID ? aW1[r * D + c] : cW1[(r - HID) * D + c];
+        sW1[r * LD1 + c] = v;
+    }
+    for (int i = tid; i < 2 * HID; i += 256) sB1[i] = i < HID ? ab1[i] : cb1[i - HID];
+    for (int i = tid; i < NT * 4 * 64; i += 256) {
+        const int l = i & 63, reg = (i >> 6) & 3, ht = i >> 8;
+        const int o = l & 15, h = 16 * ht + 4 * (l >> 4) + reg;
+        float v = 0.0f;
+        if (h < HID) {
+            if (o < A) v = aW2[o * HID + h];
+        } else if (o == A) {
+            v = cW2[h - HID];
+        }
+        sW2[i] = v;
+    }
+    if (tid < 16) sB2[tid] = tid < A ? ab2[tid] : (tid == A ? cb2[0] : 0.0f);
+    __syncthreads();
+
+    const uint64_t off = offset + (offset_dev ? *offset_dev : 0);
+    float* myOut = sOut + wave * 64 * LDO;
+    const int64_t n_chunks = (N + 255) / 256;
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const int64_t env0 = chunk * 256 + wave * 64;
+        // ---- B operands of layer 1: X^T, lane (k = lk, j = lc) of env tile et, k-step ks
+        float x[4][KS];
+#pragma unroll
+        for (int et = 0; et < 4; ++et) {
+            const int64_t e = env0 + 16 * et + lc;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int f = 4 * ks + lk;
+                x[et][ks] = (e < N && f < D) ? obs[e * D + f] : 0.0f;
+            }
+        }
+        f32x4 out[4];
+#pragma unroll
+        for (int et = 0; et < 4; ++et) out[et] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        for (int ht = 0; ht < NT; ++ht) {
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(sB1 + 16 * ht + 4 * lk);
+            f32x4 acc[4];
+#pragma unroll
+            for (int et = 0; et < 4; ++et) acc[et] = bias;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const float a = sW1[(16 * ht + lc) * LD1 + 4 * ks + lk];
+#pragma unroll
+                for (int et = 0; et < 4; ++et) acc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x[et][ks], acc[et], 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float a2 = sW2[(ht * 4 + reg) * 64 + lane];
+#pragma unroll
+                for (int et = 0; et < 4; ++et)
+                    out[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, fmaxf(acc[et][reg], 0.0f), out[et], 0, 0, 0);  // ReLU
+            }
+        }
+        // ---- out tile -> LDS so that lane = env
+        __syncthreads();  // previous iteration's readers are done with sOut
+#pragma unroll
+        for (int et = 0; et < 4; ++et)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) myOut[(16 * et + lc) * LDO + 4 * lk + reg] = out[et][reg] + sB2[4 * lk + reg];
+        __syncthreads();
+        const int64_t e = env0 + lane;
+        if (e < N) {
+            const float* row = myOut + lane * LDO;
+            float l[16];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                l[i] = i < A ? row[i] : -INFINITY;
+                mx = fmaxf(mx, l[i]);
+            }
+            const float val = row[A];
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum += i < A ? expf(l[i] - mx) : 0.0f;
+            const float lse = mx + logf(sum);
+            const float u = philox_uniform(seed, off, (uint64_t)e);
+            float cum = 0.0f, lp = 0.0f;
+            int act = -1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i < A) {
+                    const float nl = l[i] - lse;
+                    cum += expf(nl);
+                    if (act < 0 && (u < cum || i == A - 1)) {
+                        act = i;
+                        lp = nl;
+                    }
+                    if (logits_out) logits_out[e * A + i] = l[i];
+                }
+            }
+            action[e] = act;
+            if (action_f) action_f[e] = (float)act;
+            logprob[e] = lp;
+            value[e] = val;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 static thread_local std::string g_hip_err;
@@ -1083,6 +1231,47 @@ int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, 
     const int blocks = (int)((N + 255) / 256);
     hipLaunchKernelGGL(sample_kernel<16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, N, A, seed, offset, actions,
                        logprob, entropy);
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, const float* aW1, const float* ab1,
+                  const float* aW2, const float* ab2, const float* cW1, const float* cb1, const float* cW2, const float* cb2,
+                  uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob,
+                  float* value, float* logits_out, void* stream) {
+    if (!obs || !aW1 || !ab1 || !aW2 || !ab2 || !cW1 || !cb1 || !cW2 || !cb2 || !action || !logprob || !value || N < 1)
+        return PC_ERR_INVALID_ARG;
+    if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;  // the caller falls back to its own GEMMs
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1 || device < 0 || device >= count) return PC_ERR_NO_DEVICE;
+    DeviceGuard guard(device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    const int KS = D <= 20 ? 5 : (D <= 24 ? 6 : 10);
+    const size_t lds = (size_t)(512 * (4 * KS + 1) + 512 + 32 * 4 * 64 + 16 + 4 * 64 * 17) * sizeof(float);
+    static int n_cu[64] = {0};
+    if (device < 64 && n_cu[device] == 0) {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        n_cu[device] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int cus = device < 64 ? n_cu[device] : 256;
+    const int64_t chunks = (N + 255) / 256;
+    const int blocks = (int)(chunks < cus ? chunks : cus);  // one 100-KB-LDS workgroup per CU, persistent over env chunks
+    hipStream_t st = (hipStream_t)stream;
+#define PC_POL(KSV)                                                                                                      \
+    do {                                                                                                                 \
+        static bool attr_set[64] = {false};                                                                              \
+        if (device < 64 && !attr_set[device]) {                                                                          \
+            HIPCHK(hipFuncSetAttribute((const void*)policy_kernel<KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_set[device] = true;                                                                                     \
+        }                                                                                                                \
+        hipLaunchKernelGGL(policy_kernel<KSV>, dim3(blocks), dim3(256), lds, st, obs, N, D, A, aW1, ab1, aW2, ab2, cW1, cb1, \
+                           cW2, cb2, seed, offset, offset_dev, action, action_f32, logprob, value, logits_out);          \
+    } while (0)
+    if (KS == 5) PC_POL(5);
+    else if (KS == 6) PC_POL(6);
+    else PC_POL(10);
+#undef PC_POL
     HIPCHK(hipGetLastError());
     return PC_OK;
 }

@@ -38,7 +38,9 @@ class Agent(nn.Module):
 
     def get_action_and_value(self, x, action=None):  # model.py:34-41
         logits = self.actor(x)
-        dist = torch.distributions.Categorical(logits=logits)
+        # validate_args=False: the reference leaves argument validation on (a host-synchronising check of the
+        # logits / actions, no arithmetic); it has to be off inside a captured HIP graph
+        dist = torch.distributions.Categorical(logits=logits, validate_args=False)
         if action is None:
             action = dist.sample()
         logprob = dist.log_prob(action)
@@ -46,16 +48,46 @@ class Agent(nn.Module):
         return action, logprob, entropy, self.get_value(x)
 
     @torch.no_grad()
-    def act(self, x, out_action=None, out_logprob=None):
-        """Rollout-time variant of get_action_and_value(x): same distribution, the sampling tail
-        (softmax, draw, log_prob) is one HIP kernel (pc_sample, counter-based Philox stream keyed by
-        (rng_seed, call counter)).  Returns action int64 [N], logprob [N], value [N]."""
+    def act(self, x, out_action=None, out_logprob=None, out_value=None, out_action_f32=None, out_logits=None, fused=True):
+        """Rollout-time variant of get_action_and_value(x): same distribution, no autograd.
+        fused=True: ONE HIP kernel (pc_policy_act) -- both MLPs on the fp32 matrix cores, the categorical
+        draw, log_prob and the value; falls back to the two-kernel form when the shape is outside its menu.
+        fused=False: torch GEMMs for the MLPs + the sampling-tail kernel (pc_sample).
+        Counter-based Philox stream keyed by (rng_seed, call counter).  Returns action int64 [N], logprob [N],
+        value [N] (written into the out_* tensors when given)."""
+        N = x.shape[0]
+        dev = x.device
+        action = out_action if out_action is not None else torch.empty(N, dtype=torch.int64, device=dev)
+        logprob = out_logprob if out_logprob is not None else torch.empty(N, dtype=torch.float32, device=dev)
+        di = dev.index if dev.index is not None else torch.cuda.current_device()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        std_mlp = all(isinstance(m, nn.Sequential) and len(m) == 3 and isinstance(m[0], nn.Linear) and isinstance(m[1], nn.ReLU)
+                      and isinstance(m[2], nn.Linear) for m in (self.actor, self.critic))
+        if fused and std_mlp and x.is_contiguous() and x.dtype == torch.float32:
+            a1, a2, c1, c2 = self.actor[0], self.actor[2], self.critic[0], self.critic[2]
+            value = out_value if out_value is not None else torch.empty(N, dtype=torch.float32, device=dev)
+            rc = lib.pc_policy_act(di, x.data_ptr(), N, x.shape[1], a1.out_features, a2.out_features,
+                                   a1.weight.data_ptr(), a1.bias.data_ptr(), a2.weight.data_ptr(), a2.bias.data_ptr(),
+                                   c1.weight.data_ptr(), c1.bias.data_ptr(), c2.weight.data_ptr(), c2.bias.data_ptr(),
+                                   int(self.rng_seed), self._rng_offset, None, action.data_ptr(), ptr(out_action_f32),
+                                   logprob.data_ptr(), value.data_ptr(), ptr(out_logits), stream)
+            if rc == 0:
+                self._rng_offset += 1
+                return action, logprob, value
+            if rc != -5:  # PC_ERR_UNSUPPORTED -> fall through to the unfused form
+                check(rc, "pc_policy_act")
         logits = self.actor(x).contiguous()
-        N, A = logits.shape
-        action = out_action if out_action is not None else torch.empty(N, dtype=torch.int64, device=x.device)
-        logprob = out_logprob if out_logprob is not None else torch.empty(N, dtype=torch.float32, device=x.device)
-        dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
-        check(lib.pc_sample(dev, logits.data_ptr(), N, A, int(self.rng_seed), self._rng_offset, action.data_ptr(),
-                            logprob.data_ptr(), None, torch.cuda.current_stream(x.device).cuda_stream), "pc_sample")
+        A = logits.shape[1]
+        check(lib.pc_sample(di, logits.data_ptr(), N, A, int(self.rng_seed), self._rng_offset, action.data_ptr(),
+                            logprob.data_ptr(), None, stream), "pc_sample")
         self._rng_offset += 1
-        return action, logprob, self.critic(x).view(-1)
+        value = self.critic(x).view(-1)
+        if out_value is not None:
+            out_value.copy_(value)
+            value = out_value
+        if out_action_f32 is not None:
+            out_action_f32.copy_(action)
+        if out_logits is not None:
+            out_logits.copy_(logits)
+        return action, logprob, value

@@ -49,7 +49,9 @@ class PPOConfig:
     env_dtype: str = "f32"
     seed: int = 0
     full_sweep: bool = False               # opt-in: iterate over all n_steps*n_envs samples per train iter
-    fused_sampler: bool = True             # sampling tail of get_action_and_value as one HIP kernel
+    use_graphs: bool = True                # capture the minibatch update in HIP graphs (GPU only)
+    policy: str = "fused"                  # rollout policy step: "fused" (one MFMA kernel: MLPs + draw),
+                                           # "sample" (torch GEMMs + sampling kernel), "torch" (reference ops)
 
 
 def flatten_parameters(module):
@@ -89,7 +91,7 @@ def ppo_loss(agent, obs, act, old_logprob, adv, ret, clip_ratio, vf_coef, ent_co
     """One minibatch of train.py:233-255.  `adv` is the raw advantage slice; normalisation is here."""
     _, new_logprobs, entropies, new_values = agent.get_action_and_value(obs, act)
     ratios = torch.exp(new_logprobs - old_logprob)                                            # :235
-    adv = (adv - adv.mean()) / torch.max(adv.std(), torch.tensor(1e-5, device=adv.device))   # :238-240
+    adv = (adv - adv.mean()) / adv.std().clamp_min(1e-5)      # :238-240 torch.max(std, 1e-5), without the H2D scalar copy
     policy_loss1 = -adv * ratios                                                              # :243
     policy_loss2 = -adv * torch.clamp(ratios, 1.0 - clip_ratio, 1.0 + clip_ratio)             # :244
     policy_loss = torch.max(policy_loss1, policy_loss2).mean()                                # :245
@@ -102,7 +104,12 @@ def ppo_loss(agent, obs, act, old_logprob, adv, ret, clip_ratio, vf_coef, ent_co
 class PPOLearner:
     """The update half of train.py (train.py:216-269): optimizer, scheduler, minibatch index draws,
     clipped-PPO minibatch steps with the flat-bucket gradient exchange.  Pure torch: runs on any device
-    (the multi-rank path is tested on CPU with gloo); the env and the GAE scan live in Trainer."""
+    (the multi-rank path is tested on CPU with gloo); the env and the GAE scan live in Trainer.
+
+    On the GPU the minibatch step (gather, forward, loss, backward | clip, Adam, metric sums) is captured
+    once into HIP graphs and replayed: the ~70 small kernels of one step are launch-bound when issued
+    eagerly (measured 1.6 ms of host time for 0.5 ms of GPU work).  With more than one rank the capture is
+    split at the gradient all-reduce, which stays an eager RCCL call between the two graphs."""
 
     def __init__(self, agent, cfg: PPOConfig, device, rank=0, world_size=1):
         self.agent, self.cfg, self.device, self.rank, self.world_size = agent, cfg, torch.device(device), rank, world_size
@@ -111,13 +118,24 @@ class PPOLearner:
             import torch.distributed as dist
             dist.broadcast(self.flat_param, src=0)       # every rank starts from rank 0's parameters
         self.exchange = GradExchange(self.flat_grad, world_size)
-        self.optimizer = torch.optim.Adam(agent.parameters(), lr=cfg.learning_rate, eps=1e-5)            # train.py:146
+        self.graphs = bool(cfg.use_graphs) and self.device.type == "cuda"
+        if self.graphs:   # capturable Adam: step count and lr live on the device, so a captured step stays valid
+            lr = torch.tensor(cfg.learning_rate, device=self.device, dtype=torch.float32)
+            self.optimizer = torch.optim.Adam(agent.parameters(), lr=lr, eps=1e-5, capturable=True, foreach=True)
+        else:
+            self.optimizer = torch.optim.Adam(agent.parameters(), lr=cfg.learning_rate, eps=1e-5)        # train.py:146
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=1, gamma=cfg.learning_rate_decay)  # :147
         self._np_rng = np.random.default_rng(cfg.seed * 7919 + rank)
         self.n_minibatches = len(range(0, cfg.n_steps, cfg.batch_size))     # train.py:228
         idx = torch.empty(cfg.train_iters, self.n_minibatches * cfg.batch_size, dtype=torch.int64)
         self._idx_host = idx.pin_memory() if self.device.type == "cuda" else idx
+        self._idx_dev = torch.empty_like(idx, device=self.device)
         self.metrics = torch.zeros(4, device=self.device)
+        self._graph_key = None
+
+    def current_lr(self):
+        lr = self.optimizer.param_groups[0]["lr"]
+        return float(lr) if torch.is_tensor(lr) else lr
 
     def draw_indices(self, M):
         """train.py:225-230: per train iter a fresh shuffle of all M = n_steps*n_envs indices, of which only
@@ -128,18 +146,69 @@ class PPOLearner:
         host = self._idx_host.numpy()
         for i in range(cfg.train_iters):
             host[i, :K] = self._np_rng.permutation(M) if K == M else self._np_rng.choice(M, size=K, replace=False)
-        return self._idx_host.to(self.device, non_blocking=True)[:, :K]
+        self._idx_dev.copy_(self._idx_host, non_blocking=True)
+        return self._idx_dev[:, :K]
 
-    def minibatch_step(self, obs, act, logprob, adv, ret):
+    # ---- one minibatch, in the two halves the all-reduce separates ---------------------------------------
+    def _fwd_bwd(self, obs, act, logprob, adv, ret):
         cfg = self.cfg
         loss, pl, vl, ent = ppo_loss(self.agent, obs, act, logprob, adv, ret, cfg.clip_ratio, cfg.vf_coef, cfg.ent_coef)
         self.flat_grad.zero_()                                                           # train.py:258
         loss.backward()                                                                  # :259
-        self.exchange()                                # the one all-reduce per minibatch
-        nn.utils.clip_grad_norm_(self.agent.parameters(), cfg.max_grad_norm)             # :260
+        return torch.stack([pl.detach(), vl.detach(), ent.detach(), loss.detach()])
+
+    def _apply(self, terms):
+        nn.utils.clip_grad_norm_(self.agent.parameters(), self.cfg.max_grad_norm)        # train.py:260
         self.optimizer.step()                                                            # :261
         with torch.no_grad():
-            self.metrics += torch.stack([pl.detach(), vl.detach(), ent.detach(), loss.detach()])   # :263-266
+            self.metrics += terms                                                        # :263-266
+
+    def minibatch_step(self, obs, act, logprob, adv, ret):
+        terms = self._fwd_bwd(obs, act, logprob, adv, ret)
+        self.exchange()                                # the one all-reduce per minibatch
+        self._apply(terms)
+
+    # ---- HIP-graph form ------------------------------------------------------------------------------------
+    def _build_graphs(self, obs, act, logprob, adv, ret):
+        """Capture `idx -> gather -> _fwd_bwd` and `_apply` over the trajectory tensors given (their addresses
+        are baked into the graphs; Buffer keeps them alive and in place across epochs)."""
+        B = self.cfg.batch_size
+        self._g_idx = torch.zeros(B, dtype=torch.int64, device=self.device)
+        self._g_terms = torch.zeros(4, device=self.device)
+        # warm-up on a side stream (allocator / lazy optimizer-state initialisation), then undo its effect
+        saved_param, saved_metrics = self.flat_param.clone(), self.metrics.clone()
+        saved_lr = self.optimizer.param_groups[0]["lr"].clone()
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                i = self._g_idx
+                self._g_terms.copy_(self._fwd_bwd(obs[i], act[i], logprob[i], adv[i], ret[i]))
+                self._apply(self._g_terms)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        fresh = not getattr(self, "_opt_started", False)
+        if fresh:   # the warm-up steps were the optimizer's first: return its state to "never stepped"
+            for st in self.optimizer.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        else:
+            raise RuntimeError("PPOLearner graphs must be built before the first real optimizer step")
+        self.flat_param.copy_(saved_param)
+        self.metrics.copy_(saved_metrics)
+        self.optimizer.param_groups[0]["lr"].copy_(saved_lr)
+        self._graph_a, self._graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        single = self.world_size == 1
+        with torch.cuda.graph(self._graph_a):
+            i = self._g_idx
+            self._g_terms.copy_(self._fwd_bwd(obs[i], act[i], logprob[i], adv[i], ret[i]))
+            if single:
+                self._apply(self._g_terms)
+        if not single:
+            with torch.cuda.graph(self._graph_b):
+                self._apply(self._g_terms)
+        self._graph_key = (obs.data_ptr(), act.data_ptr(), logprob.data_ptr(), adv.data_ptr(), ret.data_ptr(), obs.shape[0])
 
     def update(self, obs, act, logprob, adv, ret):
         """obs [M, D], the rest [M] (the flattened trajectories of train.py:209-214)."""
@@ -153,12 +222,24 @@ class PPOLearner:
         else:
             n_mb = self.n_minibatches
             idx_all = self.draw_indices(M)
+        use_graph = self.graphs and idx_all.shape[1] >= n_mb * B
+        if use_graph and self._graph_key != (obs.data_ptr(), act.data_ptr(), logprob.data_ptr(), adv.data_ptr(),
+                                             ret.data_ptr(), M):
+            self._build_graphs(obs, act, logprob, adv, ret)
         for it in range(cfg.train_iters):                                                # :223
             for mb in range(n_mb):                                                       # :228
                 idx = idx_all[it, mb * B:(mb + 1) * B]
                 if idx.numel() == 0:
                     continue
-                self.minibatch_step(obs[idx], act[idx], logprob[idx], adv[idx], ret[idx])
+                if use_graph:
+                    self._g_idx.copy_(idx)
+                    self._graph_a.replay()
+                    if self.world_size > 1:
+                        self.exchange()
+                        self._graph_b.replay()
+                else:
+                    self.minibatch_step(obs[idx], act[idx], logprob[idx], adv[idx], ret[idx])
+        self._opt_started = True
         self.scheduler.step()                                                            # :269
 
 
@@ -189,6 +270,7 @@ class Trainer:
         self.start_time = time.time()
         self.profile_stride = 0      # bench.py: bracket every k-th env-step launch with events on the launch stream
         self.k1_events = []
+        self.phase_events = None     # bench.py: list of (start, rollout_end, update_end) events per epoch
 
     # ---- train.py:173-195 ---------------------------------------------------------------------------
     @torch.no_grad()
@@ -200,14 +282,14 @@ class Trainer:
         buf.trunc_buf[0].copy_(self.next_trunc)
         for t in range(T):
             obs = buf.obs_buf[t]
-            if cfg.fused_sampler:
-                _, _, values = agent.act(obs, out_action=self.actions, out_logprob=buf.logprob_buf[t])
-                actions = self.actions
-            else:
+            if cfg.policy == "torch":
                 actions, logprobs, _, values = agent.get_action_and_value(obs)   # train.py:181
                 buf.logprob_buf[t].copy_(logprobs)
-            buf.val_buf[t].copy_(values.view(-1))
-            buf.act_buf[t].copy_(actions)            # stored as float32 like the reference (buffer.py:13)
+                buf.val_buf[t].copy_(values.view(-1))
+                buf.act_buf[t].copy_(actions)        # stored as float32 like the reference (buffer.py:13)
+            else:   # "fused": one kernel for MLPs + draw; "sample": torch GEMMs + the sampling kernel
+                actions, _, _ = agent.act(obs, out_action=self.actions, out_logprob=buf.logprob_buf[t], out_value=buf.val_buf[t],
+                                          out_action_f32=buf.act_buf[t], fused=cfg.policy == "fused")
             last = t == T - 1
             out = (self.next_obs if last else buf.obs_buf[t + 1], buf.rew_buf[t],
                    self.next_term if last else buf.term_buf[t + 1], self.next_trunc if last else buf.trunc_buf[t + 1])
@@ -234,10 +316,18 @@ class Trainer:
 
     def run_epoch(self, sync=True):
         """One epoch = rollout + update.  Returns the reference's scalars (train.py:286-292) when sync."""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if self.phase_events is not None else None
+        if ev:
+            ev[0].record()
         self.rollout()
+        if ev:
+            ev[1].record()
         with torch.no_grad():
             rew_mean = self.buffer.rew_buf.mean()
         self.update()
+        if ev:
+            ev[2].record()
+            self.phase_events.append(ev)
         self.epoch += 1
         if not sync:
             return None
@@ -251,7 +341,7 @@ class Trainer:
             *m, avg_reward = t.tolist()
         elapsed = time.time() - self.start_time
         return {"losses/policy_loss": m[0], "losses/value_loss": m[1], "losses/entropy": m[2], "losses/total_loss": m[3],
-                "charts/avg_reward": avg_reward, "charts/learning_rate": self.optimizer.param_groups[0]["lr"],
+                "charts/avg_reward": avg_reward, "charts/learning_rate": self.learner.current_lr(),
                 "charts/SPS": self.global_step_idx / max(elapsed, 1e-9), "global_step": self.global_step_idx,
                 "elapsed": elapsed}
 

@@ -132,3 +132,38 @@ def test_sample_kernel_entropy_and_extreme_logits():
     assert torch.allclose(ent, dist.entropy(), atol=5e-6)
     assert torch.allclose(lp, dist.log_prob(act), atol=5e-6)
     assert int(act[0]) == 0 and abs(float(ent[1]) - np.log(9)) < 1e-6
+
+
+@pytest.mark.parametrize("D", [18, 23, 39])
+@pytest.mark.parametrize("N", [1000, 65536])
+def test_fused_policy_kernel_matches_torch_mlp(D, N):
+    """pc_policy_act (fp32 MFMA, hidden layer in registers) vs torch's Linear/ReLU/Linear on the same weights:
+    logits and values within 1e-5 (different fp32 summation order only), log_prob consistent with the logits it
+    reports, draws distributed as the categorical."""
+    torch.manual_seed(D)
+    agent = pc.Agent(D, 9).cuda()
+    with torch.no_grad():
+        for p in agent.parameters():          # non-trivial biases / output weights (the init has zero biases, 0.01 gain)
+            p.add_(torch.randn_like(p) * 0.1)
+    g = torch.Generator(device="cuda").manual_seed(N)
+    x = torch.rand(N, D, device="cuda", generator=g) * 2 - 0.5
+    logits = torch.empty(N, 9, device="cuda")
+    af = torch.empty(N, device="cuda")
+    agent.rng_seed = 77
+    a, lp, v = agent.act(x, out_logits=logits, out_action_f32=af)
+    with torch.no_grad():
+        ref_logits, ref_v = agent.actor(x), agent.critic(x).view(-1)
+    assert torch.allclose(logits, ref_logits, atol=1e-5, rtol=1e-5)
+    assert torch.allclose(v, ref_v, atol=1e-5, rtol=1e-5)
+    dist = torch.distributions.Categorical(logits=logits)
+    assert torch.allclose(lp, dist.log_prob(a), atol=2e-6)
+    assert torch.equal(af, a.float()) and int(a.min()) >= 0 and int(a.max()) <= 8
+    # same (seed, offset) through the unfused path: identical uniforms, so identical draws wherever the two
+    # paths' logits agree to the last bit of the CDF comparison (almost everywhere)
+    agent._rng_offset = 0
+    a2, lp2, v2 = agent.act(x, fused=False)
+    assert (a2 == a).float().mean() > 0.999
+    if N >= 65536:
+        p = torch.softmax(ref_logits.double(), -1).mean(0).cpu().numpy()
+        counts = torch.bincount(a, minlength=9).double().cpu().numpy()
+        assert np.abs(counts / N - p).max() < 0.01

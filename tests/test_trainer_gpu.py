@@ -1,0 +1,110 @@
+"""GPU tests of the whole loop: rollout plumbing against the reference's loop semantics, the HIP-graph
+update against the eager one, and a short end-to-end training run."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import ppo_car_amd as pc
+from ppo_car_amd.ppo import PPOConfig, PPOLearner, Trainer
+from conftest import TRACKS
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(**kw):
+    base = dict(n_envs=256, n_steps=64, batch_size=32, train_iters=3, track=TRACKS["big_track"], num_rays=16, seed=5)
+    base.update(kw)
+    return PPOConfig(**base)
+
+
+@pytest.mark.parametrize("policy", ["fused", "sample", "torch"])
+def test_rollout_buffer_is_consistent_with_the_env(policy):
+    """Replaying the actions the rollout stored through the float64 oracle reproduces the stored rewards, flags and
+    observations (float32 kernel: within tolerance), with the reference's row conventions: flags stored at row t are
+    those that preceded obs t (train.py:176-177,195)."""
+    cfg = _cfg(policy=policy, env_dtype="f64")
+    tr = Trainer(cfg, device="cuda")
+    first_obs = tr.next_obs.clone()
+    tr.rollout()
+    torch.cuda.synchronize()
+    buf = tr.buffer
+    T, N = cfg.n_steps, cfg.n_envs
+    acts = buf.act_buf.cpu().numpy().astype(np.int64)
+    assert acts.min() >= 0 and acts.max() <= 8
+    ora = oracle.OracleVecEnv(oracle.Track(cfg.track), N, num_rays=cfg.num_rays, reward_scaling=cfg.reward_scaling, threads=4)
+    o = ora.reset()
+    assert np.array_equal(first_obs.cpu().numpy(), o) and np.array_equal(buf.obs_buf[0].cpu().numpy(), o)
+    assert float(buf.term_buf[0].abs().sum()) == 0 and float(buf.trunc_buf[0].abs().sum()) == 0
+    for t in range(T):
+        o, r, te, trn = ora.step(acts[t])
+        nxt_obs = buf.obs_buf[t + 1] if t + 1 < T else tr.next_obs
+        nxt_te = buf.term_buf[t + 1] if t + 1 < T else tr.next_term
+        nxt_tr = buf.trunc_buf[t + 1] if t + 1 < T else tr.next_trunc
+        assert np.array_equal(nxt_obs.cpu().numpy(), o), t
+        assert np.array_equal(buf.rew_buf[t].cpu().numpy(), r.astype(np.float32)), t
+        assert np.array_equal(nxt_te.cpu().numpy() != 0, te) and np.array_equal(nxt_tr.cpu().numpy() != 0, trn)
+    # stored log-probs / values are those of the stored action under the rollout policy
+    with torch.no_grad():
+        _, lp, _, v = tr.agent.get_action_and_value(buf.obs_buf.view(-1, *tr.obs_dim), buf.act_buf.view(-1))
+    assert torch.allclose(lp, buf.logprob_buf.view(-1), atol=2e-5)
+    assert torch.allclose(v.view(-1), buf.val_buf.view(-1), atol=2e-5)
+    assert tr.global_step_idx == T * N
+    tr.close()
+
+
+def test_graph_update_equals_eager_update():
+    """Same initial parameters, same trajectories, same index draws: the HIP-graph minibatch steps and the eager
+    ones give the same parameters (capturable Adam computes its bias correction on the device: 1e-6 slack)."""
+    outs = {}
+    for use_graphs in (False, True):
+        cfg = _cfg(use_graphs=use_graphs)
+        tr = Trainer(cfg, device="cuda")
+        tr.rollout()
+        tr.update()
+        tr.rollout()          # second epoch: graphs are replayed, not rebuilt
+        tr.update()
+        torch.cuda.synchronize()
+        outs[use_graphs] = (tr.learner.flat_param.clone(), tr.learner.metrics.clone(), tr.learner.current_lr())
+        if use_graphs:
+            assert tr.learner._graph_key is not None
+        tr.close()
+    (p0, m0, lr0), (p1, m1, lr1) = outs[False], outs[True]
+    assert lr0 == pytest.approx(lr1, rel=1e-6) and lr0 == pytest.approx(3e-4 * 0.99 ** 2, rel=1e-6)
+    assert torch.allclose(p0, p1, atol=2e-5, rtol=1e-4)
+    assert torch.allclose(m0, m1, atol=1e-3, rtol=1e-3)
+
+
+def test_learner_on_gpu_matches_cpu_reference_arithmetic():
+    """One eager minibatch step on the GPU vs the same step on the CPU (same torch ops, different device)."""
+    torch.manual_seed(1)
+    a_cpu = pc.Agent(23, 9)
+    a_gpu = pc.Agent(23, 9)
+    a_gpu.load_state_dict(a_cpu.state_dict())
+    a_gpu.cuda()
+    cfg = PPOConfig(n_envs=4, n_steps=64, batch_size=64, train_iters=1, use_graphs=False)
+    L0, L1 = PPOLearner(a_cpu, cfg, "cpu"), PPOLearner(a_gpu, cfg, "cuda")
+    g = torch.Generator().manual_seed(0)
+    batch = (torch.randn(64, 23, generator=g), torch.randint(0, 9, (64,), generator=g).float(), -torch.rand(64, generator=g),
+             torch.randn(64, generator=g), torch.randn(64, generator=g))
+    L0.minibatch_step(*batch)
+    L1.minibatch_step(*[t.cuda() for t in batch])
+    assert torch.allclose(L0.flat_param, L1.flat_param.cpu(), atol=1e-6)
+    assert torch.allclose(L0.metrics, L1.metrics.cpu(), atol=1e-4)
+
+
+def test_short_training_run_improves_reward_and_logs_reference_scalars():
+    cfg = _cfg(n_envs=1024, n_steps=128, batch_size=256, train_iters=10, num_rays=12, learning_rate=1e-3, full_sweep=False)
+    tr = Trainer(cfg, device="cuda")
+    hist = [tr.run_epoch() for _ in range(12)]
+    for k in ("losses/policy_loss", "losses/value_loss", "losses/entropy", "losses/total_loss", "charts/avg_reward",
+              "charts/learning_rate", "charts/SPS"):
+        assert k in hist[0] and np.isfinite(hist[-1][k])
+    assert hist[-1]["global_step"] == 12 * 1024 * 128
+    assert hist[-1]["charts/learning_rate"] == pytest.approx(1e-3 * 0.99 ** 12, rel=1e-5)
+    first, last = np.mean([h["charts/avg_reward"] for h in hist[:3]]), np.mean([h["charts/avg_reward"] for h in hist[-3:]])
+    assert last > first                     # per-step reward goes up (fewer crashes, more forward / gates)
+    sd = tr.agent.state_dict()              # what train.py:283 saves
+    assert set(sd) == {"actor.0.weight", "actor.0.bias", "actor.2.weight", "actor.2.bias",
+                       "critic.0.weight", "critic.0.bias", "critic.2.weight", "critic.2.bias"}
+    tr.close()
