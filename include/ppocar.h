@@ -122,16 +122,23 @@ int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, 
 /* ---- the whole of Agent.get_action_and_value(x) as the rollout calls it (model.py:34-41, train.py:181):
  * both 1-hidden-layer MLPs (actor D->H->A, critic D->H->1, ReLU), the categorical draw, log_prob and the
  * value, in one launch on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products and sums).
- * Weights in torch.nn.Linear layout: aW1 [H][D], ab1 [H], aW2 [A][H], ab2 [A], cW1 [H][D], cb1 [H],
- * cW2 [1][H], cb2 [1].  RNG as pc_sample, with offset = `offset` + *offset_dev when offset_dev != NULL (a
- * device counter, so that a captured HIP graph can be replayed with a fresh stream of draws).
+ * The weights do not change during a rollout, so they are packed ONCE into the kernel's LDS image:
+ *   pc_policy_image_floats(D, H, A)  -> number of floats the image needs (negative: unsupported shape)
+ *   pc_policy_pack(...)              -> build the image (device buffer `image`) from the eight
+ *                                       torch.nn.Linear tensors: aW1 [H][D], ab1 [H], aW2 [A][H], ab2 [A],
+ *                                       cW1 [H][D], cb1 [H], cW2 [1][H], cb2 [1]
+ *   pc_policy_act(...)               -> one policy step for obs [N][D] using the image.
+ * RNG as pc_sample, with offset = `offset` + *offset_dev when offset_dev != NULL (a device counter, so a
+ * captured HIP graph can be replayed with a fresh stream of draws).
  * action [N] int64; action_f32 [N] (the float copy Buffer.act_buf stores, buffer.py:13) or NULL;
  * logprob, value [N]; logits_out [N][A] or NULL.  PC_ERR_UNSUPPORTED unless H == 256, A <= 15, D <= 40
  * (the caller then uses its own GEMMs + pc_sample). */
-int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, const float* aW1, const float* ab1,
-                  const float* aW2, const float* ab2, const float* cW1, const float* cb1, const float* cW2, const float* cb2,
-                  uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob,
-                  float* value, float* logits_out, void* stream);
+int64_t pc_policy_image_floats(int D, int H, int A);
+int pc_policy_pack(int device, int D, int H, int A, const float* aW1, const float* ab1, const float* aW2, const float* ab2,
+                   const float* cW1, const float* cb1, const float* cW2, const float* cb2, float* image, void* stream);
+int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, const float* image, uint64_t seed,
+                  uint64_t offset, const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob, float* value,
+                  float* logits_out, void* stream);
 
 const char* pc_strerror(int code);
 /* Last HIP error string seen by this thread (diagnostics for PC_ERR_HIP). */

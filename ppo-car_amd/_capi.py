@@ -70,7 +70,9 @@ _sig = {
     "pc_env_set_state": (_i, [_vp] * 9),
     "pc_gae": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _i64, _i64, _vp, _vp, _vp]),
     "pc_sample": (_i, [_i, _vp, _i64, _i, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp]),
-    "pc_policy_act": (_i, [_i, _vp, _i64, _i, _i, _i] + [_vp] * 8 + [C.c_uint64, C.c_uint64, _vp] + [_vp] * 5 + [_vp]),
+    "pc_policy_image_floats": (_i64, [_i, _i, _i]),
+    "pc_policy_pack": (_i, [_i, _i, _i, _i] + [_vp] * 8 + [_vp, _vp]),
+    "pc_policy_act": (_i, [_i, _vp, _i64, _i, _i, _i, _vp, C.c_uint64, C.c_uint64, _vp] + [_vp] * 5 + [_vp]),
     "pc_strerror": (C.c_char_p, [_i]),
     "pc_last_hip_error": (C.c_char_p, []),
     "pc_env_launch_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),

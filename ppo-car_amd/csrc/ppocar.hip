@@ -632,59 +632,99 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
 // ------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// LDS image of the policy weights, in floats.  [W1: 512 rows x LD1][b1: 512][W2 A-operands: 32 x 4 x 64][b2: 16]
+__host__ __device__ constexpr int pol_ld1(int KS) { return 4 * KS + 1; }  // odd row stride: lanes 0..15 hit 16 banks
+__host__ __device__ constexpr int pol_image_floats(int KS) { return 512 * pol_ld1(KS) + 512 + 32 * 4 * 64 + 16; }
+__host__ __device__ constexpr int pol_image_padded(int KS) { return (pol_image_floats(KS) + 3) & ~3; }
+
+// Build the image once per rollout (the weights do not change while a rollout runs): every workgroup of
+// policy_kernel then stages it with straight 16-byte coalesced copies instead of re-deriving the layout.
+__global__ __launch_bounds__(256) void policy_pack_kernel(const int KS, const int D, const int A,
+                                                          const float* __restrict__ aW1, const float* __restrict__ ab1,
+                                                          const float* __restrict__ aW2, const float* __restrict__ ab2,
+                                                          const float* __restrict__ cW1, const float* __restrict__ cb1,
+                                                          const float* __restrict__ cW2, const float* __restrict__ cb2,
+                                                          float* __restrict__ image) {
+    constexpr int HID = 256;
+    const int LD1 = 4 * KS + 1;
+    const int nW1 = 2 * HID * LD1, nB1 = 2 * HID, nW2 = 32 * 4 * 64;
+    const int total = ((nW1 + nB1 + nW2 + 16) + 3) & ~3;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        if (i < nW1) {
+            const int r = i / LD1, c = i - r * LD1;
+            if (c < D) v = r < HID ? aW1[r * D + c] : cW1[(r - HID) * D + c];
+        } else if (i < nW1 + nB1) {
+            const int j = i - nW1;
+            v = j < HID ? ab1[j] : cb1[j - HID];
+        } else if (i < nW1 + nB1 + nW2) {
+            // A operand of layer 2 for (hidden tile ht, accumulator register reg), lane l:
+            //   A[i = out o = l & 15][k = l >> 4] = W2cat[hidden 16 ht + 4 (l >> 4) + reg][o]
+            const int j = i - nW1 - nB1;
+            const int l = j & 63, reg = (j >> 6) & 3, ht = j >> 8;
+            const int o = l & 15, h = 16 * ht + 4 * (l >> 4) + reg;
+            if (h < HID) {
+                if (o < A) v = aW2[o * HID + h];
+            } else if (o == A) {
+                v = cW2[h - HID];
+            }
+        } else if (i < nW1 + nB1 + nW2 + 16) {
+            const int o = i - nW1 - nB1 - nW2;
+            v = o < A ? ab2[o] : (o == A ? cb2[0] : 0.0f);
+        }
+        image[i] = v;
+    }
+}
+
+__device__ __forceinline__ float relu_f(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+
+// 512 threads = 8 waves (2 per SIMD: while one waits on LDS or its ReLU the other feeds the matrix pipe);
+// a wave owns 32 envs (2 column tiles of 16), a workgroup 256 envs per pass.
 template <int KS>
-__global__ __launch_bounds__(256) void policy_kernel(const float* __restrict__ obs, const int64_t N, const int D, const int A,
-                                                     const float* __restrict__ aW1, const float* __restrict__ ab1,
-                                                     const float* __restrict__ aW2, const float* __restrict__ ab2,
-                                                     const float* __restrict__ cW1, const float* __restrict__ cb1,
-                                                     const float* __restrict__ cW2, const float* __restrict__ cb2,
-                                                     const uint64_t seed, const uint64_t offset,
+__global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ obs, const int64_t N, const int D, const int A,
+                                                     const float* __restrict__ image, const uint64_t seed, const uint64_t offset,
                                                      const uint64_t* __restrict__ offset_dev, int64_t* __restrict__ action,
                                                      float* __restrict__ action_f, float* __restrict__ logprob,
                                                      float* __restrict__ value, float* __restrict__ logits_out) {
-    constexpr int HID = 256, NT = 2 * HID / 16;  // 32 hidden tiles
-    constexpr int LD1 = 4 * KS + 1;              // odd row stride: lanes 0..15 hit 16 different banks
-    constexpr int LDO = 17;
-    extern __shared__ float lds[];
+    constexpr int HID = 256, NT = 2 * HID / 16;  // 32 hidden tiles: 16 actor + 16 critic
+    constexpr int LD1 = pol_ld1(KS), LDO = 17, ET = 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sW1 = lds;                        // [512][LD1]
     float* sB1 = sW1 + 2 * HID * LD1;        // [512]
-    float* sW2 = sB1 + 2 * HID;              // [NT][4][64]  A operands of layer 2, lane-ordered
+    float* sW2 = sB1 + 2 * HID;              // [NT][4][64]
     float* sB2 = sW2 + NT * 4 * 64;          // [16]
-    float* sOut = sB2 + 16;                  // [4 waves][64 envs][LDO]
+    float* sOut = lds + pol_image_padded(KS);  // [8 waves][32 envs][LDO]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, lk = lane >> 4;
 
-    // ---- stage the weights (once per workgroup; the grid is persistent)
-    for (int i = tid; i < 2 * HID * 4 * KS; i += 256) {
-        const int r = i / (4 * KS), c = i - r * (4 * KS);
-        float v = 0.0f;
-        if (c < D) v = r < HID ? aW1[r * D + c] : cW1[(r - HID) * D + c];
-        sW1[r * LD1 + c] = v;
-    }
-    for (int i = tid; i < 2 * HID; i += 256) sB1[i] = i < HID ? ab1[i] : cb1[i - HID];
-    for (int i = tid; i < NT * 4 * 64; i += 256) {
-        const int l = i & 63, reg = (i >> 6) & 3, ht = i >> 8;
-        const int o = l & 15, h = 16 * ht + 4 * (l >> 4) + reg;
-        float v = 0.0f;
-        if (h < HID) {
-            if (o < A) v = aW2[o * HID + h];
-        } else if (o == A) {
-            v = cW2[h - HID];
+    {   // stage the image: 16-byte coalesced copies, all loads of a thread in flight together
+        const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(image);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        constexpr int n4 = pol_image_padded(KS) / 4;
+        constexpr int per = (n4 + 511) / 512;
+        f32x4 tmp[per];
+#pragma unroll
+        for (int j = 0; j < per; ++j) {
+            const int i = tid + j * 512;
+            if (i < n4) tmp[j] = src[i];
         }
-        sW2[i] = v;
+#pragma unroll
+        for (int j = 0; j < per; ++j) {
+            const int i = tid + j * 512;
+            if (i < n4) dst[i] = tmp[j];
+        }
     }
-    if (tid < 16) sB2[tid] = tid < A ? ab2[tid] : (tid == A ? cb2[0] : 0.0f);
     __syncthreads();
 
     const uint64_t off = offset + (offset_dev ? *offset_dev : 0);
-    float* myOut = sOut + wave * 64 * LDO;
+    float* myOut = sOut + wave * 32 * LDO;
     const int64_t n_chunks = (N + 255) / 256;
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        const int64_t env0 = chunk * 256 + wave * 64;
+        const int64_t env0 = chunk * 256 + wave * 32;
         // ---- B operands of layer 1: X^T, lane (k = lk, j = lc) of env tile et, k-step ks
-        float x[4][KS];
+        float x[ET][KS];
 #pragma unroll
-        for (int et = 0; et < 4; ++et) {
+        for (int et = 0; et < ET; ++et) {
             const int64_t e = env0 + 16 * et + lc;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -692,37 +732,51 @@ __global__ __launch_bounds__(256) void policy_kernel(const float* __restrict__ o
                 x[et][ks] = (e < N && f < D) ? obs[e * D + f] : 0.0f;
             }
         }
-        f32x4 out[4];
+        f32x4 out[ET];
 #pragma unroll
-        for (int et = 0; et < 4; ++et) out[et] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        for (int et = 0; et < ET; ++et) out[et] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        // A operands of the first hidden tile; inside the loop the next tile's are fetched under this tile's MFMAs
+        float a1[KS], a2[4];
+        f32x4 bias = *reinterpret_cast<const f32x4*>(sB1 + 4 * lk);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a1[ks] = sW1[lc * LD1 + 4 * ks + lk];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) a2[reg] = sW2[reg * 64 + lane];
         for (int ht = 0; ht < NT; ++ht) {
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(sB1 + 16 * ht + 4 * lk);
-            f32x4 acc[4];
+            const int hn = ht + 1 < NT ? ht + 1 : ht;
+            float n1[KS], n2[4];
+            const f32x4 nbias = *reinterpret_cast<const f32x4*>(sB1 + 16 * hn + 4 * lk);
 #pragma unroll
-            for (int et = 0; et < 4; ++et) acc[et] = bias;
+            for (int ks = 0; ks < KS; ++ks) n1[ks] = sW1[(16 * hn + lc) * LD1 + 4 * ks + lk];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const float a = sW1[(16 * ht + lc) * LD1 + 4 * ks + lk];
+            for (int reg = 0; reg < 4; ++reg) n2[reg] = sW2[(hn * 4 + reg) * 64 + lane];
+            f32x4 acc[ET];
 #pragma unroll
-                for (int et = 0; et < 4; ++et) acc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x[et][ks], acc[et], 0, 0, 0);
-            }
+            for (int et = 0; et < ET; ++et) acc[et] = bias;
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const float a2 = sW2[(ht * 4 + reg) * 64 + lane];
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int et = 0; et < 4; ++et)
-                    out[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, fmaxf(acc[et][reg], 0.0f), out[et], 0, 0, 0);  // ReLU
-            }
+                for (int et = 0; et < ET; ++et) acc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], x[et][ks], acc[et], 0, 0, 0);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                for (int et = 0; et < ET; ++et)
+                    out[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[reg], relu_f(acc[et][reg]), out[et], 0, 0, 0);
+            bias = nbias;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a1[ks] = n1[ks];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) a2[reg] = n2[reg];
         }
         // ---- out tile -> LDS so that lane = env
-        __syncthreads();  // previous iteration's readers are done with sOut
+        __syncthreads();  // previous pass's readers are done with sOut
 #pragma unroll
-        for (int et = 0; et < 4; ++et)
+        for (int et = 0; et < ET; ++et)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) myOut[(16 * et + lc) * LDO + 4 * lk + reg] = out[et][reg] + sB2[4 * lk + reg];
         __syncthreads();
         const int64_t e = env0 + lane;
-        if (e < N) {
+        if (lane < 32 && e < N) {
             const float* row = myOut + lane * LDO;
             float l[16];
             float mx = -INFINITY;
@@ -1235,19 +1289,38 @@ int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, 
     return PC_OK;
 }
 
-int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, const float* aW1, const float* ab1,
-                  const float* aW2, const float* ab2, const float* cW1, const float* cb1, const float* cW2, const float* cb2,
-                  uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob,
-                  float* value, float* logits_out, void* stream) {
-    if (!obs || !aW1 || !ab1 || !aW2 || !ab2 || !cW1 || !cb1 || !cW2 || !cb2 || !action || !logprob || !value || N < 1)
-        return PC_ERR_INVALID_ARG;
+static int policy_ks(int D) { return D <= 20 ? 5 : (D <= 24 ? 6 : 10); }
+
+int64_t pc_policy_image_floats(int D, int H, int A) {
+    if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
+    return pol_image_padded(policy_ks(D));
+}
+
+int pc_policy_pack(int device, int D, int H, int A, const float* aW1, const float* ab1, const float* aW2, const float* ab2,
+                   const float* cW1, const float* cb1, const float* cW2, const float* cb2, float* image, void* stream) {
+    if (!aW1 || !ab1 || !aW2 || !ab2 || !cW1 || !cb1 || !cW2 || !cb2 || !image) return PC_ERR_INVALID_ARG;
+    if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1 || device < 0 || device >= count) return PC_ERR_NO_DEVICE;
+    DeviceGuard guard(device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    hipLaunchKernelGGL(policy_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, policy_ks(D), D, A, aW1, ab1, aW2, ab2,
+                       cW1, cb1, cW2, cb2, image);
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, const float* image, uint64_t seed,
+                  uint64_t offset, const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob, float* value,
+                  float* logits_out, void* stream) {
+    if (!obs || !image || !action || !logprob || !value || N < 1) return PC_ERR_INVALID_ARG;
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;  // the caller falls back to its own GEMMs
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1 || device < 0 || device >= count) return PC_ERR_NO_DEVICE;
     DeviceGuard guard(device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
-    const int KS = D <= 20 ? 5 : (D <= 24 ? 6 : 10);
-    const size_t lds = (size_t)(512 * (4 * KS + 1) + 512 + 32 * 4 * 64 + 16 + 4 * 64 * 17) * sizeof(float);
+    const int KS = policy_ks(D);
+    const size_t lds = (size_t)(pol_image_padded(KS) + 8 * 32 * 17) * sizeof(float);
     static int n_cu[64] = {0};
     if (device < 64 && n_cu[device] == 0) {
         hipDeviceProp_t prop;
@@ -1256,7 +1329,7 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
     }
     const int cus = device < 64 ? n_cu[device] : 256;
     const int64_t chunks = (N + 255) / 256;
-    const int blocks = (int)(chunks < cus ? chunks : cus);  // one 100-KB-LDS workgroup per CU, persistent over env chunks
+    const int blocks = (int)(chunks < cus ? chunks : cus);  // one ~100-KB-LDS workgroup per CU, persistent over env chunks
     hipStream_t st = (hipStream_t)stream;
 #define PC_POL(KSV)                                                                                                      \
     do {                                                                                                                 \
@@ -1265,8 +1338,8 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
             HIPCHK(hipFuncSetAttribute((const void*)policy_kernel<KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_set[device] = true;                                                                                     \
         }                                                                                                                \
-        hipLaunchKernelGGL(policy_kernel<KSV>, dim3(blocks), dim3(256), lds, st, obs, N, D, A, aW1, ab1, aW2, ab2, cW1, cb1, \
-                           cW2, cb2, seed, offset, offset_dev, action, action_f32, logprob, value, logits_out);          \
+        hipLaunchKernelGGL(policy_kernel<KSV>, dim3(blocks), dim3(512), lds, st, obs, N, D, A, image, seed, offset, offset_dev, \
+                           action, action_f32, logprob, value, logits_out);                                              \
     } while (0)
     if (KS == 5) PC_POL(5);
     else if (KS == 6) PC_POL(6);

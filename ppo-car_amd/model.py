@@ -47,14 +47,42 @@ class Agent(nn.Module):
         entropy = dist.entropy()
         return action, logprob, entropy, self.get_value(x)
 
+    def _std_mlp(self):
+        return all(isinstance(m, nn.Sequential) and len(m) == 3 and isinstance(m[0], nn.Linear) and isinstance(m[1], nn.ReLU)
+                   and isinstance(m[2], nn.Linear) for m in (self.actor, self.critic))
+
     @torch.no_grad()
-    def act(self, x, out_action=None, out_logprob=None, out_value=None, out_action_f32=None, out_logits=None, fused=True):
+    def pack_policy(self):
+        """Pack the current weights into the fused policy kernel's LDS image (once per rollout: the weights do
+        not change while it runs).  Returns False when the shape is outside the kernel's menu."""
+        self._image_ok = False
+        if not self._std_mlp():
+            return False
+        a1, a2, c1, c2 = self.actor[0], self.actor[2], self.critic[0], self.critic[2]
+        D, H, A = a1.in_features, a1.out_features, a2.out_features
+        n = lib.pc_policy_image_floats(D, H, A)
+        if n < 0 or c1.out_features != H or c2.out_features != 1:
+            return False
+        dev = a1.weight.device
+        if getattr(self, "_image", None) is None or self._image.numel() != n or self._image.device != dev:
+            self._image = torch.empty(n, dtype=torch.float32, device=dev)
+        di = dev.index if dev.index is not None else torch.cuda.current_device()
+        check(lib.pc_policy_pack(di, D, H, A, a1.weight.data_ptr(), a1.bias.data_ptr(), a2.weight.data_ptr(), a2.bias.data_ptr(),
+                                 c1.weight.data_ptr(), c1.bias.data_ptr(), c2.weight.data_ptr(), c2.bias.data_ptr(),
+                                 self._image.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "pc_policy_pack")
+        self._image_ok = True
+        return True
+
+    @torch.no_grad()
+    def act(self, x, out_action=None, out_logprob=None, out_value=None, out_action_f32=None, out_logits=None, fused=True,
+            repack=True, offset_dev=None):
         """Rollout-time variant of get_action_and_value(x): same distribution, no autograd.
         fused=True: ONE HIP kernel (pc_policy_act) -- both MLPs on the fp32 matrix cores, the categorical
         draw, log_prob and the value; falls back to the two-kernel form when the shape is outside its menu.
+        repack=False reuses the weight image of the last pack_policy() (the rollout packs once).
         fused=False: torch GEMMs for the MLPs + the sampling-tail kernel (pc_sample).
-        Counter-based Philox stream keyed by (rng_seed, call counter).  Returns action int64 [N], logprob [N],
-        value [N] (written into the out_* tensors when given)."""
+        Counter-based Philox stream keyed by (rng_seed, call counter [+ *offset_dev]).  Returns action int64 [N],
+        logprob [N], value [N] (written into the out_* tensors when given)."""
         N = x.shape[0]
         dev = x.device
         action = out_action if out_action is not None else torch.empty(N, dtype=torch.int64, device=dev)
@@ -62,21 +90,17 @@ class Agent(nn.Module):
         di = dev.index if dev.index is not None else torch.cuda.current_device()
         stream = torch.cuda.current_stream(dev).cuda_stream
         ptr = lambda t: t.data_ptr() if t is not None else None
-        std_mlp = all(isinstance(m, nn.Sequential) and len(m) == 3 and isinstance(m[0], nn.Linear) and isinstance(m[1], nn.ReLU)
-                      and isinstance(m[2], nn.Linear) for m in (self.actor, self.critic))
-        if fused and std_mlp and x.is_contiguous() and x.dtype == torch.float32:
-            a1, a2, c1, c2 = self.actor[0], self.actor[2], self.critic[0], self.critic[2]
-            value = out_value if out_value is not None else torch.empty(N, dtype=torch.float32, device=dev)
-            rc = lib.pc_policy_act(di, x.data_ptr(), N, x.shape[1], a1.out_features, a2.out_features,
-                                   a1.weight.data_ptr(), a1.bias.data_ptr(), a2.weight.data_ptr(), a2.bias.data_ptr(),
-                                   c1.weight.data_ptr(), c1.bias.data_ptr(), c2.weight.data_ptr(), c2.bias.data_ptr(),
-                                   int(self.rng_seed), self._rng_offset, None, action.data_ptr(), ptr(out_action_f32),
-                                   logprob.data_ptr(), value.data_ptr(), ptr(out_logits), stream)
-            if rc == 0:
+        if fused and x.is_contiguous() and x.dtype == torch.float32:
+            ok = self.pack_policy() if (repack or not getattr(self, "_image_ok", False)) else True
+            if ok:
+                a1, a2 = self.actor[0], self.actor[2]
+                value = out_value if out_value is not None else torch.empty(N, dtype=torch.float32, device=dev)
+                check(lib.pc_policy_act(di, x.data_ptr(), N, x.shape[1], a1.out_features, a2.out_features, self._image.data_ptr(),
+                                        int(self.rng_seed), self._rng_offset, ptr(offset_dev), action.data_ptr(),
+                                        ptr(out_action_f32), logprob.data_ptr(), value.data_ptr(), ptr(out_logits), stream),
+                      "pc_policy_act")
                 self._rng_offset += 1
                 return action, logprob, value
-            if rc != -5:  # PC_ERR_UNSUPPORTED -> fall through to the unfused form
-                check(rc, "pc_policy_act")
         logits = self.actor(x).contiguous()
         A = logits.shape[1]
         check(lib.pc_sample(di, logits.data_ptr(), N, A, int(self.rng_seed), self._rng_offset, action.data_ptr(),

@@ -280,6 +280,8 @@ class Trainer:
         buf.obs_buf[0].copy_(self.next_obs)
         buf.term_buf[0].copy_(self.next_term)       # flags that preceded obs 0 (train.py:176-177)
         buf.trunc_buf[0].copy_(self.next_trunc)
+        if cfg.policy == "fused":
+            agent.pack_policy()                      # weights are constant during the rollout: one LDS image for all T steps
         for t in range(T):
             obs = buf.obs_buf[t]
             if cfg.policy == "torch":
@@ -289,7 +291,7 @@ class Trainer:
                 buf.act_buf[t].copy_(actions)        # stored as float32 like the reference (buffer.py:13)
             else:   # "fused": one kernel for MLPs + draw; "sample": torch GEMMs + the sampling kernel
                 actions, _, _ = agent.act(obs, out_action=self.actions, out_logprob=buf.logprob_buf[t], out_value=buf.val_buf[t],
-                                          out_action_f32=buf.act_buf[t], fused=cfg.policy == "fused")
+                                          out_action_f32=buf.act_buf[t], fused=cfg.policy == "fused", repack=False)
             last = t == T - 1
             out = (self.next_obs if last else buf.obs_buf[t + 1], buf.rew_buf[t],
                    self.next_term if last else buf.term_buf[t + 1], self.next_trunc if last else buf.trunc_buf[t + 1])
