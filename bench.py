@@ -85,7 +85,9 @@ def main():
     ap.add_argument("--env-dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--policy", default="fused", choices=["fused", "sample", "torch"], help="rollout policy-step implementation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--event-stride", type=int, default=8, help="bracket every k-th env-step launch with HIP events")
+    ap.add_argument("--eager-rollout", action="store_true", help="no rollout graph; bracket env-step launches with events instead")
+    ap.add_argument("--no-graphs", action="store_true", help="eager update and rollout")
+    ap.add_argument("--event-stride", type=int, default=8, help="with --eager-rollout: bracket every k-th env-step launch")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,31 +112,54 @@ def main():
         wl["n_envs"] = args.n_envs
     if args.n_steps:
         wl["n_steps"] = args.n_steps
-    cfg = PPOConfig(track=os.path.join(ROOT, "tracks", "big_track.json"), env_dtype=args.env_dtype, seed=0, policy=args.policy, **wl)
+    cfg = PPOConfig(track=os.path.join(ROOT, "tracks", "big_track.json"), env_dtype=args.env_dtype, seed=0, policy=args.policy, use_graphs=not args.no_graphs, **wl)
     tr = Trainer(cfg, device=dev, rank=rank, world_size=world)
     tr.profile_stride = 0
+    # K1 probe: a second env batch of the same size and launch geometry.  When the rollout runs as a replayed HIP
+    # graph its kernels cannot be bracketed one by one, so inside the timed region (same stream) this twin is
+    # stepped PROBE times back to back between two events with the trainer's latest actions.
+    from ppo_car_amd.env import VecCarEnv
+    PROBE = 32
+    probe = VecCarEnv(cfg.n_envs, cfg.track, num_rays=cfg.num_rays, reward_scaling=cfg.reward_scaling, device=dev, dtype=cfg.env_dtype)
+    p_obs, _ = probe.reset()
+    p_out = (p_obs, torch.empty(cfg.n_envs, device=dev), torch.empty(cfg.n_envs, device=dev), torch.empty(cfg.n_envs, device=dev))
+    probe_events = []
+
+    def run_probe():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(PROBE):
+            probe.step(tr.actions, out=p_out)
+        e1.record()
+        probe_events.append((e0, e1))
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 2 if cfg.use_graphs else 0)):   # graphs: 1 eager epoch, then capture, then replay
         tr.run_epoch(sync=False)
-    tr.profile_stride = args.event_stride
+    run_probe()
+    probe_events.clear()
+    if args.eager_rollout:
+        tr.profile_stride = args.event_stride
     tr.k1_events = []
     tr.phase_events = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tr.run_epoch(sync=False)
+        run_probe()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    k1_us = float(np.mean([a.elapsed_time(b) for a, b in tr.k1_events]) * 1e3) if tr.k1_events else float("nan")
+    k1_us = float(np.mean([a.elapsed_time(b) for a, b in probe_events]) * 1e3 / PROBE)
+    k1_bracketed_us = float(np.mean([a.elapsed_time(b) for a, b in tr.k1_events]) * 1e3) if tr.k1_events else None
+    probe.close()
     info = tr.envs.launch_info()
     split = {"rollout_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in tr.phase_events])),
              "gae_update_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in tr.phase_events]))}
@@ -154,11 +179,13 @@ def main():
                                    f"n_envs={cfg.n_envs}/GPU, n_steps={cfg.n_steps}, batch_size={cfg.batch_size}, "
                                    f"train_iters={cfg.train_iters}; one step = one PPO epoch (rollout + GAE + update)",
                        "n_envs_total": cfg.n_envs * world, "parallelism": f"env-sharded dp{world}, 1 flat grad all-reduce/minibatch",
-                       "env_kernel": info, "policy_step": args.policy, "epoch_split": split, "numerics": "float64 kinematic state, float32 ray geometry" if args.env_dtype == "f32"
+                       "env_kernel": info, "policy_step": args.policy, "hip_graphs": bool(cfg.use_graphs), "epoch_split": split, "numerics": "float64 kinematic state, float32 ray geometry" if args.env_dtype == "f32"
                        else "float64 throughout (reference operation order)"},
             "roofline": {"kernel": "env_step_kernel (K1)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "launch_us": k1_us, "algorithmic_bytes_per_launch": algo_bytes,
+                         "launch_us": k1_us, "launch_us_method": f"{PROBE} back-to-back launches of K1 on an identical env batch between two "
+                         "HIP events on the launch stream, once per timed epoch", "launch_us_bracketed_in_rollout": k1_bracketed_us,
+                         "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "K1 is fp32-VALU-bound, not HBM-bound (DESIGN.md); see `valu`",
                          "valu": {"achieved": ALGO_FLOPS.get(nr, 0) * cfg.n_envs / (k1_us * 1e-6) / 1e12,
                                   "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

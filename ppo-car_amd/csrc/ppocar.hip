@@ -391,7 +391,13 @@ __device__ __forceinline__ void env_step_body(const EnvParams<T>& p, const int t
     }
 }
 
-template <typename T, int RPL>
+// MIXED = false: every env is on track 0 -- straight-line body, all track data through scalar loads.
+// MIXED = true : per-env track ids.  Waterfall: the body runs once per distinct track id present in the
+// wavefront, so header / segment addresses stay wave-uniform.  (The loop is driven by a ballot of the lanes
+// still to do: a plain readfirstlane(mine) is loop-invariant to the compiler and gets hoisted.  Inside that
+// loop the compiler can no longer prove the segment table unclobbered, so its loads become uniform VECTOR
+// loads -- slower, which is why the single-track case has its own instantiation.)
+template <typename T, int RPL, bool MIXED>
 __global__ __launch_bounds__(256) void env_step_kernel(const EnvParams<T> p, const int64_t* __restrict__ actions,
                                                        const double reward_scale, float* __restrict__ obs,
                                                        float* __restrict__ reward, float* __restrict__ term_out,
@@ -401,13 +407,9 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvParams<T> p, con
     const int64_t e = lane >> p.lg;
     const int g = (int)(lane & ((1 << p.lg) - 1));
     if (e >= p.N) return;  // whole env groups leave together (N*G lanes are a multiple of G)
-    if (p.track_id == nullptr) {
+    if constexpr (!MIXED) {
         env_step_body<T, RPL>(p, 0, e, g, actions, reward_scale, obs, reward, term_out, trunc_out, gates_passed, final_obs);
     } else {
-        // Waterfall: run the body once per distinct track id present in this wavefront so that the track
-        // header / segment loads stay wave-uniform (scalar).  One pass when the wave is uniform.  The loop
-        // is driven by a ballot of the lanes still to do (a plain readfirstlane(mine) is loop-invariant to
-        // the compiler and gets hoisted out of the loop).
         const int mine = p.track_id[e];
         uint64_t todo = __ballot(1);
         while (todo) {
@@ -928,8 +930,12 @@ struct pc_env {
 template <typename T, int RPL>
 static void launch_step(const pc_env* e, const int64_t* actions, double reward_scale, float* obs, float* reward, float* term,
                         float* trunc, int32_t* gates_passed, float* final_obs, hipStream_t st) {
-    hipLaunchKernelGGL((env_step_kernel<T, RPL>), dim3(e->blocks), dim3(256), 0, st, e->params<T>(), actions, reward_scale, obs,
-                       reward, term, trunc, gates_passed, final_obs);
+    if (e->track_id)
+        hipLaunchKernelGGL((env_step_kernel<T, RPL, true>), dim3(e->blocks), dim3(256), 0, st, e->params<T>(), actions,
+                           reward_scale, obs, reward, term, trunc, gates_passed, final_obs);
+    else
+        hipLaunchKernelGGL((env_step_kernel<T, RPL, false>), dim3(e->blocks), dim3(256), 0, st, e->params<T>(), actions,
+                           reward_scale, obs, reward, term, trunc, gates_passed, final_obs);
 }
 
 extern "C" {

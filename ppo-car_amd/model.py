@@ -75,14 +75,17 @@ class Agent(nn.Module):
 
     @torch.no_grad()
     def act(self, x, out_action=None, out_logprob=None, out_value=None, out_action_f32=None, out_logits=None, fused=True,
-            repack=True, offset_dev=None):
+            repack=True, offset_dev=None, offset=None):
         """Rollout-time variant of get_action_and_value(x): same distribution, no autograd.
         fused=True: ONE HIP kernel (pc_policy_act) -- both MLPs on the fp32 matrix cores, the categorical
         draw, log_prob and the value; falls back to the two-kernel form when the shape is outside its menu.
         repack=False reuses the weight image of the last pack_policy() (the rollout packs once).
         fused=False: torch GEMMs for the MLPs + the sampling-tail kernel (pc_sample).
-        Counter-based Philox stream keyed by (rng_seed, call counter [+ *offset_dev]).  Returns action int64 [N],
-        logprob [N], value [N] (written into the out_* tensors when given)."""
+        Counter-based Philox stream keyed by (rng_seed, offset [+ *offset_dev]); offset defaults to a per-agent
+        call counter.  Returns action int64 [N], logprob [N], value [N] (written into the out_* tensors when given)."""
+        if offset is None:
+            offset = self._rng_offset
+            self._rng_offset += 1
         N = x.shape[0]
         dev = x.device
         action = out_action if out_action is not None else torch.empty(N, dtype=torch.int64, device=dev)
@@ -96,16 +99,16 @@ class Agent(nn.Module):
                 a1, a2 = self.actor[0], self.actor[2]
                 value = out_value if out_value is not None else torch.empty(N, dtype=torch.float32, device=dev)
                 check(lib.pc_policy_act(di, x.data_ptr(), N, x.shape[1], a1.out_features, a2.out_features, self._image.data_ptr(),
-                                        int(self.rng_seed), self._rng_offset, ptr(offset_dev), action.data_ptr(),
+                                        int(self.rng_seed), int(offset), ptr(offset_dev), action.data_ptr(),
                                         ptr(out_action_f32), logprob.data_ptr(), value.data_ptr(), ptr(out_logits), stream),
                       "pc_policy_act")
-                self._rng_offset += 1
                 return action, logprob, value
+        if offset_dev is not None:
+            raise NotImplementedError("a device-side RNG offset needs the fused policy kernel")
         logits = self.actor(x).contiguous()
         A = logits.shape[1]
-        check(lib.pc_sample(di, logits.data_ptr(), N, A, int(self.rng_seed), self._rng_offset, action.data_ptr(),
+        check(lib.pc_sample(di, logits.data_ptr(), N, A, int(self.rng_seed), int(offset), action.data_ptr(),
                             logprob.data_ptr(), None, stream), "pc_sample")
-        self._rng_offset += 1
         value = self.critic(x).view(-1)
         if out_value is not None:
             out_value.copy_(value)

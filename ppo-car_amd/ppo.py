@@ -271,17 +271,19 @@ class Trainer:
         self.profile_stride = 0      # bench.py: bracket every k-th env-step launch with events on the launch stream
         self.k1_events = []
         self.phase_events = None     # bench.py: list of (start, rollout_end, update_end) events per epoch
+        self.rng_base = torch.zeros(1, dtype=torch.int64, device=self.device)   # device-side Philox offset base
+        self._rollout_graph = None
+        self._eager_rollouts = 0
 
     # ---- train.py:173-195 ---------------------------------------------------------------------------
     @torch.no_grad()
-    def rollout(self):
+    def _rollout_body(self, events=False):
         cfg, buf, envs, agent = self.cfg, self.buffer, self.envs, self.agent
         T = cfg.n_steps
         buf.obs_buf[0].copy_(self.next_obs)
         buf.term_buf[0].copy_(self.next_term)       # flags that preceded obs 0 (train.py:176-177)
         buf.trunc_buf[0].copy_(self.next_trunc)
-        if cfg.policy == "fused":
-            agent.pack_policy()                      # weights are constant during the rollout: one LDS image for all T steps
+        fused = cfg.policy == "fused" and agent.pack_policy()   # weights are constant during the rollout: one LDS image
         for t in range(T):
             obs = buf.obs_buf[t]
             if cfg.policy == "torch":
@@ -289,13 +291,16 @@ class Trainer:
                 buf.logprob_buf[t].copy_(logprobs)
                 buf.val_buf[t].copy_(values.view(-1))
                 buf.act_buf[t].copy_(actions)        # stored as float32 like the reference (buffer.py:13)
-            else:   # "fused": one kernel for MLPs + draw; "sample": torch GEMMs + the sampling kernel
+            elif fused:   # one kernel: both MLPs + draw; Philox offset = rollout-step index + the device-side base
                 actions, _, _ = agent.act(obs, out_action=self.actions, out_logprob=buf.logprob_buf[t], out_value=buf.val_buf[t],
-                                          out_action_f32=buf.act_buf[t], fused=cfg.policy == "fused", repack=False)
+                                          out_action_f32=buf.act_buf[t], fused=True, repack=False, offset=t, offset_dev=self.rng_base)
+            else:         # "sample": torch GEMMs + the sampling kernel
+                actions, _, _ = agent.act(obs, out_action=self.actions, out_logprob=buf.logprob_buf[t], out_value=buf.val_buf[t],
+                                          out_action_f32=buf.act_buf[t], fused=False)
             last = t == T - 1
             out = (self.next_obs if last else buf.obs_buf[t + 1], buf.rew_buf[t],
                    self.next_term if last else buf.term_buf[t + 1], self.next_trunc if last else buf.trunc_buf[t + 1])
-            if self.profile_stride and t % self.profile_stride == 0:
+            if events and self.profile_stride and t % self.profile_stride == 0:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 envs.step(actions, out=out)
@@ -303,8 +308,26 @@ class Trainer:
                 self.k1_events.append((e0, e1))
             else:
                 envs.step(actions, out=out)          # train.py:185 -- zero-copy into the buffer rows
-        buf.ptr = T
-        self.global_step_idx += cfg.n_envs * T * self.world_size   # train.py:174, whole job
+        self.rng_base += T                           # next rollout draws from fresh Philox counters
+
+    def rollout(self):
+        """n_steps vector-env steps into the buffer.  With use_graphs (and the fused policy step) the whole rollout
+        -- 2 kernels per step -- is captured into ONE HIP graph after a first eager pass and replayed afterwards:
+        at small n_envs the per-step host work (~50 us of Python / ctypes) exceeds the GPU work."""
+        cfg = self.cfg
+        graphable = cfg.use_graphs and cfg.policy == "fused" and self.device.type == "cuda" and not self.profile_stride
+        if graphable and self._rollout_graph is None and self._eager_rollouts >= 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._rollout_body()
+            self._rollout_graph = g
+        if graphable and self._rollout_graph is not None:
+            self._rollout_graph.replay()
+        else:
+            self._rollout_body(events=True)
+            self._eager_rollouts += 1
+        self.buffer.ptr = cfg.n_steps
+        self.global_step_idx += cfg.n_envs * cfg.n_steps * self.world_size   # train.py:174, whole job
 
     # ---- train.py:197-269 ---------------------------------------------------------------------------
     def update(self):

@@ -108,3 +108,27 @@ def test_short_training_run_improves_reward_and_logs_reference_scalars():
     assert set(sd) == {"actor.0.weight", "actor.0.bias", "actor.2.weight", "actor.2.bias",
                        "critic.0.weight", "critic.0.bias", "critic.2.weight", "critic.2.bias"}
     tr.close()
+
+
+def test_graph_rollout_is_bitwise_the_eager_rollout():
+    """The captured-and-replayed rollout (one HIP graph for all steps) and the eager one draw from the same
+    Philox counters (device-side base + step index), so whole buffers must agree bit for bit."""
+    res = {}
+    for use_graphs in (False, True):
+        cfg = _cfg(use_graphs=use_graphs, n_envs=512, n_steps=48)
+        tr = Trainer(cfg, device="cuda")
+        snaps = []
+        for ep in range(3):            # graph mode: epoch 0 eager, capture before epoch 1, replay epochs 1 and 2
+            tr.rollout()
+            torch.cuda.synchronize()
+            snaps.append([t.clone() for t in (tr.buffer.obs_buf, tr.buffer.act_buf, tr.buffer.rew_buf, tr.buffer.val_buf,
+                                              tr.buffer.logprob_buf, tr.buffer.term_buf, tr.next_obs)])
+            tr.buffer.ptr = 0          # no update in between: weights stay fixed, so both modes see the same policy
+        res[use_graphs] = snaps
+        assert (tr._rollout_graph is not None) == use_graphs
+        assert int(tr.rng_base) == 3 * 48
+        tr.close()
+    for ep in range(3):
+        for a, b in zip(res[False][ep], res[True][ep]):
+            assert torch.equal(a, b), ep
+    assert not torch.equal(res[True][0][1], res[True][1][1])     # different epochs draw different actions
