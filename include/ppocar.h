@@ -140,6 +140,26 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
                   uint64_t offset, const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob, float* value,
                   float* logits_out, void* stream);
 
+/* ---- the non-GEMM work of one PPO minibatch step (train.py:230-261), three launches:
+ * pc_ppo_gather : traj_*[batch_indices] (train.py:233-238,249): idx [B] int64 into the flattened trajectories
+ *                 obs [M][D], act / logprob / adv / ret [M]  ->  o_obs [B][D], o_act / o_logprob / o_adv / o_ret [B].
+ * pc_ppo_loss   : the clipped-PPO loss (train.py:235-255: ratio, per-minibatch advantage normalisation with the
+ *                 unbiased std, max(-A r, -A clamp(r)), 0.5 (v - ret)^2, entropy) given the network outputs
+ *                 logits [B][A], values [B]; writes its gradients dlogits [B][A], dvalues [B] (what autograd would
+ *                 hand to the two MLPs) and adds (policy_loss, value_loss, entropy, total) to metrics[4]
+ *                 (train.py:263-266).  2 <= B <= 1024.
+ * pc_clip_adam  : nn.utils.clip_grad_norm_(max_norm) (train.py:260) + Adam.step() (train.py:261; eps/betas as
+ *                 train.py:146 configures) over flat float32 buffers of n elements; lr and the step counter live on
+ *                 the device (HIP-graph replay); grad_scale = 1/world_size folds the gradient average in. */
+int pc_ppo_gather(int device, const int64_t* idx, int B, int D, const float* obs, const float* act, const float* logprob,
+                  const float* adv, const float* ret, float* o_obs, float* o_act, float* o_logprob, float* o_adv, float* o_ret,
+                  void* stream);
+int pc_ppo_loss(int device, const float* logits, const float* values, const float* act, const float* old_logprob,
+                const float* adv, const float* ret, int B, int A, double clip_ratio, double vf_coef, double ent_coef,
+                float* dlogits, float* dvalues, float* metrics, void* stream);
+int pc_clip_adam(int device, float* param, float* grad, float* exp_avg, float* exp_avg_sq, float* step_count, const float* lr_dev,
+                 int64_t n, double max_norm, double grad_scale, double beta1, double beta2, double eps, void* stream);
+
 const char* pc_strerror(int code);
 /* Last HIP error string seen by this thread (diagnostics for PC_ERR_HIP). */
 const char* pc_last_hip_error(void);

@@ -680,9 +680,14 @@ __global__ __launch_bounds__(256) void policy_pack_kernel(const int KS, const in
 
 __device__ __forceinline__ float relu_f(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
 
-// 512 threads = 8 waves (2 per SIMD: while one waits on LDS or its ReLU the other feeds the matrix pipe);
-// a wave owns 32 envs (2 column tiles of 16), a workgroup 256 envs per pass.
-template <int KS>
+// 512 threads = 8 waves (2 per SIMD: while one waits on LDS or its ReLU the other feeds the matrix pipe).
+// SPLIT = false (large batches): a wave owns 32 envs (2 column tiles of 16) and walks all 32 hidden tiles;
+//                a workgroup covers 256 envs per pass.
+// SPLIT = true  (small batches): the 8 waves of a workgroup share the SAME 32 envs and take 4 hidden tiles
+//                each; their partial [16 x 32] outputs are summed through LDS.  A pass is 8x shorter, so a
+//                batch that cannot fill the chip with 256-env workgroups (n_envs < ~32 k) finishes in a
+//                fraction of the single-pass latency of the other form.
+template <int KS, bool SPLIT>
 __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ obs, const int64_t N, const int D, const int A,
                                                      const float* __restrict__ image, const uint64_t seed, const uint64_t offset,
                                                      const uint64_t* __restrict__ offset_dev, int64_t* __restrict__ action,
@@ -690,6 +695,7 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
                                                      float* __restrict__ value, float* __restrict__ logits_out) {
     constexpr int HID = 256, NT = 2 * HID / 16;  // 32 hidden tiles: 16 actor + 16 critic
     constexpr int LD1 = pol_ld1(KS), LDO = 17, ET = 2;
+    constexpr int ENVS_PER_WG = SPLIT ? 32 : 256;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sW1 = lds;                        // [512][LD1]
     float* sB1 = sW1 + 2 * HID * LD1;        // [512]
@@ -720,9 +726,10 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
 
     const uint64_t off = offset + (offset_dev ? *offset_dev : 0);
     float* myOut = sOut + wave * 32 * LDO;
-    const int64_t n_chunks = (N + 255) / 256;
+    const int ht0 = SPLIT ? wave * (NT / 8) : 0, ht1 = SPLIT ? ht0 + NT / 8 : NT;
+    const int64_t n_chunks = (N + ENVS_PER_WG - 1) / ENVS_PER_WG;
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        const int64_t env0 = chunk * 256 + wave * 32;
+        const int64_t env0 = chunk * ENVS_PER_WG + (SPLIT ? 0 : wave * 32);
         // ---- B operands of layer 1: X^T, lane (k = lk, j = lc) of env tile et, k-step ks
         float x[ET][KS];
 #pragma unroll
@@ -739,13 +746,13 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
         for (int et = 0; et < ET; ++et) out[et] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         // A operands of the first hidden tile; inside the loop the next tile's are fetched under this tile's MFMAs
         float a1[KS], a2[4];
-        f32x4 bias = *reinterpret_cast<const f32x4*>(sB1 + 4 * lk);
+        f32x4 bias = *reinterpret_cast<const f32x4*>(sB1 + 16 * ht0 + 4 * lk);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a1[ks] = sW1[lc * LD1 + 4 * ks + lk];
+        for (int ks = 0; ks < KS; ++ks) a1[ks] = sW1[(16 * ht0 + lc) * LD1 + 4 * ks + lk];
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) a2[reg] = sW2[reg * 64 + lane];
-        for (int ht = 0; ht < NT; ++ht) {
-            const int hn = ht + 1 < NT ? ht + 1 : ht;
+        for (int reg = 0; reg < 4; ++reg) a2[reg] = sW2[(ht0 * 4 + reg) * 64 + lane];
+        for (int ht = ht0; ht < ht1; ++ht) {
+            const int hn = ht + 1 < ht1 ? ht + 1 : ht;
             float n1[KS], n2[4];
             const f32x4 nbias = *reinterpret_cast<const f32x4*>(sB1 + 16 * hn + 4 * lk);
 #pragma unroll
@@ -775,19 +782,26 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
 #pragma unroll
         for (int et = 0; et < ET; ++et)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) myOut[(16 * et + lc) * LDO + 4 * lk + reg] = out[et][reg] + sB2[4 * lk + reg];
+            for (int reg = 0; reg < 4; ++reg) myOut[(16 * et + lc) * LDO + 4 * lk + reg] = out[et][reg];
         __syncthreads();
         const int64_t e = env0 + lane;
-        if (lane < 32 && e < N) {
-            const float* row = myOut + lane * LDO;
+        if (lane < 32 && e < N && (!SPLIT || wave == 0)) {
             float l[16];
+            float val = 0.0f;
             float mx = -INFINITY;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                l[i] = i < A ? row[i] : -INFINITY;
+                float v = sB2[i];
+                if constexpr (SPLIT) {   // sum the 8 waves' partial tiles, fixed order
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) v += sOut[(w * 32 + lane) * LDO + i];
+                } else {
+                    v += myOut[lane * LDO + i];
+                }
+                if (i == A) val = v;
+                l[i] = i < A ? v : -INFINITY;
                 mx = fmaxf(mx, l[i]);
             }
-            const float val = row[A];
             float sum = 0.0f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) sum += i < A ? expf(l[i] - mx) : 0.0f;
@@ -813,6 +827,143 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
             value[e] = val;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// K6-K8: the PPO minibatch step's non-GEMM work (train.py:230-261), three launches instead of ~140
+// ------------------------------------------------------------------------------------------
+// K6: gather one minibatch -- traj_obs[batch_indices] etc. (train.py:233-238,249)
+__global__ __launch_bounds__(256) void ppo_gather_kernel(const int64_t* __restrict__ idx, const int B, const int D,
+                                                         const float* __restrict__ obs, const float* __restrict__ act,
+                                                         const float* __restrict__ logprob, const float* __restrict__ adv,
+                                                         const float* __restrict__ ret, float* __restrict__ o_obs,
+                                                         float* __restrict__ o_act, float* __restrict__ o_logprob,
+                                                         float* __restrict__ o_adv, float* __restrict__ o_ret) {
+    const int W = D + 4;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * W) return;
+    const int b = i / W, c = i - b * W;
+    const int64_t src = idx[b];
+    if (c < D) o_obs[b * D + c] = obs[src * D + c];
+    else if (c == D) o_act[b] = act[src];
+    else if (c == D + 1) o_logprob[b] = logprob[src];
+    else if (c == D + 2) o_adv[b] = adv[src];
+    else o_ret[b] = ret[src];
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {  // all threads get the sum; blockDim <= 1024
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.0f;
+    for (int i = 0; i < nw; ++i) t += sh[i];
+    return t;
+}
+
+// K7: clipped-PPO loss of one minibatch, forward AND backward w.r.t. the network outputs (train.py:235-255):
+//   ratio = exp(new_lp - old_lp); A = (adv - mean) / max(std_unbiased, 1e-5)
+//   L_pi = mean(max(-A r, -A clamp(r, 1-c, 1+c))); L_v = 0.5 mean((v - ret)^2); H = mean(entropy)
+//   loss = L_pi + vf L_v - ec H
+// One workgroup, one sample per thread (B <= 1024).  Gradients as autograd produces them:
+//   dloss/dv_i      = vf (v_i - ret_i) / B
+//   dloss/dlp_i     = (1/B) r_i * (-A_i if -A_i r_i >= -A_i clamp(r_i) else 0)     [torch.max / clamp backward]
+//   dloss/dlogit_ik = dloss/dlp_i (1[k = a_i] - p_ik) + (ec/B) p_ik (log p_ik + H_i)
+// metrics[0..3] += (L_pi, L_v, H, loss)  (train.py:263-266).
+template <int AMAX>
+__global__ __launch_bounds__(1024) void ppo_loss_kernel(const float* __restrict__ logits, const float* __restrict__ values,
+                                                        const float* __restrict__ act, const float* __restrict__ old_lp,
+                                                        const float* __restrict__ adv, const float* __restrict__ ret, const int B,
+                                                        const int A, const float clip, const float vf, const float ec,
+                                                        float* __restrict__ dlogits, float* __restrict__ dvalues,
+                                                        float* __restrict__ metrics) {
+    __shared__ float sh[16];
+    const int i = threadIdx.x;
+    const bool on = i < B;
+    const float invB = 1.0f / (float)B;
+    const float a_raw = on ? adv[i] : 0.0f;
+    const float mean = block_sum(a_raw, sh) * invB;
+    const float dev = on ? a_raw - mean : 0.0f;
+    const float var = block_sum(dev * dev, sh) / (float)(B - 1);   // unbiased, as Tensor.std() (train.py:239)
+    const float sd = fmaxf(sqrtf(var), 1e-5f);                     // torch.max(std, 1e-5) (train.py:239-240)
+    float pl = 0.0f, vl = 0.0f, ent = 0.0f;
+    if (on) {
+        float l[AMAX];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < AMAX; ++k) {
+            l[k] = k < A ? logits[i * A + k] : -INFINITY;
+            mx = fmaxf(mx, l[k]);
+        }
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < AMAX; ++k) sum += k < A ? expf(l[k] - mx) : 0.0f;
+        const float lse = mx + logf(sum);
+        const int a = (int)act[i];
+        float new_lp = 0.0f;
+        float pk[AMAX], lpk[AMAX];
+#pragma unroll
+        for (int k = 0; k < AMAX; ++k) {
+            lpk[k] = k < A ? l[k] - lse : 0.0f;
+            pk[k] = k < A ? expf(lpk[k]) : 0.0f;
+            ent -= pk[k] * lpk[k];
+            if (k == a) new_lp = lpk[k];
+        }
+        const float r = expf(new_lp - old_lp[i]);                                  // :235
+        const float An = dev / sd;                                                 // :238-240
+        const float rc = fminf(fmaxf(r, 1.0f - clip), 1.0f + clip);
+        const float pl1 = -An * r, pl2 = -An * rc;                                 // :243-244
+        pl = fmaxf(pl1, pl2);                                                      // :245
+        const float dv = values[i] - ret[i];
+        vl = 0.5f * dv * dv;                                                       // :249
+        const float g_lp = (pl1 >= pl2 ? -An : 0.0f) * r * invB;
+        dvalues[i] = vf * dv * invB;
+#pragma unroll
+        for (int k = 0; k < AMAX; ++k)
+            if (k < A) dlogits[i * A + k] = g_lp * ((k == a ? 1.0f : 0.0f) - pk[k]) + ec * invB * pk[k] * (lpk[k] + ent);
+    }
+    const float s_pl = block_sum(pl, sh) * invB, s_vl = block_sum(vl, sh) * invB, s_en = block_sum(ent, sh) * invB;
+    if (i == 0) {
+        metrics[0] += s_pl;
+        metrics[1] += s_vl;
+        metrics[2] += s_en;
+        metrics[3] += s_pl + vf * s_vl - ec * s_en;                                // :255
+    }
+}
+
+// K8: nn.utils.clip_grad_norm_(params, max_norm) (train.py:260) + Adam.step() (train.py:261, lr from the device,
+// eps 1e-5, betas (0.9, 0.999), no weight decay / amsgrad) over the flat parameter bucket, one workgroup.
+// grad_scale folds the 1/world_size of the gradient average in.  state[0] = step count (float), updated here.
+__global__ __launch_bounds__(1024) void clip_adam_kernel(float* __restrict__ param, float* __restrict__ grad,
+                                                         float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
+                                                         float* __restrict__ step_count, const float* __restrict__ lr_dev,
+                                                         const int n, const float max_norm, const float grad_scale,
+                                                         const float beta1, const float beta2, const float eps) {
+    __shared__ float sh[16];
+    float ss = 0.0f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float g = grad[i] * grad_scale;
+        ss += g * g;
+    }
+    const float total_norm = sqrtf(block_sum(ss, sh));
+    const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);   // clip_coef_clamped
+    const float step = step_count[0] + 1.0f;
+    const float bc1 = 1.0f - powf(beta1, step), bc2 = 1.0f - powf(beta2, step);
+    const float step_size = lr_dev[0] / bc1;
+    const float bc2_sqrt = sqrtf(bc2);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float g = grad[i] * grad_scale * coef;
+        grad[i] = g;                                                   // clip_grad_norm_ scales the grads in place
+        const float m = exp_avg[i] + (1.0f - beta1) * (g - exp_avg[i]);            // exp_avg.lerp_(grad, 1 - beta1)
+        const float v = beta2 * exp_avg_sq[i] + (1.0f - beta2) * g * g;            // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+        exp_avg[i] = m;
+        exp_avg_sq[i] = v;
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        param[i] -= step_size * (m / denom);                                        // param.addcdiv_(exp_avg, denom, -step_size)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) step_count[0] = step;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1334,23 +1485,69 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
         n_cu[device] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int cus = device < 64 ? n_cu[device] : 256;
-    const int64_t chunks = (N + 255) / 256;
+    const bool split = N < 32768;  // too few 256-env workgroups to fill the chip: split the hidden tiles over the waves instead
+    const int64_t chunks = split ? (N + 31) / 32 : (N + 255) / 256;
     const int blocks = (int)(chunks < cus ? chunks : cus);  // one ~100-KB-LDS workgroup per CU, persistent over env chunks
     hipStream_t st = (hipStream_t)stream;
-#define PC_POL(KSV)                                                                                                      \
+#define PC_POL(KSV, SPL)                                                                                                 \
     do {                                                                                                                 \
         static bool attr_set[64] = {false};                                                                              \
         if (device < 64 && !attr_set[device]) {                                                                          \
-            HIPCHK(hipFuncSetAttribute((const void*)policy_kernel<KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HIPCHK(hipFuncSetAttribute((const void*)policy_kernel<KSV, SPL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_set[device] = true;                                                                                     \
         }                                                                                                                \
-        hipLaunchKernelGGL(policy_kernel<KSV>, dim3(blocks), dim3(512), lds, st, obs, N, D, A, image, seed, offset, offset_dev, \
+        hipLaunchKernelGGL((policy_kernel<KSV, SPL>), dim3(blocks), dim3(512), lds, st, obs, N, D, A, image, seed, offset, offset_dev, \
                            action, action_f32, logprob, value, logits_out);                                              \
     } while (0)
-    if (KS == 5) PC_POL(5);
-    else if (KS == 6) PC_POL(6);
-    else PC_POL(10);
+    if (split) {
+        if (KS == 5) PC_POL(5, true);
+        else if (KS == 6) PC_POL(6, true);
+        else PC_POL(10, true);
+    } else {
+        if (KS == 5) PC_POL(5, false);
+        else if (KS == 6) PC_POL(6, false);
+        else PC_POL(10, false);
+    }
 #undef PC_POL
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_ppo_gather(int device, const int64_t* idx, int B, int D, const float* obs, const float* act, const float* logprob,
+                  const float* adv, const float* ret, float* o_obs, float* o_act, float* o_logprob, float* o_adv, float* o_ret,
+                  void* stream) {
+    if (!idx || !obs || !act || !logprob || !adv || !ret || !o_obs || !o_act || !o_logprob || !o_adv || !o_ret || B < 1 || D < 1)
+        return PC_ERR_INVALID_ARG;
+    DeviceGuard guard(device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    const int total = B * (D + 4);
+    hipLaunchKernelGGL(ppo_gather_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, idx, B, D, obs, act,
+                       logprob, adv, ret, o_obs, o_act, o_logprob, o_adv, o_ret);
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_ppo_loss(int device, const float* logits, const float* values, const float* act, const float* old_logprob,
+                const float* adv, const float* ret, int B, int A, double clip_ratio, double vf_coef, double ent_coef,
+                float* dlogits, float* dvalues, float* metrics, void* stream) {
+    if (!logits || !values || !act || !old_logprob || !adv || !ret || !dlogits || !dvalues || !metrics) return PC_ERR_INVALID_ARG;
+    if (B < 2 || B > 1024 || A < 1 || A > 16) return PC_ERR_UNSUPPORTED;
+    DeviceGuard guard(device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    const int threads = ((B + 63) / 64) * 64;
+    hipLaunchKernelGGL(ppo_loss_kernel<16>, dim3(1), dim3(threads), 0, (hipStream_t)stream, logits, values, act, old_logprob, adv,
+                       ret, B, A, (float)clip_ratio, (float)vf_coef, (float)ent_coef, dlogits, dvalues, metrics);
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_clip_adam(int device, float* param, float* grad, float* exp_avg, float* exp_avg_sq, float* step_count, const float* lr_dev,
+                 int64_t n, double max_norm, double grad_scale, double beta1, double beta2, double eps, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step_count || !lr_dev || n < 1 || n > (1 << 26)) return PC_ERR_INVALID_ARG;
+    DeviceGuard guard(device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, step_count,
+                       lr_dev, (int)n, (float)max_norm, (float)grad_scale, (float)beta1, (float)beta2, (float)eps);
     HIPCHK(hipGetLastError());
     return PC_OK;
 }

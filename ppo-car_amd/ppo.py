@@ -21,6 +21,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ._capi import check, lib
 from .buffer import Buffer
 from .env import VecCarEnv
 from .model import Agent
@@ -49,7 +50,9 @@ class PPOConfig:
     env_dtype: str = "f32"
     seed: int = 0
     full_sweep: bool = False               # opt-in: iterate over all n_steps*n_envs samples per train iter
-    use_graphs: bool = True                # capture the minibatch update in HIP graphs (GPU only)
+    use_graphs: bool = True                # capture the minibatch update / the rollout in HIP graphs (GPU only)
+    fused_update: bool = True              # GPU only: minibatch gather, PPO loss fwd+bwd and clip+Adam as three HIP kernels
+                                           # (the MLP GEMMs stay torch autograd); False = the reference's torch ops throughout
     policy: str = "fused"                  # rollout policy step: "fused" (one MFMA kernel: MLPs + draw),
                                            # "sample" (torch GEMMs + sampling kernel), "torch" (reference ops)
 
@@ -119,6 +122,12 @@ class PPOLearner:
             dist.broadcast(self.flat_param, src=0)       # every rank starts from rank 0's parameters
         self.exchange = GradExchange(self.flat_grad, world_size)
         self.graphs = bool(cfg.use_graphs) and self.device.type == "cuda"
+        self.fused = bool(cfg.fused_update) and self.device.type == "cuda" and 2 <= cfg.batch_size <= 1024
+        if self.fused:    # Adam state of the fused clip+Adam kernel (pc_clip_adam): flat, on the device
+            self.exp_avg = torch.zeros_like(self.flat_param)
+            self.exp_avg_sq = torch.zeros_like(self.flat_param)
+            self.step_count = torch.zeros(1, device=self.device)
+            self.lr_dev = torch.full((1,), cfg.learning_rate, device=self.device, dtype=torch.float32)
         if self.graphs:   # capturable Adam: step count and lr live on the device, so a captured step stays valid
             lr = torch.tensor(cfg.learning_rate, device=self.device, dtype=torch.float32)
             self.optimizer = torch.optim.Adam(agent.parameters(), lr=lr, eps=1e-5, capturable=True, foreach=True)
@@ -134,8 +143,52 @@ class PPOLearner:
         self._graph_key = None
 
     def current_lr(self):
+        if self.fused:
+            return float(self.lr_dev)
         lr = self.optimizer.param_groups[0]["lr"]
         return float(lr) if torch.is_tensor(lr) else lr
+
+    def _dev_index(self):
+        return self.device.index if self.device.index is not None else torch.cuda.current_device()
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    # ---- fused form of one minibatch (HIP kernels for everything but the MLP GEMMs) ----------------------
+    def _fused_alloc(self, D, A):
+        B = self.cfg.batch_size
+        z = lambda *sh: torch.zeros(*sh, device=self.device, dtype=torch.float32)
+        self._f = dict(obs=z(B, D), act=z(B), lp=z(B), adv=z(B), ret=z(B), dlogits=z(B, A), dvalues=z(B, 1))
+
+    def _fused_fwd_bwd(self, idx, obs, act, logprob, adv, ret):
+        """gather -> MLP forward (torch) -> loss fwd+bwd kernel -> MLP backward (torch autograd) into flat_grad"""
+        cfg, f, B = self.cfg, self._f, self.cfg.batch_size
+        di, st = self._dev_index(), self._stream()
+        check(lib.pc_ppo_gather(di, idx.data_ptr(), B, obs.shape[1], obs.data_ptr(), act.data_ptr(), logprob.data_ptr(),
+                                adv.data_ptr(), ret.data_ptr(), f["obs"].data_ptr(), f["act"].data_ptr(), f["lp"].data_ptr(),
+                                f["adv"].data_ptr(), f["ret"].data_ptr(), st), "pc_ppo_gather")
+        logits = self.agent.actor(f["obs"])
+        values = self.agent.critic(f["obs"])
+        check(lib.pc_ppo_loss(di, logits.data_ptr(), values.data_ptr(), f["act"].data_ptr(), f["lp"].data_ptr(),
+                              f["adv"].data_ptr(), f["ret"].data_ptr(), B, logits.shape[1], cfg.clip_ratio, cfg.vf_coef,
+                              cfg.ent_coef, f["dlogits"].data_ptr(), f["dvalues"].data_ptr(), self.metrics.data_ptr(), st),
+              "pc_ppo_loss")
+        self.flat_grad.zero_()
+        torch.autograd.backward([logits, values], [f["dlogits"], f["dvalues"]])
+
+    def _fused_apply(self):
+        cfg = self.cfg
+        check(lib.pc_clip_adam(self._dev_index(), self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                               self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(), self.lr_dev.data_ptr(),
+                               self.flat_param.numel(), cfg.max_grad_norm, 1.0 / self.world_size, 0.9, 0.999, 1e-5,
+                               self._stream()), "pc_clip_adam")
+
+    def fused_minibatch_step(self, idx, obs, act, logprob, adv, ret):
+        self._fused_fwd_bwd(idx, obs, act, logprob, adv, ret)
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)     # the 1/W is folded into pc_clip_adam
+        self._fused_apply()
 
     def draw_indices(self, M):
         """train.py:225-230: per train iter a fresh shuffle of all M = n_steps*n_envs indices, of which only
@@ -170,44 +223,58 @@ class PPOLearner:
 
     # ---- HIP-graph form ------------------------------------------------------------------------------------
     def _build_graphs(self, obs, act, logprob, adv, ret):
-        """Capture `idx -> gather -> _fwd_bwd` and `_apply` over the trajectory tensors given (their addresses
-        are baked into the graphs; Buffer keeps them alive and in place across epochs)."""
+        """Capture `idx -> gather -> forward -> loss -> backward` and `clip -> Adam` over the trajectory tensors
+        given (their addresses are baked into the graphs; Buffer keeps them alive and in place across epochs)."""
         B = self.cfg.batch_size
         self._g_idx = torch.zeros(B, dtype=torch.int64, device=self.device)
         self._g_terms = torch.zeros(4, device=self.device)
+        if getattr(self, "_opt_started", False):
+            raise RuntimeError("PPOLearner graphs must be built before the first real optimizer step")
+
+        def half_a():
+            i = self._g_idx
+            if self.fused:
+                self._fused_fwd_bwd(i, obs, act, logprob, adv, ret)
+            else:
+                self._g_terms.copy_(self._fwd_bwd(obs[i], act[i], logprob[i], adv[i], ret[i]))
+
+        def half_b():
+            if self.fused:
+                self._fused_apply()
+            else:
+                self._apply(self._g_terms)
+
         # warm-up on a side stream (allocator / lazy optimizer-state initialisation), then undo its effect
         saved_param, saved_metrics = self.flat_param.clone(), self.metrics.clone()
-        saved_lr = self.optimizer.param_groups[0]["lr"].clone()
+        saved_lr = self.lr_dev.clone() if self.fused else self.optimizer.param_groups[0]["lr"].clone()
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
             for _ in range(3):
-                i = self._g_idx
-                self._g_terms.copy_(self._fwd_bwd(obs[i], act[i], logprob[i], adv[i], ret[i]))
-                self._apply(self._g_terms)
+                half_a()
+                half_b()
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
-        fresh = not getattr(self, "_opt_started", False)
-        if fresh:   # the warm-up steps were the optimizer's first: return its state to "never stepped"
+        if self.fused:   # the warm-up steps were the optimizer's first: return its state to "never stepped"
+            self.exp_avg.zero_(); self.exp_avg_sq.zero_(); self.step_count.zero_()
+            self.lr_dev.copy_(saved_lr)
+        else:
             for st in self.optimizer.state.values():
                 for v in st.values():
                     if torch.is_tensor(v):
                         v.zero_()
-        else:
-            raise RuntimeError("PPOLearner graphs must be built before the first real optimizer step")
+            self.optimizer.param_groups[0]["lr"].copy_(saved_lr)
         self.flat_param.copy_(saved_param)
         self.metrics.copy_(saved_metrics)
-        self.optimizer.param_groups[0]["lr"].copy_(saved_lr)
         self._graph_a, self._graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         single = self.world_size == 1
         with torch.cuda.graph(self._graph_a):
-            i = self._g_idx
-            self._g_terms.copy_(self._fwd_bwd(obs[i], act[i], logprob[i], adv[i], ret[i]))
+            half_a()
             if single:
-                self._apply(self._g_terms)
+                half_b()
         if not single:
             with torch.cuda.graph(self._graph_b):
-                self._apply(self._g_terms)
+                half_b()
         self._graph_key = (obs.data_ptr(), act.data_ptr(), logprob.data_ptr(), adv.data_ptr(), ret.data_ptr(), obs.shape[0])
 
     def update(self, obs, act, logprob, adv, ret):
@@ -222,7 +289,10 @@ class PPOLearner:
         else:
             n_mb = self.n_minibatches
             idx_all = self.draw_indices(M)
-        use_graph = self.graphs and idx_all.shape[1] >= n_mb * B
+        full = idx_all.shape[1] >= n_mb * B          # every minibatch has exactly B samples
+        if self.fused and full and getattr(self, "_f", None) is None:
+            self._fused_alloc(obs.shape[1], self.agent.actor[2].out_features)
+        use_graph = self.graphs and full
         if use_graph and self._graph_key != (obs.data_ptr(), act.data_ptr(), logprob.data_ptr(), adv.data_ptr(),
                                              ret.data_ptr(), M):
             self._build_graphs(obs, act, logprob, adv, ret)
@@ -235,12 +305,21 @@ class PPOLearner:
                     self._g_idx.copy_(idx)
                     self._graph_a.replay()
                     if self.world_size > 1:
-                        self.exchange()
+                        if self.fused:
+                            import torch.distributed as dist
+                            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+                        else:
+                            self.exchange()
                         self._graph_b.replay()
+                elif self.fused and full:
+                    self.fused_minibatch_step(idx, obs, act, logprob, adv, ret)
                 else:
                     self.minibatch_step(obs[idx], act[idx], logprob[idx], adv[idx], ret[idx])
         self._opt_started = True
-        self.scheduler.step()                                                            # :269
+        if self.fused:
+            self.lr_dev.mul_(cfg.learning_rate_decay)                                    # StepLR(step_size=1), :147,:269
+        else:
+            self.scheduler.step()                                                        # :269
 
 
 class Trainer:
