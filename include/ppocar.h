@@ -134,11 +134,30 @@ int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, 
  * logprob, value [N]; logits_out [N][A] or NULL.  PC_ERR_UNSUPPORTED unless H == 256, A <= 15, D <= 40
  * (the caller then uses its own GEMMs + pc_sample). */
 int64_t pc_policy_image_floats(int D, int H, int A);
+/* Work decomposition of pc_policy_act: -1 = automatic (hidden tiles split across the waves of a workgroup below 32768
+ * envs), 0 = never split, 1 = always.  The two forms differ in fp32 summation order (last-bit differences).  Tuning /
+ * test knob, process-wide. */
+int pc_policy_set_split(int mode);
 int pc_policy_pack(int device, int D, int H, int A, const float* aW1, const float* ab1, const float* aW2, const float* ab2,
                    const float* cW1, const float* cb1, const float* cW2, const float* cb2, float* image, void* stream);
 int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, const float* image, uint64_t seed,
                   uint64_t offset, const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob, float* value,
                   float* logits_out, void* stream);
+
+/* ---- the whole rollout of one epoch (train.py:173-195) as ONE persistent launch: for t in 0..T-1
+ *   (action, logprob, value) = Agent.get_action_and_value(obs_t)      [pc_policy_act's arithmetic and RNG, offset + t]
+ *   obs_{t+1}, reward, terminated, truncated = envs.step(action)      [pc_env_step's arithmetic]
+ *   Buffer.store(...)                                                 [rows written in place]
+ * Inputs: the env handle (F32 handles on a single track), the policy weight image of pc_policy_pack, and next_obs /
+ * next_term / next_trunc [N] = observation and flags the rollout starts from (the caller has copied them into row 0 of
+ * obs_buf / term_buf / trunc_buf, as Trainer does).  Outputs: obs_buf [T][N][D] rows 1..T-1, act_buf (float32, buffer.py:13),
+ * rew_buf, val_buf, logprob_buf [T][N] rows 0..T-1, term_buf / trunc_buf rows 1..T-1, and next_obs / next_term / next_trunc
+ * overwritten with the state after step T-1.  Bit-identical to T x (pc_policy_act; pc_env_step).
+ * PC_ERR_UNSUPPORTED for F64 or mixed-track handles and ray counts other than 12 / 16 / 32 (callers fall back to the
+ * two-kernel loop). */
+int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
+               const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
+               float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, void* stream);
 
 /* ---- the non-GEMM work of one PPO minibatch step (train.py:230-261), three launches:
  * pc_ppo_gather : traj_*[batch_indices] (train.py:233-238,249): idx [B] int64 into the flattened trajectories

@@ -71,8 +71,10 @@ _sig = {
     "pc_gae": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _i64, _i64, _vp, _vp, _vp]),
     "pc_sample": (_i, [_i, _vp, _i64, _i, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp]),
     "pc_policy_image_floats": (_i64, [_i, _i, _i]),
+    "pc_policy_set_split": (_i, [_i]),
     "pc_policy_pack": (_i, [_i, _i, _i, _i] + [_vp] * 8 + [_vp, _vp]),
     "pc_policy_act": (_i, [_i, _vp, _i64, _i, _i, _i, _vp, C.c_uint64, C.c_uint64, _vp] + [_vp] * 5 + [_vp]),
+    "pc_rollout": (_i, [_vp, _vp, _i, _i64, _d, C.c_uint64, C.c_uint64, _vp] + [_vp] * 10 + [_vp]),
     "pc_ppo_gather": (_i, [_i, _vp, _i, _i] + [_vp] * 10 + [_vp]),
     "pc_ppo_loss": (_i, [_i] + [_vp] * 6 + [_i, _i, _d, _d, _d, _vp, _vp, _vp, _vp]),
     "pc_clip_adam": (_i, [_i] + [_vp] * 6 + [_i64, _d, _d, _d, _d, _d, _vp]),

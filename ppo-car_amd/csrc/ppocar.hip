@@ -40,6 +40,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -190,29 +191,64 @@ template <> struct Math<float> {
 // ------------------------------------------------------------------------------------------
 // K1: env step
 // ------------------------------------------------------------------------------------------
-template <typename T, int RPL>
-__device__ __forceinline__ void env_step_body(const EnvParams<T>& p, const int trk, const int64_t e, const int g,
-                                              const int64_t* __restrict__ actions, const double reward_scale,
-                                              float* __restrict__ obs, float* __restrict__ reward,
-                                              float* __restrict__ term_out, float* __restrict__ trunc_out,
-                                              int32_t* __restrict__ gates_passed, float* __restrict__ final_obs) {
-    // trk is the same in every active lane; readfirstlane tells the compiler so, which turns the
-    // header and every wall-segment load below into scalar loads (s_load_dwordx8 into SGPRs)
-    const TrackHdr h = p.hdr[__builtin_amdgcn_readfirstlane(trk)];
-    const int G = 1 << p.lg;
+// Wave-uniform tables are read through the CONSTANT address space: the compiler then knows the memory is
+// invariant and emits scalar loads (s_load_dwordx8 into SGPRs) even inside loops that also store to global
+// memory (the mixed-track waterfall, the persistent rollout kernel), where its no-clobber analysis gives up.
+template <typename S> __device__ __forceinline__ S cload(const S* ptr) {
+    static_assert(sizeof(S) % 4 == 0, "word-sized records");
+    typedef const __attribute__((address_space(4))) int* CI;
+    const CI w = (CI)(const void*)ptr;
+    int raw[sizeof(S) / 4];
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(S) / 4; ++i) raw[i] = w[i];
+    S out;
+    __builtin_memcpy(&out, raw, sizeof(S));
+    return out;
+}
 
-    // ---- state in (coalesced 32/16-byte vectors; the G lanes of an env read the same address)
+struct EnvRegs {  // one env's state, held identically by all lanes of its group
+    double px, py, vx, vy, rot;
+    int k, time, next, passed;
+};
+
+template <typename T> __device__ __forceinline__ EnvRegs env_load(const EnvParams<T>& p, const int64_t e) {
     const double4 sv = p.pv[e];
     const int4 si = p.iv[e];
-    double rot_old = 0.0;
-    if constexpr (sizeof(T) == 8) rot_old = p.rot[e];
-    const int64_t a = actions[e];
+    EnvRegs st;
+    st.px = sv.x; st.py = sv.y; st.vx = sv.z; st.vy = sv.w;
+    st.rot = 0.0;
+    if constexpr (sizeof(T) == 8) st.rot = p.rot[e];
+    st.k = si.x; st.time = si.y; st.next = si.z; st.passed = si.w;
+    return st;
+}
+
+template <typename T> __device__ __forceinline__ void env_store(const EnvParams<T>& p, const int64_t e, const EnvRegs& st) {
+    double4 ov;
+    ov.x = st.px; ov.y = st.py; ov.z = st.vx; ov.w = st.vy;
+    p.pv[e] = ov;
+    p.iv[e] = make_int4(st.k, st.time, st.next, st.passed);
+    if constexpr (sizeof(T) == 8) p.rot[e] = st.rot;
+}
+
+// One CarEnv.step (car_env.py:693-760) + TransformReward + same-step auto-reset for the env whose state the
+// 2^lg lanes of this group hold in `st` (updated in place, identically in every lane).  Lane g sweeps rays
+// g, g + G, ...  Observation entries go to orow (global row), frow (pre-reset obs, optional) and lrow (an LDS
+// copy for the persistent rollout kernel, optional).  The per-env scalars come back in registers.
+template <typename T, int RPL>
+__device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int trk, const int g, const int lg, EnvRegs& st,
+                                              const int64_t a, const double reward_scale, float* __restrict__ orow,
+                                              float* __restrict__ frow, float* lrow, float& reward_f, bool& term, bool& trunc,
+                                              int& passed_out) {
+    // trk is the same in every active lane; readfirstlane tells the compiler so
+    const TrackHdr h = cload(p.hdr + __builtin_amdgcn_readfirstlane(trk));
+    const int G = 1 << lg;
+    const double rot_old = st.rot;
 
     // ---- action translation (car_env.py:698-722): thrust first with the PRE-turn heading, then the turn
     const bool fwd = (a == 0) | (a == 4) | (a == 5), bwd = (a == 1) | (a == 6) | (a == 7);
     const bool left = (a == 2) | (a == 4) | (a == 6), right = (a == 3) | (a == 5) | (a == 7);
     double ch0, sh0;  // heading before the turn
-    Math<T>::heading(p, h, si.x, rot_old, ch0, sh0);
+    Math<T>::heading(p, h, st.k, rot_old, ch0, sh0);
     double accx = 0.0, accy = 0.0;
     if (fwd) {  // Car.move_car("forward") :423-430
         accx = ch0 * 0.8;
@@ -222,7 +258,7 @@ __device__ __forceinline__ void env_step_body(const EnvParams<T>& p, const int t
         accy = -sh0 * 0.8;
     }
     double rot_new = rot_old;
-    int k_new = si.x;
+    int k_new = st.k;
     if (left) {  // :440
         rot_new -= 5.0;
         k_new -= 1;
@@ -236,21 +272,21 @@ __device__ __forceinline__ void env_step_body(const EnvParams<T>& p, const int t
     if (turned) Math<T>::heading(p, h, k_new, rot_new, ch1, sh1);
 
     // ---- Car.update physics (car_env.py:452-461), float64 in both modes
-    double nvx = sv.z + accx, nvy = sv.w + accy;  // :452
-    if (!(fwd | bwd)) {                           // :454 ||acc|| == 0  <=>  no thrust
-        nvx *= 1 - 0.2;                           // :455
+    double nvx = st.vx + accx, nvy = st.vy + accy;  // :452
+    if (!(fwd | bwd)) {                             // :454 ||acc|| == 0  <=>  no thrust
+        nvx *= 1 - 0.2;                             // :455
         nvy *= 1 - 0.2;
     }
     nvx = nvx < -10.0 ? -10.0 : (nvx > 10.0 ? 10.0 : nvx);  // :457 np.clip per component
     nvy = nvy < -10.0 ? -10.0 : (nvy > 10.0 ? 10.0 : nvy);
-    const double opx = sv.x, opy = sv.y;
+    const double opx = st.px, opy = st.py;
     const double npx = opx + nvx, npy = opy + nvy;  // :459
 
     // ---- my rays: directions at the new pose; gate test at the OLD pose for the collision rays
     T dx[RPL], dy[RPL], best[RPL];
     bool gate_hit = false;
     uint64_t colmask = 0;  // which of my ray slots are collision rays
-    const Seg gate = p.segs[h.gate_off + si.z];  // only gate[next] can fire (the oracle does the full scan)
+    const Seg gate = p.segs[h.gate_off + st.next];  // only gate[next] can fire (the oracle does the full scan)
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
         const int ray = g + s * G;
@@ -274,14 +310,14 @@ __device__ __forceinline__ void env_step_body(const EnvParams<T>& p, const int t
 
     // ---- wall sweep: Car.get_distances (:360-374) -- also serves Car.check_collision (E2)
     if constexpr (sizeof(T) == 4) {
-        const Vtx* __restrict__ vt = p.vtx + h.vtx_off;
-        Vtx nxt = vt[0];  // wave-uniform -> s_load_dwordx8, operands stay in SGPRs
+        const Vtx* vt = p.vtx + h.vtx_off;
+        Vtx nxt = cload(vt);  // wave-uniform -> s_load_dwordx8, operands stay in SGPRs
         float axp = 0.0f, ayp = 0.0f, cp[RPL];
 #pragma unroll
         for (int s = 0; s < RPL; ++s) cp[s] = 0.0f;
         for (int k = 0; k < h.nV; ++k) {
             const Vtx v = nxt;
-            nxt = vt[k + 1 < h.nV ? k + 1 : k];  // scalar prefetch of the next vertex under this one's VALU work
+            nxt = cload(vt + (k + 1 < h.nV ? k + 1 : k));  // scalar prefetch of the next vertex under this one's VALU work
             const float ax = (float)(v.x - npx), ay = (float)(v.y - npy);
             float c[RPL];
 #pragma unroll
@@ -297,11 +333,11 @@ __device__ __forceinline__ void env_step_body(const EnvParams<T>& p, const int t
             for (int s = 0; s < RPL; ++s) cp[s] = c[s];
         }
     } else {
-        const Seg* __restrict__ walls = p.segs + h.wall_off;
-        Seg nxt = walls[0];
+        const Seg* walls = p.segs + h.wall_off;
+        Seg nxt = cload(walls);
         for (int w = 0; w < h.S; ++w) {
             const Seg sg = nxt;  // wave-uniform -> s_load_dwordx8
-            nxt = walls[w + 1 < h.S ? w + 1 : w];
+            nxt = cload(walls + (w + 1 < h.S ? w + 1 : w));
 #pragma unroll
             for (int s = 0; s < RPL; ++s) {
                 const double d = cast_ref(sg.x1, sg.y1, sg.x2, sg.y2, npx, npy, dx[s], dy[s]);
@@ -322,7 +358,7 @@ __device__ __forceinline__ void env_step_body(const EnvParams<T>& p, const int t
     // ---- bookkeeping (car_env.py:694-750), float64 reward exactly as the reference accumulates it
     double rw = 0.0;
     if (fwd) rw += 0.01;  // :700,:710,:714
-    int next = si.z, passed = si.w;
+    int next = st.next, passed = st.passed;
     if (gate_hit) {               // :726 (gate.get_index() == next_gate_index by E1)
         rw += 1.0;                // :727
         if (next == h.G - 1) {    // :730 remaining == 0
@@ -334,9 +370,10 @@ __device__ __forceinline__ void env_step_body(const EnvParams<T>& p, const int t
             next += 1;            // :741
         }
     }
-    const int time = si.y + 1;  // :745
+    const int time = st.time + 1;  // :745
     const bool destroyed = wall_hit | (h.start_collides != 0);
-    bool term = false, trunc = false;
+    term = false;
+    trunc = false;
     if (destroyed) {  // :746-748
         term = true;
         rw -= 3.0;
@@ -344,17 +381,19 @@ __device__ __forceinline__ void env_step_body(const EnvParams<T>& p, const int t
         trunc = true;
     }
     const bool done = term | trunc;
+    reward_f = (float)(rw * reward_scale);  // TransformReward then float32 store (buffer.py:29)
+    passed_out = passed;
 
-    // ---- outputs.  Auto-reset (gymnasium 0.29.1 AsyncVectorEnv): a done env returns its reset obs.
+    // ---- observation.  Auto-reset (gymnasium 0.29.1 AsyncVectorEnv): a done env returns its reset obs.
     const float* __restrict__ robs = p.reset_obs + (size_t)trk * p.D;
-    float* __restrict__ orow = obs + (size_t)e * p.D;
-    float* __restrict__ frow = final_obs ? final_obs + (size_t)e * p.D : nullptr;
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
         const int ray = g + s * G;
         if (ray < p.R) {
             const float v = Math<T>::norm_dist(best[s]);  // :593
-            orow[6 + ray] = done ? robs[6 + ray] : v;
+            const float o = done ? robs[6 + ray] : v;
+            orow[6 + ray] = o;
+            if (lrow) lrow[6 + ray] = o;
             if (frow) frow[6 + ray] = v;
         }
     }
@@ -368,35 +407,48 @@ __device__ __forceinline__ void env_step_body(const EnvParams<T>& p, const int t
         hd[5] = (float)sh1;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            orow[i] = done ? robs[i] : hd[i];
+            const float o = done ? robs[i] : hd[i];
+            orow[i] = o;
+            if (lrow) lrow[i] = o;
             if (frow) frow[i] = hd[i];
         }
-        reward[e] = (float)(rw * reward_scale);  // TransformReward then float32 store (buffer.py:29)
+    }
+    // ---- new state (every lane of the group keeps the same copy)
+    if (done) {  // CarEnv.reset (:677-686): start pose, zero velocity, counters cleared
+        st.px = h.start_x; st.py = h.start_y; st.vx = 0.0; st.vy = 0.0; st.rot = h.start_rot;
+        st.k = 0; st.time = 0; st.next = 0; st.passed = 0;
+    } else {
+        st.px = npx; st.py = npy; st.vx = nvx; st.vy = nvy; st.rot = rot_new;
+        st.k = k_new; st.time = time; st.next = next; st.passed = passed;
+    }
+}
+
+template <typename T, int RPL>
+__device__ __forceinline__ void env_step_body(const EnvParams<T>& p, const int trk, const int64_t e, const int g,
+                                              const int64_t* __restrict__ actions, const double reward_scale,
+                                              float* __restrict__ obs, float* __restrict__ reward,
+                                              float* __restrict__ term_out, float* __restrict__ trunc_out,
+                                              int32_t* __restrict__ gates_passed, float* __restrict__ final_obs) {
+    // state in (coalesced 32/16-byte vectors; the G lanes of an env read the same address)
+    EnvRegs st = env_load<T>(p, e);
+    float rw;
+    bool term, trunc;
+    int passed;
+    env_step_core<T, RPL>(p, trk, g, p.lg, st, actions[e], reward_scale, obs + (size_t)e * p.D,
+                          final_obs ? final_obs + (size_t)e * p.D : nullptr, nullptr, rw, term, trunc, passed);
+    if (g == 0) {
+        reward[e] = rw;
         term_out[e] = term ? 1.0f : 0.0f;
         trunc_out[e] = trunc ? 1.0f : 0.0f;
         if (gates_passed) gates_passed[e] = passed;
-        double4 ov;
-        int4 oi;
-        if (done) {  // CarEnv.reset (:677-686): start pose, zero velocity, counters cleared
-            ov.x = h.start_x; ov.y = h.start_y; ov.z = 0.0; ov.w = 0.0;
-            oi = make_int4(0, 0, 0, 0);
-            if constexpr (sizeof(T) == 8) p.rot[e] = h.start_rot;
-        } else {
-            ov.x = npx; ov.y = npy; ov.z = nvx; ov.w = nvy;
-            oi = make_int4(k_new, time, next, passed);
-            if constexpr (sizeof(T) == 8) p.rot[e] = rot_new;
-        }
-        p.pv[e] = ov;
-        p.iv[e] = oi;
+        env_store<T>(p, e, st);
     }
 }
 
 // MIXED = false: every env is on track 0 -- straight-line body, all track data through scalar loads.
 // MIXED = true : per-env track ids.  Waterfall: the body runs once per distinct track id present in the
 // wavefront, so header / segment addresses stay wave-uniform.  (The loop is driven by a ballot of the lanes
-// still to do: a plain readfirstlane(mine) is loop-invariant to the compiler and gets hoisted.  Inside that
-// loop the compiler can no longer prove the segment table unclobbered, so its loads become uniform VECTOR
-// loads -- slower, which is why the single-track case has its own instantiation.)
+// still to do: a plain readfirstlane(mine) is loop-invariant to the compiler and gets hoisted.)
 template <typename T, int RPL, bool MIXED>
 __global__ __launch_bounds__(256) void env_step_kernel(const EnvParams<T> p, const int64_t* __restrict__ actions,
                                                        const double reward_scale, float* __restrict__ obs,
@@ -680,6 +732,120 @@ __global__ __launch_bounds__(256) void policy_pack_kernel(const int KS, const in
 
 __device__ __forceinline__ float relu_f(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
 
+// One wave's MFMA work for 32 envs (2 column tiles) over hidden tiles [ht0, ht1) (an even count): layer 1,
+// ReLU, layer 2.  x[et][ks] = B operands of layer 1 (X^T), out[et] = the [16 outs x 16 envs] accumulators of
+// layer 2.  Two hidden tiles are in flight per iteration: four independent layer-1 accumulator chains keep
+// the matrix pipe issuing while one tile's ReLU (accumulator read-back) and layer-2 operands are prepared,
+// and the next pair's A operands are fetched from LDS under this pair's MFMAs.
+template <int KS>
+__device__ __forceinline__ void policy_pass(const float* sW1, const float* sB1, const float* sW2, const int ht0, const int ht1,
+                                            const float (&x)[2][KS], f32x4 (&out)[2], const int lc, const int lk, const int lane) {
+    constexpr int LD1 = pol_ld1(KS), ET = 2, TP = 2;
+    float a1[TP][KS], a2[TP][4];
+    f32x4 bias[TP];
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        bias[j] = *reinterpret_cast<const f32x4*>(sB1 + 16 * (ht0 + j) + 4 * lk);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a1[j][ks] = sW1[(16 * (ht0 + j) + lc) * LD1 + 4 * ks + lk];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) a2[j][reg] = sW2[((ht0 + j) * 4 + reg) * 64 + lane];
+    }
+    for (int ht = ht0; ht < ht1; ht += TP) {
+        const int hn = ht + TP < ht1 ? ht + TP : ht;
+        float n1[TP][KS], n2[TP][4];
+        f32x4 nbias[TP];
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            nbias[j] = *reinterpret_cast<const f32x4*>(sB1 + 16 * (hn + j) + 4 * lk);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) n1[j][ks] = sW1[(16 * (hn + j) + lc) * LD1 + 4 * ks + lk];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) n2[j][reg] = sW2[((hn + j) * 4 + reg) * 64 + lane];
+        }
+        f32x4 acc[TP][ET];
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int et = 0; et < ET; ++et) acc[j][et] = bias[j];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int et = 0; et < ET; ++et)
+                    acc[j][et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j][ks], x[et][ks], acc[j][et], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                for (int et = 0; et < ET; ++et)
+                    out[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[j][reg], relu_f(acc[j][et][reg]), out[et], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            bias[j] = nbias[j];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a1[j][ks] = n1[j][ks];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) a2[j][reg] = n2[j][reg];
+        }
+    }
+}
+
+// Softmax / Philox draw / log_prob for one env given its 16 output values (logits 0..A-1, value at A).
+__device__ __forceinline__ void policy_tail(const float (&v)[16], const int A, const uint64_t seed, const uint64_t off,
+                                            const uint64_t e, int& act, float& lp, float& val, float* __restrict__ logits_row) {
+    float l[16];
+    float mx = -INFINITY;
+    val = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i == A) val = v[i];
+        l[i] = i < A ? v[i] : -INFINITY;
+        mx = fmaxf(mx, l[i]);
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += i < A ? expf(l[i] - mx) : 0.0f;
+    const float lse = mx + logf(sum);
+    const float u = philox_uniform(seed, off, e);
+    float cum = 0.0f;
+    lp = 0.0f;
+    act = -1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i < A) {
+            const float nl = l[i] - lse;
+            cum += expf(nl);
+            if (act < 0 && (u < cum || i == A - 1)) {  // inverse CDF; last bin absorbs rounding
+                act = i;
+                lp = nl;
+            }
+            if (logits_row) logits_row[i] = l[i];
+        }
+    }
+}
+
+template <int KS> __device__ __forceinline__ void policy_stage_image(const float* __restrict__ image, float* lds, const int tid) {
+    // 16-byte coalesced copies, all loads of a thread in flight together
+    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(image);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    constexpr int n4 = pol_image_padded(KS) / 4;
+    constexpr int per = (n4 + 511) / 512;
+    f32x4 tmp[per];
+#pragma unroll
+    for (int j = 0; j < per; ++j) {
+        const int i = tid + j * 512;
+        if (i < n4) tmp[j] = src[i];
+    }
+#pragma unroll
+    for (int j = 0; j < per; ++j) {
+        const int i = tid + j * 512;
+        if (i < n4) dst[i] = tmp[j];
+    }
+}
+
 // 512 threads = 8 waves (2 per SIMD: while one waits on LDS or its ReLU the other feeds the matrix pipe).
 // SPLIT = false (large batches): a wave owns 32 envs (2 column tiles of 16) and walks all 32 hidden tiles;
 //                a workgroup covers 256 envs per pass.
@@ -704,24 +870,7 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
     float* sOut = lds + pol_image_padded(KS);  // [8 waves][32 envs][LDO]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, lk = lane >> 4;
-
-    {   // stage the image: 16-byte coalesced copies, all loads of a thread in flight together
-        const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(image);
-        f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        constexpr int n4 = pol_image_padded(KS) / 4;
-        constexpr int per = (n4 + 511) / 512;
-        f32x4 tmp[per];
-#pragma unroll
-        for (int j = 0; j < per; ++j) {
-            const int i = tid + j * 512;
-            if (i < n4) tmp[j] = src[i];
-        }
-#pragma unroll
-        for (int j = 0; j < per; ++j) {
-            const int i = tid + j * 512;
-            if (i < n4) dst[i] = tmp[j];
-        }
-    }
+    policy_stage_image<KS>(image, lds, tid);
     __syncthreads();
 
     const uint64_t off = offset + (offset_dev ? *offset_dev : 0);
@@ -744,39 +893,7 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
         f32x4 out[ET];
 #pragma unroll
         for (int et = 0; et < ET; ++et) out[et] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-        // A operands of the first hidden tile; inside the loop the next tile's are fetched under this tile's MFMAs
-        float a1[KS], a2[4];
-        f32x4 bias = *reinterpret_cast<const f32x4*>(sB1 + 16 * ht0 + 4 * lk);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a1[ks] = sW1[(16 * ht0 + lc) * LD1 + 4 * ks + lk];
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) a2[reg] = sW2[(ht0 * 4 + reg) * 64 + lane];
-        for (int ht = ht0; ht < ht1; ++ht) {
-            const int hn = ht + 1 < ht1 ? ht + 1 : ht;
-            float n1[KS], n2[4];
-            const f32x4 nbias = *reinterpret_cast<const f32x4*>(sB1 + 16 * hn + 4 * lk);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) n1[ks] = sW1[(16 * hn + lc) * LD1 + 4 * ks + lk];
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) n2[reg] = sW2[(hn * 4 + reg) * 64 + lane];
-            f32x4 acc[ET];
-#pragma unroll
-            for (int et = 0; et < ET; ++et) acc[et] = bias;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int et = 0; et < ET; ++et) acc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], x[et][ks], acc[et], 0, 0, 0);
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-#pragma unroll
-                for (int et = 0; et < ET; ++et)
-                    out[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[reg], relu_f(acc[et][reg]), out[et], 0, 0, 0);
-            bias = nbias;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a1[ks] = n1[ks];
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) a2[reg] = n2[reg];
-        }
+        policy_pass<KS>(sW1, sB1, sW2, ht0, ht1, x, out, lc, lk, lane);
         // ---- out tile -> LDS so that lane = env
         __syncthreads();  // previous pass's readers are done with sOut
 #pragma unroll
@@ -786,47 +903,138 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
         __syncthreads();
         const int64_t e = env0 + lane;
         if (lane < 32 && e < N && (!SPLIT || wave == 0)) {
-            float l[16];
-            float val = 0.0f;
-            float mx = -INFINITY;
+            float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                float v = sB2[i];
+                float t = sB2[i];
                 if constexpr (SPLIT) {   // sum the 8 waves' partial tiles, fixed order
 #pragma unroll
-                    for (int w = 0; w < 8; ++w) v += sOut[(w * 32 + lane) * LDO + i];
+                    for (int w = 0; w < 8; ++w) t += sOut[(w * 32 + lane) * LDO + i];
                 } else {
-                    v += myOut[lane * LDO + i];
+                    t += myOut[lane * LDO + i];
                 }
-                if (i == A) val = v;
-                l[i] = i < A ? v : -INFINITY;
-                mx = fmaxf(mx, l[i]);
+                v[i] = t;
             }
-            float sum = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sum += i < A ? expf(l[i] - mx) : 0.0f;
-            const float lse = mx + logf(sum);
-            const float u = philox_uniform(seed, off, (uint64_t)e);
-            float cum = 0.0f, lp = 0.0f;
-            int act = -1;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (i < A) {
-                    const float nl = l[i] - lse;
-                    cum += expf(nl);
-                    if (act < 0 && (u < cum || i == A - 1)) {
-                        act = i;
-                        lp = nl;
-                    }
-                    if (logits_out) logits_out[e * A + i] = l[i];
-                }
-            }
+            int act;
+            float lp, val;
+            policy_tail(v, A, seed, off, (uint64_t)e, act, lp, val, logits_out ? logits_out + e * A : nullptr);
             action[e] = act;
             if (action_f) action_f[e] = (float)act;
             logprob[e] = lp;
             value[e] = val;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// K9: the whole rollout (train.py:173-195) as ONE persistent launch.
+// A workgroup (8 waves) owns 256 envs for all T steps: the policy weights stay in LDS, the env state in
+// registers, the observation of step t passes from the env phase to the policy phase through LDS; per step an
+// env costs 116 B of HBM writes (its buffer rows) and no reads.  Envs never interact and the weights are fixed
+// during a rollout, so there is no inter-workgroup communication at all.
+// The two halves of the workgroup (4 waves, 128 envs each) run in ANTI-PHASE: while half A runs the policy
+// step of its envs on the matrix cores (MFMA pipe), half B runs the env step of its envs (VALU pipe), then
+// they swap -- every SIMD hosts one wave of each half, so both pipes work all the time.  One __syncthreads per
+// phase; 2T + 1 phases.
+//   P(t): X^T from LDS -> policy_pass -> draw -> action to LDS, (act, logprob, value) rows t to HBM
+//   E(t): action from LDS -> env_step_core (2 lanes per env) -> obs row t+1 to HBM and LDS, (rew, term, trunc)
+// Same arithmetic, same Philox counters as the policy_kernel / env_step_kernel pair: bit-identical buffers.
+// ------------------------------------------------------------------------------------------
+template <int KS, int RPL>
+__global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, const float* __restrict__ image, const int A,
+                                                      const int T, const double reward_scale, const uint64_t seed,
+                                                      const uint64_t offset, const uint64_t* __restrict__ offset_dev,
+                                                      float* __restrict__ obs_buf, float* __restrict__ act_buf,
+                                                      float* __restrict__ rew_buf, float* __restrict__ val_buf,
+                                                      float* __restrict__ term_buf, float* __restrict__ trunc_buf,
+                                                      float* __restrict__ logprob_buf, float* __restrict__ next_obs,
+                                                      float* __restrict__ next_term, float* __restrict__ next_trunc,
+                                                      const int dbg) {
+    constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, LDX = 4 * KS + 1, ET = 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sW1 = lds;
+    float* sB1 = sW1 + 2 * HID * LD1;
+    float* sW2 = sB1 + 2 * HID;
+    float* sB2 = sW2 + NT * 4 * 64;
+    float* sOut = lds + pol_image_padded(KS);      // [8 waves][32 envs][LDO]
+    float* sObs = sOut + 8 * 32 * LDO;             // [256 envs][LDX]   observation of the step in flight
+    int* sAct = reinterpret_cast<int*>(sObs + 256 * LDX);  // [256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lc = lane & 15, lk = lane >> 4;
+    const int half = wave >> 2, hw = wave & 3;     // which half of the workgroup, wave inside the half
+    const int64_t N = p.N;
+    const int D = p.D;
+    policy_stage_image<KS>(image, lds, tid);
+
+    // env-phase identity: 2 lanes per env, 128 envs per half
+    const int ll = tid & 255, el = half * 128 + (ll >> 1), g = ll & 1;
+    const int64_t e_env = (int64_t)blockIdx.x * 256 + el;
+    const bool e_valid = e_env < N;
+    EnvRegs st = {};
+    if (e_valid) st = env_load<float>(p, e_env);
+    for (int f = g; f < 4 * KS; f += 2) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
+    // policy-phase identity: wave hw of the half owns envs [half*128 + 32 hw, +32)
+    const int pbase = half * 128 + hw * 32;
+    float* myOut = sOut + wave * 32 * LDO;
+    const uint64_t off0 = offset + (offset_dev ? *offset_dev : 0);
+    __syncthreads();
+
+    for (int s = 0; s <= 2 * T; ++s) {
+        const int sp = s - half;  // half 0 starts one phase ahead of half 1
+        if (sp >= 0 && sp < 2 * T) {
+            const int t = sp >> 1;
+            if ((sp & 1) == 0) {
+                // ---------------- P(t)
+                float x[ET][KS];
+#pragma unroll
+                for (int et = 0; et < ET; ++et)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) x[et][ks] = sObs[(pbase + 16 * et + lc) * LDX + 4 * ks + lk];
+                f32x4 out[ET];
+#pragma unroll
+                for (int et = 0; et < ET; ++et) out[et] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                if (!(dbg & 1)) policy_pass<KS>(sW1, sB1, sW2, 0, NT, x, out, lc, lk, lane);  // dbg: timing ablations only
+#pragma unroll
+                for (int et = 0; et < ET; ++et)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) myOut[(16 * et + lc) * LDO + 4 * lk + reg] = out[et][reg];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the tile is written and read by this wave only
+                __builtin_amdgcn_wave_barrier();
+                const int64_t e = (int64_t)blockIdx.x * 256 + pbase + lane;
+                if (lane < 32 && e < N) {
+                    float v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v[i] = sB2[i] + myOut[lane * LDO + i];
+                    int act;
+                    float lp, val;
+                    policy_tail(v, A, seed, off0 + (uint64_t)t, (uint64_t)e, act, lp, val, nullptr);
+                    sAct[pbase + lane] = act;
+                    const int64_t row = (int64_t)t * N + e;
+                    act_buf[row] = (float)act;     // stored as float32 like the reference (buffer.py:13)
+                    logprob_buf[row] = lp;
+                    val_buf[row] = val;
+                }
+            } else if (e_valid && !(dbg & 2)) {
+                // ---------------- E(t)
+                const bool last = t + 1 == T;
+                float* orow = last ? next_obs + e_env * D : obs_buf + ((int64_t)(t + 1) * N + e_env) * D;
+                float rw;
+                bool term, trunc;
+                int passed;
+                env_step_core<float, RPL>(p, 0, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw, term,
+                                          trunc, passed);
+                if (g == 0) {
+                    rew_buf[(int64_t)t * N + e_env] = rw;
+                    float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;    // flags that precede obs t+1
+                    float* tc = last ? next_trunc : trunc_buf + (int64_t)(t + 1) * N;  // (train.py:176-177,195)
+                    tr[e_env] = term ? 1.0f : 0.0f;
+                    tc[e_env] = trunc ? 1.0f : 0.0f;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (e_valid && g == 0) env_store<float>(p, e_env, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1447,6 +1655,13 @@ int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, 
 }
 
 static int policy_ks(int D) { return D <= 20 ? 5 : (D <= 24 ? 6 : 10); }
+static int g_policy_split_mode = -1;  // -1 auto (split below 32768 envs), 0 never, 1 always
+
+int pc_policy_set_split(int mode) {
+    if (mode < -1 || mode > 1) return PC_ERR_INVALID_ARG;
+    g_policy_split_mode = mode;
+    return PC_OK;
+}
 
 int64_t pc_policy_image_floats(int D, int H, int A) {
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
@@ -1485,7 +1700,8 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
         n_cu[device] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int cus = device < 64 ? n_cu[device] : 256;
-    const bool split = N < 32768;  // too few 256-env workgroups to fill the chip: split the hidden tiles over the waves instead
+    // too few 256-env workgroups to fill the chip: split the hidden tiles over the waves instead
+    const bool split = g_policy_split_mode < 0 ? N < 32768 : g_policy_split_mode == 1;
     const int64_t chunks = split ? (N + 31) / 32 : (N + 255) / 256;
     const int blocks = (int)(chunks < cus ? chunks : cus);  // one ~100-KB-LDS workgroup per CU, persistent over env chunks
     hipStream_t st = (hipStream_t)stream;
@@ -1548,6 +1764,45 @@ int pc_clip_adam(int device, float* param, float* grad, float* exp_avg, float* e
     if (!guard.ok) return PC_ERR_NO_DEVICE;
     hipLaunchKernelGGL(clip_adam_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, step_count,
                        lr_dev, (int)n, (float)max_norm, (float)grad_scale, (float)beta1, (float)beta2, (float)eps);
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
+               const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
+               float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, void* stream) {
+    if (!e || !image || !obs_buf || !act_buf || !rew_buf || !val_buf || !term_buf || !trunc_buf || !logprob_buf || !next_obs ||
+        !next_term || !next_trunc || T < 1 || T > (1 << 24))
+        return PC_ERR_INVALID_ARG;
+    if (e->dtype != PC_DTYPE_F32 || e->track_id || A < 1 || A > 15) return PC_ERR_UNSUPPORTED;
+    const int KS = policy_ks(e->D);
+    const int rpl = (e->R + 1) / 2;  // 2 lanes per env
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    const size_t lds = (size_t)(pol_image_padded(KS) + 8 * 32 * 17 + 256 * (4 * KS + 1) + 256) * sizeof(float);
+    if (lds > 160 * 1024) return PC_ERR_UNSUPPORTED;  // 32 -> 33 rays: weight image + observation tile exceed one CU's LDS
+    const int blocks = (int)((e->N + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    EnvParams<float> prm = e->params<float>();
+    prm.lg = 1;
+    const char* dbg_env = getenv("PPOCAR_ROLLOUT_ABLATE");  // developer timing ablation: 1 = skip policy MFMAs, 2 = skip env step
+    const int dbg = dbg_env ? atoi(dbg_env) : 0;
+#define PC_ROLL(KSV, RPLV)                                                                                               \
+    do {                                                                                                                 \
+        static bool attr_set[64] = {false};                                                                              \
+        if (e->device < 64 && !attr_set[e->device]) {                                                                    \
+            HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<KSV, RPLV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_set[e->device] = true;                                                                                  \
+        }                                                                                                                \
+        hipLaunchKernelGGL((rollout_kernel<KSV, RPLV>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, seed, \
+                           offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs,  \
+                           next_term, next_trunc, dbg);                                                                  \
+    } while (0)
+    if (KS == 5 && rpl == 6) PC_ROLL(5, 6);          // 12 rays, D = 18
+    else if (KS == 6 && rpl == 9) PC_ROLL(6, 9);     // 16 -> 17 rays, D = 23
+    else if (KS == 10 && rpl == 17) PC_ROLL(10, 17); // 32 -> 33 rays, D = 39
+    else return PC_ERR_UNSUPPORTED;
+#undef PC_ROLL
     HIPCHK(hipGetLastError());
     return PC_OK;
 }

@@ -53,6 +53,8 @@ class PPOConfig:
     use_graphs: bool = True                # capture the minibatch update / the rollout in HIP graphs (GPU only)
     fused_update: bool = True              # GPU only: minibatch gather, PPO loss fwd+bwd and clip+Adam as three HIP kernels
                                            # (the MLP GEMMs stay torch autograd); False = the reference's torch ops throughout
+    rollout_kernel: str = "auto"           # "mega": the whole rollout as one persistent launch (pc_rollout); "steps": two
+                                           # kernels per step (HIP-graph replayed); "auto": mega when n_envs >= 16384
     policy: str = "fused"                  # rollout policy step: "fused" (one MFMA kernel: MLPs + draw),
                                            # "sample" (torch GEMMs + sampling kernel), "torch" (reference ops)
 
@@ -353,6 +355,7 @@ class Trainer:
         self.rng_base = torch.zeros(1, dtype=torch.int64, device=self.device)   # device-side Philox offset base
         self._rollout_graph = None
         self._eager_rollouts = 0
+        self.rollout_mode = None
 
     # ---- train.py:173-195 ---------------------------------------------------------------------------
     @torch.no_grad()
@@ -389,22 +392,55 @@ class Trainer:
                 envs.step(actions, out=out)          # train.py:185 -- zero-copy into the buffer rows
         self.rng_base += T                           # next rollout draws from fresh Philox counters
 
+    @torch.no_grad()
+    def _rollout_mega(self):
+        """pc_rollout: policy step + env step + Buffer.store for all n_steps in ONE persistent launch."""
+        cfg, buf, agent = self.cfg, self.buffer, self.agent
+        if not agent.pack_policy():
+            return False
+        buf.obs_buf[0].copy_(self.next_obs)
+        buf.term_buf[0].copy_(self.next_term)
+        buf.trunc_buf[0].copy_(self.next_trunc)
+        rc = lib.pc_rollout(self.envs._h, agent._image.data_ptr(), self.act_dim, cfg.n_steps, float(cfg.reward_scaling),
+                            int(agent.rng_seed), 0, self.rng_base.data_ptr(), buf.obs_buf.data_ptr(), buf.act_buf.data_ptr(),
+                            buf.rew_buf.data_ptr(), buf.val_buf.data_ptr(), buf.term_buf.data_ptr(), buf.trunc_buf.data_ptr(),
+                            buf.logprob_buf.data_ptr(), self.next_obs.data_ptr(), self.next_term.data_ptr(),
+                            self.next_trunc.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
+        if rc == -5:       # PC_ERR_UNSUPPORTED: shape outside the persistent kernel's menu
+            return False
+        check(rc, "pc_rollout")
+        self.rng_base += cfg.n_steps
+        return True
+
     def rollout(self):
-        """n_steps vector-env steps into the buffer.  With use_graphs (and the fused policy step) the whole rollout
-        -- 2 kernels per step -- is captured into ONE HIP graph after a first eager pass and replayed afterwards:
-        at small n_envs the per-step host work (~50 us of Python / ctypes) exceeds the GPU work."""
+        """n_steps vector-env steps into the buffer.
+        mega : one persistent launch for the whole rollout (pc_rollout) -- large batches.
+        steps: two kernels per step (fused policy step + env step); with use_graphs the whole sequence is captured
+               into ONE HIP graph after a first eager pass and replayed (at small n_envs the per-step host work, ~50 us
+               of Python / ctypes, exceeds the GPU work).
+        All forms draw from the same Philox counters and produce bit-identical buffers."""
         cfg = self.cfg
-        graphable = cfg.use_graphs and cfg.policy == "fused" and self.device.type == "cuda" and not self.profile_stride
-        if graphable and self._rollout_graph is None and self._eager_rollouts >= 1:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._rollout_body()
-            self._rollout_graph = g
-        if graphable and self._rollout_graph is not None:
-            self._rollout_graph.replay()
-        else:
-            self._rollout_body(events=True)
-            self._eager_rollouts += 1
+        mode = cfg.rollout_kernel
+        if mode == "auto":
+            mode = "mega" if cfg.n_envs >= 16384 else "steps"
+        done = False
+        if mode == "mega" and cfg.policy == "fused" and self.device.type == "cuda" and not self.profile_stride:
+            done = self._rollout_mega()
+            self.rollout_mode = "mega" if done else "steps"
+        if not done:
+            graphable = cfg.use_graphs and cfg.policy == "fused" and self.device.type == "cuda" and not self.profile_stride
+            if graphable and self._rollout_graph is None and self._eager_rollouts >= 1:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._rollout_body()
+                self._rollout_graph = g
+            if graphable and self._rollout_graph is not None:
+                self._rollout_graph.replay()
+                self.rollout_mode = "steps-graph"
+            else:
+                self._rollout_body(events=True)
+                self._eager_rollouts += 1
+                self.rollout_mode = "steps-eager"
         self.buffer.ptr = cfg.n_steps
         self.global_step_idx += cfg.n_envs * cfg.n_steps * self.world_size   # train.py:174, whole job
 

@@ -183,3 +183,37 @@ def test_fused_and_torch_updates_agree_inside_the_trainer():
     # identical rollouts in epoch 1 (same seeds, same init); the second rollout runs on slightly different weights,
     # so only a loose agreement is meaningful after two epochs
     assert torch.allclose(outs[False][0], outs[True][0], atol=5e-3)
+
+
+@pytest.mark.parametrize("num_rays,n_envs", [(16, 1000), (12, 512), (32, 300)])
+def test_persistent_rollout_kernel_is_bitwise_the_two_kernel_rollout(num_rays, n_envs):
+    """pc_rollout (one persistent launch: policy phase on the MFMA pipe and env phase on the VALU pipe alternating in
+    the two halves of each workgroup, weights in LDS, env state in registers) must fill the buffer with exactly the
+    bits of the per-step policy_kernel / env_step_kernel sequence, over several epochs (auto-resets included)."""
+    from ppo_car_amd._capi import lib
+    res = {}
+    lib.pc_policy_set_split(0)      # same fp32 summation order in both forms (the split form differs in the last bits)
+    for mode in ("steps", "mega"):
+        cfg = _cfg(rollout_kernel=mode, use_graphs=False, n_envs=n_envs, n_steps=80, num_rays=num_rays)
+        tr = Trainer(cfg, device="cuda")
+        snaps = []
+        for ep in range(3):
+            tr.rollout()
+            torch.cuda.synchronize()
+            # 32 -> 33 rays: weight image + observation tile exceed 160 KB of LDS -> pc_rollout reports
+            # PC_ERR_UNSUPPORTED and the trainer falls back to the two-kernel loop
+            assert tr.rollout_mode == ("mega" if mode == "mega" and num_rays != 32 else "steps-eager")
+            b = tr.buffer
+            snaps.append([t.clone() for t in (b.obs_buf, b.act_buf, b.rew_buf, b.val_buf, b.logprob_buf, b.term_buf, b.trunc_buf,
+                                              tr.next_obs, tr.next_term, tr.next_trunc)])
+            tr.buffer.ptr = 0
+        st = tr.envs.get_state()
+        res[mode] = (snaps, st)
+        tr.close()
+    lib.pc_policy_set_split(-1)
+    for ep in range(3):
+        for i, (a, b) in enumerate(zip(res["steps"][0][ep], res["mega"][0][ep])):
+            assert torch.equal(a, b), (ep, i)
+    for k in res["steps"][1]:
+        assert np.array_equal(res["steps"][1][k], res["mega"][1][k]), k
+    assert float(res["mega"][0][2][5].sum()) > 0        # episodes ended (terminations) inside the window
