@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--env-dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--policy", default="fused", choices=["fused", "sample", "torch"], help="rollout policy-step implementation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--eager-rollout", action="store_true", help="no rollout graph; bracket env-step launches with events instead")
     ap.add_argument("--rollout-kernel", default="auto", choices=["auto", "mega", "steps"], help="persistent rollout kernel or 2 kernels/step")
     ap.add_argument("--no-graphs", action="store_true", help="eager update and rollout")
@@ -101,12 +103,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path for the hot path")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from ppo_car_amd.ppo import PPOConfig, Trainer
     wl = dict(WORKLOADS[args.workload])

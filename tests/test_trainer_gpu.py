@@ -217,3 +217,39 @@ def test_persistent_rollout_kernel_is_bitwise_the_two_kernel_rollout(num_rays, n
     for k in res["steps"][1]:
         assert np.array_equal(res["steps"][1][k], res["mega"][1][k]), k
     assert float(res["mega"][0][2][5].sum()) > 0        # episodes ended (terminations) inside the window
+
+
+def _two_rank_worker(rank, world, port, out_dir, use_graphs):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # both ranks share cuda:0 here; RCCL needs one GPU per rank
+    torch.cuda.set_device(0)
+    cfg = _cfg(n_envs=512, n_steps=64, batch_size=32, train_iters=2, use_graphs=use_graphs, seed=11)
+    tr = Trainer(cfg, device="cuda:0", rank=rank, world_size=world)
+    s1 = tr.run_epoch()
+    s2 = tr.run_epoch()
+    torch.cuda.synchronize()
+    torch.save({"param": tr.learner.flat_param.cpu(), "acts": tr.buffer.act_buf.cpu(), "scalars": s2, "step": tr.global_step_idx},
+               os.path.join(out_dir, f"r{rank}_{int(use_graphs)}.pt"))
+    tr.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_graphs", [True, False])
+def test_two_ranks_on_one_gpu_keep_replicas_identical(tmp_path, use_graphs):
+    """world_size 2 with the real kernels (both ranks on cuda:0, gloo as the transport): different env shards and
+    action streams per rank, ONE all-reduce of the flat gradient bucket per minibatch (between the two captured
+    graphs in graph mode), identical parameters afterwards."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), use_graphs), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / f"r0_{int(use_graphs)}.pt")
+    r1 = torch.load(tmp_path / f"r1_{int(use_graphs)}.pt")
+    assert torch.equal(r0["param"], r1["param"])                 # replicas bit-identical after 2 epochs
+    assert not torch.equal(r0["acts"], r1["acts"])               # but the shards sampled different actions
+    assert r0["step"] == r1["step"] == 2 * 2 * 512 * 64          # global_step counts the whole job (train.py:174)
+    assert r0["scalars"]["charts/avg_reward"] == pytest.approx(r1["scalars"]["charts/avg_reward"])   # all-reduced scalars
