@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--eager-rollout", action="store_true", help="no rollout graph; bracket env-step launches with events instead")
     ap.add_argument("--rollout-kernel", default="auto", choices=["auto", "mega", "steps"], help="persistent rollout kernel or 2 kernels/step")
     ap.add_argument("--no-graphs", action="store_true", help="eager update and rollout")
+    ap.add_argument("--torch-mlp", action="store_true", help="torch autograd GEMMs for the MLPs inside the minibatch step (fused loss/Adam kernels only)")
     ap.add_argument("--torch-update", action="store_true", help="reference torch ops for the whole minibatch step (no fused loss/Adam kernels)")
     ap.add_argument("--event-stride", type=int, default=8, help="with --eager-rollout: bracket every k-th env-step launch")
     args = ap.parse_args()
@@ -121,7 +122,7 @@ def main():
         wl["n_envs"] = args.n_envs
     if args.n_steps:
         wl["n_steps"] = args.n_steps
-    cfg = PPOConfig(track=os.path.join(ROOT, "tracks", "big_track.json"), env_dtype=args.env_dtype, seed=0, policy=args.policy, use_graphs=not args.no_graphs, fused_update=not args.torch_update,
+    cfg = PPOConfig(track=os.path.join(ROOT, "tracks", "big_track.json"), env_dtype=args.env_dtype, seed=0, policy=args.policy, use_graphs=not args.no_graphs, fused_update=not args.torch_update, custom_mlp=not args.torch_mlp,
                     rollout_kernel=args.rollout_kernel, **wl)
     tr = Trainer(cfg, device=dev, rank=rank, world_size=world)
     tr.profile_stride = 0
@@ -189,7 +190,7 @@ def main():
                                    f"n_envs={cfg.n_envs}/GPU, n_steps={cfg.n_steps}, batch_size={cfg.batch_size}, "
                                    f"train_iters={cfg.train_iters}; one step = one PPO epoch (rollout + GAE + update)",
                        "n_envs_total": cfg.n_envs * world, "parallelism": f"env-sharded dp{world}, 1 flat grad all-reduce/minibatch",
-                       "env_kernel": info, "policy_step": args.policy, "rollout": tr.rollout_mode, "hip_graphs": bool(cfg.use_graphs), "fused_update": bool(cfg.fused_update), "epoch_split": split, "numerics": "float64 kinematic state, float32 ray geometry" if args.env_dtype == "f32"
+                       "env_kernel": info, "policy_step": args.policy, "rollout": tr.rollout_mode, "hip_graphs": bool(cfg.use_graphs), "fused_update": bool(cfg.fused_update), "custom_mlp_update": bool(tr.learner.custom), "epoch_split": split, "numerics": "float64 kinematic state, float32 ray geometry" if args.env_dtype == "f32"
                        else "float64 throughout (reference operation order)"},
             "roofline": {"kernel": "env_step_kernel (K1)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,

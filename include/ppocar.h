@@ -179,6 +179,22 @@ int pc_ppo_loss(int device, const float* logits, const float* values, const floa
 int pc_clip_adam(int device, float* param, float* grad, float* exp_avg, float* exp_avg_sq, float* step_count, const float* lr_dev,
                  int64_t n, double max_norm, double grad_scale, double beta1, double beta2, double eps, void* stream);
 
+/* ---- one whole PPO minibatch step (train.py:230-261) with no library GEMM: gather, both MLPs forward, the clipped-PPO
+ * loss, both MLPs backward, and (apply != 0) clip_grad_norm_ + Adam, as three launches.  `param` / `grad` / `exp_avg` /
+ * `exp_avg_sq` are flat float32 buffers in torch's module.parameters() order (actor.0.weight [H][D], actor.0.bias,
+ * actor.2.weight [A][H], actor.2.bias, critic.0.weight, critic.0.bias, critic.2.weight [1][H], critic.2.bias); idx [B]
+ * indexes the flattened trajectories obs [M][D], act / old_logprob / adv / ret [M].  grad receives the (clipped, when
+ * applied) gradient; metrics[4] += (policy_loss, value_loss, entropy, total); step_count [1] float and lr_dev [1] live on
+ * the device.  apply == 0 stops after the gradient (multi-rank: all-reduce it, then pc_clip_adam).  workspace: device
+ * buffer of pc_ppo_workspace_floats(B, D, H, A) floats.  Deterministic (fixed summation order, no atomics).
+ * PC_ERR_UNSUPPORTED unless H == 256, A <= 15, D <= 40, 2 <= B <= 1024. */
+int64_t pc_ppo_workspace_floats(int B, int D, int H, int A);
+int pc_ppo_minibatch(int device, const int64_t* idx, int B, int D, int H, int A, const float* obs, const float* act,
+                     const float* old_logprob, const float* adv, const float* ret, float* param, float* grad, float* exp_avg,
+                     float* exp_avg_sq, float* step_count, const float* lr_dev, double clip_ratio, double vf_coef, double ent_coef,
+                     double max_norm, double beta1, double beta2, double eps, float* metrics, float* workspace, int apply,
+                     void* stream);
+
 const char* pc_strerror(int code);
 /* Last HIP error string seen by this thread (diagnostics for PC_ERR_HIP). */
 const char* pc_last_hip_error(void);

@@ -78,6 +78,8 @@ _sig = {
     "pc_ppo_gather": (_i, [_i, _vp, _i, _i] + [_vp] * 10 + [_vp]),
     "pc_ppo_loss": (_i, [_i] + [_vp] * 6 + [_i, _i, _d, _d, _d, _vp, _vp, _vp, _vp]),
     "pc_clip_adam": (_i, [_i] + [_vp] * 6 + [_i64, _d, _d, _d, _d, _d, _vp]),
+    "pc_ppo_workspace_floats": (_i64, [_i, _i, _i, _i]),
+    "pc_ppo_minibatch": (_i, [_i, _vp, _i, _i, _i, _i] + [_vp] * 5 + [_vp] * 6 + [_d] * 7 + [_vp, _vp, _i, _vp]),
     "pc_strerror": (C.c_char_p, [_i]),
     "pc_last_hip_error": (C.c_char_p, []),
     "pc_env_launch_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),

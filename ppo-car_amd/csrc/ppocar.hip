@@ -1175,6 +1175,275 @@ __global__ __launch_bounds__(1024) void clip_adam_kernel(float* __restrict__ par
 }
 
 // ------------------------------------------------------------------------------------------
+// K10-K12: one PPO minibatch step (train.py:230-261) without any library GEMM: the two MLPs are 14.9 k
+// parameters and a minibatch is 44 MFLOP -- twelve library GEMM launches of 5-21 us each were the cost.
+//   K10 ppo_fwdbwd_kernel : gather + forward + loss + backward for 8 samples per workgroup; thread u owns
+//                           hidden unit u of BOTH nets (its W1 rows, W2 column and their gradient accumulators
+//                           live in registers); per-workgroup gradient partials, no atomics (deterministic)
+//   K11 grad_reduce_kernel: sums the partials into the flat gradient, per-block squared-norm partials, metrics
+//   K12 adam_kernel       : clip_grad_norm_ + Adam over the flat bucket, one element per thread
+// Parameter order = torch's module.parameters(): aW1 [H][D], ab1 [H], aW2 [A][H], ab2 [A], cW1, cb1, cW2 [1][H], cb2.
+// ------------------------------------------------------------------------------------------
+constexpr int FB_S = 8;  // samples per workgroup
+
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+template <int DMAX>
+__global__ __launch_bounds__(256) void ppo_fwdbwd_kernel(const int64_t* __restrict__ idx, const int B, const int D, const int A,
+                                                         const float* __restrict__ obs, const float* __restrict__ act,
+                                                         const float* __restrict__ old_lp, const float* __restrict__ adv,
+                                                         const float* __restrict__ ret, const float* __restrict__ param,
+                                                         const float clip, const float vf, const float ec,
+                                                         float* __restrict__ partial, float* __restrict__ metric_partial) {
+    constexpr int H = 256, S = FB_S;
+    __shared__ float sh[16];
+    __shared__ float sX[S][DMAX];
+    __shared__ float sPart[4][S][16];
+    __shared__ float sOut[S][16];
+    __shared__ float sDout[S][16];
+    __shared__ float sMet[S][3];
+    const int u = threadIdx.x, lane = u & 63, wave = u >> 6;
+    // flat parameter offsets
+    const int o_aW1 = 0, o_ab1 = H * D, o_aW2 = o_ab1 + H, o_ab2 = o_aW2 + A * H, o_cW1 = o_ab2 + A, o_cb1 = o_cW1 + H * D,
+              o_cW2 = o_cb1 + H, o_cb2 = o_cW2 + H, n_param = o_cb2 + 1;
+
+    // ---- per-minibatch advantage statistics (train.py:238-240), recomputed identically by every workgroup
+    float a_loc[4], a_sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = u + j * 256;
+        a_loc[j] = i < B ? adv[idx[i]] : 0.0f;
+        a_sum += a_loc[j];
+    }
+    const float invB = 1.0f / (float)B;
+    const float mean = block_sum(a_sum, sh) * invB;
+    float d2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = u + j * 256;
+        const float dv = i < B ? a_loc[j] - mean : 0.0f;
+        d2 += dv * dv;
+    }
+    const float sd = fmaxf(sqrtf(block_sum(d2, sh) / (float)(B - 1)), 1e-5f);
+
+    // ---- my weights
+    float w1a[DMAX], w1c[DMAX], w2a[16];
+#pragma unroll
+    for (int f = 0; f < DMAX; ++f) {
+        w1a[f] = f < D ? param[o_aW1 + u * D + f] : 0.0f;
+        w1c[f] = f < D ? param[o_cW1 + u * D + f] : 0.0f;
+    }
+#pragma unroll
+    for (int o = 0; o < 16; ++o) w2a[o] = o < A ? param[o_aW2 + o * H + u] : 0.0f;
+    const float w2c = param[o_cW2 + u], b1a = param[o_ab1 + u], b1c = param[o_cb1 + u];
+
+    // ---- gather my workgroup's samples (train.py:233-238)
+    const int s0 = blockIdx.x * S;
+    for (int i = u; i < S * DMAX; i += 256) {
+        const int sidx = i / DMAX, f = i - sidx * DMAX;
+        const int b = s0 + sidx;
+        sX[sidx][f] = (b < B && f < D) ? obs[idx[b] * D + f] : 0.0f;
+    }
+    __syncthreads();
+
+    // ---- forward, layer 1 (Linear + ReLU), both nets
+    float ha[S], hc[S];
+#pragma unroll
+    for (int sidx = 0; sidx < S; ++sidx) {
+        float za = b1a, zc = b1c;
+#pragma unroll
+        for (int f = 0; f < DMAX; ++f) {
+            za = __builtin_fmaf(w1a[f], sX[sidx][f], za);
+            zc = __builtin_fmaf(w1c[f], sX[sidx][f], zc);
+        }
+        ha[sidx] = fmaxf(za, 0.0f);
+        hc[sidx] = fmaxf(zc, 0.0f);
+    }
+    // ---- forward, layer 2: sum over the 256 hidden units = over the threads (wave butterfly, then 4 partials)
+#pragma unroll
+    for (int sidx = 0; sidx < S; ++sidx) {
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            if (o <= A) {  // uniform
+                const float pv = o < A ? w2a[o] * ha[sidx] : w2c * hc[sidx];
+                const float r = wave_sum(pv);
+                if (lane == 0) sPart[wave][sidx][o] = r;
+            }
+        }
+    }
+    __syncthreads();
+    if (u < S * 16) {
+        const int sidx = u >> 4, o = u & 15;
+        if (o <= A) sOut[sidx][o] = (o < A ? param[o_ab2 + o] : param[o_cb2]) + sPart[0][sidx][o] + sPart[1][sidx][o] + sPart[2][sidx][o] + sPart[3][sidx][o];
+    }
+    __syncthreads();
+    // ---- loss and its gradient w.r.t. the outputs, one thread per sample (train.py:235-255; as ppo_loss_kernel)
+    if (u < S) {
+        const int b = s0 + u;
+        float pl = 0.0f, vl = 0.0f, ent = 0.0f;
+        if (b < B) {
+            const int64_t src = idx[b];
+            float l[16], mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                l[k] = k < A ? sOut[u][k] : -INFINITY;
+                mx = fmaxf(mx, l[k]);
+            }
+            float sum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sum += k < A ? expf(l[k] - mx) : 0.0f;
+            const float lse = mx + logf(sum);
+            const int a = (int)act[src];
+            float new_lp = 0.0f, pk[16], lpk[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                lpk[k] = k < A ? l[k] - lse : 0.0f;
+                pk[k] = k < A ? expf(lpk[k]) : 0.0f;
+                ent -= pk[k] * lpk[k];
+                if (k == a) new_lp = lpk[k];
+            }
+            const float r = expf(new_lp - old_lp[src]);                       // :235
+            const float An = (adv[src] - mean) / sd;                          // :238-240
+            const float rc = fminf(fmaxf(r, 1.0f - clip), 1.0f + clip);
+            const float pl1 = -An * r, pl2 = -An * rc;                        // :243-244
+            pl = fmaxf(pl1, pl2);                                             // :245
+            const float dv = sOut[u][A] - ret[src];
+            vl = 0.5f * dv * dv;                                              // :249
+            const float g_lp = (pl1 >= pl2 ? -An : 0.0f) * r * invB;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                sDout[u][k] = k < A ? g_lp * ((k == a ? 1.0f : 0.0f) - pk[k]) + ec * invB * pk[k] * (lpk[k] + ent)
+                                    : (k == A ? vf * dv * invB : 0.0f);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sDout[u][k] = 0.0f;
+        }
+        sMet[u][0] = pl;
+        sMet[u][1] = vl;
+        sMet[u][2] = ent;
+    }
+    __syncthreads();
+    // ---- backward: every thread for its hidden unit; gradient accumulators in registers
+    float g1a[DMAX], g1c[DMAX], g2a[16], g2c = 0.0f, gb1a = 0.0f, gb1c = 0.0f;
+#pragma unroll
+    for (int f = 0; f < DMAX; ++f) {
+        g1a[f] = 0.0f;
+        g1c[f] = 0.0f;
+    }
+#pragma unroll
+    for (int o = 0; o < 16; ++o) g2a[o] = 0.0f;
+#pragma unroll
+    for (int sidx = 0; sidx < S; ++sidx) {
+        float dha = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            if (o < A) {
+                const float d = sDout[sidx][o];
+                dha = __builtin_fmaf(w2a[o], d, dha);
+                g2a[o] = __builtin_fmaf(d, ha[sidx], g2a[o]);
+            }
+        }
+        const float dval = sDout[sidx][A];
+        g2c = __builtin_fmaf(dval, hc[sidx], g2c);
+        dha = ha[sidx] > 0.0f ? dha : 0.0f;                      // ReLU backward (threshold at 0)
+        const float dhc = hc[sidx] > 0.0f ? w2c * dval : 0.0f;
+        gb1a += dha;
+        gb1c += dhc;
+#pragma unroll
+        for (int f = 0; f < DMAX; ++f) {
+            g1a[f] = __builtin_fmaf(dha, sX[sidx][f], g1a[f]);
+            g1c[f] = __builtin_fmaf(dhc, sX[sidx][f], g1c[f]);
+        }
+    }
+    // ---- this workgroup's gradient partial, in flat parameter order
+    float* __restrict__ P = partial + (size_t)blockIdx.x * n_param;
+#pragma unroll
+    for (int f = 0; f < DMAX; ++f) {
+        if (f < D) {
+            P[o_aW1 + u * D + f] = g1a[f];
+            P[o_cW1 + u * D + f] = g1c[f];
+        }
+    }
+    P[o_ab1 + u] = gb1a;
+    P[o_cb1 + u] = gb1c;
+#pragma unroll
+    for (int o = 0; o < 16; ++o)
+        if (o < A) P[o_aW2 + o * H + u] = g2a[o];
+    P[o_cW2 + u] = g2c;
+    if (u <= A) {  // output-layer biases: sum of dout over my samples
+        float t = 0.0f;
+#pragma unroll
+        for (int sidx = 0; sidx < S; ++sidx) t += sDout[sidx][u];
+        if (u < A) P[o_ab2 + u] = t;
+        else P[o_cb2] = t;
+    }
+    if (u < 3) {
+        float t = 0.0f;
+#pragma unroll
+        for (int sidx = 0; sidx < S; ++sidx) t += sMet[sidx][u];
+        metric_partial[blockIdx.x * 4 + u] = t;
+    }
+}
+
+// K11: flat_grad[i] = sum_p partial[p][i] (fixed order: deterministic); block-wise squared-norm partials for the clip;
+// block 0 folds the metric partials into the running sums (train.py:263-266) and advances the Adam step counter.
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restrict__ partial, const int n_part, const int n,
+                                                          float* __restrict__ grad, float* __restrict__ norm_partial,
+                                                          const float* __restrict__ metric_partial, const int B, const float vf,
+                                                          const float ec, float* __restrict__ metrics, float* __restrict__ step_count) {
+    __shared__ float sh[16];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float g = 0.0f;
+    if (i < n)
+        for (int pidx = 0; pidx < n_part; ++pidx) g += partial[(size_t)pidx * n + i];
+    if (i < n) grad[i] = g;
+    const float ss = block_sum(g * g, sh);
+    if (threadIdx.x == 0) norm_partial[blockIdx.x] = ss;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 3) {
+            float t = 0.0f;
+            for (int pidx = 0; pidx < n_part; ++pidx) t += metric_partial[pidx * 4 + threadIdx.x];
+            sh[threadIdx.x] = t / (float)B;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            metrics[0] += sh[0];
+            metrics[1] += sh[1];
+            metrics[2] += sh[2];
+            metrics[3] += sh[0] + vf * sh[1] - ec * sh[2];  // :255
+            if (step_count) step_count[0] += 1.0f;
+        }
+    }
+}
+
+// K12: clip_grad_norm_ + Adam, one element per thread; the squared norm arrives as per-block partials of K11 and
+// the step counter has already been advanced there.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ exp_avg,
+                                                   float* __restrict__ exp_avg_sq, const float* __restrict__ step_count,
+                                                   const float* __restrict__ lr_dev, const float* __restrict__ norm_partial,
+                                                   const int n_norm, const int n, const float max_norm, const float beta1,
+                                                   const float beta2, const float eps) {
+    float ss = 0.0f;
+    for (int j = 0; j < n_norm; ++j) ss += norm_partial[j];  // same order in every thread
+    const float coef = fminf(max_norm / (sqrtf(ss) + 1e-6f), 1.0f);
+    const float step = step_count[0];
+    const float bc1 = 1.0f - powf(beta1, step), bc2_sqrt = sqrtf(1.0f - powf(beta2, step));
+    const float step_size = lr_dev[0] / bc1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float g = grad[i] * coef;
+    grad[i] = g;
+    const float m = exp_avg[i] + (1.0f - beta1) * (g - exp_avg[i]);
+    const float v = beta2 * exp_avg_sq[i] + (1.0f - beta2) * g * g;
+    exp_avg[i] = m;
+    exp_avg_sq[i] = v;
+    param[i] -= step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 static thread_local std::string g_hip_err;
@@ -1803,6 +2072,45 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     else if (KS == 10 && rpl == 17) PC_ROLL(10, 17); // 32 -> 33 rays, D = 39
     else return PC_ERR_UNSUPPORTED;
 #undef PC_ROLL
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
+
+int64_t pc_ppo_workspace_floats(int B, int D, int H, int A) {
+    if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40 || B < 2 || B > 1024) return PC_ERR_UNSUPPORTED;
+    const int64_t n_param = 2 * ((int64_t)H * D + H) + (int64_t)A * H + A + H + 1;
+    const int64_t n_part = (B + FB_S - 1) / FB_S;
+    return n_part * n_param + n_part * 4 + (n_param + 255) / 256;
+}
+
+int pc_ppo_minibatch(int device, const int64_t* idx, int B, int D, int H, int A, const float* obs, const float* act,
+                     const float* old_logprob, const float* adv, const float* ret, float* param, float* grad, float* exp_avg,
+                     float* exp_avg_sq, float* step_count, const float* lr_dev, double clip_ratio, double vf_coef, double ent_coef,
+                     double max_norm, double beta1, double beta2, double eps, float* metrics, float* workspace, int apply,
+                     void* stream) {
+    if (!idx || !obs || !act || !old_logprob || !adv || !ret || !param || !grad || !metrics || !workspace) return PC_ERR_INVALID_ARG;
+    if (apply && (!exp_avg || !exp_avg_sq || !step_count || !lr_dev)) return PC_ERR_INVALID_ARG;
+    if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40 || B < 2 || B > 1024) return PC_ERR_UNSUPPORTED;
+    DeviceGuard guard(device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    const int n_param = 2 * (H * D + H) + A * H + A + H + 1;
+    const int n_part = (B + FB_S - 1) / FB_S;
+    const int n_blk = (n_param + 255) / 256;
+    float* partial = workspace;
+    float* metric_partial = partial + (size_t)n_part * n_param;
+    float* norm_partial = metric_partial + n_part * 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (D <= 24)
+        hipLaunchKernelGGL(ppo_fwdbwd_kernel<24>, dim3(n_part), dim3(256), 0, st, idx, B, D, A, obs, act, old_logprob, adv, ret, param,
+                           (float)clip_ratio, (float)vf_coef, (float)ent_coef, partial, metric_partial);
+    else
+        hipLaunchKernelGGL(ppo_fwdbwd_kernel<40>, dim3(n_part), dim3(256), 0, st, idx, B, D, A, obs, act, old_logprob, adv, ret, param,
+                           (float)clip_ratio, (float)vf_coef, (float)ent_coef, partial, metric_partial);
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3(n_blk), dim3(256), 0, st, partial, n_part, n_param, grad, norm_partial, metric_partial, B,
+                       (float)vf_coef, (float)ent_coef, metrics, apply ? step_count : nullptr);
+    if (apply)
+        hipLaunchKernelGGL(adam_kernel, dim3(n_blk), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, step_count, lr_dev, norm_partial,
+                           n_blk, n_param, (float)max_norm, (float)beta1, (float)beta2, (float)eps);
     HIPCHK(hipGetLastError());
     return PC_OK;
 }

@@ -53,6 +53,8 @@ class PPOConfig:
     use_graphs: bool = True                # capture the minibatch update / the rollout in HIP graphs (GPU only)
     fused_update: bool = True              # GPU only: minibatch gather, PPO loss fwd+bwd and clip+Adam as three HIP kernels
                                            # (the MLP GEMMs stay torch autograd); False = the reference's torch ops throughout
+    custom_mlp: bool = True                # with fused_update: the MLP forward/backward too are HIP kernels (pc_ppo_minibatch,
+                                           # no library GEMM); False = torch autograd GEMMs between the fused loss / Adam kernels
     rollout_kernel: str = "auto"           # "mega": the whole rollout as one persistent launch (pc_rollout); "steps": two
                                            # kernels per step (HIP-graph replayed); "auto": mega when n_envs >= 16384
     policy: str = "fused"                  # rollout policy step: "fused" (one MFMA kernel: MLPs + draw),
@@ -130,6 +132,13 @@ class PPOLearner:
             self.exp_avg_sq = torch.zeros_like(self.flat_param)
             self.step_count = torch.zeros(1, device=self.device)
             self.lr_dev = torch.full((1,), cfg.learning_rate, device=self.device, dtype=torch.float32)
+        a1 = agent.actor[0] if isinstance(agent.actor, nn.Sequential) else None
+        self.custom = (self.fused and bool(cfg.custom_mlp) and agent._std_mlp() and a1.out_features == 256
+                       and lib.pc_ppo_workspace_floats(cfg.batch_size, a1.in_features, 256, agent.actor[2].out_features) > 0)
+        if self.custom:
+            self._ws = torch.empty(lib.pc_ppo_workspace_floats(cfg.batch_size, a1.in_features, 256, agent.actor[2].out_features),
+                                   device=self.device, dtype=torch.float32)
+        self._epoch_graph = None
         if self.graphs:   # capturable Adam: step count and lr live on the device, so a captured step stays valid
             lr = torch.tensor(cfg.learning_rate, device=self.device, dtype=torch.float32)
             self.optimizer = torch.optim.Adam(agent.parameters(), lr=lr, eps=1e-5, capturable=True, foreach=True)
@@ -184,6 +193,21 @@ class PPOLearner:
                                self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(), self.lr_dev.data_ptr(),
                                self.flat_param.numel(), cfg.max_grad_norm, 1.0 / self.world_size, 0.9, 0.999, 1e-5,
                                self._stream()), "pc_clip_adam")
+
+    def custom_minibatch_step(self, idx, obs, act, logprob, adv, ret):
+        """pc_ppo_minibatch: gather + forward + loss + backward (+ clip + Adam when single-rank) with no library GEMM."""
+        cfg, a1, a2 = self.cfg, self.agent.actor[0], self.agent.actor[2]
+        single = self.world_size == 1
+        check(lib.pc_ppo_minibatch(self._dev_index(), idx.data_ptr(), cfg.batch_size, a1.in_features, a1.out_features, a2.out_features,
+                                   obs.data_ptr(), act.data_ptr(), logprob.data_ptr(), adv.data_ptr(), ret.data_ptr(),
+                                   self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                   self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(), self.lr_dev.data_ptr(), cfg.clip_ratio,
+                                   cfg.vf_coef, cfg.ent_coef, cfg.max_grad_norm, 0.9, 0.999, 1e-5, self.metrics.data_ptr(),
+                                   self._ws.data_ptr(), 1 if single else 0, self._stream()), "pc_ppo_minibatch")
+        if not single:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)     # the 1/W is folded into pc_clip_adam
+            self._fused_apply()
 
     def fused_minibatch_step(self, idx, obs, act, logprob, adv, ret):
         self._fused_fwd_bwd(idx, obs, act, logprob, adv, ret)
@@ -294,6 +318,30 @@ class PPOLearner:
         full = idx_all.shape[1] >= n_mb * B          # every minibatch has exactly B samples
         if self.fused and full and getattr(self, "_f", None) is None:
             self._fused_alloc(obs.shape[1], self.agent.actor[2].out_features)
+        if self.custom and full and not cfg.full_sweep:
+            # three tiny launches per minibatch, indices read in place from the epoch's index block; single rank +
+            # graphs: the whole epoch's update (train_iters x n_mb minibatches) is ONE captured graph
+            args = (obs, act, logprob, adv, ret)
+            if self.graphs and self.world_size == 1:
+                key = tuple(t.data_ptr() for t in args) + (M, idx_all.data_ptr())
+                if self._epoch_graph is None or self._epoch_key != key:
+                    if getattr(self, "_opt_started", False) and self._epoch_graph is None:
+                        pass   # (capture does not execute: safe at any time)
+                    torch.cuda.synchronize(self.device)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        for it in range(cfg.train_iters):
+                            for mb in range(n_mb):
+                                self.custom_minibatch_step(idx_all[it, mb * B:(mb + 1) * B], *args)
+                    self._epoch_graph, self._epoch_key = g, key
+                self._epoch_graph.replay()
+            else:
+                for it in range(cfg.train_iters):
+                    for mb in range(n_mb):
+                        self.custom_minibatch_step(idx_all[it, mb * B:(mb + 1) * B], *args)
+            self._opt_started = True
+            self.lr_dev.mul_(cfg.learning_rate_decay)                                    # StepLR(step_size=1), :147,:269
+            return
         use_graph = self.graphs and full
         if use_graph and self._graph_key != (obs.data_ptr(), act.data_ptr(), logprob.data_ptr(), adv.data_ptr(),
                                              ret.data_ptr(), M):

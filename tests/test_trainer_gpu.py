@@ -67,7 +67,7 @@ def test_graph_update_equals_eager_update():
         torch.cuda.synchronize()
         outs[use_graphs] = (tr.learner.flat_param.clone(), tr.learner.metrics.clone(), tr.learner.current_lr())
         if use_graphs:
-            assert tr.learner._graph_key is not None
+            assert tr.learner._graph_key is not None or tr.learner._epoch_graph is not None
         tr.close()
     (p0, m0, lr0), (p1, m1, lr1) = outs[False], outs[True]
     assert lr0 == pytest.approx(lr1, rel=1e-6) and lr0 == pytest.approx(3e-4 * 0.99 ** 2, rel=1e-6)
@@ -253,3 +253,55 @@ def test_two_ranks_on_one_gpu_keep_replicas_identical(tmp_path, use_graphs):
     assert not torch.equal(r0["acts"], r1["acts"])               # but the shards sampled different actions
     assert r0["step"] == r1["step"] == 2 * 2 * 512 * 64          # global_step counts the whole job (train.py:174)
     assert r0["scalars"]["charts/avg_reward"] == pytest.approx(r1["scalars"]["charts/avg_reward"])   # all-reduced scalars
+
+
+@pytest.mark.parametrize("B,D", [(512, 23), (100, 18), (1024, 39)])
+def test_custom_minibatch_kernels_match_torch_autograd(B, D):
+    """pc_ppo_minibatch (gather + both MLPs forward + loss + backward, no library GEMM, then clip + Adam) against torch:
+    the raw gradient against autograd's, then parameters and metric sums over several optimizer steps."""
+    from ppo_car_amd.ppo import ppo_loss
+    M = 5000
+    g = torch.Generator().manual_seed(B + D)
+    obs = (torch.rand(M, D, generator=g) * 2 - 0.3).cuda()
+    act = torch.randint(0, 9, (M,), generator=g).float().cuda()
+    lp = (-torch.rand(M, generator=g) * 2.5).cuda()
+    adv = (torch.randn(M, generator=g) * 3 + 0.5).cuda()
+    ret = torch.randn(M, generator=g).cuda()
+    idxs = [torch.randperm(M, generator=g)[:B].cuda() for _ in range(5)]
+    res = {}
+    for custom in (False, True):
+        torch.manual_seed(3)
+        agent = pc.Agent(D, 9).cuda()
+        with torch.no_grad():
+            for p_ in agent.parameters():
+                p_.add_(torch.randn_like(p_) * 0.05)
+        cfg = PPOConfig(n_envs=8, n_steps=B, batch_size=B, train_iters=1, use_graphs=False, fused_update=custom, custom_mlp=custom,
+                        max_grad_norm=0.5)
+        L = PPOLearner(agent, cfg, "cuda")
+        assert L.custom == custom
+        if custom:   # raw (unclipped) gradient of the first minibatch: apply = 0
+            from ppo_car_amd._capi import check, lib
+            i = idxs[0]
+            check(lib.pc_ppo_minibatch(0, i.data_ptr(), B, D, 256, 9, obs.data_ptr(), act.data_ptr(), lp.data_ptr(), adv.data_ptr(),
+                                       ret.data_ptr(), L.flat_param.data_ptr(), L.flat_grad.data_ptr(), None, None, None, None, 0.2,
+                                       0.5, 0.001, 0.5, 0.9, 0.999, 1e-5, L.metrics.data_ptr(), L._ws.data_ptr(), 0,
+                                       torch.cuda.current_stream().cuda_stream), "pc_ppo_minibatch")
+            raw = L.flat_grad.clone()
+            L.metrics.zero_()
+        else:
+            i = idxs[0]
+            loss, *_ = ppo_loss(agent, obs[i], act[i], lp[i], adv[i], ret[i], 0.2, 0.5, 0.001)
+            L.flat_grad.zero_()
+            loss.backward()
+            raw = L.flat_grad.clone()
+        for i in idxs:
+            if custom:
+                L.custom_minibatch_step(i, obs, act, lp, adv, ret)
+            else:
+                L.minibatch_step(obs[i], act[i], lp[i], adv[i], ret[i])
+        torch.cuda.synchronize()
+        res[custom] = (raw, L.flat_param.clone(), L.metrics.clone())
+    (g0, p0, m0), (g1, p1, m1) = res[False], res[True]
+    assert torch.allclose(g0, g1, atol=2e-6, rtol=2e-4), float((g0 - g1).abs().max())
+    assert torch.allclose(m0, m1, atol=2e-4, rtol=1e-5)
+    assert float((p0 - p1).abs().max()) < 1e-5
