@@ -128,7 +128,10 @@ __device__ __forceinline__ float cast_fast(float best, float c1, float c2, float
                                            float dy) {
     const float den = __builtin_fmaf(ey, dx, -(ex * dy));
     const float u = un * __builtin_amdgcn_rcpf(den);
-    const bool better = (c1 * c2 < 0.0f) & (u > 0.0f) & (u < best);
+    // u > 0 and u < best in ONE compare: for non-negative floats the unsigned bit patterns order like the values,
+    // and a negative (or NaN) u has the sign (or all exponent) bits set, i.e. compares above any finite best.
+    // (u == +0 passes where the reference's u > 0 rejects: the ray origin exactly on a wall line.)
+    const bool better = (c1 * c2 < 0.0f) & (__float_as_uint(u) < __float_as_uint(best));
     return better ? u : best;
 }
 
