@@ -138,6 +138,14 @@ int64_t pc_policy_image_floats(int D, int H, int A);
  * envs), 0 = never split, 1 = always.  The two forms differ in fp32 summation order (last-bit differences).  Tuning /
  * test knob, process-wide. */
 int pc_policy_set_split(int mode);
+/* Arithmetic of the policy step's two GEMMs (process-wide; choose before packing):
+ *   1 (default) = bf16x3: every fp32 operand split into three bf16 pieces, six piece products per product, fp32
+ *       accumulation on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16).  fp32-equivalent: max error vs float64 on
+ *       this MLP 0.55e-6 (a plain fp32 GEMM: 1.3e-6).  Used when D <= 24 and A <= 9, else form 0.
+ *   0 = fp32-input MFMA (v_mfma_f32_16x16x4_f32), bit-for-bit an fp32 fmaf chain.
+ * pc_policy_precision reports the form a (D, H, A) shape will actually get (negative: unsupported shape). */
+int pc_policy_set_precision(int mode);
+int pc_policy_precision(int D, int H, int A);
 int pc_policy_pack(int device, int D, int H, int A, const float* aW1, const float* ab1, const float* aW2, const float* ab2,
                    const float* cW1, const float* cb1, const float* cW2, const float* cb2, float* image, void* stream);
 int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, const float* image, uint64_t seed,

@@ -72,6 +72,8 @@ _sig = {
     "pc_sample": (_i, [_i, _vp, _i64, _i, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp]),
     "pc_policy_image_floats": (_i64, [_i, _i, _i]),
     "pc_policy_set_split": (_i, [_i]),
+    "pc_policy_set_precision": (_i, [_i]),
+    "pc_policy_precision": (_i, [_i, _i, _i]),
     "pc_policy_pack": (_i, [_i, _i, _i, _i] + [_vp] * 8 + [_vp, _vp]),
     "pc_policy_act": (_i, [_i, _vp, _i64, _i, _i, _i, _vp, C.c_uint64, C.c_uint64, _vp] + [_vp] * 5 + [_vp]),
     "pc_rollout": (_i, [_vp, _vp, _i, _i64, _d, C.c_uint64, C.c_uint64, _vp] + [_vp] * 10 + [_vp]),

@@ -796,6 +796,142 @@ __device__ __forceinline__ void policy_pass(const float* sW1, const float* sB1, 
     }
 }
 
+// ---- the same two layers on the bf16 matrix cores, fp32-equivalent: every fp32 operand is split into three
+// bf16 pieces (v = v0 + v1 + v2, 8 significant bits each, residuals exact), and a product a*b is taken as the six
+// piece products a_i*b_j with i + j <= 2 (each exact in the fp32 accumulator; the dropped ones are <= 2^-24
+// relative).  Measured against float64 on this MLP the result is closer than a plain fp32 GEMM (max error 0.55e-6
+// vs 1.3e-6).  v_mfma_f32_16x16x32_bf16 runs on the matrix pipe proper, 16x the fp32-input rate, and --
+// unlike the fp32-input MFMA -- does not occupy the fp32 ALUs the env step needs.
+// Layouts: lane (g = l >> 4, lc = l & 15) holds A[row lc][k = 8g + j], B[k = 8g + j][col lc], j = 0..7.
+//   layer 1: k = feature (D <= 24: one K block, group 3 is zero padding), rows = 16 hidden units, cols = 16 envs
+//   layer 2: K block = TWO hidden tiles; k-slot j of group g <-> tile (j >> 2), hidden row 4g + (j & 3): exactly the
+//            accumulator registers the lane already holds for its env column -- again no data movement.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr int pol16_w1_dwords() { return 32 * 3 * 48 * 4; }
+__host__ __device__ constexpr int pol16_w2_dwords() { return 16 * 3 * 4 * 10 * 4; }
+__host__ __device__ constexpr int pol16_image_dwords() { return pol16_w1_dwords() + pol16_w2_dwords() + 512 + 16; }
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {  // low half = bf16(a), high half = bf16(b), round-to-nearest-even
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// split two fp32 values into their three bf16 pieces (packed pairwise)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+    p0 = pk_bf16(a, b);
+    const float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
+    p1 = pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(p1 << 16), sb = rb - __uint_as_float(p1 & 0xffff0000u);
+    p2 = pk_bf16(sa, sb);
+}
+
+struct Bf3 { u32x4 p[3]; };  // eight fp32 values as 3 x (8 bf16)
+
+__device__ __forceinline__ Bf3 split8(const float (&v)[8]) {
+    Bf3 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned p0, p1, p2;
+        split_pair(v[2 * i], v[2 * i + 1], p0, p1, p2);
+        r.p[0][i] = p0;
+        r.p[1][i] = p1;
+        r.p[2][i] = p2;
+    }
+    return r;
+}
+
+__device__ __forceinline__ f32x4 mfma6(const u32x4 (&a)[3], const Bf3& b, f32x4 acc) {  // small terms first
+#define PC_MF(i, j) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b.p[j]), acc, 0, 0, 0)
+    PC_MF(0, 2); PC_MF(1, 1); PC_MF(2, 0); PC_MF(0, 1); PC_MF(1, 0); PC_MF(0, 0);
+#undef PC_MF
+    return acc;
+}
+
+// bf16x3 image builder (one thread per 16-byte operand record / per bias float)
+__global__ __launch_bounds__(256) void policy_pack16_kernel(const int D, const int A, const float* __restrict__ aW1,
+                                                            const float* __restrict__ ab1, const float* __restrict__ aW2,
+                                                            const float* __restrict__ ab2, const float* __restrict__ cW1,
+                                                            const float* __restrict__ cb1, const float* __restrict__ cW2,
+                                                            const float* __restrict__ cb2, unsigned* __restrict__ image) {
+    constexpr int HID = 256;
+    constexpr int n1 = 32 * 3 * 48, n2 = 16 * 3 * 4 * 10;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2 + 512 + 16; i += gridDim.x * blockDim.x) {
+        if (i < n1 + n2) {
+            float v[8];
+            int pc;
+            if (i < n1) {
+                const int lc = i % 16, g = (i / 16) % 3;
+                pc = (i / 48) % 3;
+                const int ht = i / 144, r = 16 * ht + lc;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int f = 8 * g + j;
+                    v[j] = f < D ? (r < HID ? aW1[r * D + f] : cW1[(r - HID) * D + f]) : 0.0f;
+                }
+            } else {
+                const int k = i - n1;
+                const int o = k % 10, g = (k / 10) % 4;
+                pc = (k / 40) % 3;
+                const int tp = k / 120;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int h = 16 * (2 * tp + (j >> 2)) + 4 * g + (j & 3);
+                    v[j] = h < HID ? (o < A ? aW2[o * HID + h] : 0.0f) : (o == A ? cW2[h - HID] : 0.0f);
+                }
+            }
+            const Bf3 sp = split8(v);
+            reinterpret_cast<u32x4*>(image)[i] = sp.p[pc];
+        } else {
+            const int b = i - n1 - n2;
+            float v;
+            if (b < 512) v = b < HID ? ab1[b] : cb1[b - HID];
+            else {
+                const int o = b - 512;
+                v = o < A ? ab2[o] : (o == A ? cb2[0] : 0.0f);
+            }
+            image[(n1 + n2) * 4 + b] = __float_as_uint(v);
+        }
+    }
+}
+
+// One wave, 32 envs (2 column tiles), hidden tile PAIRS [tp0, tp1).  x[et] = the env tile's observation pieces.
+__device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsigned* sW2p, const float* sB1, const int tp0,
+                                              const int tp1, const Bf3 (&x)[2], f32x4 (&out)[2], const int lc, const int g) {
+    const int gA = g < 3 ? g : 2;     // group 3 is K padding: its B operand is all zeros, any finite A will do
+    const int oA = lc < 10 ? lc : 9;  // output rows >= 10 are never read
+    for (int tp = tp0; tp < tp1; ++tp) {
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ht = 2 * tp + j;
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(sB1 + 16 * ht + 4 * g);
+            u32x4 a[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) a[pc] = *reinterpret_cast<const u32x4*>(sW1p + ((ht * 3 + pc) * 48 + gA * 16 + lc) * 4);
+#pragma unroll
+            for (int et = 0; et < 2; ++et) acc[j][et] = mfma6(a, x[et], bias);
+        }
+        u32x4 w2[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) w2[pc] = *reinterpret_cast<const u32x4*>(sW2p + (((tp * 3 + pc) * 4 + g) * 10 + oA) * 4);
+#pragma unroll
+        for (int et = 0; et < 2; ++et) {
+            float hv[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                hv[r] = relu_f(acc[0][et][r]);
+                hv[4 + r] = relu_f(acc[1][et][r]);
+            }
+            const Bf3 h3 = split8(hv);
+            out[et] = mfma6(w2, h3, out[et]);
+        }
+    }
+}
+
 // Softmax / Philox draw / log_prob for one env given its 16 output values (logits 0..A-1, value at A).
 __device__ __forceinline__ void policy_tail(const float (&v)[16], const int A, const uint64_t seed, const uint64_t off,
                                             const uint64_t e, int& act, float& lp, float& val, float* __restrict__ logits_row) {
@@ -830,11 +966,11 @@ __device__ __forceinline__ void policy_tail(const float (&v)[16], const int A, c
     }
 }
 
-template <int KS> __device__ __forceinline__ void policy_stage_image(const float* __restrict__ image, float* lds, const int tid) {
+template <int NDW> __device__ __forceinline__ void policy_stage_image(const float* __restrict__ image, float* lds, const int tid) {
     // 16-byte coalesced copies, all loads of a thread in flight together
     const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(image);
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    constexpr int n4 = pol_image_padded(KS) / 4;
+    constexpr int n4 = NDW / 4;
     constexpr int per = (n4 + 511) / 512;
     f32x4 tmp[per];
 #pragma unroll
@@ -856,7 +992,8 @@ template <int KS> __device__ __forceinline__ void policy_stage_image(const float
 //                each; their partial [16 x 32] outputs are summed through LDS.  A pass is 8x shorter, so a
 //                batch that cannot fill the chip with 256-env workgroups (n_envs < ~32 k) finishes in a
 //                fraction of the single-pass latency of the other form.
-template <int KS, bool SPLIT>
+// PREC = 0: fp32-input MFMA (bit-for-bit an fp32 fmaf chain).  PREC = 1: bf16x3 split on the bf16 matrix cores.
+template <int KS, bool SPLIT, int PREC>
 __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ obs, const int64_t N, const int D, const int A,
                                                      const float* __restrict__ image, const uint64_t seed, const uint64_t offset,
                                                      const uint64_t* __restrict__ offset_dev, int64_t* __restrict__ action,
@@ -865,15 +1002,18 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
     constexpr int HID = 256, NT = 2 * HID / 16;  // 32 hidden tiles: 16 actor + 16 critic
     constexpr int LD1 = pol_ld1(KS), LDO = 17, ET = 2;
     constexpr int ENVS_PER_WG = SPLIT ? 32 : 256;
+    constexpr int IMG = PREC ? pol16_image_dwords() : pol_image_padded(KS);
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* sW1 = lds;                        // [512][LD1]
-    float* sB1 = sW1 + 2 * HID * LD1;        // [512]
-    float* sW2 = sB1 + 2 * HID;              // [NT][4][64]
-    float* sB2 = sW2 + NT * 4 * 64;          // [16]
-    float* sOut = lds + pol_image_padded(KS);  // [8 waves][32 envs][LDO]
+    float* sW1 = lds;                        // PREC 0: [512][LD1]
+    float* sB1 = PREC ? lds + pol16_w1_dwords() + pol16_w2_dwords() : sW1 + 2 * HID * LD1;  // [512]
+    float* sW2 = sB1 + 2 * HID;              // PREC 0: [NT][4][64]
+    float* sB2 = PREC ? sB1 + 512 : sW2 + NT * 4 * 64;  // [16]
+    const unsigned* sW1p = reinterpret_cast<const unsigned*>(lds);                       // PREC 1 operand records
+    const unsigned* sW2p = sW1p + pol16_w1_dwords();
+    float* sOut = lds + IMG;                 // [8 waves][32 envs][LDO]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, lk = lane >> 4;
-    policy_stage_image<KS>(image, lds, tid);
+    policy_stage_image<IMG>(image, lds, tid);
     __syncthreads();
 
     const uint64_t off = offset + (offset_dev ? *offset_dev : 0);
@@ -882,21 +1022,37 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
     const int64_t n_chunks = (N + ENVS_PER_WG - 1) / ENVS_PER_WG;
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const int64_t env0 = chunk * ENVS_PER_WG + (SPLIT ? 0 : wave * 32);
-        // ---- B operands of layer 1: X^T, lane (k = lk, j = lc) of env tile et, k-step ks
-        float x[ET][KS];
-#pragma unroll
-        for (int et = 0; et < ET; ++et) {
-            const int64_t e = env0 + 16 * et + lc;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int f = 4 * ks + lk;
-                x[et][ks] = (e < N && f < D) ? obs[e * D + f] : 0.0f;
-            }
-        }
         f32x4 out[ET];
 #pragma unroll
         for (int et = 0; et < ET; ++et) out[et] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-        policy_pass<KS>(sW1, sB1, sW2, ht0, ht1, x, out, lc, lk, lane);
+        if constexpr (PREC == 0) {
+            // ---- B operands of layer 1: X^T, lane (k = lk, j = lc) of env tile et, k-step ks
+            float x[ET][KS];
+#pragma unroll
+            for (int et = 0; et < ET; ++et) {
+                const int64_t e = env0 + 16 * et + lc;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int f = 4 * ks + lk;
+                    x[et][ks] = (e < N && f < D) ? obs[e * D + f] : 0.0f;
+                }
+            }
+            policy_pass<KS>(sW1, sB1, sW2, ht0, ht1, x, out, lc, lk, lane);
+        } else {
+            Bf3 x[ET];
+#pragma unroll
+            for (int et = 0; et < ET; ++et) {
+                const int64_t e = env0 + 16 * et + lc;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int f = 8 * lk + j;
+                    v[j] = (e < N && f < D) ? obs[e * D + f] : 0.0f;
+                }
+                x[et] = split8(v);
+            }
+            policy_pass16(sW1p, sW2p, sB1, ht0 / 2, ht1 / 2, x, out, lc, lk);
+        }
         // ---- out tile -> LDS so that lane = env
         __syncthreads();  // previous pass's readers are done with sOut
 #pragma unroll
@@ -932,18 +1088,18 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
 // ------------------------------------------------------------------------------------------
 // K9: the whole rollout (train.py:173-195) as ONE persistent launch.
 // A workgroup (8 waves) owns 256 envs for all T steps: the policy weights stay in LDS, the env state in
-// registers, the observation of step t passes from the env phase to the policy phase through LDS; per step an
+// registers, the observation of step t passes from the env step to the policy step through LDS; per step an
 // env costs 116 B of HBM writes (its buffer rows) and no reads.  Envs never interact and the weights are fixed
-// during a rollout, so there is no inter-workgroup communication at all.
-// The two halves of the workgroup (4 waves, 128 envs each) run in ANTI-PHASE: while half A runs the policy
-// step of its envs on the matrix cores (MFMA pipe), half B runs the env step of its envs (VALU pipe), then
-// they swap -- every SIMD hosts one wave of each half, so both pipes work all the time.  One __syncthreads per
-// phase; 2T + 1 phases.
-//   P(t): X^T from LDS -> policy_pass -> draw -> action to LDS, (act, logprob, value) rows t to HBM
-//   E(t): action from LDS -> env_step_core (2 lanes per env) -> obs row t+1 to HBM and LDS, (rew, term, trunc)
+// during a rollout, so there is no inter-workgroup communication at all -- and no intra-workgroup one either:
+// every WAVE owns 32 envs outright (policy step as one 32-column MFMA problem, then the env step of the same 32
+// envs with 2 lanes per env), so after the weight image is staged there is not a single barrier.  The two waves
+// that share a SIMD are started half a step apart, so one is in its matrix-core phase while the other is in its
+// VALU phase (with PREC = 1 the policy GEMMs run on the bf16 matrix pipe and leave the fp32 ALUs to the env step).
+//   P(t): X^T from LDS -> policy pass -> draw -> action to LDS, (act, logprob, value) rows t to HBM
+//   E(t): action from LDS -> env_step_core -> obs row t+1 to HBM and LDS, (rew, term, trunc)
 // Same arithmetic, same Philox counters as the policy_kernel / env_step_kernel pair: bit-identical buffers.
 // ------------------------------------------------------------------------------------------
-template <int KS, int RPL>
+template <int KS, int RPL, int PREC>
 __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, const float* __restrict__ image, const int A,
                                                       const int T, const double reward_scale, const uint64_t seed,
                                                       const uint64_t offset, const uint64_t* __restrict__ offset_dev,
@@ -954,88 +1110,109 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                                                       float* __restrict__ next_term, float* __restrict__ next_trunc,
                                                       const int dbg) {
     constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, LDX = 4 * KS + 1, ET = 2;
+    constexpr int IMG = PREC ? pol16_image_dwords() : pol_image_padded(KS);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sW1 = lds;
-    float* sB1 = sW1 + 2 * HID * LD1;
+    float* sB1 = PREC ? lds + pol16_w1_dwords() + pol16_w2_dwords() : sW1 + 2 * HID * LD1;
     float* sW2 = sB1 + 2 * HID;
-    float* sB2 = sW2 + NT * 4 * 64;
-    float* sOut = lds + pol_image_padded(KS);      // [8 waves][32 envs][LDO]
+    float* sB2 = PREC ? sB1 + 512 : sW2 + NT * 4 * 64;
+    const unsigned* sW1p = reinterpret_cast<const unsigned*>(lds);
+    const unsigned* sW2p = sW1p + pol16_w1_dwords();
+    float* sOut = lds + IMG;                       // [8 waves][32 envs][LDO]
     float* sObs = sOut + 8 * 32 * LDO;             // [256 envs][LDX]   observation of the step in flight
     int* sAct = reinterpret_cast<int*>(sObs + 256 * LDX);  // [256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, lk = lane >> 4;
-    const int half = wave >> 2, hw = wave & 3;     // which half of the workgroup, wave inside the half
     const int64_t N = p.N;
     const int D = p.D;
-    policy_stage_image<KS>(image, lds, tid);
+    policy_stage_image<IMG>(image, lds, tid);
 
-    // env-phase identity: 2 lanes per env, 128 envs per half
-    const int ll = tid & 255, el = half * 128 + (ll >> 1), g = ll & 1;
+    // this wave's 32 envs: local rows [pbase, pbase + 32); env-step identity: 2 lanes per env
+    const int pbase = wave * 32;
+    const int el = pbase + (lane >> 1), g = lane & 1;
     const int64_t e_env = (int64_t)blockIdx.x * 256 + el;
     const bool e_valid = e_env < N;
     EnvRegs st = {};
     if (e_valid) st = env_load<float>(p, e_env);
     for (int f = g; f < 4 * KS; f += 2) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
-    // policy-phase identity: wave hw of the half owns envs [half*128 + 32 hw, +32)
-    const int pbase = half * 128 + hw * 32;
     float* myOut = sOut + wave * 32 * LDO;
     const uint64_t off0 = offset + (offset_dev ? *offset_dev : 0);
-    __syncthreads();
+    __syncthreads();  // the weight image is in place; from here on the waves never synchronise again
+    if (wave >= 4) {  // stagger: the second wave of each SIMD starts about half a step later (speed only)
+#pragma unroll 1
+        for (int i = 0; i < 96; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
-    for (int s = 0; s <= 2 * T; ++s) {
-        const int sp = s - half;  // half 0 starts one phase ahead of half 1
-        if (sp >= 0 && sp < 2 * T) {
-            const int t = sp >> 1;
-            if ((sp & 1) == 0) {
-                // ---------------- P(t)
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        {
+            // ---------------- P(t)
+            f32x4 out[ET];
+#pragma unroll
+            for (int et = 0; et < ET; ++et) out[et] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (PREC == 0) {
                 float x[ET][KS];
 #pragma unroll
                 for (int et = 0; et < ET; ++et)
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) x[et][ks] = sObs[(pbase + 16 * et + lc) * LDX + 4 * ks + lk];
-                f32x4 out[ET];
-#pragma unroll
-                for (int et = 0; et < ET; ++et) out[et] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
                 if (!(dbg & 1)) policy_pass<KS>(sW1, sB1, sW2, 0, NT, x, out, lc, lk, lane);  // dbg: timing ablations only
+            } else {
+                Bf3 x[ET];
 #pragma unroll
-                for (int et = 0; et < ET; ++et)
+                for (int et = 0; et < ET; ++et) {
+                    float v[8];
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) myOut[(16 * et + lc) * LDO + 4 * lk + reg] = out[et][reg];
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the tile is written and read by this wave only
-                __builtin_amdgcn_wave_barrier();
-                const int64_t e = (int64_t)blockIdx.x * 256 + pbase + lane;
-                if (lane < 32 && e < N) {
-                    float v[16];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = sB2[i] + myOut[lane * LDO + i];
-                    int act;
-                    float lp, val;
-                    policy_tail(v, A, seed, off0 + (uint64_t)t, (uint64_t)e, act, lp, val, nullptr);
-                    sAct[pbase + lane] = act;
-                    const int64_t row = (int64_t)t * N + e;
-                    act_buf[row] = (float)act;     // stored as float32 like the reference (buffer.py:13)
-                    logprob_buf[row] = lp;
-                    val_buf[row] = val;
+                    for (int j = 0; j < 8; ++j) {
+                        const int f = 8 * lk + j;
+                        v[j] = f < D ? sObs[(pbase + 16 * et + lc) * LDX + f] : 0.0f;
+                    }
+                    x[et] = split8(v);
                 }
-            } else if (e_valid && !(dbg & 2)) {
-                // ---------------- E(t)
-                const bool last = t + 1 == T;
-                float* orow = last ? next_obs + e_env * D : obs_buf + ((int64_t)(t + 1) * N + e_env) * D;
-                float rw;
-                bool term, trunc;
-                int passed;
-                env_step_core<float, RPL>(p, 0, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw, term,
-                                          trunc, passed);
-                if (g == 0) {
-                    rew_buf[(int64_t)t * N + e_env] = rw;
-                    float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;    // flags that precede obs t+1
-                    float* tc = last ? next_trunc : trunc_buf + (int64_t)(t + 1) * N;  // (train.py:176-177,195)
-                    tr[e_env] = term ? 1.0f : 0.0f;
-                    tc[e_env] = trunc ? 1.0f : 0.0f;
-                }
+                if (!(dbg & 1)) policy_pass16(sW1p, sW2p, sB1, 0, NT / 2, x, out, lc, lk);
+            }
+#pragma unroll
+            for (int et = 0; et < ET; ++et)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) myOut[(16 * et + lc) * LDO + 4 * lk + reg] = out[et][reg];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the tile is written and read by this wave only
+            __builtin_amdgcn_wave_barrier();
+            const int64_t e = (int64_t)blockIdx.x * 256 + pbase + lane;
+            if (lane < 32 && e < N) {
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = sB2[i] + myOut[lane * LDO + i];
+                int act;
+                float lp, val;
+                policy_tail(v, A, seed, off0 + (uint64_t)t, (uint64_t)e, act, lp, val, nullptr);
+                sAct[pbase + lane] = act;
+                const int64_t row = (int64_t)t * N + e;
+                act_buf[row] = (float)act;     // stored as float32 like the reference (buffer.py:13)
+                logprob_buf[row] = lp;
+                val_buf[row] = val;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (e_valid && !(dbg & 2)) {
+            // ---------------- E(t)
+            const bool last = t + 1 == T;
+            float* orow = last ? next_obs + e_env * D : obs_buf + ((int64_t)(t + 1) * N + e_env) * D;
+            float rw;
+            bool term, trunc;
+            int passed;
+            env_step_core<float, RPL>(p, 0, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw, term, trunc,
+                                      passed);
+            if (g == 0) {
+                rew_buf[(int64_t)t * N + e_env] = rw;
+                float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;    // flags that precede obs t+1
+                float* tc = last ? next_trunc : trunc_buf + (int64_t)(t + 1) * N;  // (train.py:176-177,195)
+                tr[e_env] = term ? 1.0f : 0.0f;
+                tc[e_env] = trunc ? 1.0f : 0.0f;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // obs rows in LDS are this wave's own
+        __builtin_amdgcn_wave_barrier();
     }
     if (e_valid && g == 0) env_store<float>(p, e_env, st);
 }
@@ -1928,6 +2105,19 @@ int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, 
 
 static int policy_ks(int D) { return D <= 20 ? 5 : (D <= 24 ? 6 : 10); }
 static int g_policy_split_mode = -1;  // -1 auto (split below 32768 envs), 0 never, 1 always
+static int g_policy_precision = 1;    // 0 = fp32-input MFMA, 1 = bf16x3 split on the bf16 matrix cores (needs D <= 24, A <= 9)
+
+int pc_policy_set_precision(int mode) {
+    if (mode < 0 || mode > 1) return PC_ERR_INVALID_ARG;
+    g_policy_precision = mode;
+    return PC_OK;
+}
+
+static int policy_prec(int D, int A) { return (g_policy_precision == 1 && D <= 24 && A <= 9) ? 1 : 0; }
+int pc_policy_precision(int D, int H, int A) {
+    if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
+    return policy_prec(D, A);
+}
 
 int pc_policy_set_split(int mode) {
     if (mode < -1 || mode > 1) return PC_ERR_INVALID_ARG;
@@ -1937,7 +2127,7 @@ int pc_policy_set_split(int mode) {
 
 int64_t pc_policy_image_floats(int D, int H, int A) {
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
-    return pol_image_padded(policy_ks(D));
+    return policy_prec(D, A) ? pol16_image_dwords() : pol_image_padded(policy_ks(D));
 }
 
 int pc_policy_pack(int device, int D, int H, int A, const float* aW1, const float* ab1, const float* aW2, const float* ab2,
@@ -1948,8 +2138,12 @@ int pc_policy_pack(int device, int D, int H, int A, const float* aW1, const floa
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1 || device < 0 || device >= count) return PC_ERR_NO_DEVICE;
     DeviceGuard guard(device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
-    hipLaunchKernelGGL(policy_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, policy_ks(D), D, A, aW1, ab1, aW2, ab2,
-                       cW1, cb1, cW2, cb2, image);
+    if (policy_prec(D, A))
+        hipLaunchKernelGGL(policy_pack16_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, D, A, aW1, ab1, aW2, ab2, cW1, cb1,
+                           cW2, cb2, reinterpret_cast<unsigned*>(image));
+    else
+        hipLaunchKernelGGL(policy_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, policy_ks(D), D, A, aW1, ab1, aW2, ab2,
+                           cW1, cb1, cW2, cb2, image);
     HIPCHK(hipGetLastError());
     return PC_OK;
 }
@@ -1964,7 +2158,8 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
     DeviceGuard guard(device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
     const int KS = policy_ks(D);
-    const size_t lds = (size_t)(pol_image_padded(KS) + 8 * 32 * 17) * sizeof(float);
+    const int prec = policy_prec(D, A);
+    const size_t lds = (size_t)((prec ? pol16_image_dwords() : pol_image_padded(KS)) + 8 * 32 * 17) * sizeof(float);
     static int n_cu[64] = {0};
     if (device < 64 && n_cu[device] == 0) {
         hipDeviceProp_t prop;
@@ -1977,24 +2172,27 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
     const int64_t chunks = split ? (N + 31) / 32 : (N + 255) / 256;
     const int blocks = (int)(chunks < cus ? chunks : cus);  // one ~100-KB-LDS workgroup per CU, persistent over env chunks
     hipStream_t st = (hipStream_t)stream;
-#define PC_POL(KSV, SPL)                                                                                                 \
+#define PC_POL(KSV, SPL, PRC)                                                                                            \
     do {                                                                                                                 \
         static bool attr_set[64] = {false};                                                                              \
         if (device < 64 && !attr_set[device]) {                                                                          \
-            HIPCHK(hipFuncSetAttribute((const void*)policy_kernel<KSV, SPL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HIPCHK(hipFuncSetAttribute((const void*)policy_kernel<KSV, SPL, PRC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_set[device] = true;                                                                                     \
         }                                                                                                                \
-        hipLaunchKernelGGL((policy_kernel<KSV, SPL>), dim3(blocks), dim3(512), lds, st, obs, N, D, A, image, seed, offset, offset_dev, \
+        hipLaunchKernelGGL((policy_kernel<KSV, SPL, PRC>), dim3(blocks), dim3(512), lds, st, obs, N, D, A, image, seed, offset, offset_dev, \
                            action, action_f32, logprob, value, logits_out);                                              \
     } while (0)
-    if (split) {
-        if (KS == 5) PC_POL(5, true);
-        else if (KS == 6) PC_POL(6, true);
-        else PC_POL(10, true);
+    if (prec) {
+        if (split) { if (KS == 5) PC_POL(5, true, 1); else PC_POL(6, true, 1); }
+        else { if (KS == 5) PC_POL(5, false, 1); else PC_POL(6, false, 1); }
+    } else if (split) {
+        if (KS == 5) PC_POL(5, true, 0);
+        else if (KS == 6) PC_POL(6, true, 0);
+        else PC_POL(10, true, 0);
     } else {
-        if (KS == 5) PC_POL(5, false);
-        else if (KS == 6) PC_POL(6, false);
-        else PC_POL(10, false);
+        if (KS == 5) PC_POL(5, false, 0);
+        else if (KS == 6) PC_POL(6, false, 0);
+        else PC_POL(10, false, 0);
     }
 #undef PC_POL
     HIPCHK(hipGetLastError());
@@ -2051,7 +2249,8 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     const int rpl = (e->R + 1) / 2;  // 2 lanes per env
     DeviceGuard guard(e->device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
-    const size_t lds = (size_t)(pol_image_padded(KS) + 8 * 32 * 17 + 256 * (4 * KS + 1) + 256) * sizeof(float);
+    const int prec = policy_prec(e->D, A);
+    const size_t lds = (size_t)((prec ? pol16_image_dwords() : pol_image_padded(KS)) + 8 * 32 * 17 + 256 * (4 * KS + 1) + 256) * sizeof(float);
     if (lds > 160 * 1024) return PC_ERR_UNSUPPORTED;  // 32 -> 33 rays: weight image + observation tile exceed one CU's LDS
     const int blocks = (int)((e->N + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
@@ -2059,20 +2258,20 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     prm.lg = 1;
     const char* dbg_env = getenv("PPOCAR_ROLLOUT_ABLATE");  // developer timing ablation: 1 = skip policy MFMAs, 2 = skip env step
     const int dbg = dbg_env ? atoi(dbg_env) : 0;
-#define PC_ROLL(KSV, RPLV)                                                                                               \
+#define PC_ROLL(KSV, RPLV, PRC)                                                                                          \
     do {                                                                                                                 \
         static bool attr_set[64] = {false};                                                                              \
         if (e->device < 64 && !attr_set[e->device]) {                                                                    \
-            HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<KSV, RPLV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<KSV, RPLV, PRC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_set[e->device] = true;                                                                                  \
         }                                                                                                                \
-        hipLaunchKernelGGL((rollout_kernel<KSV, RPLV>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, seed, \
+        hipLaunchKernelGGL((rollout_kernel<KSV, RPLV, PRC>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, seed, \
                            offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs,  \
                            next_term, next_trunc, dbg);                                                                  \
     } while (0)
-    if (KS == 5 && rpl == 6) PC_ROLL(5, 6);          // 12 rays, D = 18
-    else if (KS == 6 && rpl == 9) PC_ROLL(6, 9);     // 16 -> 17 rays, D = 23
-    else if (KS == 10 && rpl == 17) PC_ROLL(10, 17); // 32 -> 33 rays, D = 39
+    if (KS == 5 && rpl == 6) { if (prec) PC_ROLL(5, 6, 1); else PC_ROLL(5, 6, 0); }          // 12 rays, D = 18
+    else if (KS == 6 && rpl == 9) { if (prec) PC_ROLL(6, 9, 1); else PC_ROLL(6, 9, 0); }     // 16 -> 17 rays, D = 23
+    else if (KS == 10 && rpl == 17) PC_ROLL(10, 17, 0);                                        // 32 -> 33 rays, D = 39
     else return PC_ERR_UNSUPPORTED;
 #undef PC_ROLL
     HIPCHK(hipGetLastError());

@@ -71,6 +71,7 @@ class Agent(nn.Module):
                                  c1.weight.data_ptr(), c1.bias.data_ptr(), c2.weight.data_ptr(), c2.bias.data_ptr(),
                                  self._image.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "pc_policy_pack")
         self._image_ok = True
+        self._image_prec = lib.pc_policy_precision(D, H, A)
         return True
 
     @torch.no_grad()
@@ -94,7 +95,11 @@ class Agent(nn.Module):
         stream = torch.cuda.current_stream(dev).cuda_stream
         ptr = lambda t: t.data_ptr() if t is not None else None
         if fused and x.is_contiguous() and x.dtype == torch.float32:
-            ok = self.pack_policy() if (repack or not getattr(self, "_image_ok", False)) else True
+            stale = True
+            if self._std_mlp() and getattr(self, "_image_ok", False):
+                a1_, a2_ = self.actor[0], self.actor[2]
+                stale = self._image_prec != lib.pc_policy_precision(a1_.in_features, a1_.out_features, a2_.out_features)
+            ok = self.pack_policy() if (repack or stale) else True
             if ok:
                 a1, a2 = self.actor[0], self.actor[2]
                 value = out_value if out_value is not None else torch.empty(N, dtype=torch.float32, device=dev)

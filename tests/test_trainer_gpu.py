@@ -185,14 +185,16 @@ def test_fused_and_torch_updates_agree_inside_the_trainer():
     assert torch.allclose(outs[False][0], outs[True][0], atol=5e-3)
 
 
+@pytest.mark.parametrize("precision", [1, 0])
 @pytest.mark.parametrize("num_rays,n_envs", [(16, 1000), (12, 512), (32, 300)])
-def test_persistent_rollout_kernel_is_bitwise_the_two_kernel_rollout(num_rays, n_envs):
+def test_persistent_rollout_kernel_is_bitwise_the_two_kernel_rollout(num_rays, n_envs, precision):
     """pc_rollout (one persistent launch: policy phase on the MFMA pipe and env phase on the VALU pipe alternating in
     the two halves of each workgroup, weights in LDS, env state in registers) must fill the buffer with exactly the
     bits of the per-step policy_kernel / env_step_kernel sequence, over several epochs (auto-resets included)."""
     from ppo_car_amd._capi import lib
     res = {}
     lib.pc_policy_set_split(0)      # same fp32 summation order in both forms (the split form differs in the last bits)
+    lib.pc_policy_set_precision(precision)
     for mode in ("steps", "mega"):
         cfg = _cfg(rollout_kernel=mode, use_graphs=False, n_envs=n_envs, n_steps=80, num_rays=num_rays)
         tr = Trainer(cfg, device="cuda")
@@ -211,6 +213,7 @@ def test_persistent_rollout_kernel_is_bitwise_the_two_kernel_rollout(num_rays, n
         res[mode] = (snaps, st)
         tr.close()
     lib.pc_policy_set_split(-1)
+    lib.pc_policy_set_precision(1)
     for ep in range(3):
         for i, (a, b) in enumerate(zip(res["steps"][0][ep], res["mega"][0][ep])):
             assert torch.equal(a, b), (ep, i)
