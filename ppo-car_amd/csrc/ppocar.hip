@@ -79,6 +79,7 @@ template <typename T> struct EnvParams {
     int q;               // n // 4: stride of the collision rays (car_env.py:389)
     int step_deg;        // 360 // n (car_env.py:269)
     int R, D;            // actual ray count, obs dim 6 + R
+    uint64_t colbits;    // bit r set <=> ray r < 64 is one of Car.check_collision's rays (r < n and r % (n // 4) == 0)
     double4* __restrict__ pv;               // [N] (px, py, vx, vy): kinematic state, float64 in BOTH modes
     int4* __restrict__ iv;                  // [N] (rot_k [F32 only], time_step, next_gate, passed)
     double* __restrict__ rot;               // [N] heading in degrees, F64 only
@@ -302,7 +303,8 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
         }
         best[s] = (T)1000;  // Ray.get_distance :198
         // Car.check_collision's rays: r in range(0, n, n // 4) (:389) -- nominal n, not R
-        const bool is_col = valid & (ray < p.n_nominal) & (ray % p.q == 0);
+        // (host-built bitmask for rays < 64: a runtime modulo per ray slot costs ~20 VALU instructions)
+        const bool is_col = valid & (ray < 64 ? (bool)((p.colbits >> ray) & 1) : ((ray < p.n_nominal) & (ray % p.q == 0)));
         colmask |= (uint64_t)is_col << s;
         if (is_col) {  // Car.get_passed_gate (:394-408) uses the rays of the PREVIOUS update
             T odx = dx[s], ody = dy[s];
@@ -1138,9 +1140,9 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     float* myOut = sOut + wave * 32 * LDO;
     const uint64_t off0 = offset + (offset_dev ? *offset_dev : 0);
     __syncthreads();  // the weight image is in place; from here on the waves never synchronise again
-    if (wave >= 4) {  // stagger: the second wave of each SIMD starts about half a step later (speed only)
+    if (wave >= 4) {  // stagger: the second wave of each SIMD starts about half a step (~15 us) later (speed only)
 #pragma unroll 1
-        for (int i = 0; i < 96; ++i) __builtin_amdgcn_s_sleep(127);
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);  // 4 x 127 x 64 cycles
     }
 
 #pragma unroll 1
@@ -1366,9 +1368,18 @@ __global__ __launch_bounds__(1024) void clip_adam_kernel(float* __restrict__ par
 // ------------------------------------------------------------------------------------------
 constexpr int FB_S = 8;  // samples per workgroup
 
+// 64-lane sum with DPP row operations (VALU only; the __shfl_xor butterfly goes through the LDS crossbar
+// with ~100 cycles of dependent latency per step).  The total lands in lane 63; readlane broadcasts it.
 __device__ __forceinline__ float wave_sum(float v) {
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+#define PC_DPP(ctrl, rmask) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+    PC_DPP(0x111, 0xf);  // row_shr:1
+    PC_DPP(0x112, 0xf);  // row_shr:2
+    PC_DPP(0x114, 0xf);  // row_shr:4
+    PC_DPP(0x118, 0xf);  // row_shr:8   -> lane 15 of each row holds the row sum
+    PC_DPP(0x142, 0xa);  // row_bcast:15 -> rows 1 and 3 add the previous row's total
+    PC_DPP(0x143, 0xc);  // row_bcast:31 -> rows 2 and 3 add lane 31's total
+#undef PC_DPP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 template <int DMAX>
@@ -1390,6 +1401,26 @@ __global__ __launch_bounds__(256) void ppo_fwdbwd_kernel(const int64_t* __restri
     const int o_aW1 = 0, o_ab1 = H * D, o_aW2 = o_ab1 + H, o_ab2 = o_aW2 + A * H, o_cW1 = o_ab2 + A, o_cb1 = o_cW1 + H * D,
               o_cW2 = o_cb1 + H, o_cb2 = o_cW2 + H, n_param = o_cb2 + 1;
 
+    // ---- my weights and my workgroup's samples first: their loads fly while the statistics are reduced
+    // ---- my weights
+    float w1a[DMAX], w1c[DMAX], w2a[16];
+#pragma unroll
+    for (int f = 0; f < DMAX; ++f) {
+        w1a[f] = f < D ? param[o_aW1 + u * D + f] : 0.0f;
+        w1c[f] = f < D ? param[o_cW1 + u * D + f] : 0.0f;
+    }
+#pragma unroll
+    for (int o = 0; o < 16; ++o) w2a[o] = o < A ? param[o_aW2 + o * H + u] : 0.0f;
+    const float w2c = param[o_cW2 + u], b1a = param[o_ab1 + u], b1c = param[o_cb1 + u];
+
+    // ---- gather my workgroup's samples (train.py:233-238)
+    const int s0 = blockIdx.x * S;
+    for (int i = u; i < S * DMAX; i += 256) {
+        const int sidx = i / DMAX, f = i - sidx * DMAX;
+        const int b = s0 + sidx;
+        sX[sidx][f] = (b < B && f < D) ? obs[idx[b] * D + f] : 0.0f;
+    }
+
     // ---- per-minibatch advantage statistics (train.py:238-240), recomputed identically by every workgroup
     float a_loc[4], a_sum = 0.0f;
 #pragma unroll
@@ -1409,24 +1440,6 @@ __global__ __launch_bounds__(256) void ppo_fwdbwd_kernel(const int64_t* __restri
     }
     const float sd = fmaxf(sqrtf(block_sum(d2, sh) / (float)(B - 1)), 1e-5f);
 
-    // ---- my weights
-    float w1a[DMAX], w1c[DMAX], w2a[16];
-#pragma unroll
-    for (int f = 0; f < DMAX; ++f) {
-        w1a[f] = f < D ? param[o_aW1 + u * D + f] : 0.0f;
-        w1c[f] = f < D ? param[o_cW1 + u * D + f] : 0.0f;
-    }
-#pragma unroll
-    for (int o = 0; o < 16; ++o) w2a[o] = o < A ? param[o_aW2 + o * H + u] : 0.0f;
-    const float w2c = param[o_cW2 + u], b1a = param[o_ab1 + u], b1c = param[o_cb1 + u];
-
-    // ---- gather my workgroup's samples (train.py:233-238)
-    const int s0 = blockIdx.x * S;
-    for (int i = u; i < S * DMAX; i += 256) {
-        const int sidx = i / DMAX, f = i - sidx * DMAX;
-        const int b = s0 + sidx;
-        sX[sidx][f] = (b < B && f < D) ? obs[idx[b] * D + f] : 0.0f;
-    }
     __syncthreads();
 
     // ---- forward, layer 1 (Linear + ReLU), both nets
@@ -1577,8 +1590,17 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restric
     __shared__ float sh[16];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float g = 0.0f;
-    if (i < n)
-        for (int pidx = 0; pidx < n_part; ++pidx) g += partial[(size_t)pidx * n + i];
+    if (i < n) {
+        int pidx = 0;
+        for (; pidx + 8 <= n_part; pidx += 8) {  // 8 independent loads in flight; summed in index order
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = partial[(size_t)(pidx + j) * n + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g += t[j];
+        }
+        for (; pidx < n_part; ++pidx) g += partial[(size_t)pidx * n + i];
+    }
     if (i < n) grad[i] = g;
     const float ss = block_sum(g * g, sh);
     if (threadIdx.x == 0) norm_partial[blockIdx.x] = ss;
@@ -1692,6 +1714,8 @@ struct pc_env {
         p.step_deg = 360 / n_nominal;
         p.R = R;
         p.D = D;
+        p.colbits = 0;
+        for (int r = 0; r < 64 && r < n_nominal; r += n_nominal / 4) p.colbits |= 1ull << r;
         p.pv = pv;
         p.iv = iv;
         p.rot = rot;
