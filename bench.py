@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--n-steps", type=int, default=None)
     ap.add_argument("--env-dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--policy", default="fused", choices=["fused", "sample", "torch"], help="rollout policy-step implementation")
+    ap.add_argument("--policy-arith", default="bf16x3", choices=["bf16x3", "fp32"], help="arithmetic of the fused policy step's GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
@@ -117,6 +118,10 @@ def main():
             dist.init_process_group("gloo")
 
     from ppo_car_amd.ppo import PPOConfig, Trainer
+    from ppo_car_amd._capi import lib as _lib
+    _lib.pc_policy_set_precision({"bf16x3": 1, "fp32": 0}[args.policy_arith])
+    POLICY_ARITH = {"bf16x3": "bf16x3 split, 6 products, fp32 accumulate on the bf16 matrix cores (fp32-equivalent; DESIGN.md section 5)",
+                    "fp32": "fp32-input MFMA (exact fp32 fmaf chain)"}[args.policy_arith]
     wl = dict(WORKLOADS[args.workload])
     if args.n_envs:
         wl["n_envs"] = args.n_envs
@@ -157,6 +162,7 @@ def main():
         tr.profile_stride = args.event_stride
     tr.k1_events = []
     tr.phase_events = []
+    tr.mega_events = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -179,8 +185,23 @@ def main():
     if rank == 0:
         env_steps = cfg.n_envs * cfg.n_steps * args.steps * world
         nr = cfg.num_rays
-        algo_bytes = ALGO_BYTES.get(nr, 4 * (6 + tr.obs_dim[0] - 6) + 84) * cfg.n_envs
-        achieved = algo_bytes / (k1_us * 1e-6) / 1e9
+        per_step_bytes = ALGO_BYTES.get(nr, 4 * (tr.obs_dim[0]) + 84)     # algorithmic bytes per env step
+        per_step_flops = ALGO_FLOPS.get(nr, 0)
+        k1 = {"kernel": "env_step_kernel (K1), stand-alone", "launch_us": k1_us, "achieved": per_step_bytes * cfg.n_envs / (k1_us * 1e-6) / 1e9,
+              "unit": "GB/s", "frac": per_step_bytes * cfg.n_envs / (k1_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+              "launch_us_method": f"{PROBE} back-to-back launches on an identical env batch between two HIP events on the launch stream, "
+                                  "once per timed epoch", "launch_us_bracketed_in_rollout": k1_bracketed_us}
+        if tr.mega_events:
+            # the timed region's dominant kernel is the persistent rollout kernel: ONE launch does n_steps env steps (+ policy steps)
+            # for every env; algorithmic bytes = SURVEY's per-env-step figure x n_envs x n_steps
+            dom_us = float(np.mean([a.elapsed_time(b) for a, b in tr.mega_events]) * 1e3)
+            algo_bytes = per_step_bytes * cfg.n_envs * cfg.n_steps
+            dom_name = "rollout_kernel (K9: policy step + env step + Buffer.store for all n_steps, one persistent launch)"
+            dom_method = "HIP events on the launch stream around each pc_rollout launch inside the timed epochs"
+            units = cfg.n_envs * cfg.n_steps
+        else:
+            dom_us, algo_bytes, dom_name, dom_method, units = k1_us, per_step_bytes * cfg.n_envs, k1["kernel"], k1["launch_us_method"], cfg.n_envs
+        achieved = algo_bytes / (dom_us * 1e-6) / 1e9
         out = {
             "metric": "env steps/sec (whole node) on big_track.json, 16 rays",
             "value": env_steps / dt, "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -190,23 +211,28 @@ def main():
                                    f"n_envs={cfg.n_envs}/GPU, n_steps={cfg.n_steps}, batch_size={cfg.batch_size}, "
                                    f"train_iters={cfg.train_iters}; one step = one PPO epoch (rollout + GAE + update)",
                        "n_envs_total": cfg.n_envs * world, "parallelism": f"env-sharded dp{world}, 1 flat grad all-reduce/minibatch",
-                       "env_kernel": info, "policy_step": args.policy, "rollout": tr.rollout_mode, "hip_graphs": bool(cfg.use_graphs), "fused_update": bool(cfg.fused_update), "custom_mlp_update": bool(tr.learner.custom), "epoch_split": split, "numerics": "float64 kinematic state, float32 ray geometry" if args.env_dtype == "f32"
+                       "env_kernel": info, "policy_step": args.policy, "rollout": tr.rollout_mode,
+                       "policy_gemm_arithmetic": POLICY_ARITH, "hip_graphs": bool(cfg.use_graphs),
+                       "fused_update": bool(cfg.fused_update), "custom_mlp_update": bool(tr.learner.custom), "epoch_split": split,
+                       "numerics": "float64 kinematic state, float32 ray geometry" if args.env_dtype == "f32"
                        else "float64 throughout (reference operation order)"},
-            "roofline": {"kernel": "env_step_kernel (K1)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": dom_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "launch_us": k1_us, "launch_us_method": f"{PROBE} back-to-back launches of K1 on an identical env batch between two "
-                         "HIP events on the launch stream, once per timed epoch", "launch_us_bracketed_in_rollout": k1_bracketed_us,
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "K1 is fp32-VALU-bound, not HBM-bound (DESIGN.md); see `valu`",
-                         "valu": {"achieved": ALGO_FLOPS.get(nr, 0) * cfg.n_envs / (k1_us * 1e-6) / 1e12,
-                                  "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": ALGO_FLOPS.get(nr, 0) * cfg.n_envs / (k1_us * 1e-6) / 1e12 / VALU_PEAK_TFLOPS}},
+                         "launch_us": dom_us, "launch_us_method": dom_method, "algorithmic_bytes_per_launch": algo_bytes,
+                         "env_steps_per_launch": units,
+                         "note": "the path is bound by the SIMDs' vector-issue port (fp32 VALU ray geometry + operand splitting), "
+                                 "not by HBM: DESIGN.md section 4; `valu` prices the same launch against the fp32 vector peak",
+                         "valu": {"achieved": per_step_flops * units / (dom_us * 1e-6) / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": per_step_flops * units / (dom_us * 1e-6) / 1e12 / VALU_PEAK_TFLOPS,
+                                  "counts": "SURVEY 8(d) env-step flops only (policy MFMA work not included)"},
+                         "k1_standalone": k1},
         }
         traffic_file = os.path.join(ROOT, "profiles", "k1_traffic.json")
         if os.path.exists(traffic_file):
             try:
                 tf = json.load(open(traffic_file))
-                key = f"{args.env_dtype}_n{nr}_N{cfg.n_envs}"
+                key = (f"rollout_{args.env_dtype}_n{nr}_N{cfg.n_envs}_T{cfg.n_steps}" if tr.mega_events
+                       else f"{args.env_dtype}_n{nr}_N{cfg.n_envs}")
                 if key in tf:
                     out["roofline"]["traffic"] = tf[key]["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = tf[key].get("source", "profiles/k1_traffic.json")

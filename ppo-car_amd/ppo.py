@@ -404,6 +404,7 @@ class Trainer:
         self._rollout_graph = None
         self._eager_rollouts = 0
         self.rollout_mode = None
+        self.mega_events = None      # bench.py: list of (start, end) events around each pc_rollout launch
 
     # ---- train.py:173-195 ---------------------------------------------------------------------------
     @torch.no_grad()
@@ -449,6 +450,10 @@ class Trainer:
         buf.obs_buf[0].copy_(self.next_obs)
         buf.term_buf[0].copy_(self.next_term)
         buf.trunc_buf[0].copy_(self.next_trunc)
+        ev = None
+        if self.mega_events is not None:    # bench.py: HIP events on the launch stream around the one launch
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         rc = lib.pc_rollout(self.envs._h, agent._image.data_ptr(), self.act_dim, cfg.n_steps, float(cfg.reward_scaling),
                             int(agent.rng_seed), 0, self.rng_base.data_ptr(), buf.obs_buf.data_ptr(), buf.act_buf.data_ptr(),
                             buf.rew_buf.data_ptr(), buf.val_buf.data_ptr(), buf.term_buf.data_ptr(), buf.trunc_buf.data_ptr(),
@@ -457,6 +462,9 @@ class Trainer:
         if rc == -5:       # PC_ERR_UNSUPPORTED: shape outside the persistent kernel's menu
             return False
         check(rc, "pc_rollout")
+        if ev is not None:
+            ev[1].record()
+            self.mega_events.append(ev)
         self.rng_base += cfg.n_steps
         return True
 
