@@ -541,5 +541,37 @@ class Trainer:
                 "charts/SPS": self.global_step_idx / max(elapsed, 1e-9), "global_step": self.global_step_idx,
                 "elapsed": elapsed}
 
+    # ---- checkpoint / resume (the reference only saves agent.state_dict(), train.py:283,301) ----
+    def state_dict(self):
+        """Everything needed to continue a run bit-for-bit: policy, optimizer, lr, env state, RNG counters."""
+        L = self.learner
+        opt = ({"exp_avg": L.exp_avg, "exp_avg_sq": L.exp_avg_sq, "step_count": L.step_count, "lr_dev": L.lr_dev} if L.fused
+               else {"optimizer": L.optimizer.state_dict(), "scheduler": L.scheduler.state_dict()})
+        return {"agent": self.agent.state_dict(), "opt": opt, "fused": L.fused, "env": self.envs.get_state(),
+                "next_obs": self.next_obs, "next_term": self.next_term, "next_trunc": self.next_trunc,
+                "rng_base": self.rng_base, "np_rng": L._np_rng.bit_generator.state, "epoch": self.epoch,
+                "global_step_idx": self.global_step_idx, "agent_rng_offset": self.agent._rng_offset,
+                "config": dataclasses.asdict(self.cfg)}
+
+    def load_state_dict(self, sd):
+        L = self.learner
+        if sd["fused"] != L.fused:
+            raise ValueError("checkpoint was written with a different update path (fused_update)")
+        with torch.no_grad():
+            self.agent.load_state_dict(sd["agent"])        # parameters are views into the flat buffer: copied in place
+            if L.fused:
+                for k in ("exp_avg", "exp_avg_sq", "step_count", "lr_dev"):
+                    getattr(L, k).copy_(sd["opt"][k])
+            else:
+                L.optimizer.load_state_dict(sd["opt"]["optimizer"])
+                L.scheduler.load_state_dict(sd["opt"]["scheduler"])
+            self.envs.set_state(**sd["env"])
+            self.next_obs.copy_(sd["next_obs"]); self.next_term.copy_(sd["next_term"]); self.next_trunc.copy_(sd["next_trunc"])
+            self.rng_base.copy_(sd["rng_base"])
+        L._np_rng.bit_generator.state = sd["np_rng"]
+        L._opt_started = True
+        self.epoch, self.global_step_idx = sd["epoch"], sd["global_step_idx"]
+        self.agent._rng_offset = sd["agent_rng_offset"]
+
     def close(self):
         self.envs.close()

@@ -308,3 +308,38 @@ def test_custom_minibatch_kernels_match_torch_autograd(B, D):
     assert torch.allclose(g0, g1, atol=2e-6, rtol=2e-4), float((g0 - g1).abs().max())
     assert torch.allclose(m0, m1, atol=2e-4, rtol=1e-5)
     assert float((p0 - p1).abs().max()) < 1e-5
+
+
+def test_checkpoint_resume_continues_bit_for_bit(tmp_path):
+    """3 epochs in one go == 2 epochs, save, fresh trainer, load, 1 more epoch (policy, optimizer state, env state,
+    device Philox counters and the host index generator all restored)."""
+    cfg = _cfg(n_envs=512, n_steps=48, batch_size=64, train_iters=3)
+    a = Trainer(cfg, device="cuda")
+    for _ in range(3):
+        a.run_epoch(sync=False)
+    torch.cuda.synchronize()
+    b = Trainer(cfg, device="cuda")
+    for _ in range(2):
+        b.run_epoch(sync=False)
+    torch.save(b.state_dict(), tmp_path / "t.pt")
+    b.close()
+    c = Trainer(cfg, device="cuda")
+    c.load_state_dict(torch.load(tmp_path / "t.pt", map_location="cuda", weights_only=False))
+    assert c.epoch == 2 and c.global_step_idx == 2 * 512 * 48
+    c.run_epoch(sync=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a.learner.flat_param, c.learner.flat_param)
+    assert torch.equal(a.buffer.act_buf, c.buffer.act_buf) and torch.equal(a.next_obs, c.next_obs)
+    sa, sc = a.envs.get_state(), c.envs.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sc[k]), k
+    a.close(); c.close()
+
+
+def test_evaluate_entry_point(tmp_path):
+    import evaluate
+    torch.manual_seed(0)
+    agent = pc.Agent(18, 9)
+    torch.save(agent.state_dict(), tmp_path / "model.dat")
+    out = evaluate.main(["--checkpoint", str(tmp_path / "model.dat"), "--track", TRACKS["big_track"], "--episodes", "4"])
+    assert out["episodes"] == 4 and 1 <= out["mean_steps"] <= 1000 and len(out["returns"]) == 4

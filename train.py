@@ -45,6 +45,7 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--full-sweep", action="store_true", help="use every sample each train iter instead of train.py:228's loop bound")
     p.add_argument("--out-dir", default=".", help="where checkpoints/ and logs/ are created")
+    p.add_argument("--resume", default=None, help="trainer_<epoch>.pt written by an earlier run: continue it exactly")
     return p.parse_args(argv)
 
 
@@ -81,12 +82,17 @@ def main(argv=None):
                     reward_scaling=args.reward_scaling, track=args.track, num_rays=args.num_rays, env_dtype=args.env_dtype,
                     seed=args.seed, full_sweep=args.full_sweep)
     trainer = Trainer(cfg, device=torch.device("cuda", local_rank), rank=rank, world_size=world)
+    first_epoch = 1
+    if args.resume:
+        path = args.resume if world == 1 else args.resume.replace(".pt", f".rank{rank}.pt")
+        trainer.load_state_dict(torch.load(path, map_location=trainer.device, weights_only=False))
+        first_epoch = trainer.epoch + 1
     if rank == 0:
         print(trainer.agent.actor)      # train.py:148-149
         print(trainer.agent.critic)
     start = time.time()
     try:
-        for epoch in range(1, args.n_epochs + 1):
+        for epoch in range(first_epoch, args.n_epochs + 1):
             scalars = trainer.run_epoch(sync=True)
             if rank == 0:
                 print(f"Epoch {epoch} done in {time.time() - start:.2f}s. Avg reward: {scalars['charts/avg_reward']:.4f}. ",
@@ -95,6 +101,10 @@ def main(argv=None):
                 log.flush()
                 if epoch % 10 == 0:                                                                # train.py:280-283
                     torch.save(trainer.agent.state_dict(), os.path.join(ckpt_dir, f"checkpoint_{epoch}.dat"))
+            if epoch % 10 == 0:   # full resumable state next to the reference-format file (every rank: env shards differ)
+                os.makedirs(ckpt_dir, exist_ok=True)
+                name = f"trainer_{epoch}.pt" if world == 1 else f"trainer_{epoch}.rank{rank}.pt"
+                torch.save(trainer.state_dict(), os.path.join(ckpt_dir, name))
     finally:
         trainer.close()                                                                            # train.py:296
         if rank == 0:
