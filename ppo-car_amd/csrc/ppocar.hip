@@ -1,13 +1,18 @@
 // ppocar.hip -- HIP kernels (gfx950 / CDNA4) and the C-ABI of libppocar.so.
 //
 // Kernels
-//   env_step_kernel<T, RPL>   K1: the whole CarEnv.step transition (car_env.py:693-760) for one
-//                             vector-env call, with TransformReward and gymnasium's same-step
-//                             auto-reset folded in (train.py:65,68,185).
-//   env_reset_kernel<T>       K2: CarEnv.reset for every env (car_env.py:605-691).
-//   reset_obs_kernel<T>       computes each track's constant reset observation once at create.
-//   gae_kernel                K3: Buffer.calculate_advantages (buffer.py:36-64).
-//   sample_kernel             K4: Categorical(logits).sample / log_prob / entropy (model.py:35-40).
+//   K1  env_step_kernel<T, RPL, MIXED>  the whole CarEnv.step transition (car_env.py:693-760) for one vector-env call,
+//                                       with TransformReward and gymnasium's same-step auto-reset folded in
+//                                       (train.py:65,68,185)
+//   K2  env_reset_kernel<T>             CarEnv.reset for every env (car_env.py:605-691); reset_obs_kernel<T> computes
+//                                       each track's constant reset observation once at create
+//   K3  gae_kernel                      Buffer.calculate_advantages (buffer.py:36-64)
+//   K4  sample_kernel                   Categorical(logits).sample / log_prob / entropy (model.py:35-40)
+//   K5  policy_kernel<KS, SPLIT, PREC>  Agent.get_action_and_value(x) of the rollout (model.py:34-41): both MLPs on the
+//                                       matrix cores + the draw; policy_pack*_kernel build its LDS weight image
+//   K6-8 ppo_gather / ppo_loss / clip_adam   non-GEMM pieces of a PPO minibatch step (train.py:230-261)
+//   K9  rollout_kernel<KS, RPL, PREC>   the whole rollout (train.py:173-195) as one persistent launch
+//   K10-12 ppo_fwdbwd / grad_reduce / adam   one PPO minibatch step without any library GEMM
 //
 // Work decomposition of K1: an env is owned by G = 2^lg consecutive lanes of one
 // wavefront ("lanes per env", chosen on the host from n_envs so the chip is filled); lane g of the

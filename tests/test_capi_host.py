@@ -150,3 +150,21 @@ def test_buffer_store_get_semantics_cpu_storage():
     assert torch.equal(obs[2], torch.full((N, D), 2.0)) and torch.equal(lp, torch.full((T, N), -1.0))
     with pytest.raises(AssertionError):
         buf.get()
+
+
+def test_shape_menus_are_reported_without_a_gpu():
+    """The size / precision queries validate shapes on the host: callers use them to decide on their fallbacks."""
+    lib = _capi.lib
+    assert lib.pc_policy_image_floats(23, 256, 9) > 0 and lib.pc_policy_image_floats(39, 256, 9) > 0
+    assert lib.pc_policy_image_floats(23, 128, 9) == _capi.PC_ERR_UNSUPPORTED      # hidden size other than 256
+    assert lib.pc_policy_image_floats(41, 256, 9) == _capi.PC_ERR_UNSUPPORTED
+    assert lib.pc_policy_image_floats(23, 256, 16) == _capi.PC_ERR_UNSUPPORTED
+    assert lib.pc_policy_precision(23, 256, 9) == 1 and lib.pc_policy_precision(39, 256, 9) == 0   # bf16x3 covers D <= 24
+    assert lib.pc_policy_set_precision(0) == 0 and lib.pc_policy_precision(23, 256, 9) == 0
+    assert lib.pc_policy_set_precision(1) == 0 and lib.pc_policy_set_precision(7) == _capi.PC_ERR_INVALID_ARG
+    assert lib.pc_policy_set_split(2) == _capi.PC_ERR_INVALID_ARG and lib.pc_policy_set_split(-1) == 0
+    n = lib.pc_ppo_workspace_floats(512, 23, 256, 9)
+    n_param = 2 * (256 * 23 + 256) + 9 * 256 + 9 + 256 + 1
+    assert n_param == 14858 and n == 64 * n_param + 64 * 4 + (n_param + 255) // 256
+    assert lib.pc_ppo_workspace_floats(2048, 23, 256, 9) == _capi.PC_ERR_UNSUPPORTED    # batch above 1024
+    assert lib.pc_ppo_workspace_floats(512, 23, 64, 9) == _capi.PC_ERR_UNSUPPORTED
