@@ -819,8 +819,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ constexpr int pol16_w1_dwords() { return 32 * 3 * 48 * 4; }
-__host__ __device__ constexpr int pol16_w2_dwords() { return 16 * 3 * 4 * 10 * 4; }
-__host__ __device__ constexpr int pol16_image_dwords() { return pol16_w1_dwords() + pol16_w2_dwords() + 512 + 16; }
+__host__ __device__ constexpr int pol16_w2_dwords() { return 8 * 3 * 4 * 10 * 4; }  // actor tile pairs only
+// [W1 records][W2 records (actor)][b1: 512][b2: 16][critic output weights, fp32: 256]
+__host__ __device__ constexpr int pol16_image_dwords() { return pol16_w1_dwords() + pol16_w2_dwords() + 512 + 16 + 256; }
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {  // low half = bf16(a), high half = bf16(b), round-to-nearest-even
     const f32x2 v = {a, b};
@@ -865,8 +866,8 @@ __global__ __launch_bounds__(256) void policy_pack16_kernel(const int D, const i
                                                             const float* __restrict__ cb1, const float* __restrict__ cW2,
                                                             const float* __restrict__ cb2, unsigned* __restrict__ image) {
     constexpr int HID = 256;
-    constexpr int n1 = 32 * 3 * 48, n2 = 16 * 3 * 4 * 10;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2 + 512 + 16; i += gridDim.x * blockDim.x) {
+    constexpr int n1 = 32 * 3 * 48, n2 = 8 * 3 * 4 * 10;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2 + 512 + 16 + 256; i += gridDim.x * blockDim.x) {
         if (i < n1 + n2) {
             float v[8];
             int pc;
@@ -886,8 +887,8 @@ __global__ __launch_bounds__(256) void policy_pack16_kernel(const int D, const i
                 const int tp = k / 120;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int h = 16 * (2 * tp + (j >> 2)) + 4 * g + (j & 3);
-                    v[j] = h < HID ? (o < A ? aW2[o * HID + h] : 0.0f) : (o == A ? cW2[h - HID] : 0.0f);
+                    const int h = 16 * (2 * tp + (j >> 2)) + 4 * g + (j & 3);   // actor hidden unit (tp < 8)
+                    v[j] = o < A ? aW2[o * HID + h] : 0.0f;
                 }
             }
             const Bf3 sp = split8(v);
@@ -896,9 +897,11 @@ __global__ __launch_bounds__(256) void policy_pack16_kernel(const int D, const i
             const int b = i - n1 - n2;
             float v;
             if (b < 512) v = b < HID ? ab1[b] : cb1[b - HID];
-            else {
+            else if (b < 528) {
                 const int o = b - 512;
                 v = o < A ? ab2[o] : (o == A ? cb2[0] : 0.0f);
+            } else {
+                v = cW2[b - 528];   // critic output layer, plain fp32
             }
             image[(n1 + n2) * 4 + b] = __float_as_uint(v);
         }
@@ -906,8 +909,12 @@ __global__ __launch_bounds__(256) void policy_pack16_kernel(const int D, const i
 }
 
 // One wave, 32 envs (2 column tiles), hidden tile PAIRS [tp0, tp1).  x[et] = the env tile's observation pieces.
-__device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsigned* sW2p, const float* sB1, const int tp0,
-                                              const int tp1, const Bf3 (&x)[2], f32x4 (&out)[2], const int lc, const int g) {
+// Pairs 0..7 are the actor: ReLU, split, layer 2 on the matrix cores into out[et] (rows 0..A-1).  Pairs 8..15 are
+// the critic, whose output layer is ONE dot product per env: it is taken in plain fp32 on the VALU straight from
+// the accumulator registers (val[et] = this lane's partial over its hidden rows; the caller sums the 4 lane groups).
+__device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsigned* sW2p, const float* sB1, const float* sW2c,
+                                              const int tp0, const int tp1, const Bf3 (&x)[2], f32x4 (&out)[2], float (&val)[2],
+                                              const int lc, const int g) {
     const int gA = g < 3 ? g : 2;     // group 3 is K padding: its B operand is all zeros, any finite A will do
     const int oA = lc < 10 ? lc : 9;  // output rows >= 10 are never read
     for (int tp = tp0; tp < tp1; ++tp) {
@@ -922,19 +929,30 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
 #pragma unroll
             for (int et = 0; et < 2; ++et) acc[j][et] = mfma6(a, x[et], bias);
         }
-        u32x4 w2[3];
+        if (tp < 8) {  // actor (uniform branch)
+            u32x4 w2[3];
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) w2[pc] = *reinterpret_cast<const u32x4*>(sW2p + (((tp * 3 + pc) * 4 + g) * 10 + oA) * 4);
+            for (int pc = 0; pc < 3; ++pc) w2[pc] = *reinterpret_cast<const u32x4*>(sW2p + (((tp * 3 + pc) * 4 + g) * 10 + oA) * 4);
 #pragma unroll
-        for (int et = 0; et < 2; ++et) {
-            float hv[8];
+            for (int et = 0; et < 2; ++et) {
+                float hv[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                hv[r] = relu_f(acc[0][et][r]);
-                hv[4 + r] = relu_f(acc[1][et][r]);
+                for (int r = 0; r < 4; ++r) {
+                    hv[r] = relu_f(acc[0][et][r]);
+                    hv[4 + r] = relu_f(acc[1][et][r]);
+                }
+                const Bf3 h3 = split8(hv);
+                out[et] = mfma6(w2, h3, out[et]);
             }
-            const Bf3 h3 = split8(hv);
-            out[et] = mfma6(w2, h3, out[et]);
+        } else {       // critic
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(sW2c + 16 * (2 * tp + j - 16) + 4 * g);
+#pragma unroll
+                for (int et = 0; et < 2; ++et)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) val[et] = __builtin_fmaf(w[r], relu_f(acc[j][et][r]), val[et]);
+            }
         }
     }
 }
@@ -1017,6 +1035,7 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
     float* sB2 = PREC ? sB1 + 512 : sW2 + NT * 4 * 64;  // [16]
     const unsigned* sW1p = reinterpret_cast<const unsigned*>(lds);                       // PREC 1 operand records
     const unsigned* sW2p = sW1p + pol16_w1_dwords();
+    const float* sW2c = sB2 + 16;            // PREC 1: critic output weights [256]
     float* sOut = lds + IMG;                 // [8 waves][32 envs][LDO]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, lk = lane >> 4;
@@ -1058,7 +1077,15 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
                 }
                 x[et] = split8(v);
             }
-            policy_pass16(sW1p, sW2p, sB1, ht0 / 2, ht1 / 2, x, out, lc, lk);
+            float val[ET] = {0.0f, 0.0f};
+            policy_pass16(sW1p, sW2p, sB1, sW2c, ht0 / 2, ht1 / 2, x, out, val, lc, lk);
+#pragma unroll
+            for (int et = 0; et < ET; ++et) {  // the env column's value: sum of the 4 lane groups' partials -> output row A
+                float t = val[et];
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                if (A >> 2 == lk) out[et][A & 3] += t;
+            }
         }
         // ---- out tile -> LDS so that lane = env
         __syncthreads();  // previous pass's readers are done with sOut
@@ -1125,6 +1152,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     float* sB2 = PREC ? sB1 + 512 : sW2 + NT * 4 * 64;
     const unsigned* sW1p = reinterpret_cast<const unsigned*>(lds);
     const unsigned* sW2p = sW1p + pol16_w1_dwords();
+    const float* sW2c = sB2 + 16;                  // PREC 1: critic output weights [256]
     float* sOut = lds + IMG;                       // [8 waves][32 envs][LDO]
     float* sObs = sOut + 8 * 32 * LDO;             // [256 envs][LDX]   observation of the step in flight
     int* sAct = reinterpret_cast<int*>(sObs + 256 * LDX);  // [256]
@@ -1176,7 +1204,15 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                     }
                     x[et] = split8(v);
                 }
-                if (!(dbg & 1)) policy_pass16(sW1p, sW2p, sB1, 0, NT / 2, x, out, lc, lk);
+                float val[ET] = {0.0f, 0.0f};
+                if (!(dbg & 1)) policy_pass16(sW1p, sW2p, sB1, sW2c, 0, NT / 2, x, out, val, lc, lk);
+#pragma unroll
+                for (int et = 0; et < ET; ++et) {
+                    float tv = val[et];
+                    tv += __shfl_xor(tv, 16, 64);
+                    tv += __shfl_xor(tv, 32, 64);
+                    if (A >> 2 == lk) out[et][A & 3] += tv;
+                }
             }
 #pragma unroll
             for (int et = 0; et < ET; ++et)

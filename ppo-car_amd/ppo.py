@@ -148,7 +148,12 @@ class PPOLearner:
         self._np_rng = np.random.default_rng(cfg.seed * 7919 + rank)
         self.n_minibatches = len(range(0, cfg.n_steps, cfg.batch_size))     # train.py:228
         idx = torch.empty(cfg.train_iters, self.n_minibatches * cfg.batch_size, dtype=torch.int64)
-        self._idx_host = idx.pin_memory() if self.device.type == "cuda" else idx
+        # two pinned staging buffers, used alternately: epochs are queued without host synchronisation, so the async
+        # H2D copy of epoch k may still be pending when the host draws the indices of epoch k+1
+        cuda = self.device.type == "cuda"
+        self._idx_hosts = [idx.clone().pin_memory() if cuda else idx.clone() for _ in range(2)]
+        self._idx_events = [torch.cuda.Event() if cuda else None for _ in range(2)]
+        self._idx_turn = 0
         self._idx_dev = torch.empty_like(idx, device=self.device)
         self.metrics = torch.zeros(4, device=self.device)
         self._graph_key = None
@@ -222,10 +227,17 @@ class PPOLearner:
         on the host (the reference shuffles on the host too) for all iters at once, one async copy."""
         cfg = self.cfg
         K = min(self.n_minibatches * cfg.batch_size, M)   # a slice past the end of the shuffled array is just shorter
-        host = self._idx_host.numpy()
+        turn = self._idx_turn
+        self._idx_turn ^= 1
+        if self._idx_events[turn] is not None:
+            self._idx_events[turn].synchronize()          # the copy that last read this staging buffer has completed
+        host_t = self._idx_hosts[turn]
+        host = host_t.numpy()
         for i in range(cfg.train_iters):
             host[i, :K] = self._np_rng.permutation(M) if K == M else self._np_rng.choice(M, size=K, replace=False)
-        self._idx_dev.copy_(self._idx_host, non_blocking=True)
+        self._idx_dev.copy_(host_t, non_blocking=True)
+        if self._idx_events[turn] is not None:
+            self._idx_events[turn].record(torch.cuda.current_stream(self.device))
         return self._idx_dev[:, :K]
 
     # ---- one minibatch, in the two halves the all-reduce separates ---------------------------------------
