@@ -167,6 +167,11 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
                const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
                float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, void* stream);
 
+/* Work decomposition of pc_rollout: -1 = automatic (256 envs per workgroup with independent waves from 32768 envs up,
+ * else 32 envs per workgroup with the policy's hidden tiles split over the waves -- also the only form that fits LDS
+ * at 33 rays), 0 / 1 force one form.  Both are bit-identical to the per-step kernels.  Tuning / test knob. */
+int pc_rollout_set_form(int form);
+
 /* ---- the non-GEMM work of one PPO minibatch step (train.py:230-261), three launches:
  * pc_ppo_gather : traj_*[batch_indices] (train.py:233-238,249): idx [B] int64 into the flattened trajectories
  *                 obs [M][D], act / logprob / adv / ret [M]  ->  o_obs [B][D], o_act / o_logprob / o_adv / o_ret [B].

@@ -239,15 +239,23 @@ template <typename T> __device__ __forceinline__ void env_store(const EnvParams<
     if constexpr (sizeof(T) == 8) p.rot[e] = st.rot;
 }
 
+// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, NOT for its outstanding
+// global stores (__syncthreads() waits vmcnt(0) too: ~1 us of store latency per barrier in the rollout loop).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // One CarEnv.step (car_env.py:693-760) + TransformReward + same-step auto-reset for the env whose state the
 // 2^lg lanes of this group hold in `st` (updated in place, identically in every lane).  Lane g sweeps rays
 // g, g + G, ...  Observation entries go to orow (global row), frow (pre-reset obs, optional) and lrow (an LDS
 // copy for the persistent rollout kernel, optional).  The per-env scalars come back in registers.
-template <typename T, int RPL>
+template <typename T, int RPL, int PARTS = 1>
 __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int trk, const int g, const int lg, EnvRegs& st,
                                               const int64_t a, const double reward_scale, float* __restrict__ orow,
                                               float* __restrict__ frow, float* lrow, float& reward_f, bool& term, bool& trunc,
-                                              int& passed_out) {
+                                              int& passed_out, const int part = 0, float* exch = nullptr) {
+    // PARTS > 1 (rollout_small_kernel): the env's wall sweep is split over PARTS waves of the workgroup -- this wave
+    // sweeps vertex range `part`, the per-ray minima meet in LDS (`exch`: this env's [R][PARTS] floats) across ONE
+    // workgroup barrier, and every wave then finishes the step on identical values (min is exact: bit-identical to
+    // PARTS == 1).  Only part 0 stores.  Every thread of the workgroup must make the call.
     // trk is the same in every active lane; readfirstlane tells the compiler so
     const TrackHdr h = cload(p.hdr + __builtin_amdgcn_readfirstlane(trk));
     const int G = 1 << lg;
@@ -321,18 +329,22 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
     // ---- wall sweep: Car.get_distances (:360-374) -- also serves Car.check_collision (E2)
     if constexpr (sizeof(T) == 4) {
         const Vtx* vt = p.vtx + h.vtx_off;
-        Vtx nxt = cload(vt);  // wave-uniform -> s_load_dwordx8, operands stay in SGPRs
         float axp = 0.0f, ayp = 0.0f, cp[RPL];
 #pragma unroll
         for (int s = 0; s < RPL; ++s) cp[s] = 0.0f;
-        for (int k = 0; k < h.nV; ++k) {
+        // vertex range of this part; one vertex earlier than kbeg supplies the chain's previous side value
+        const int kbeg = PARTS > 1 ? h.nV * part / PARTS : 0;
+        const int kend = PARTS > 1 ? h.nV * (part + 1) / PARTS : h.nV;
+        const int k0 = kbeg > 0 ? kbeg - 1 : 0;
+        Vtx nxt = cload(vt + k0);  // wave-uniform -> s_load_dwordx8, operands stay in SGPRs
+        for (int k = k0; k < kend; ++k) {
             const Vtx v = nxt;
-            nxt = cload(vt + (k + 1 < h.nV ? k + 1 : k));  // scalar prefetch of the next vertex under this one's VALU work
+            nxt = cload(vt + (k + 1 < kend ? k + 1 : k));  // scalar prefetch of the next vertex under this one's VALU work
             const float ax = (float)(v.x - npx), ay = (float)(v.y - npy);
             float c[RPL];
 #pragma unroll
             for (int s = 0; s < RPL; ++s) c[s] = cross_f(ax, ay, dx[s], dy[s]);
-            if (!v.brk) {  // uniform: vertex k closes the segment (k-1, k)
+            if (!v.brk && k >= kbeg) {  // uniform: vertex k closes the segment (k-1, k)
                 const float un = __builtin_fmaf(v.ey, axp, -(v.ex * ayp));
 #pragma unroll
                 for (int s = 0; s < RPL; ++s) best[s] = cast_fast(best[s], cp[s], c[s], un, v.ex, v.ey, dx[s], dy[s]);
@@ -355,6 +367,25 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
             }
         }
     }
+    if constexpr (PARTS > 1) {
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const int ray = g + s * G;
+            if (ray < p.R) exch[ray * PARTS + part] = (float)best[s];
+        }
+        lds_barrier();
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const int ray = g + s * G;
+            if (ray < p.R) {
+                float m = exch[ray * PARTS];
+#pragma unroll
+                for (int q = 1; q < PARTS; ++q) m = fminf(m, exch[ray * PARTS + q]);
+                best[s] = (T)m;
+            }
+        }
+    }
+    const bool store = PARTS == 1 || part == 0;
     bool wall_hit = false;
 #pragma unroll
     for (int s = 0; s < RPL; ++s) wall_hit |= ((colmask >> s) & 1) & (best[s] < (T)10);  // :390
@@ -399,7 +430,7 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
         const int ray = g + s * G;
-        if (ray < p.R) {
+        if (ray < p.R && store && orow) {
             const float v = Math<T>::norm_dist(best[s]);  // :593
             const float o = done ? robs[6 + ray] : v;
             orow[6 + ray] = o;
@@ -407,7 +438,7 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
             if (frow) frow[6 + ray] = v;
         }
     }
-    if (g == 0) {
+    if (g == 0 && store && orow) {
         float hd[6];
         hd[0] = Math<T>::norm(npx, 1280.0);  // :578-581
         hd[1] = Math<T>::norm(npy, 720.0);
@@ -650,24 +681,29 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         l[i] = i < A ? logits[e * A + i] : -INFINITY;
         mx = fmaxf(mx, l[i]);
     }
+    float ex[AMAX];
     float sum = 0.0f;
 #pragma unroll
-    for (int i = 0; i < AMAX; ++i) sum += i < A ? expf(l[i] - mx) : 0.0f;
+    for (int i = 0; i < AMAX; ++i) {
+        if (i >= A) break;
+        ex[i] = expf(l[i] - mx);
+        sum += ex[i];
+    }
     const float lse = mx + logf(sum);  // Categorical(logits=...) normalises: logits - logsumexp
+    const float inv = 1.0f / sum;
     const float u = philox_uniform(seed, offset, (uint64_t)e);
     float cum = 0.0f, ent = 0.0f, lp = 0.0f;
     int act = -1;
 #pragma unroll
     for (int i = 0; i < AMAX; ++i) {
-        if (i < A) {
-            const float nl = l[i] - lse;
-            const float pr = expf(nl);
-            cum += pr;
-            ent -= pr * fmaxf(nl, -3.4028234663852886e38f);  // torch clamps log-probs at finfo.min
-            if (act < 0 && (u < cum || i == A - 1)) {        // inverse CDF; last bin absorbs rounding
-                act = i;
-                lp = nl;
-            }
+        if (i >= A) break;
+        const float nl = l[i] - lse;
+        const float pr = ex[i] * inv;                        // same draw as policy_tail (the fused policy step)
+        cum += pr;
+        ent -= pr * fmaxf(nl, -3.4028234663852886e38f);  // torch clamps log-probs at finfo.min
+        if (act < 0 && (u < cum || i == A - 1)) {        // inverse CDF; last bin absorbs rounding
+            act = i;
+            lp = nl;
         }
     }
     actions[e] = act;
@@ -960,34 +996,38 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
 // Softmax / Philox draw / log_prob for one env given its 16 output values (logits 0..A-1, value at A).
 __device__ __forceinline__ void policy_tail(const float (&v)[16], const int A, const uint64_t seed, const uint64_t off,
                                             const uint64_t e, int& act, float& lp, float& val, float* __restrict__ logits_row) {
-    float l[16];
+    // A is wave-uniform: the loops leave at i == A with a scalar branch instead of predicating all 16 slots, and the
+    // inverse CDF reuses the exponentials of the log-sum-exp pass (p_i = e_i / sum) -- one expf per action in all.
     float mx = -INFINITY;
     val = 0.0f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         if (i == A) val = v[i];
-        l[i] = i < A ? v[i] : -INFINITY;
-        mx = fmaxf(mx, l[i]);
+        if (i < A) mx = fmaxf(mx, v[i]);
     }
+    float ex[16];
     float sum = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sum += i < A ? expf(l[i] - mx) : 0.0f;
-    const float lse = mx + logf(sum);
+    for (int i = 0; i < 16; ++i) {
+        if (i >= A) break;
+        ex[i] = expf(v[i] - mx);
+        sum += ex[i];
+    }
+    const float lse = mx + logf(sum);  // Categorical(logits=...) normalises: logits - logsumexp
+    const float inv = 1.0f / sum;
     const float u = philox_uniform(seed, off, e);
     float cum = 0.0f;
     lp = 0.0f;
     act = -1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        if (i < A) {
-            const float nl = l[i] - lse;
-            cum += expf(nl);
-            if (act < 0 && (u < cum || i == A - 1)) {  // inverse CDF; last bin absorbs rounding
-                act = i;
-                lp = nl;
-            }
-            if (logits_row) logits_row[i] = l[i];
+        if (i >= A) break;
+        cum += ex[i] * inv;
+        if (act < 0 && (u < cum || i == A - 1)) {  // inverse CDF; last bin absorbs rounding
+            act = i;
+            lp = v[i] - lse;
         }
+        if (logits_row) logits_row[i] = v[i];
     }
 }
 
@@ -1133,6 +1173,37 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
 //   E(t): action from LDS -> env_step_core -> obs row t+1 to HBM and LDS, (rew, term, trunc)
 // Same arithmetic, same Philox counters as the policy_kernel / env_step_kernel pair: bit-identical buffers.
 // ------------------------------------------------------------------------------------------
+// Persistent rollout kernels: the small per-track tables every env step GATHERS from (heading table, reward gates, ray
+// table, reset observation) are copied into LDS once and the EnvParams pointers redirected, so that a gather on the
+// step's critical path costs an LDS access instead of a global-memory round trip.  Single-track batches only (the
+// kernels' precondition).  The caller synchronises the workgroup before the first use.
+constexpr int TAB_MAX_GATES = 64;
+constexpr int TAB_FLOATS = 72 * 4 + TAB_MAX_GATES * 8 + 40 * 2 + 40;
+__device__ __forceinline__ EnvParams<float> stage_tables(const EnvParams<float>& p, float* sTab, const int tid, const int nthreads) {
+    const TrackHdr h0 = cload(p.hdr);
+    int* dst = reinterpret_cast<int*>(sTab);
+    EnvParams<float> q = p;
+    const int* head = reinterpret_cast<const int*>(p.headtab + h0.head_off);
+    for (int i = tid; i < 72 * 4; i += nthreads) dst[i] = head[i];
+    q.headtab = reinterpret_cast<const double2*>(sTab) - h0.head_off;
+    if (h0.G <= TAB_MAX_GATES) {
+        const int* gates = reinterpret_cast<const int*>(p.segs + h0.gate_off);
+        for (int i = tid; i < h0.G * 8; i += nthreads) dst[72 * 4 + i] = gates[i];
+        q.segs = reinterpret_cast<const Seg*>(sTab + 72 * 4) - h0.gate_off;   // the F32 step reads only gates from segs
+    }
+    if (p.R <= 40) {
+        const int* ray = reinterpret_cast<const int*>(p.raytab);
+        for (int i = tid; i < p.R * 2; i += nthreads) dst[72 * 4 + TAB_MAX_GATES * 8 + i] = ray[i];
+        q.raytab = reinterpret_cast<const float2*>(sTab + 72 * 4 + TAB_MAX_GATES * 8);
+    }
+    if (p.D <= 40) {
+        const int* ro = reinterpret_cast<const int*>(p.reset_obs);
+        for (int i = tid; i < p.D; i += nthreads) dst[72 * 4 + TAB_MAX_GATES * 8 + 80 + i] = ro[i];
+        q.reset_obs = sTab + 72 * 4 + TAB_MAX_GATES * 8 + 80;
+    }
+    return q;
+}
+
 template <int KS, int RPL, int PREC>
 __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, const float* __restrict__ image, const int A,
                                                       const int T, const double reward_scale, const uint64_t seed,
@@ -1155,12 +1226,14 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const float* sW2c = sB2 + 16;                  // PREC 1: critic output weights [256]
     float* sOut = lds + IMG;                       // [8 waves][32 envs][LDO]
     float* sObs = sOut + 8 * 32 * LDO;             // [256 envs][LDX]   observation of the step in flight
-    int* sAct = reinterpret_cast<int*>(sObs + 256 * LDX);  // [256]
+    int* sAct = reinterpret_cast<int*>(sObs + 256 * LDX);
+    float* sTab = reinterpret_cast<float*>(sAct + 256);    // staged per-track tables (stage_tables)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, lk = lane >> 4;
     const int64_t N = p.N;
     const int D = p.D;
     policy_stage_image<IMG>(image, lds, tid);
+    const EnvParams<float> q = stage_tables(p, sTab, tid, 512);
 
     // this wave's 32 envs: local rows [pbase, pbase + 32); env-step identity: 2 lanes per env
     const int pbase = wave * 32;
@@ -1244,7 +1317,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
             float rw;
             bool term, trunc;
             int passed;
-            env_step_core<float, RPL>(p, 0, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw, term, trunc,
+            env_step_core<float, RPL>(q, 0, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw, term, trunc,
                                       passed);
             if (g == 0) {
                 rew_buf[(int64_t)t * N + e_env] = rw;
@@ -1258,6 +1331,139 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
         __builtin_amdgcn_wave_barrier();
     }
     if (e_valid && g == 0) env_store<float>(p, e_env, st);
+}
+
+// K9s: the same persistent rollout for SMALL batches (n_envs < ~32 k): a workgroup owns only 32 envs, so that
+// n_envs / 32 workgroups fill the chip.  Per step: the 8 waves split the policy's hidden tiles exactly as
+// policy_kernel<SPLIT> does (partial output tiles summed through LDS, same order: bit-identical), wave 0 draws the
+// 32 actions, then all 512 lanes run the env step with 16 lanes per env.  Three workgroup barriers per step.
+template <int KS, int RPL, int PREC>
+__global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<float> p, const float* __restrict__ image, const int A,
+                                                            const int T, const double reward_scale, const uint64_t seed,
+                                                            const uint64_t offset, const uint64_t* __restrict__ offset_dev,
+                                                            float* __restrict__ obs_buf, float* __restrict__ act_buf,
+                                                            float* __restrict__ rew_buf, float* __restrict__ val_buf,
+                                                            float* __restrict__ term_buf, float* __restrict__ trunc_buf,
+                                                            float* __restrict__ logprob_buf, float* __restrict__ next_obs,
+                                                            float* __restrict__ next_term, float* __restrict__ next_trunc,
+                                                            const int dbg) {
+    constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, LDX = 4 * KS + 1, ET = 2;
+    constexpr int IMG = PREC ? pol16_image_dwords() : pol_image_padded(KS);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sW1 = lds;
+    float* sB1 = PREC ? lds + pol16_w1_dwords() + pol16_w2_dwords() : sW1 + 2 * HID * LD1;
+    float* sW2 = sB1 + 2 * HID;
+    float* sB2 = PREC ? sB1 + 512 : sW2 + NT * 4 * 64;
+    const unsigned* sW1p = reinterpret_cast<const unsigned*>(lds);
+    const unsigned* sW2p = sW1p + pol16_w1_dwords();
+    const float* sW2c = sB2 + 16;
+    float* sOut = lds + IMG;                       // [8 waves][32 envs][LDO] partial output tiles
+    float* sObs = sOut + 8 * 32 * LDO;             // [32 envs][LDX]
+    int* sAct = reinterpret_cast<int*>(sObs + 32 * LDX);
+    float* sTab = reinterpret_cast<float*>(sAct + 32);     // staged per-track tables (stage_tables)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lc = lane & 15, lk = lane >> 4;
+    const int64_t N = p.N;
+    const int D = p.D;
+    policy_stage_image<IMG>(image, lds, tid);
+    const EnvParams<float> q = stage_tables(p, sTab, tid, 512);
+
+    // env step: wave w sweeps quarter (w & 3) of the wall vertices for 16 envs, 4 lanes (ray groups) per env
+    constexpr int PARTS = 4;
+    const int part = __builtin_amdgcn_readfirstlane(wave & 3);
+    const int el = (wave >> 2) * 16 + (lane >> 2), g = lane & 3;
+    float* exch = sOut + el * (PARTS * 34);        // [rays][PARTS] of this env; aliases the partial output tiles (idle now)
+    const int64_t e_env = (int64_t)blockIdx.x * 32 + el;
+    const bool e_valid = e_env < N;
+    EnvRegs st = {};
+    if (e_valid) st = env_load<float>(p, e_env);
+    for (int f = g + 4 * part; f < 4 * KS; f += 16) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
+    float* myOut = sOut + wave * 32 * LDO;
+    const int ht0 = wave * (NT / 8), ht1 = ht0 + NT / 8;
+    const uint64_t off0 = offset + (offset_dev ? *offset_dev : 0);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        // ---------------- P(t), hidden tiles [ht0, ht1) of this wave, all 32 envs
+        f32x4 out[ET];
+#pragma unroll
+        for (int et = 0; et < ET; ++et) out[et] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (PREC == 0) {
+            float x[ET][KS];
+#pragma unroll
+            for (int et = 0; et < ET; ++et)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) x[et][ks] = sObs[(16 * et + lc) * LDX + 4 * ks + lk];
+            if (!(dbg & 1)) policy_pass<KS>(sW1, sB1, sW2, ht0, ht1, x, out, lc, lk, lane);  // dbg: timing ablations only
+        } else {
+            Bf3 x[ET];
+#pragma unroll
+            for (int et = 0; et < ET; ++et) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int f = 8 * lk + j;
+                    v[j] = f < D ? sObs[(16 * et + lc) * LDX + f] : 0.0f;
+                }
+                x[et] = split8(v);
+            }
+            float val[ET] = {0.0f, 0.0f};
+            if (!(dbg & 1)) policy_pass16(sW1p, sW2p, sB1, sW2c, ht0 / 2, ht1 / 2, x, out, val, lc, lk);
+#pragma unroll
+            for (int et = 0; et < ET; ++et) {
+                float tv = val[et];
+                tv += __shfl_xor(tv, 16, 64);
+                tv += __shfl_xor(tv, 32, 64);
+                if (A >> 2 == lk) out[et][A & 3] += tv;
+            }
+        }
+#pragma unroll
+        for (int et = 0; et < ET; ++et)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) myOut[(16 * et + lc) * LDO + 4 * lk + reg] = out[et][reg];
+        lds_barrier();
+        const int64_t e = (int64_t)blockIdx.x * 32 + lane;
+        if (wave == 0 && lane < 32 && e < N) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float tsum = sB2[i];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) tsum += sOut[(w * 32 + lane) * LDO + i];  // fixed order, as policy_kernel<SPLIT>
+                v[i] = tsum;
+            }
+            int act;
+            float lp, val;
+            if (!(dbg & 4)) policy_tail(v, A, seed, off0 + (uint64_t)t, (uint64_t)e, act, lp, val, nullptr);
+            else { act = 0; lp = v[0]; val = v[1]; }
+            sAct[lane] = act;
+            const int64_t row = (int64_t)t * N + e;
+            act_buf[row] = (float)act;
+            logprob_buf[row] = lp;
+            val_buf[row] = val;
+        }
+        lds_barrier();
+        // ---------------- E(t): 4 waves x 4 lanes per env (one more barrier inside, where the sweep parts meet)
+        if (!(dbg & 2)) {
+            const bool last = t + 1 == T;
+            float* orow = !e_valid ? nullptr : (last ? next_obs + e_env * D : obs_buf + ((int64_t)(t + 1) * N + e_env) * D);
+            float rw;
+            bool term, trunc;
+            int passed;
+            env_step_core<float, RPL, PARTS>(q, 0, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
+                                             e_valid && part == 0 ? sObs + el * LDX : nullptr, rw, term, trunc, passed, part, exch);
+            if (e_valid && g == 0 && part == 0) {
+                rew_buf[(int64_t)t * N + e_env] = rw;
+                float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;
+                float* tc = last ? next_trunc : trunc_buf + (int64_t)(t + 1) * N;
+                tr[e_env] = term ? 1.0f : 0.0f;
+                tc[e_env] = trunc ? 1.0f : 0.0f;
+            }
+        }
+        lds_barrier();
+    }
+    if (e_valid && g == 0 && part == 0) env_store<float>(p, e_env, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2170,7 +2376,14 @@ int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, 
 
 static int policy_ks(int D) { return D <= 20 ? 5 : (D <= 24 ? 6 : 10); }
 static int g_policy_split_mode = -1;  // -1 auto (split below 32768 envs), 0 never, 1 always
+static int g_rollout_form = -1;       // pc_rollout: -1 auto, 0 = 256 envs per workgroup, 1 = 32 envs per workgroup
 static int g_policy_precision = 1;    // 0 = fp32-input MFMA, 1 = bf16x3 split on the bf16 matrix cores (needs D <= 24, A <= 9)
+
+int pc_rollout_set_form(int form) {
+    if (form < -1 || form > 1) return PC_ERR_INVALID_ARG;
+    g_rollout_form = form;
+    return PC_OK;
+}
 
 int pc_policy_set_precision(int mode) {
     if (mode < 0 || mode > 1) return PC_ERR_INVALID_ARG;
@@ -2311,17 +2524,24 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
         return PC_ERR_INVALID_ARG;
     if (e->dtype != PC_DTYPE_F32 || e->track_id || A < 1 || A > 15) return PC_ERR_UNSUPPORTED;
     const int KS = policy_ks(e->D);
-    const int rpl = (e->R + 1) / 2;  // 2 lanes per env
     DeviceGuard guard(e->device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
     const int prec = policy_prec(e->D, A);
-    const size_t lds = (size_t)((prec ? pol16_image_dwords() : pol_image_padded(KS)) + 8 * 32 * 17 + 256 * (4 * KS + 1) + 256) * sizeof(float);
-    if (lds > 160 * 1024) return PC_ERR_UNSUPPORTED;  // 32 -> 33 rays: weight image + observation tile exceed one CU's LDS
-    const int blocks = (int)((e->N + 255) / 256);
+    const int img = prec ? pol16_image_dwords() : pol_image_padded(KS);
+    const size_t lds_big = (size_t)(img + 8 * 32 * 17 + 256 * (4 * KS + 1) + 256 + TAB_FLOATS) * sizeof(float);
+    const size_t lds_small = (size_t)(img + 8 * 32 * 17 + 32 * (4 * KS + 1) + 32 + TAB_FLOATS) * sizeof(float);
+    // large batches: 256 envs per workgroup, every wave independent (at 33 rays the 256-env observation tile does not fit
+    // LDS: PC_ERR_UNSUPPORTED, the per-step kernels are the faster choice there anyway); small batches: 32 envs per
+    // workgroup, hidden tiles and wall-sweep parts split over the waves
+    const bool small = g_rollout_form == 1 || (g_rollout_form < 0 && e->N < 32768);
+    const size_t lds = small ? lds_small : lds_big;
+    if (lds > 160 * 1024) return PC_ERR_UNSUPPORTED;
+    const int rpl = small ? (e->R + 3) / 4 : (e->R + 1) / 2;  // 4 (x 4 sweep parts) or 2 lanes per env
+    const int blocks = (int)(small ? (e->N + 31) / 32 : (e->N + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
     EnvParams<float> prm = e->params<float>();
-    prm.lg = 1;
-    const char* dbg_env = getenv("PPOCAR_ROLLOUT_ABLATE");  // developer timing ablation: 1 = skip policy MFMAs, 2 = skip env step
+    prm.lg = small ? 2 : 1;
+    const char* dbg_env = getenv("PPOCAR_ROLLOUT_ABLATE");  // developer timing ablation: 1 = skip policy MFMAs, 2 = skip env step, 4 = skip sampling
     const int dbg = dbg_env ? atoi(dbg_env) : 0;
 #define PC_ROLL(KSV, RPLV, PRC)                                                                                          \
     do {                                                                                                                 \
@@ -2334,10 +2554,26 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
                            offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs,  \
                            next_term, next_trunc, dbg);                                                                  \
     } while (0)
-    if (KS == 5 && rpl == 6) { if (prec) PC_ROLL(5, 6, 1); else PC_ROLL(5, 6, 0); }          // 12 rays, D = 18
-    else if (KS == 6 && rpl == 9) { if (prec) PC_ROLL(6, 9, 1); else PC_ROLL(6, 9, 0); }     // 16 -> 17 rays, D = 23
-    else if (KS == 10 && rpl == 17) PC_ROLL(10, 17, 0);                                        // 32 -> 33 rays, D = 39
+#define PC_ROLLS(KSV, RPLV, PRC)                                                                                         \
+    do {                                                                                                                 \
+        static bool attr_set[64] = {false};                                                                              \
+        if (e->device < 64 && !attr_set[e->device]) {                                                                    \
+            HIPCHK(hipFuncSetAttribute((const void*)rollout_small_kernel<KSV, RPLV, PRC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_set[e->device] = true;                                                                                  \
+        }                                                                                                                \
+        hipLaunchKernelGGL((rollout_small_kernel<KSV, RPLV, PRC>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, \
+                           seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, \
+                           next_term, next_trunc, dbg);                                                                     \
+    } while (0)
+    if (small) {
+        if (KS == 5 && rpl == 3) { if (prec) PC_ROLLS(5, 3, 1); else PC_ROLLS(5, 3, 0); }        // 12 rays
+        else if (KS == 6 && rpl == 5) { if (prec) PC_ROLLS(6, 5, 1); else PC_ROLLS(6, 5, 0); }   // 16 -> 17 rays
+        else if (KS == 10 && rpl == 9) PC_ROLLS(10, 9, 0);                                         // 32 -> 33 rays
+        else return PC_ERR_UNSUPPORTED;
+    } else if (KS == 5 && rpl == 6) { if (prec) PC_ROLL(5, 6, 1); else PC_ROLL(5, 6, 0); }       // 12 rays, D = 18
+    else if (KS == 6 && rpl == 9) { if (prec) PC_ROLL(6, 9, 1); else PC_ROLL(6, 9, 0); }          // 16 -> 17 rays, D = 23
     else return PC_ERR_UNSUPPORTED;
+#undef PC_ROLLS
 #undef PC_ROLL
     HIPCHK(hipGetLastError());
     return PC_OK;

@@ -56,7 +56,7 @@ class PPOConfig:
     custom_mlp: bool = True                # with fused_update: the MLP forward/backward too are HIP kernels (pc_ppo_minibatch,
                                            # no library GEMM); False = torch autograd GEMMs between the fused loss / Adam kernels
     rollout_kernel: str = "auto"           # "mega": the whole rollout as one persistent launch (pc_rollout); "steps": two
-                                           # kernels per step (HIP-graph replayed); "auto": mega when n_envs >= 16384
+                                           # kernels per step (HIP-graph replayed); "auto": mega whenever pc_rollout supports the shape
     policy: str = "fused"                  # rollout policy step: "fused" (one MFMA kernel: MLPs + draw),
                                            # "sample" (torch GEMMs + sampling kernel), "torch" (reference ops)
 
@@ -490,7 +490,7 @@ class Trainer:
         cfg = self.cfg
         mode = cfg.rollout_kernel
         if mode == "auto":
-            mode = "mega" if cfg.n_envs >= 16384 else "steps"
+            mode = "mega" if cfg.n_envs >= 256 else "steps"
         done = False
         if mode == "mega" and cfg.policy == "fused" and self.device.type == "cuda" and not self.profile_stride:
             done = self._rollout_mega()

@@ -115,7 +115,7 @@ def test_graph_rollout_is_bitwise_the_eager_rollout():
     Philox counters (device-side base + step index), so whole buffers must agree bit for bit."""
     res = {}
     for use_graphs in (False, True):
-        cfg = _cfg(use_graphs=use_graphs, n_envs=512, n_steps=48)
+        cfg = _cfg(use_graphs=use_graphs, n_envs=512, n_steps=48, rollout_kernel="steps")
         tr = Trainer(cfg, device="cuda")
         snaps = []
         for ep in range(3):            # graph mode: epoch 0 eager, capture before epoch 1, replay epochs 1 and 2
@@ -185,41 +185,65 @@ def test_fused_and_torch_updates_agree_inside_the_trainer():
     assert torch.allclose(outs[False][0], outs[True][0], atol=5e-3)
 
 
+@pytest.mark.parametrize("form", [0, 1])
 @pytest.mark.parametrize("precision", [1, 0])
 @pytest.mark.parametrize("num_rays,n_envs", [(16, 1000), (12, 512), (32, 300)])
-def test_persistent_rollout_kernel_is_bitwise_the_two_kernel_rollout(num_rays, n_envs, precision):
-    """pc_rollout (one persistent launch: policy phase on the MFMA pipe and env phase on the VALU pipe alternating in
-    the two halves of each workgroup, weights in LDS, env state in registers) must fill the buffer with exactly the
-    bits of the per-step policy_kernel / env_step_kernel sequence, over several epochs (auto-resets included)."""
+def test_persistent_rollout_kernel_is_bitwise_the_two_kernel_rollout(num_rays, n_envs, precision, form):
+    """pc_rollout (one persistent launch, weights in LDS, env state in registers) must fill the buffer with exactly the
+    bits of the per-step policy_kernel / env_step_kernel sequence, over several epochs (auto-resets included), in both
+    of its forms: 0 = 256 envs per workgroup, every wave independent (the whole-tile policy kernel's summation order);
+    1 = 32 envs per workgroup, hidden tiles split over the waves (the split policy kernel's summation order)."""
     from ppo_car_amd._capi import lib
     res = {}
-    lib.pc_policy_set_split(0)      # same fp32 summation order in both forms (the split form differs in the last bits)
+    lib.pc_policy_set_split(form)   # same fp32 summation order in the per-step policy kernel as in this rollout form
     lib.pc_policy_set_precision(precision)
-    for mode in ("steps", "mega"):
-        cfg = _cfg(rollout_kernel=mode, use_graphs=False, n_envs=n_envs, n_steps=80, num_rays=num_rays)
-        tr = Trainer(cfg, device="cuda")
-        snaps = []
-        for ep in range(3):
-            tr.rollout()
-            torch.cuda.synchronize()
-            # 32 -> 33 rays: weight image + observation tile exceed 160 KB of LDS -> pc_rollout reports
-            # PC_ERR_UNSUPPORTED and the trainer falls back to the two-kernel loop
-            assert tr.rollout_mode == ("mega" if mode == "mega" and num_rays != 32 else "steps-eager")
-            b = tr.buffer
-            snaps.append([t.clone() for t in (b.obs_buf, b.act_buf, b.rew_buf, b.val_buf, b.logprob_buf, b.term_buf, b.trunc_buf,
-                                              tr.next_obs, tr.next_term, tr.next_trunc)])
-            tr.buffer.ptr = 0
-        st = tr.envs.get_state()
-        res[mode] = (snaps, st)
-        tr.close()
-    lib.pc_policy_set_split(-1)
-    lib.pc_policy_set_precision(1)
+    lib.pc_rollout_set_form(form)
+    try:
+        for mode in ("steps", "mega"):
+            cfg = _cfg(rollout_kernel=mode, use_graphs=False, n_envs=n_envs, n_steps=80, num_rays=num_rays)
+            tr = Trainer(cfg, device="cuda")
+            snaps = []
+            for ep in range(3):
+                tr.rollout()
+                torch.cuda.synchronize()
+                # 32 -> 33 rays: weight image + a 256-env observation tile exceed 160 KB of LDS -> form 0 reports
+                # PC_ERR_UNSUPPORTED and the trainer falls back to the two-kernel loop; form 1 fits
+                mega_ok = mode == "mega" and (num_rays != 32 or form == 1)
+                assert tr.rollout_mode == ("mega" if mega_ok else "steps-eager")
+                b = tr.buffer
+                snaps.append([t.clone() for t in (b.obs_buf, b.act_buf, b.rew_buf, b.val_buf, b.logprob_buf, b.term_buf,
+                                                  b.trunc_buf, tr.next_obs, tr.next_term, tr.next_trunc)])
+                tr.buffer.ptr = 0
+            st = tr.envs.get_state()
+            res[mode] = (snaps, st)
+            tr.close()
+    finally:
+        lib.pc_policy_set_split(-1)
+        lib.pc_policy_set_precision(1)
+        lib.pc_rollout_set_form(-1)
     for ep in range(3):
         for i, (a, b) in enumerate(zip(res["steps"][0][ep], res["mega"][0][ep])):
             assert torch.equal(a, b), (ep, i)
     for k in res["steps"][1]:
         assert np.array_equal(res["steps"][1][k], res["mega"][1][k]), k
     assert float(res["mega"][0][2][5].sum()) > 0        # episodes ended (terminations) inside the window
+
+
+def test_rollout_forms_agree_with_default_dispatch():
+    """Automatic dispatch: below 32768 envs pc_rollout takes the 32-env-per-workgroup form and the per-step policy
+    kernel its split form -- the two must still be bit-identical (this is what a user switching rollout_kernel sees)."""
+    res = {}
+    for mode in ("steps", "mega"):
+        tr = Trainer(_cfg(rollout_kernel=mode, use_graphs=False, n_envs=4096, n_steps=48, num_rays=16), device="cuda")
+        tr.rollout()
+        torch.cuda.synchronize()
+        assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
+        b = tr.buffer
+        res[mode] = [t.clone() for t in (b.obs_buf, b.act_buf, b.rew_buf, b.val_buf, b.logprob_buf, b.term_buf, b.trunc_buf,
+                                         tr.next_obs)]
+        tr.close()
+    for i, (a, b) in enumerate(zip(res["steps"], res["mega"])):
+        assert torch.equal(a, b), i
 
 
 def _two_rank_worker(rank, world, port, out_dir, use_graphs):
