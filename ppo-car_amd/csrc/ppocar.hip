@@ -97,6 +97,8 @@ template <typename T> struct EnvParams {
     const float* __restrict__ reset_obs;    // [n_tracks][D]
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 #define PC_PI 3.141592653589793238462643383279502884 /* NPY_PI */
 
 __device__ __forceinline__ double d_radians(double deg) { return deg * (PC_PI / 180.0); }  // np.radians
@@ -239,6 +241,19 @@ template <typename T> __device__ __forceinline__ void env_store(const EnvParams<
     if constexpr (sizeof(T) == 8) p.rot[e] = st.rot;
 }
 
+// 0x80000000 in an SGPR the optimiser cannot see through, and (a & m) | c as ONE instruction (the compiler splits the
+// and-or when the mask is a literal: VOP3 takes no literals on gfx9).
+__device__ __forceinline__ unsigned sign_mask() {
+    unsigned m;
+    asm("s_brev_b32 %0, 1" : "=s"(m));
+    return m;
+}
+__device__ __forceinline__ unsigned and_or(unsigned a, unsigned m, unsigned c) {
+    unsigned d;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(m), "v"(c));
+    return d;
+}
+
 // Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, NOT for its outstanding
 // global stores (__syncthreads() waits vmcnt(0) too: ~1 us of store latency per barrier in the rollout loop).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -328,32 +343,75 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
 
     // ---- wall sweep: Car.get_distances (:360-374) -- also serves Car.check_collision (E2)
     if constexpr (sizeof(T) == 4) {
-        const Vtx* vt = p.vtx + h.vtx_off;
-        float axp = 0.0f, ayp = 0.0f, cp[RPL];
+        // Ray slots in PAIRS (packed fp32: one v_pk_* per two rays); an odd last slot is padded with a direction-0 ray that
+        // never hits.  The running minimum is kept as the float's bit pattern: for non-negative floats unsigned order is
+        // value order, so   best = min_u32(best, u_bits | sign(-(c1*c2)))   accepts u exactly when the endpoints lie
+        // on strictly opposite sides of the ray line (c1*c2 < 0) AND 0 <= u < best -- a rejected candidate (same side,
+        // u negative, u NaN) has its sign or all exponent bits set and compares above any finite best.  Two VALU
+        // instructions per ray after the products instead of two compares and a select.
+        // (u == +0 passes where the reference's u > 0 rejects: the ray origin exactly on a wall line.)
+        constexpr int NP = (RPL + 1) / 2;
+        f32x2 dx2[NP], dy2[NP];
+        unsigned bb[2 * NP];
 #pragma unroll
-        for (int s = 0; s < RPL; ++s) cp[s] = 0.0f;
+        for (int j = 0; j < NP; ++j) {
+            dx2[j] = (f32x2){dx[2 * j], 2 * j + 1 < RPL ? dx[2 * j + 1] : 0.0f};
+            dy2[j] = (f32x2){dy[2 * j], 2 * j + 1 < RPL ? dy[2 * j + 1] : 0.0f};
+            bb[2 * j] = bb[2 * j + 1] = 0x447a0000u;  // 1000.0f, Ray.get_distance :198
+        }
+        const unsigned sgn = sign_mask();
+        const Vtx* vt = p.vtx + h.vtx_off;
+        // side values of vertex k: a_k = p_k - pos (float64, then rounded), c_k = cross(a_k, dir) per ray
+        auto side = [&](const Vtx& v, float& ax, float& ay, f32x2 (&c)[NP]) {
+            ax = (float)(v.x - npx);
+            ay = (float)(v.y - npy);
+            const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay};
+#pragma unroll
+            for (int j = 0; j < NP; ++j) c[j] = __builtin_elementwise_fma(ay2, dx2[j], -(ax2 * dy2[j]));
+        };
+        // vertex k closes the segment (k-1, k): (axp, ayp, cp) belong to k-1, c to k
+        auto close = [&](const Vtx& v, const float axp, const float ayp, const f32x2 (&cp)[NP], const f32x2 (&c)[NP]) {
+            const float un = __builtin_fmaf(v.ey, axp, -(v.ex * ayp));
+            const f32x2 un2 = {un, un}, ex2 = {v.ex, v.ex}, ey2 = {v.ey, v.ey};
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const f32x2 den = __builtin_elementwise_fma(ey2, dx2[j], -(ex2 * dy2[j]));
+                const f32x2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                const f32x2 u = un2 * rc;
+                const f32x2 t = cp[j] * (-c[j]);  // sign clear <=> strictly opposite sides
+                bb[2 * j] = min(bb[2 * j], and_or(__float_as_uint(t.x), sgn, __float_as_uint(u.x)));
+                bb[2 * j + 1] = min(bb[2 * j + 1], and_or(__float_as_uint(t.y), sgn, __float_as_uint(u.y)));
+            }
+        };
         // vertex range of this part; one vertex earlier than kbeg supplies the chain's previous side value
         const int kbeg = PARTS > 1 ? h.nV * part / PARTS : 0;
         const int kend = PARTS > 1 ? h.nV * (part + 1) / PARTS : h.nV;
         const int k0 = kbeg > 0 ? kbeg - 1 : 0;
-        Vtx nxt = cload(vt + k0);  // wave-uniform -> s_load_dwordx8, operands stay in SGPRs
-        for (int k = k0; k < kend; ++k) {
-            const Vtx v = nxt;
-            nxt = cload(vt + (k + 1 < kend ? k + 1 : k));  // scalar prefetch of the next vertex under this one's VALU work
-            const float ax = (float)(v.x - npx), ay = (float)(v.y - npy);
-            float c[RPL];
+        // two vertices per trip, the "previous vertex" registers alternating between sets A and B (no copies);
+        // wave-uniform vertex records -> s_load_dwordx8, prefetched one vertex ahead under the VALU work
+        float axA = 0.0f, ayA = 0.0f, axB = 0.0f, ayB = 0.0f;
+        f32x2 cA[NP], cB[NP];
 #pragma unroll
-            for (int s = 0; s < RPL; ++s) c[s] = cross_f(ax, ay, dx[s], dy[s]);
-            if (!v.brk && k >= kbeg) {  // uniform: vertex k closes the segment (k-1, k)
-                const float un = __builtin_fmaf(v.ey, axp, -(v.ex * ayp));
-#pragma unroll
-                for (int s = 0; s < RPL; ++s) best[s] = cast_fast(best[s], cp[s], c[s], un, v.ex, v.ey, dx[s], dy[s]);
-            }
-            axp = ax;
-            ayp = ay;
-#pragma unroll
-            for (int s = 0; s < RPL; ++s) cp[s] = c[s];
+        for (int j = 0; j < NP; ++j) cA[j] = cB[j] = (f32x2){0.0f, 0.0f};
+        Vtx nxt = cload(vt + k0);
+        int k = k0;
+        for (; k + 1 < kend; k += 2) {
+            const Vtx v0 = nxt;
+            nxt = cload(vt + k + 1);
+            side(v0, axB, ayB, cB);
+            if (!v0.brk && k >= kbeg) close(v0, axA, ayA, cA, cB);
+            const Vtx v1 = nxt;
+            nxt = cload(vt + (k + 2 < kend ? k + 2 : k + 1));
+            side(v1, axA, ayA, cA);
+            if (!v1.brk) close(v1, axB, ayB, cB, cA);
         }
+        if (k < kend) {
+            const Vtx v0 = nxt;
+            side(v0, axB, ayB, cB);
+            if (!v0.brk && k >= kbeg) close(v0, axA, ayA, cA, cB);
+        }
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) best[s] = __uint_as_float(bb[s]);
     } else {
         const Seg* walls = p.segs + h.wall_off;
         Seg nxt = cload(walls);
@@ -851,7 +909,6 @@ __device__ __forceinline__ void policy_pass(const float* sW1, const float* sB1, 
 //            accumulator registers the lane already holds for its env column -- again no data movement.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ constexpr int pol16_w1_dwords() { return 32 * 3 * 48 * 4; }
