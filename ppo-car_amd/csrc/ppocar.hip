@@ -713,8 +713,12 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
     c[2] = n2;
 }
 
-__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, uint64_t idx) {
-    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+// The stream: draw number `offset` of element `idx` is word (offset & 3) of the Philox block with counter
+// (idx, offset >> 2) and key `seed` -- all four words of a block are used, so a kernel that walks consecutive
+// offsets (the persistent rollout) runs the ten rounds once per four draws.
+struct PhiloxBlock { uint32_t w[4]; };
+__device__ __forceinline__ PhiloxBlock philox_block(uint64_t seed, uint64_t block, uint64_t idx) {
+    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)block, (uint32_t)(block >> 32)};
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -722,7 +726,14 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, 
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
-    return ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1) open, 24 bits
+    return PhiloxBlock{{c[0], c[1], c[2], c[3]}};
+}
+__device__ __forceinline__ float philox_word_uniform(const PhiloxBlock& b, const unsigned word) {  // word: wave-uniform
+    const uint32_t x = word == 0 ? b.w[0] : word == 1 ? b.w[1] : word == 2 ? b.w[2] : b.w[3];
+    return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1) open, 24 bits
+}
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, uint64_t idx) {
+    return philox_word_uniform(philox_block(seed, offset >> 2, idx), (unsigned)(offset & 3));
 }
 
 template <int AMAX>
@@ -1051,8 +1062,8 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
 }
 
 // Softmax / Philox draw / log_prob for one env given its 16 output values (logits 0..A-1, value at A).
-__device__ __forceinline__ void policy_tail(const float (&v)[16], const int A, const uint64_t seed, const uint64_t off,
-                                            const uint64_t e, int& act, float& lp, float& val, float* __restrict__ logits_row) {
+__device__ __forceinline__ void policy_tail(const float (&v)[16], const int A, const float u, int& act, float& lp, float& val,
+                                            float* __restrict__ logits_row) {
     // A is wave-uniform: the loops leave at i == A with a scalar branch instead of predicating all 16 slots, and the
     // inverse CDF reuses the exponentials of the log-sum-exp pass (p_i = e_i / sum) -- one expf per action in all.
     float mx = -INFINITY;
@@ -1072,7 +1083,6 @@ __device__ __forceinline__ void policy_tail(const float (&v)[16], const int A, c
     }
     const float lse = mx + logf(sum);  // Categorical(logits=...) normalises: logits - logsumexp
     const float inv = 1.0f / sum;
-    const float u = philox_uniform(seed, off, e);
     float cum = 0.0f;
     lp = 0.0f;
     act = -1;
@@ -1207,7 +1217,7 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
             }
             int act;
             float lp, val;
-            policy_tail(v, A, seed, off, (uint64_t)e, act, lp, val, logits_out ? logits_out + e * A : nullptr);
+            policy_tail(v, A, philox_uniform(seed, off, (uint64_t)e), act, lp, val, logits_out ? logits_out + e * A : nullptr);
             action[e] = act;
             if (action_f) action_f[e] = (float)act;
             logprob[e] = lp;
@@ -1234,7 +1244,7 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
 // table, reset observation) are copied into LDS once and the EnvParams pointers redirected, so that a gather on the
 // step's critical path costs an LDS access instead of a global-memory round trip.  Single-track batches only (the
 // kernels' precondition).  The caller synchronises the workgroup before the first use.
-constexpr int TAB_MAX_GATES = 64;
+constexpr int TAB_MAX_GATES = 128;
 constexpr int TAB_FLOATS = 72 * 4 + TAB_MAX_GATES * 8 + 40 * 2 + 40;
 __device__ __forceinline__ EnvParams<float> stage_tables(const EnvParams<float>& p, float* sTab, const int tid, const int nthreads) {
     const TrackHdr h0 = cload(p.hdr);
@@ -1302,6 +1312,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     for (int f = g; f < 4 * KS; f += 2) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
     float* myOut = sOut + wave * 32 * LDO;
     const uint64_t off0 = offset + (offset_dev ? *offset_dev : 0);
+    PhiloxBlock rnd = {};  // the sampling lanes' current Philox block (4 steps' draws)
     __syncthreads();  // the weight image is in place; from here on the waves never synchronise again
     if (wave >= 4) {  // stagger: the second wave of each SIMD starts about half a step (~15 us) later (speed only)
 #pragma unroll 1
@@ -1357,7 +1368,9 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 for (int i = 0; i < 16; ++i) v[i] = sB2[i] + myOut[lane * LDO + i];
                 int act;
                 float lp, val;
-                policy_tail(v, A, seed, off0 + (uint64_t)t, (uint64_t)e, act, lp, val, nullptr);
+                const uint64_t o = off0 + (uint64_t)t;
+                if (t == 0 || (o & 3) == 0) rnd = philox_block(seed, o >> 2, (uint64_t)e);  // uniform: ten rounds per 4 steps
+                policy_tail(v, A, philox_word_uniform(rnd, (unsigned)(o & 3)), act, lp, val, nullptr);
                 sAct[pbase + lane] = act;
                 const int64_t row = (int64_t)t * N + e;
                 act_buf[row] = (float)act;     // stored as float32 like the reference (buffer.py:13)
@@ -1438,6 +1451,7 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     float* myOut = sOut + wave * 32 * LDO;
     const int ht0 = wave * (NT / 8), ht1 = ht0 + NT / 8;
     const uint64_t off0 = offset + (offset_dev ? *offset_dev : 0);
+    PhiloxBlock rnd = {};  // the sampling lanes' current Philox block (4 steps' draws)
     __syncthreads();
 
 #pragma unroll 1
@@ -1492,7 +1506,9 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
             }
             int act;
             float lp, val;
-            if (!(dbg & 4)) policy_tail(v, A, seed, off0 + (uint64_t)t, (uint64_t)e, act, lp, val, nullptr);
+            const uint64_t o = off0 + (uint64_t)t;
+            if (t == 0 || (o & 3) == 0) rnd = philox_block(seed, o >> 2, (uint64_t)e);  // uniform: ten rounds per 4 steps
+            if (!(dbg & 4)) policy_tail(v, A, philox_word_uniform(rnd, (unsigned)(o & 3)), act, lp, val, nullptr);
             else { act = 0; lp = v[0]; val = v[1]; }
             sAct[lane] = act;
             const int64_t row = (int64_t)t * N + e;
