@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--n-steps", type=int, default=None)
     ap.add_argument("--env-dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--policy", default="fused", choices=["fused", "sample", "torch"], help="rollout policy-step implementation")
-    ap.add_argument("--policy-arith", default="bf16x3", choices=["bf16x3", "fp32"], help="arithmetic of the fused policy step's GEMMs")
+    ap.add_argument("--policy-arith", default="fp16x2", choices=["fp16x2", "bf16x3", "fp32"], help="arithmetic of the fused policy step's GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
@@ -119,8 +119,9 @@ def main():
 
     from ppo_car_amd.ppo import PPOConfig, Trainer
     from ppo_car_amd._capi import lib as _lib
-    _lib.pc_policy_set_precision({"bf16x3": 1, "fp32": 0}[args.policy_arith])
-    POLICY_ARITH = {"bf16x3": "bf16x3 split, 6 products, fp32 accumulate on the bf16 matrix cores (fp32-equivalent; DESIGN.md section 5)",
+    _lib.pc_policy_set_precision({"fp16x2": 2, "bf16x3": 1, "fp32": 0}[args.policy_arith])
+    POLICY_ARITH = {"fp16x2": "fp16x2 split (v = h + 2^-11 l), 3 products, two fp32 accumulators on the fp16 matrix cores (fp32-class; DESIGN.md section 5)",
+                    "bf16x3": "bf16x3 split, 6 products, fp32 accumulate on the bf16 matrix cores (fp32-equivalent; DESIGN.md section 5)",
                     "fp32": "fp32-input MFMA (exact fp32 fmaf chain)"}[args.policy_arith]
     wl = dict(WORKLOADS[args.workload])
     if args.n_envs:

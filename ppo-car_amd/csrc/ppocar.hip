@@ -922,10 +922,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__host__ __device__ constexpr int pol16_w1_dwords() { return 32 * 3 * 48 * 4; }
-__host__ __device__ constexpr int pol16_w2_dwords() { return 8 * 3 * 4 * 10 * 4; }  // actor tile pairs only
+// Split forms: PREC 1 = three bf16 pieces per operand, PREC 2 = two fp16 pieces (the second scaled by 2^11, below).
+__host__ __device__ constexpr int pol_np(int PREC) { return PREC == 2 ? 2 : 3; }
+__host__ __device__ constexpr int polx_w1_dwords(int PREC) { return 32 * pol_np(PREC) * 48 * 4; }
+__host__ __device__ constexpr int polx_w2_dwords(int PREC) { return 8 * pol_np(PREC) * 4 * 10 * 4; }  // actor tile pairs only
 // [W1 records][W2 records (actor)][b1: 512][b2: 16][critic output weights, fp32: 256]
-__host__ __device__ constexpr int pol16_image_dwords() { return pol16_w1_dwords() + pol16_w2_dwords() + 512 + 16 + 256; }
+__host__ __device__ constexpr int polx_image_dwords(int PREC) { return polx_w1_dwords(PREC) + polx_w2_dwords(PREC) + 512 + 16 + 256; }
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {  // low half = bf16(a), high half = bf16(b), round-to-nearest-even
     const f32x2 v = {a, b};
@@ -941,44 +943,82 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsig
     p2 = pk_bf16(sa, sb);
 }
 
-struct Bf3 { u32x4 p[3]; };  // eight fp32 values as 3 x (8 bf16)
+template <int PREC> struct Pieces { u32x4 p[pol_np(PREC)]; };  // eight fp32 values as pol_np x (8 halves)
 
-__device__ __forceinline__ Bf3 split8(const float (&v)[8]) {
-    Bf3 r;
+// ---- PREC 2: fp16 x 2.  v = h + 2^-11 * l with h = fp16(v) and l = fp16((v - h) * 2^11): the residual is exact in
+// fp32 and the scaling keeps it out of fp16's subnormal range, so the pair carries 22 significant bits of v whatever
+// its magnitude.  A product a*b is taken as a_h*b_h (into one fp32 accumulator) and a_h*b_l + a_l*b_h (into a
+// second one, folded in as acc_hi + 2^-11 * acc_lo); the dropped a_l*b_l is <= 2^-22 relative.  Three MFMAs per
+// K block instead of six and two conversions per operand instead of three; against float64 this MLP's error is
+// 1.3e-7 (plain fp32 GEMM 0.8e-7, bf16x3 1.0e-7; emulation in DESIGN.md section 5).  Operands are clamped to fp16's
+// finite range at their sources (observations, weights, ReLU as med3(x, 0, 65504)).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+#define PC_H_SCALE 2048.0f
+#define PC_H_UNSCALE 4.8828125e-4f
+#define PC_H_MAX 65504.0f
+__device__ __forceinline__ float clamp_h(float v) { return __builtin_amdgcn_fmed3f(v, -PC_H_MAX, PC_H_MAX); }
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {  // low half = fp16(a), high half = fp16(b), round-to-nearest-even
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2v));
+}
+__device__ __forceinline__ void split_pair_h(float a, float b, unsigned& p0, unsigned& p1) {
+    p0 = pk_f16(a, b);
+    const f16x2v h = __builtin_bit_cast(f16x2v, p0);
+    const f32x2 r = ((f32x2){a, b} - (f32x2){(float)h.x, (float)h.y}) * (f32x2){PC_H_SCALE, PC_H_SCALE};
+    p1 = pk_f16(r.x, r.y);
+}
+
+template <int PREC> __device__ __forceinline__ Pieces<PREC> split8(const float (&v)[8]) {
+    Pieces<PREC> r;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        unsigned p0, p1, p2;
-        split_pair(v[2 * i], v[2 * i + 1], p0, p1, p2);
-        r.p[0][i] = p0;
-        r.p[1][i] = p1;
-        r.p[2][i] = p2;
+        if constexpr (PREC == 2) {
+            unsigned p0, p1;
+            split_pair_h(v[2 * i], v[2 * i + 1], p0, p1);
+            r.p[0][i] = p0;
+            r.p[1][i] = p1;
+        } else {
+            unsigned p0, p1, p2;
+            split_pair(v[2 * i], v[2 * i + 1], p0, p1, p2);
+            r.p[0][i] = p0;
+            r.p[1][i] = p1;
+            r.p[2][i] = p2;
+        }
     }
     return r;
 }
 
-__device__ __forceinline__ f32x4 mfma6(const u32x4 (&a)[3], const Bf3& b, f32x4 acc) {  // small terms first
+__device__ __forceinline__ f32x4 mfma6(const u32x4 (&a)[3], const Pieces<1>& b, f32x4 acc) {  // small terms first
 #define PC_MF(i, j) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b.p[j]), acc, 0, 0, 0)
     PC_MF(0, 2); PC_MF(1, 1); PC_MF(2, 0); PC_MF(0, 1); PC_MF(1, 0); PC_MF(0, 0);
 #undef PC_MF
     return acc;
 }
+// fp16 x 2: hi += a_h*b_h, lo += a_h*b_l + a_l*b_h (two independent accumulator chains)
+__device__ __forceinline__ void mfma3(const u32x4 (&a)[2], const Pieces<2>& b, f32x4& hi, f32x4& lo) {
+#define PC_MF(acc, i, j) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[i]), __builtin_bit_cast(f16x8, b.p[j]), acc, 0, 0, 0)
+    PC_MF(lo, 0, 1); PC_MF(hi, 0, 0); PC_MF(lo, 1, 0);
+#undef PC_MF
+}
 
-// bf16x3 image builder (one thread per 16-byte operand record / per bias float)
+// image builder of the split forms (one thread per 16-byte operand record / per bias float)
+template <int PREC>
 __global__ __launch_bounds__(256) void policy_pack16_kernel(const int D, const int A, const float* __restrict__ aW1,
                                                             const float* __restrict__ ab1, const float* __restrict__ aW2,
                                                             const float* __restrict__ ab2, const float* __restrict__ cW1,
                                                             const float* __restrict__ cb1, const float* __restrict__ cW2,
                                                             const float* __restrict__ cb2, unsigned* __restrict__ image) {
-    constexpr int HID = 256;
-    constexpr int n1 = 32 * 3 * 48, n2 = 8 * 3 * 4 * 10;
+    constexpr int HID = 256, NP = pol_np(PREC);
+    constexpr int n1 = 32 * NP * 48, n2 = 8 * NP * 4 * 10;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2 + 512 + 16 + 256; i += gridDim.x * blockDim.x) {
         if (i < n1 + n2) {
             float v[8];
             int pc;
             if (i < n1) {
                 const int lc = i % 16, g = (i / 16) % 3;
-                pc = (i / 48) % 3;
-                const int ht = i / 144, r = 16 * ht + lc;
+                pc = (i / 48) % NP;
+                const int ht = i / (48 * NP), r = 16 * ht + lc;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int f = 8 * g + j;
@@ -987,15 +1027,19 @@ __global__ __launch_bounds__(256) void policy_pack16_kernel(const int D, const i
             } else {
                 const int k = i - n1;
                 const int o = k % 10, g = (k / 10) % 4;
-                pc = (k / 40) % 3;
-                const int tp = k / 120;
+                pc = (k / 40) % NP;
+                const int tp = k / (40 * NP);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int h = 16 * (2 * tp + (j >> 2)) + 4 * g + (j & 3);   // actor hidden unit (tp < 8)
                     v[j] = o < A ? aW2[o * HID + h] : 0.0f;
                 }
             }
-            const Bf3 sp = split8(v);
+            if constexpr (PREC == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = clamp_h(v[j]);
+            }
+            const Pieces<PREC> sp = split8<PREC>(v);
             reinterpret_cast<u32x4*>(image)[i] = sp.p[pc];
         } else {
             const int b = i - n1 - n2;
@@ -1016,37 +1060,55 @@ __global__ __launch_bounds__(256) void policy_pack16_kernel(const int D, const i
 // Pairs 0..7 are the actor: ReLU, split, layer 2 on the matrix cores into out[et] (rows 0..A-1).  Pairs 8..15 are
 // the critic, whose output layer is ONE dot product per env: it is taken in plain fp32 on the VALU straight from
 // the accumulator registers (val[et] = this lane's partial over its hidden rows; the caller sums the 4 lane groups).
+template <int PREC>
 __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsigned* sW2p, const float* sB1, const float* sW2c,
-                                              const int tp0, const int tp1, const Bf3 (&x)[2], f32x4 (&out)[2], float (&val)[2],
-                                              const int lc, const int g) {
+                                              const int tp0, const int tp1, const Pieces<PREC> (&x)[2], f32x4 (&out)[2],
+                                              float (&val)[2], const int lc, const int g) {
+    constexpr int NP = pol_np(PREC);
     const int gA = g < 3 ? g : 2;     // group 3 is K padding: its B operand is all zeros, any finite A will do
     const int oA = lc < 10 ? lc : 9;  // output rows >= 10 are never read
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 outlo[2] = {zero4, zero4};  // PREC 2: the scaled cross terms of layer 2
     for (int tp = tp0; tp < tp1; ++tp) {
         f32x4 acc[2][2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int ht = 2 * tp + j;
             const f32x4 bias = *reinterpret_cast<const f32x4*>(sB1 + 16 * ht + 4 * g);
-            u32x4 a[3];
+            u32x4 a[NP];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) a[pc] = *reinterpret_cast<const u32x4*>(sW1p + ((ht * 3 + pc) * 48 + gA * 16 + lc) * 4);
+            for (int pc = 0; pc < NP; ++pc) a[pc] = *reinterpret_cast<const u32x4*>(sW1p + ((ht * NP + pc) * 48 + gA * 16 + lc) * 4);
 #pragma unroll
-            for (int et = 0; et < 2; ++et) acc[j][et] = mfma6(a, x[et], bias);
+            for (int et = 0; et < 2; ++et) {
+                if constexpr (PREC == 2) {
+                    f32x4 hi = bias, lo = zero4;
+                    mfma3(a, x[et], hi, lo);
+                    acc[j][et] = __builtin_elementwise_fma(lo, (f32x4){PC_H_UNSCALE, PC_H_UNSCALE, PC_H_UNSCALE, PC_H_UNSCALE}, hi);
+                } else {
+                    acc[j][et] = mfma6(a, x[et], bias);
+                }
+            }
         }
         if (tp < 8) {  // actor (uniform branch)
-            u32x4 w2[3];
+            u32x4 w2[NP];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) w2[pc] = *reinterpret_cast<const u32x4*>(sW2p + (((tp * 3 + pc) * 4 + g) * 10 + oA) * 4);
+            for (int pc = 0; pc < NP; ++pc) w2[pc] = *reinterpret_cast<const u32x4*>(sW2p + (((tp * NP + pc) * 4 + g) * 10 + oA) * 4);
 #pragma unroll
             for (int et = 0; et < 2; ++et) {
                 float hv[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    hv[r] = relu_f(acc[0][et][r]);
-                    hv[4 + r] = relu_f(acc[1][et][r]);
+                    if constexpr (PREC == 2) {
+                        hv[r] = __builtin_amdgcn_fmed3f(acc[0][et][r], 0.0f, PC_H_MAX);  // ReLU, saturating at fp16's range
+                        hv[4 + r] = __builtin_amdgcn_fmed3f(acc[1][et][r], 0.0f, PC_H_MAX);
+                    } else {
+                        hv[r] = relu_f(acc[0][et][r]);
+                        hv[4 + r] = relu_f(acc[1][et][r]);
+                    }
                 }
-                const Bf3 h3 = split8(hv);
-                out[et] = mfma6(w2, h3, out[et]);
+                const Pieces<PREC> h3 = split8<PREC>(hv);
+                if constexpr (PREC == 2) mfma3(w2, h3, out[et], outlo[et]);
+                else out[et] = mfma6(w2, h3, out[et]);
             }
         } else {       // critic
 #pragma unroll
@@ -1058,6 +1120,11 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
                     for (int r = 0; r < 4; ++r) val[et] = __builtin_fmaf(w[r], relu_f(acc[j][et][r]), val[et]);
             }
         }
+    }
+    if constexpr (PREC == 2) {
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+            out[et] = __builtin_elementwise_fma(outlo[et], (f32x4){PC_H_UNSCALE, PC_H_UNSCALE, PC_H_UNSCALE, PC_H_UNSCALE}, out[et]);
     }
 }
 
@@ -1134,14 +1201,14 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
     constexpr int HID = 256, NT = 2 * HID / 16;  // 32 hidden tiles: 16 actor + 16 critic
     constexpr int LD1 = pol_ld1(KS), LDO = 17, ET = 2;
     constexpr int ENVS_PER_WG = SPLIT ? 32 : 256;
-    constexpr int IMG = PREC ? pol16_image_dwords() : pol_image_padded(KS);
+    constexpr int IMG = PREC ? polx_image_dwords(PREC) : pol_image_padded(KS);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sW1 = lds;                        // PREC 0: [512][LD1]
-    float* sB1 = PREC ? lds + pol16_w1_dwords() + pol16_w2_dwords() : sW1 + 2 * HID * LD1;  // [512]
+    float* sB1 = PREC ? lds + polx_w1_dwords(PREC) + polx_w2_dwords(PREC) : sW1 + 2 * HID * LD1;  // [512]
     float* sW2 = sB1 + 2 * HID;              // PREC 0: [NT][4][64]
     float* sB2 = PREC ? sB1 + 512 : sW2 + NT * 4 * 64;  // [16]
     const unsigned* sW1p = reinterpret_cast<const unsigned*>(lds);                       // PREC 1 operand records
-    const unsigned* sW2p = sW1p + pol16_w1_dwords();
+    const unsigned* sW2p = sW1p + polx_w1_dwords(PREC ? PREC : 1);
     const float* sW2c = sB2 + 16;            // PREC 1: critic output weights [256]
     float* sOut = lds + IMG;                 // [8 waves][32 envs][LDO]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1172,7 +1239,7 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
             }
             policy_pass<KS>(sW1, sB1, sW2, ht0, ht1, x, out, lc, lk, lane);
         } else {
-            Bf3 x[ET];
+            Pieces<PREC> x[ET];
 #pragma unroll
             for (int et = 0; et < ET; ++et) {
                 const int64_t e = env0 + 16 * et + lc;
@@ -1181,11 +1248,12 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
                 for (int j = 0; j < 8; ++j) {
                     const int f = 8 * lk + j;
                     v[j] = (e < N && f < D) ? obs[e * D + f] : 0.0f;
+                    if constexpr (PREC == 2) v[j] = clamp_h(v[j]);
                 }
-                x[et] = split8(v);
+                x[et] = split8<PREC>(v);
             }
             float val[ET] = {0.0f, 0.0f};
-            policy_pass16(sW1p, sW2p, sB1, sW2c, ht0 / 2, ht1 / 2, x, out, val, lc, lk);
+            policy_pass16<PREC>(sW1p, sW2p, sB1, sW2c, ht0 / 2, ht1 / 2, x, out, val, lc, lk);
 #pragma unroll
             for (int et = 0; et < ET; ++et) {  // the env column's value: sum of the 4 lane groups' partials -> output row A
                 float t = val[et];
@@ -1282,14 +1350,14 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                                                       float* __restrict__ next_term, float* __restrict__ next_trunc,
                                                       const int dbg) {
     constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, LDX = 4 * KS + 1, ET = 2;
-    constexpr int IMG = PREC ? pol16_image_dwords() : pol_image_padded(KS);
+    constexpr int IMG = PREC ? polx_image_dwords(PREC) : pol_image_padded(KS);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sW1 = lds;
-    float* sB1 = PREC ? lds + pol16_w1_dwords() + pol16_w2_dwords() : sW1 + 2 * HID * LD1;
+    float* sB1 = PREC ? lds + polx_w1_dwords(PREC) + polx_w2_dwords(PREC) : sW1 + 2 * HID * LD1;
     float* sW2 = sB1 + 2 * HID;
     float* sB2 = PREC ? sB1 + 512 : sW2 + NT * 4 * 64;
     const unsigned* sW1p = reinterpret_cast<const unsigned*>(lds);
-    const unsigned* sW2p = sW1p + pol16_w1_dwords();
+    const unsigned* sW2p = sW1p + polx_w1_dwords(PREC ? PREC : 1);
     const float* sW2c = sB2 + 16;                  // PREC 1: critic output weights [256]
     float* sOut = lds + IMG;                       // [8 waves][32 envs][LDO]
     float* sObs = sOut + 8 * 32 * LDO;             // [256 envs][LDX]   observation of the step in flight
@@ -1334,7 +1402,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                     for (int ks = 0; ks < KS; ++ks) x[et][ks] = sObs[(pbase + 16 * et + lc) * LDX + 4 * ks + lk];
                 if (!(dbg & 1)) policy_pass<KS>(sW1, sB1, sW2, 0, NT, x, out, lc, lk, lane);  // dbg: timing ablations only
             } else {
-                Bf3 x[ET];
+                Pieces<PREC> x[ET];
 #pragma unroll
                 for (int et = 0; et < ET; ++et) {
                     float v[8];
@@ -1342,11 +1410,12 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                     for (int j = 0; j < 8; ++j) {
                         const int f = 8 * lk + j;
                         v[j] = f < D ? sObs[(pbase + 16 * et + lc) * LDX + f] : 0.0f;
+                        if constexpr (PREC == 2) v[j] = clamp_h(v[j]);
                     }
-                    x[et] = split8(v);
+                    x[et] = split8<PREC>(v);
                 }
                 float val[ET] = {0.0f, 0.0f};
-                if (!(dbg & 1)) policy_pass16(sW1p, sW2p, sB1, sW2c, 0, NT / 2, x, out, val, lc, lk);
+                if (!(dbg & 1)) policy_pass16<PREC>(sW1p, sW2p, sB1, sW2c, 0, NT / 2, x, out, val, lc, lk);
 #pragma unroll
                 for (int et = 0; et < ET; ++et) {
                     float tv = val[et];
@@ -1418,14 +1487,14 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                                                             float* __restrict__ next_term, float* __restrict__ next_trunc,
                                                             const int dbg) {
     constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, LDX = 4 * KS + 1, ET = 2;
-    constexpr int IMG = PREC ? pol16_image_dwords() : pol_image_padded(KS);
+    constexpr int IMG = PREC ? polx_image_dwords(PREC) : pol_image_padded(KS);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sW1 = lds;
-    float* sB1 = PREC ? lds + pol16_w1_dwords() + pol16_w2_dwords() : sW1 + 2 * HID * LD1;
+    float* sB1 = PREC ? lds + polx_w1_dwords(PREC) + polx_w2_dwords(PREC) : sW1 + 2 * HID * LD1;
     float* sW2 = sB1 + 2 * HID;
     float* sB2 = PREC ? sB1 + 512 : sW2 + NT * 4 * 64;
     const unsigned* sW1p = reinterpret_cast<const unsigned*>(lds);
-    const unsigned* sW2p = sW1p + pol16_w1_dwords();
+    const unsigned* sW2p = sW1p + polx_w1_dwords(PREC ? PREC : 1);
     const float* sW2c = sB2 + 16;
     float* sOut = lds + IMG;                       // [8 waves][32 envs][LDO] partial output tiles
     float* sObs = sOut + 8 * 32 * LDO;             // [32 envs][LDX]
@@ -1468,7 +1537,7 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 for (int ks = 0; ks < KS; ++ks) x[et][ks] = sObs[(16 * et + lc) * LDX + 4 * ks + lk];
             if (!(dbg & 1)) policy_pass<KS>(sW1, sB1, sW2, ht0, ht1, x, out, lc, lk, lane);  // dbg: timing ablations only
         } else {
-            Bf3 x[ET];
+            Pieces<PREC> x[ET];
 #pragma unroll
             for (int et = 0; et < ET; ++et) {
                 float v[8];
@@ -1476,11 +1545,12 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 for (int j = 0; j < 8; ++j) {
                     const int f = 8 * lk + j;
                     v[j] = f < D ? sObs[(16 * et + lc) * LDX + f] : 0.0f;
+                    if constexpr (PREC == 2) v[j] = clamp_h(v[j]);
                 }
-                x[et] = split8(v);
+                x[et] = split8<PREC>(v);
             }
             float val[ET] = {0.0f, 0.0f};
-            if (!(dbg & 1)) policy_pass16(sW1p, sW2p, sB1, sW2c, ht0 / 2, ht1 / 2, x, out, val, lc, lk);
+            if (!(dbg & 1)) policy_pass16<PREC>(sW1p, sW2p, sB1, sW2c, ht0 / 2, ht1 / 2, x, out, val, lc, lk);
 #pragma unroll
             for (int et = 0; et < ET; ++et) {
                 float tv = val[et];
@@ -2450,7 +2520,7 @@ int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, 
 static int policy_ks(int D) { return D <= 20 ? 5 : (D <= 24 ? 6 : 10); }
 static int g_policy_split_mode = -1;  // -1 auto (split below 32768 envs), 0 never, 1 always
 static int g_rollout_form = -1;       // pc_rollout: -1 auto, 0 = 256 envs per workgroup, 1 = 32 envs per workgroup
-static int g_policy_precision = 1;    // 0 = fp32-input MFMA, 1 = bf16x3 split on the bf16 matrix cores (needs D <= 24, A <= 9)
+static int g_policy_precision = 2;    // 0 = fp32-input MFMA; split forms on the 16-bit matrix cores (need D <= 24, A <= 9): 1 = bf16 x 3, 2 = fp16 x 2
 
 int pc_rollout_set_form(int form) {
     if (form < -1 || form > 1) return PC_ERR_INVALID_ARG;
@@ -2459,12 +2529,12 @@ int pc_rollout_set_form(int form) {
 }
 
 int pc_policy_set_precision(int mode) {
-    if (mode < 0 || mode > 1) return PC_ERR_INVALID_ARG;
+    if (mode < 0 || mode > 2) return PC_ERR_INVALID_ARG;
     g_policy_precision = mode;
     return PC_OK;
 }
 
-static int policy_prec(int D, int A) { return (g_policy_precision == 1 && D <= 24 && A <= 9) ? 1 : 0; }
+static int policy_prec(int D, int A) { return (g_policy_precision >= 1 && D <= 24 && A <= 9) ? g_policy_precision : 0; }
 int pc_policy_precision(int D, int H, int A) {
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
     return policy_prec(D, A);
@@ -2478,7 +2548,8 @@ int pc_policy_set_split(int mode) {
 
 int64_t pc_policy_image_floats(int D, int H, int A) {
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
-    return policy_prec(D, A) ? pol16_image_dwords() : pol_image_padded(policy_ks(D));
+    const int prec = policy_prec(D, A);
+    return prec ? polx_image_dwords(prec) : pol_image_padded(policy_ks(D));
 }
 
 int pc_policy_pack(int device, int D, int H, int A, const float* aW1, const float* ab1, const float* aW2, const float* ab2,
@@ -2489,8 +2560,12 @@ int pc_policy_pack(int device, int D, int H, int A, const float* aW1, const floa
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1 || device < 0 || device >= count) return PC_ERR_NO_DEVICE;
     DeviceGuard guard(device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
-    if (policy_prec(D, A))
-        hipLaunchKernelGGL(policy_pack16_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, D, A, aW1, ab1, aW2, ab2, cW1, cb1,
+    const int prec = policy_prec(D, A);
+    if (prec == 1)
+        hipLaunchKernelGGL(policy_pack16_kernel<1>, dim3(64), dim3(256), 0, (hipStream_t)stream, D, A, aW1, ab1, aW2, ab2, cW1, cb1,
+                           cW2, cb2, reinterpret_cast<unsigned*>(image));
+    else if (prec == 2)
+        hipLaunchKernelGGL(policy_pack16_kernel<2>, dim3(64), dim3(256), 0, (hipStream_t)stream, D, A, aW1, ab1, aW2, ab2, cW1, cb1,
                            cW2, cb2, reinterpret_cast<unsigned*>(image));
     else
         hipLaunchKernelGGL(policy_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, policy_ks(D), D, A, aW1, ab1, aW2, ab2,
@@ -2510,7 +2585,7 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
     if (!guard.ok) return PC_ERR_NO_DEVICE;
     const int KS = policy_ks(D);
     const int prec = policy_prec(D, A);
-    const size_t lds = (size_t)((prec ? pol16_image_dwords() : pol_image_padded(KS)) + 8 * 32 * 17) * sizeof(float);
+    const size_t lds = (size_t)((prec ? polx_image_dwords(prec) : pol_image_padded(KS)) + 8 * 32 * 17) * sizeof(float);
     static int n_cu[64] = {0};
     if (device < 64 && n_cu[device] == 0) {
         hipDeviceProp_t prop;
@@ -2533,9 +2608,12 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
         hipLaunchKernelGGL((policy_kernel<KSV, SPL, PRC>), dim3(blocks), dim3(512), lds, st, obs, N, D, A, image, seed, offset, offset_dev, \
                            action, action_f32, logprob, value, logits_out);                                              \
     } while (0)
-    if (prec) {
+    if (prec == 1) {
         if (split) { if (KS == 5) PC_POL(5, true, 1); else PC_POL(6, true, 1); }
         else { if (KS == 5) PC_POL(5, false, 1); else PC_POL(6, false, 1); }
+    } else if (prec == 2) {
+        if (split) { if (KS == 5) PC_POL(5, true, 2); else PC_POL(6, true, 2); }
+        else { if (KS == 5) PC_POL(5, false, 2); else PC_POL(6, false, 2); }
     } else if (split) {
         if (KS == 5) PC_POL(5, true, 0);
         else if (KS == 6) PC_POL(6, true, 0);
@@ -2600,7 +2678,7 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     DeviceGuard guard(e->device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
     const int prec = policy_prec(e->D, A);
-    const int img = prec ? pol16_image_dwords() : pol_image_padded(KS);
+    const int img = prec ? polx_image_dwords(prec) : pol_image_padded(KS);
     const size_t lds_big = (size_t)(img + 8 * 32 * 17 + 256 * (4 * KS + 1) + 256 + TAB_FLOATS) * sizeof(float);
     const size_t lds_small = (size_t)(img + 8 * 32 * 17 + 32 * (4 * KS + 1) + 32 + TAB_FLOATS) * sizeof(float);
     // large batches: 256 envs per workgroup, every wave independent (at 33 rays the 256-env observation tile does not fit
@@ -2639,12 +2717,12 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
                            next_term, next_trunc, dbg);                                                                     \
     } while (0)
     if (small) {
-        if (KS == 5 && rpl == 3) { if (prec) PC_ROLLS(5, 3, 1); else PC_ROLLS(5, 3, 0); }        // 12 rays
-        else if (KS == 6 && rpl == 5) { if (prec) PC_ROLLS(6, 5, 1); else PC_ROLLS(6, 5, 0); }   // 16 -> 17 rays
+        if (KS == 5 && rpl == 3) { if (prec == 2) PC_ROLLS(5, 3, 2); else if (prec) PC_ROLLS(5, 3, 1); else PC_ROLLS(5, 3, 0); }        // 12 rays
+        else if (KS == 6 && rpl == 5) { if (prec == 2) PC_ROLLS(6, 5, 2); else if (prec) PC_ROLLS(6, 5, 1); else PC_ROLLS(6, 5, 0); }   // 16 -> 17 rays
         else if (KS == 10 && rpl == 9) PC_ROLLS(10, 9, 0);                                         // 32 -> 33 rays
         else return PC_ERR_UNSUPPORTED;
-    } else if (KS == 5 && rpl == 6) { if (prec) PC_ROLL(5, 6, 1); else PC_ROLL(5, 6, 0); }       // 12 rays, D = 18
-    else if (KS == 6 && rpl == 9) { if (prec) PC_ROLL(6, 9, 1); else PC_ROLL(6, 9, 0); }          // 16 -> 17 rays, D = 23
+    } else if (KS == 5 && rpl == 6) { if (prec == 2) PC_ROLL(5, 6, 2); else if (prec) PC_ROLL(5, 6, 1); else PC_ROLL(5, 6, 0); }       // 12 rays, D = 18
+    else if (KS == 6 && rpl == 9) { if (prec == 2) PC_ROLL(6, 9, 2); else if (prec) PC_ROLL(6, 9, 1); else PC_ROLL(6, 9, 0); }          // 16 -> 17 rays, D = 23
     else return PC_ERR_UNSUPPORTED;
 #undef PC_ROLLS
 #undef PC_ROLL

@@ -139,14 +139,14 @@ def policy_precision(request):
     from ppo_car_amd._capi import lib
     lib.pc_policy_set_precision(request.param)
     yield request.param
-    lib.pc_policy_set_precision(1)
+    lib.pc_policy_set_precision(2)
 
 
-@pytest.mark.parametrize("policy_precision", [0, 1], indirect=True)
+@pytest.mark.parametrize("policy_precision", [0, 1, 2], indirect=True)
 @pytest.mark.parametrize("D", [18, 23, 39])
 @pytest.mark.parametrize("N", [1000, 65536])
 def test_fused_policy_kernel_matches_torch_mlp(D, N, policy_precision):
-    """pc_policy_act (fp32 MFMA, hidden layer in registers) vs torch's Linear/ReLU/Linear on the same weights:
+    """pc_policy_act (0: fp32 MFMA, 1: bf16 x 3, 2: fp16 x 2 split forms; hidden layer in registers) vs torch's Linear/ReLU/Linear on the same weights:
     logits and values within 1e-5 (different fp32 summation order only), log_prob consistent with the logits it
     reports, draws distributed as the categorical."""
     torch.manual_seed(D)
@@ -163,10 +163,10 @@ def test_fused_policy_kernel_matches_torch_mlp(D, N, policy_precision):
     with torch.no_grad():
         ref_logits, ref_v = agent.actor(x), agent.critic(x).view(-1)
     from ppo_car_amd._capi import lib
-    assert lib.pc_policy_precision(D, 256, 9) == (policy_precision if D <= 24 else 0)   # bf16x3 covers D <= 24
+    assert lib.pc_policy_precision(D, 256, 9) == (policy_precision if D <= 24 else 0)   # the split forms cover D <= 24
     assert torch.allclose(logits, ref_logits, atol=1e-5, rtol=1e-5)
     assert torch.allclose(v, ref_v, atol=1e-5, rtol=1e-5)
-    # against float64: both forms are fp32-class (the bf16x3 split is the closer one)
+    # against float64: all three forms are fp32-class
     with torch.no_grad():
         a1, a2 = agent.actor[0], agent.actor[2]
         ref64 = torch.relu(x.double() @ a1.weight.double().T + a1.bias.double()) @ a2.weight.double().T + a2.bias.double()

@@ -186,7 +186,7 @@ def test_fused_and_torch_updates_agree_inside_the_trainer():
 
 
 @pytest.mark.parametrize("form", [0, 1])
-@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("precision", [2, 1, 0])
 @pytest.mark.parametrize("num_rays,n_envs", [(16, 1000), (12, 512), (32, 300)])
 def test_persistent_rollout_kernel_is_bitwise_the_two_kernel_rollout(num_rays, n_envs, precision, form):
     """pc_rollout (one persistent launch, weights in LDS, env state in registers) must fill the buffer with exactly the
@@ -219,7 +219,7 @@ def test_persistent_rollout_kernel_is_bitwise_the_two_kernel_rollout(num_rays, n
             tr.close()
     finally:
         lib.pc_policy_set_split(-1)
-        lib.pc_policy_set_precision(1)
+        lib.pc_policy_set_precision(2)
         lib.pc_rollout_set_form(-1)
     for ep in range(3):
         for i, (a, b) in enumerate(zip(res["steps"][0][ep], res["mega"][0][ep])):
