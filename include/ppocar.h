@@ -171,7 +171,9 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
 
 /* Work decomposition of pc_rollout: -1 = automatic (256 envs per workgroup with independent waves from 32768 envs up,
  * else 32 envs per workgroup with the policy's hidden tiles split over the waves -- also the only form that fits LDS
- * at 33 rays), 0 / 1 force one form.  Both are bit-identical to the per-step kernels.  Tuning / test knob. */
+ * at 33 rays), 0 / 1 force one form; 2 / 3 = forms 0 / 1 with the env step forming 1/den arithmetically instead of
+ * reading the track's 1/den table from LDS (what happens anyway when the table does not fit).  All are bit-identical
+ * to the per-step kernels.  Tuning / test knob. */
 int pc_rollout_set_form(int form);
 
 /* ---- the non-GEMM work of one PPO minibatch step (train.py:230-261), three launches:

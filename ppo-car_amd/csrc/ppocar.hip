@@ -62,7 +62,9 @@ struct TrackHdr {        // one per track, read with scalar loads
     int gate_off, G;     // segs[gate_off .. gate_off+G): the reward gates
     int head_off;        // F32: heading table [72] (cos, sin) of radians(start_rot + 5 j)
     int start_collides;  // Car.update at reset already hits a wall (car_env.py:686,468-469)
-    int vtx_off, nV;     // F32: the walls again as vertex chains, vtx[vtx_off .. vtx_off+nV)
+    int vtx_off, nV;     // F32: the walls again as vertex chains, vtx[vtx_off .. vtx_off+nV); nV is padded to a multiple of 4
+    int dir_off;         // F32: ray direction table [361] of this track in dirtab (entry 360 = (0, 0): no ray)
+    int rden_off;        // F32: 1/den table [361][nV] of this track in rden (row 360 = +inf: never hits)
     double start_x, start_y, start_rot;
 };
 
@@ -93,11 +95,15 @@ template <typename T> struct EnvParams {
     const Seg* __restrict__ segs;           // walls and gates of all tracks
     const Vtx* __restrict__ vtx;            // F32 only: wall vertex chains of all tracks
     const double2* __restrict__ headtab;    // F32 only: (cos, sin) of radians(start_rot + 5 j), j < 72, per track
-    const float2* __restrict__ raytab;      // F32 only: [R] (cos, sin) of radians(i * step_deg)
+    // F32 only.  A ray's direction angle is start_rot + 5 k + step_deg * ray degrees (k = integer turn count): an integer
+    // offset from start_rot, so all directions live on a 360-entry lattice per track.
+    const float2* __restrict__ dirtab;      // [n_tracks][361] (cos, sin) of radians(start_rot + j), float64 libm, rounded
+    const float* __restrict__ rden;         // [n_tracks][361][nV] 1 / (ey*dx - ex*dy) exactly as the sweep computes it (device-built)
     const float* __restrict__ reset_obs;    // [n_tracks][D]
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define PC_PI 3.141592653589793238462643383279502884 /* NPY_PI */
 
@@ -153,7 +159,7 @@ template <> struct Math<double> {
         c = cos(a);
         s = sin(a);
     }
-    static __device__ __forceinline__ void ray_dir(const EnvParams<double>& p, int ray, double rot, double, double,
+    static __device__ __forceinline__ void ray_dir(const EnvParams<double>& p, const TrackHdr&, int ray, int, double rot,
                                                    double& dx, double& dy) {
         const double a = d_radians(rot + (double)(ray * p.step_deg));  // Ray.update(x, y, rot + a) :463-466, :153
         dx = cos(a);
@@ -179,12 +185,16 @@ template <> struct Math<float> {
         c = cs.x;
         s = cs.y;
     }
-    static __device__ __forceinline__ void ray_dir(const EnvParams<float>& p, int ray, double, double ch, double sh,
+    // lattice index of ray `ray` at turn count k: (5 k + step_deg * ray) mod 360; 360 = "no ray"
+    static __device__ __forceinline__ int dir_index(const EnvParams<float>& p, int k, int ray) {
+        const int m = 5 * mod72(k) + ray * p.step_deg;  // ray * step_deg < 360 for every ray < R
+        return m >= 360 ? m - 360 : m;
+    }
+    static __device__ __forceinline__ void ray_dir(const EnvParams<float>& p, const TrackHdr& h, int ray, int k, double,
                                                    float& dx, float& dy) {
-        const float2 cs = p.raytab[ray];  // cos/sin(radians(ray * step)); angle addition in float32
-        const float c = (float)ch, s = (float)sh;
-        dx = __builtin_fmaf(c, cs.x, -(s * cs.y));
-        dy = __builtin_fmaf(s, cs.x, c * cs.y);
+        const float2 cs = p.dirtab[h.dir_off + dir_index(p, k, ray)];
+        dx = cs.x;
+        dy = cs.y;
     }
     static __device__ __forceinline__ float cast(const Seg& sg, double px, double py, float dx, float dy) {
         const float ax1 = (float)(sg.x1 - px), ay1 = (float)(sg.y1 - py);
@@ -241,6 +251,8 @@ template <typename T> __device__ __forceinline__ void env_store(const EnvParams<
     if constexpr (sizeof(T) == 8) p.rot[e] = st.rot;
 }
 
+typedef const __attribute__((address_space(3))) float* lds_cfp;  // read-only float data in LDS (ds_read, not flat)
+
 // 0x80000000 in an SGPR the optimiser cannot see through, and (a & m) | c as ONE instruction (the compiler splits the
 // and-or when the mask is a literal: VOP3 takes no literals on gfx9).
 __device__ __forceinline__ unsigned sign_mask() {
@@ -262,11 +274,14 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // 2^lg lanes of this group hold in `st` (updated in place, identically in every lane).  Lane g sweeps rays
 // g, g + G, ...  Observation entries go to orow (global row), frow (pre-reset obs, optional) and lrow (an LDS
 // copy for the persistent rollout kernel, optional).  The per-env scalars come back in registers.
-template <typename T, int RPL, int PARTS = 1>
+template <typename T, int RPL, int PARTS = 1, bool TAB = false>
 __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int trk, const int g, const int lg, EnvRegs& st,
                                               const int64_t a, const double reward_scale, float* __restrict__ orow,
                                               float* __restrict__ frow, float* lrow, float& reward_f, bool& term, bool& trunc,
-                                              int& passed_out, const int part = 0, float* exch = nullptr) {
+                                              int& passed_out, const int part = 0, float* exch = nullptr, lds_cfp rdl = nullptr) {
+    // TAB (persistent kernels, when the track's 1/den table fits LDS): `rdl` = this track's [361][nV] table in LDS; the sweep
+    // reads 1/den instead of forming den and its reciprocal (9 quarter-rate v_rcp_f32 per vertex otherwise) -- the table
+    // holds exactly the bits the arithmetic path produces, so both paths are interchangeable.
     // PARTS > 1 (rollout_small_kernel): the env's wall sweep is split over PARTS waves of the workgroup -- this wave
     // sweeps vertex range `part`, the per-ray minima meet in LDS (`exch`: this env's [R][PARTS] floats) across ONE
     // workgroup barrier, and every wave then finishes the step on identical values (min is exact: bit-identical to
@@ -316,6 +331,7 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
 
     // ---- my rays: directions at the new pose; gate test at the OLD pose for the collision rays
     T dx[RPL], dy[RPL], best[RPL];
+    int didx[RPL];  // F32: the slots' direction-lattice indices
     bool gate_hit = false;
     uint64_t colmask = 0;  // which of my ray slots are collision rays
     const Seg gate = p.segs[h.gate_off + st.next];  // only gate[next] can fire (the oracle does the full scan)
@@ -324,10 +340,17 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
         const int ray = g + s * G;
         const bool valid = ray < p.R;
         const int rr = valid ? ray : 0;
-        Math<T>::ray_dir(p, rr, rot_new, ch1, sh1, dx[s], dy[s]);
-        if (!valid) {  // den == 0 for every segment -> never hits
-            dx[s] = 0;
-            dy[s] = 0;
+        if constexpr (sizeof(T) == 4) {  // direction lattice: entry / row 360 = "no ray" (direction 0, 1/den = +inf)
+            didx[s] = valid ? Math<float>::dir_index(p, k_new, ray) : 360;
+            const float2 cs = p.dirtab[h.dir_off + didx[s]];
+            dx[s] = cs.x;
+            dy[s] = cs.y;
+        } else {
+            Math<T>::ray_dir(p, h, rr, k_new, rot_new, dx[s], dy[s]);
+            if (!valid) {  // den == 0 for every segment -> never hits
+                dx[s] = 0;
+                dy[s] = 0;
+            }
         }
         best[s] = (T)1000;  // Ray.get_distance :198
         // Car.check_collision's rays: r in range(0, n, n // 4) (:389) -- nominal n, not R
@@ -336,7 +359,7 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
         colmask |= (uint64_t)is_col << s;
         if (is_col) {  // Car.get_passed_gate (:394-408) uses the rays of the PREVIOUS update
             T odx = dx[s], ody = dy[s];
-            if (turned) Math<T>::ray_dir(p, rr, rot_old, ch0, sh0, odx, ody);
+            if (turned) Math<T>::ray_dir(p, h, rr, st.k, rot_old, odx, ody);
             gate_hit |= Math<T>::cast(gate, opx, opy, odx, ody) < (T)10;  // :387,:390
         }
     }
@@ -369,46 +392,67 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
 #pragma unroll
             for (int j = 0; j < NP; ++j) c[j] = __builtin_elementwise_fma(ay2, dx2[j], -(ax2 * dy2[j]));
         };
-        // vertex k closes the segment (k-1, k): (axp, ayp, cp) belong to k-1, c to k
-        auto close = [&](const Vtx& v, const float axp, const float ayp, const f32x2 (&cp)[NP], const f32x2 (&c)[NP]) {
+        // vertex k closes the segment (k-1, k): (axp, ayp, cp) belong to k-1, c to k; rdv = the slots' 1/den (TAB)
+        auto close = [&](const Vtx& v, const float axp, const float ayp, const f32x2 (&cp)[NP], const f32x2 (&c)[NP],
+                         const float (&rdv)[2 * NP]) {
             const float un = __builtin_fmaf(v.ey, axp, -(v.ex * ayp));
             const f32x2 un2 = {un, un}, ex2 = {v.ex, v.ex}, ey2 = {v.ey, v.ey};
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                const f32x2 den = __builtin_elementwise_fma(ey2, dx2[j], -(ex2 * dy2[j]));
-                const f32x2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                const f32x2 u = un2 * rc;
+                f32x2 u;
+                if constexpr (TAB) {
+                    u = (f32x2){un * rdv[2 * j], un * rdv[2 * j + 1]};
+                } else {
+                    const f32x2 den = __builtin_elementwise_fma(ey2, dx2[j], -(ex2 * dy2[j]));  // = rden_build_kernel's
+                    const f32x2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                    u = un2 * rc;
+                }
                 const f32x2 t = cp[j] * (-c[j]);  // sign clear <=> strictly opposite sides
                 bb[2 * j] = min(bb[2 * j], and_or(__float_as_uint(t.x), sgn, __float_as_uint(u.x)));
                 bb[2 * j + 1] = min(bb[2 * j + 1], and_or(__float_as_uint(t.y), sgn, __float_as_uint(u.y)));
             }
         };
-        // vertex range of this part; one vertex earlier than kbeg supplies the chain's previous side value
-        const int kbeg = PARTS > 1 ? h.nV * part / PARTS : 0;
-        const int kend = PARTS > 1 ? h.nV * (part + 1) / PARTS : h.nV;
-        const int k0 = kbeg > 0 ? kbeg - 1 : 0;
-        // two vertices per trip, the "previous vertex" registers alternating between sets A and B (no copies);
-        // wave-uniform vertex records -> s_load_dwordx8, prefetched one vertex ahead under the VALU work
+        // Vertex GROUPS of four (the host pads every track's chain to a multiple of 4 with chain-break sentinels);
+        // this part's groups [gbeg, gend).  The vertex before the range supplies the chain's previous side values.
+        const int ngrp = h.nV >> 2;
+        const int gbeg = PARTS > 1 ? ngrp * part / PARTS : 0;
+        const int gend = PARTS > 1 ? ngrp * (part + 1) / PARTS : ngrp;
+        // The "previous vertex" registers alternate between sets A and B (no copies); wave-uniform vertex records ->
+        // s_load_dwordx8, prefetched one vertex ahead under the VALU work.
         float axA = 0.0f, ayA = 0.0f, axB = 0.0f, ayB = 0.0f;
         f32x2 cA[NP], cB[NP];
 #pragma unroll
         for (int j = 0; j < NP; ++j) cA[j] = cB[j] = (f32x2){0.0f, 0.0f};
-        Vtx nxt = cload(vt + k0);
-        int k = k0;
-        for (; k + 1 < kend; k += 2) {
-            const Vtx v0 = nxt;
-            nxt = cload(vt + k + 1);
-            side(v0, axB, ayB, cB);
-            if (!v0.brk && k >= kbeg) close(v0, axA, ayA, cA, cB);
-            const Vtx v1 = nxt;
-            nxt = cload(vt + (k + 2 < kend ? k + 2 : k + 1));
-            side(v1, axA, ayA, cA);
-            if (!v1.brk) close(v1, axB, ayB, cB, cA);
+        if (PARTS > 1 && gbeg > 0) side(cload(vt + 4 * gbeg - 1), axA, ayA, cA);
+        // TAB: one 16-byte LDS read per ray slot and group = the slot's 1/den for the group's four vertices
+        typedef const __attribute__((address_space(3))) f32x4* lds_row;
+        lds_row rrow[2 * NP];
+        if constexpr (TAB) {
+#pragma unroll
+            for (int s = 0; s < 2 * NP; ++s) rrow[s] = (lds_row)(rdl + (s < RPL ? didx[s] : 360) * h.nV) + gbeg;
         }
-        if (k < kend) {
-            const Vtx v0 = nxt;
-            side(v0, axB, ayB, cB);
-            if (!v0.brk && k >= kbeg) close(v0, axA, ayA, cA, cB);
+        Vtx nxt = cload(vt + (gbeg < gend ? 4 * gbeg : 0));
+        for (int gq = gbeg; gq < gend; ++gq) {
+            f32x4 rd[2 * NP];
+            if constexpr (TAB) {
+#pragma unroll
+                for (int s = 0; s < 2 * NP; ++s) rd[s] = rrow[s][gq - gbeg];
+            }
+            const int k = 4 * gq;
+#define PC_VERTEX(I, PAX, PAY, PC, NAX, NAY, NC)                                                                         \
+            {                                                                                                            \
+                const Vtx v = nxt;                                                                                       \
+                nxt = cload(vt + (k + I + 1 < 4 * gend ? k + I + 1 : k + I));                                            \
+                side(v, NAX, NAY, NC);                                                                                   \
+                float rdv[2 * NP];                                                                                       \
+                _Pragma("unroll") for (int s = 0; s < 2 * NP; ++s) rdv[s] = TAB ? rd[s][I] : 0.0f;                      \
+                if (!v.brk) close(v, PAX, PAY, PC, NC, rdv);                                                             \
+            }
+            PC_VERTEX(0, axA, ayA, cA, axB, ayB, cB)
+            PC_VERTEX(1, axB, ayB, cB, axA, ayA, cA)
+            PC_VERTEX(2, axA, ayA, cA, axB, ayB, cB)
+            PC_VERTEX(3, axB, ayB, cB, axA, ayA, cA)
+#undef PC_VERTEX
         }
 #pragma unroll
         for (int s = 0; s < RPL; ++s) best[s] = __uint_as_float(bb[s]);
@@ -580,6 +624,23 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvParams<T> p, con
 // ------------------------------------------------------------------------------------------
 // CarEnv.reset (car_env.py:677-688) for ONE track: Car.reset + Car.update with zero velocity, then
 // _get_obs.  One thread per track; runs once at pc_env_create.  Also reports start_collides.
+// F32: the 1/den table of every track, rden[rden_off + idx * nV + k] for lattice direction idx and chain vertex k, by the
+// very instructions the sweep uses (fma of the float32 edge and direction, v_rcp_f32): table and arithmetic path agree
+// bit for bit.  Row 360 ("no ray") is +inf.
+__global__ void rden_build_kernel(const EnvParams<float> p, const int n_tracks, float* __restrict__ rden) {
+    for (int trk = 0; trk < n_tracks; ++trk) {
+        const TrackHdr h = p.hdr[trk];
+        const int total = 361 * h.nV;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+            const int idx = i / h.nV, k = i - idx * h.nV;
+            const Vtx v = p.vtx[h.vtx_off + k];
+            const float2 d = p.dirtab[h.dir_off + idx];
+            const float den = __builtin_fmaf(v.ey, d.x, -(v.ex * d.y));
+            rden[h.rden_off + i] = idx == 360 ? __builtin_inff() : __builtin_amdgcn_rcpf(den);
+        }
+    }
+}
+
 template <typename T>
 __global__ void reset_obs_kernel(const EnvParams<T> p, int n_tracks, float* __restrict__ reset_obs,
                                  int* __restrict__ start_collides) {
@@ -602,7 +663,7 @@ __global__ void reset_obs_kernel(const EnvParams<T> p, int n_tracks, float* __re
     bool hit = false;
     for (int ray = 0; ray < p.R; ++ray) {
         T dx, dy;
-        Math<T>::ray_dir(p, ray, h.start_rot, ch, sh, dx, dy);
+        Math<T>::ray_dir(p, h, ray, 0, h.start_rot, dx, dy);
         T best = (T)1000;
         for (int w = 0; w < h.S; ++w) {
             const T d = Math<T>::cast(p.segs[h.wall_off + w], npx, npy, dx, dy);
@@ -799,7 +860,6 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
 // dependent successor.  The [16 x 64] output goes through LDS so that lane = env for the softmax / Philox
 // draw; outputs are written coalesced.
 // ------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // LDS image of the policy weights, in floats.  [W1: 512 rows x LD1][b1: 512][W2 A-operands: 32 x 4 x 64][b2: 16]
 __host__ __device__ constexpr int pol_ld1(int KS) { return 4 * KS + 1; }  // odd row stride: lanes 0..15 hit 16 banks
@@ -1313,7 +1373,7 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
 // step's critical path costs an LDS access instead of a global-memory round trip.  Single-track batches only (the
 // kernels' precondition).  The caller synchronises the workgroup before the first use.
 constexpr int TAB_MAX_GATES = 128;
-constexpr int TAB_FLOATS = 72 * 4 + TAB_MAX_GATES * 8 + 40 * 2 + 40;
+constexpr int TAB_DIR = 72 * 4 + TAB_MAX_GATES * 8, TAB_RESET = TAB_DIR + 361 * 2 + 2, TAB_FLOATS = TAB_RESET + 40;
 __device__ __forceinline__ EnvParams<float> stage_tables(const EnvParams<float>& p, float* sTab, const int tid, const int nthreads) {
     const TrackHdr h0 = cload(p.hdr);
     int* dst = reinterpret_cast<int*>(sTab);
@@ -1326,15 +1386,15 @@ __device__ __forceinline__ EnvParams<float> stage_tables(const EnvParams<float>&
         for (int i = tid; i < h0.G * 8; i += nthreads) dst[72 * 4 + i] = gates[i];
         q.segs = reinterpret_cast<const Seg*>(sTab + 72 * 4) - h0.gate_off;   // the F32 step reads only gates from segs
     }
-    if (p.R <= 40) {
-        const int* ray = reinterpret_cast<const int*>(p.raytab);
-        for (int i = tid; i < p.R * 2; i += nthreads) dst[72 * 4 + TAB_MAX_GATES * 8 + i] = ray[i];
-        q.raytab = reinterpret_cast<const float2*>(sTab + 72 * 4 + TAB_MAX_GATES * 8);
+    {
+        const int* dir = reinterpret_cast<const int*>(p.dirtab + h0.dir_off);
+        for (int i = tid; i < 361 * 2; i += nthreads) dst[TAB_DIR + i] = dir[i];
+        q.dirtab = reinterpret_cast<const float2*>(sTab + TAB_DIR) - h0.dir_off;
     }
     if (p.D <= 40) {
         const int* ro = reinterpret_cast<const int*>(p.reset_obs);
-        for (int i = tid; i < p.D; i += nthreads) dst[72 * 4 + TAB_MAX_GATES * 8 + 80 + i] = ro[i];
-        q.reset_obs = sTab + 72 * 4 + TAB_MAX_GATES * 8 + 80;
+        for (int i = tid; i < p.D; i += nthreads) dst[TAB_RESET + i] = ro[i];
+        q.reset_obs = sTab + TAB_RESET;
     }
     return q;
 }
@@ -1348,7 +1408,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                                                       float* __restrict__ term_buf, float* __restrict__ trunc_buf,
                                                       float* __restrict__ logprob_buf, float* __restrict__ next_obs,
                                                       float* __restrict__ next_term, float* __restrict__ next_trunc,
-                                                      const int dbg) {
+                                                      const int rden_lds, const int dbg) {
     constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, LDX = 4 * KS + 1, ET = 2;
     constexpr int IMG = PREC ? polx_image_dwords(PREC) : pol_image_padded(KS);
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1369,6 +1429,14 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const int D = p.D;
     policy_stage_image<IMG>(image, lds, tid);
     const EnvParams<float> q = stage_tables(p, sTab, tid, 512);
+    // the track's 1/den table, when the host found room for it: rden_lds = its size in floats (else 0)
+    float* sRden = sTab + TAB_FLOATS;
+    {
+        const TrackHdr h0 = cload(p.hdr);
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.rden + h0.rden_off);
+        for (int i = tid; i < rden_lds / 4; i += 512) reinterpret_cast<f32x4*>(sRden)[i] = src[i];
+    }
+    const lds_cfp rdl = (lds_cfp)sRden;
 
     // this wave's 32 envs: local rows [pbase, pbase + 32); env-step identity: 2 lanes per env
     const int pbase = wave * 32;
@@ -1456,8 +1524,12 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
             float rw;
             bool term, trunc;
             int passed;
-            env_step_core<float, RPL>(q, 0, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw, term, trunc,
-                                      passed);
+            if (rden_lds)  // uniform
+                env_step_core<float, RPL, 1, true>(q, 0, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw,
+                                                   term, trunc, passed, 0, nullptr, rdl);
+            else
+                env_step_core<float, RPL>(q, 0, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw, term,
+                                          trunc, passed);
             if (g == 0) {
                 rew_buf[(int64_t)t * N + e_env] = rw;
                 float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;    // flags that precede obs t+1
@@ -1485,7 +1557,7 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                                                             float* __restrict__ term_buf, float* __restrict__ trunc_buf,
                                                             float* __restrict__ logprob_buf, float* __restrict__ next_obs,
                                                             float* __restrict__ next_term, float* __restrict__ next_trunc,
-                                                            const int dbg) {
+                                                            const int rden_lds, const int dbg) {
     constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, LDX = 4 * KS + 1, ET = 2;
     constexpr int IMG = PREC ? polx_image_dwords(PREC) : pol_image_padded(KS);
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1506,6 +1578,14 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     const int D = p.D;
     policy_stage_image<IMG>(image, lds, tid);
     const EnvParams<float> q = stage_tables(p, sTab, tid, 512);
+    // the track's 1/den table, when the host found room for it: rden_lds = its size in floats (else 0)
+    float* sRden = sTab + TAB_FLOATS;
+    {
+        const TrackHdr h0 = cload(p.hdr);
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.rden + h0.rden_off);
+        for (int i = tid; i < rden_lds / 4; i += 512) reinterpret_cast<f32x4*>(sRden)[i] = src[i];
+    }
+    const lds_cfp rdl = (lds_cfp)sRden;
 
     // env step: wave w sweeps quarter (w & 3) of the wall vertices for 16 envs, 4 lanes (ray groups) per env
     constexpr int PARTS = 4;
@@ -1594,8 +1674,13 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
             float rw;
             bool term, trunc;
             int passed;
-            env_step_core<float, RPL, PARTS>(q, 0, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
-                                             e_valid && part == 0 ? sObs + el * LDX : nullptr, rw, term, trunc, passed, part, exch);
+            if (rden_lds)  // uniform
+                env_step_core<float, RPL, PARTS, true>(q, 0, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
+                                                       e_valid && part == 0 ? sObs + el * LDX : nullptr, rw, term, trunc, passed, part,
+                                                       exch, rdl);
+            else
+                env_step_core<float, RPL, PARTS>(q, 0, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
+                                                 e_valid && part == 0 ? sObs + el * LDX : nullptr, rw, term, trunc, passed, part, exch);
             if (e_valid && g == 0 && part == 0) {
                 rew_buf[(int64_t)t * N + e_env] = rw;
                 float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;
@@ -2092,7 +2177,8 @@ struct pc_env {
     Seg* segs = nullptr;
     Vtx* vtx = nullptr;
     double2* headtab = nullptr;
-    float2* raytab = nullptr;
+    float2* dirtab = nullptr;
+    float* rden = nullptr;
     float* reset_obs = nullptr;
 
     template <typename T> EnvParams<T> params() const {
@@ -2114,7 +2200,8 @@ struct pc_env {
         p.segs = segs;
         p.vtx = vtx;
         p.headtab = headtab;
-        p.raytab = raytab;
+        p.dirtab = dirtab;
+        p.rden = rden;
         p.reset_obs = reset_obs;
         return p;
     }
@@ -2239,7 +2326,8 @@ void pc_env_destroy(pc_env* e) {
     (void)hipFree(e->segs);
     (void)hipFree(e->vtx);
     (void)hipFree(e->headtab);
-    (void)hipFree(e->raytab);
+    (void)hipFree(e->dirtab);
+    (void)hipFree(e->rden);
     (void)hipFree(e->reset_obs);
     delete e;
 }
@@ -2250,6 +2338,8 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
     std::vector<Seg> segs;
     std::vector<Vtx> vtx;
     std::vector<double2> headtab;
+    std::vector<float2> dirtab;
+    size_t rden_floats = 0;
     e->hdr_host.resize(e->n_tracks);
     for (int k = 0; k < e->n_tracks; ++k) {
         const pc_track* t = tracks[k];
@@ -2268,7 +2358,17 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
             if (!cont) vtx.push_back(Vtx{sg.x1, sg.y1, 0.f, 0.f, 1, 0});
             vtx.push_back(Vtx{sg.x2, sg.y2, (float)(sg.x1 - sg.x2), (float)(sg.y1 - sg.y2), 0, 0});
         }
+        while ((vtx.size() - h.vtx_off) % 4)  // the sweep walks vertex groups of four: pad with chain-break sentinels
+            vtx.push_back(Vtx{vtx.back().x, vtx.back().y, 0.f, 0.f, 1, 0});
         h.nV = (int)vtx.size() - h.vtx_off;
+        h.dir_off = (int)dirtab.size();
+        for (int j = 0; j < 360; ++j) {  // direction lattice: start_rot + j degrees, np.radians then libm cos/sin
+            const double a = (t->start_rot + (double)j) * (PC_PI / 180.0);
+            dirtab.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
+        }
+        dirtab.push_back(make_float2(0.f, 0.f));
+        h.rden_off = (int)rden_floats;
+        rden_floats += (size_t)361 * h.nV;
         h.head_off = (int)headtab.size();
         h.start_collides = 0;
         h.start_x = t->start_x;
@@ -2278,12 +2378,6 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
             const double a = (t->start_rot + 5.0 * j) * (PC_PI / 180.0);
             headtab.push_back(make_double2(std::cos(a), std::sin(a)));
         }
-    }
-    std::vector<float2> raytab(e->R);
-    const int step = 360 / e->n_nominal;
-    for (int i = 0; i < e->R; ++i) {
-        const double a = (double)(i * step) * (PC_PI / 180.0);
-        raytab[i] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
     // ---- device buffers
     const size_t N = (size_t)e->N;
@@ -2303,8 +2397,13 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
     HIPCHK(hipMemcpy(e->vtx, vtx.data(), vtx.size() * sizeof(Vtx), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&e->headtab, headtab.size() * sizeof(double2)));
     HIPCHK(hipMemcpy(e->headtab, headtab.data(), headtab.size() * sizeof(double2), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void**)&e->raytab, raytab.size() * sizeof(float2)));
-    HIPCHK(hipMemcpy(e->raytab, raytab.data(), raytab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&e->dirtab, dirtab.size() * sizeof(float2)));
+    HIPCHK(hipMemcpy(e->dirtab, dirtab.data(), dirtab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    if (!f64) {
+        HIPCHK(hipMalloc((void**)&e->rden, rden_floats * sizeof(float)));
+        hipLaunchKernelGGL(rden_build_kernel, dim3(64), dim3(256), 0, 0, e->params<float>(), e->n_tracks, e->rden);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipMalloc((void**)&e->reset_obs, (size_t)e->n_tracks * e->D * sizeof(float)));
     // ---- per-track reset observation + start_collides, computed on the device by the same arithmetic
     int* d_sc = nullptr;
@@ -2520,11 +2619,13 @@ int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, 
 static int policy_ks(int D) { return D <= 20 ? 5 : (D <= 24 ? 6 : 10); }
 static int g_policy_split_mode = -1;  // -1 auto (split below 32768 envs), 0 never, 1 always
 static int g_rollout_form = -1;       // pc_rollout: -1 auto, 0 = 256 envs per workgroup, 1 = 32 envs per workgroup
+static int g_rollout_rden = 1;        // pc_rollout: stage the 1/den table in LDS when it fits (0: never; test / tuning knob)
 static int g_policy_precision = 2;    // 0 = fp32-input MFMA; split forms on the 16-bit matrix cores (need D <= 24, A <= 9): 1 = bf16 x 3, 2 = fp16 x 2
 
 int pc_rollout_set_form(int form) {
-    if (form < -1 || form > 1) return PC_ERR_INVALID_ARG;
-    g_rollout_form = form;
+    if (form < -1 || form > 3) return PC_ERR_INVALID_ARG;
+    g_rollout_rden = form >= 2 ? 0 : 1;              // forms 2 / 3 = forms 0 / 1 without the LDS 1/den table
+    g_rollout_form = form >= 2 ? form - 2 : form;
     return PC_OK;
 }
 
@@ -2685,8 +2786,13 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     // LDS: PC_ERR_UNSUPPORTED, the per-step kernels are the faster choice there anyway); small batches: 32 envs per
     // workgroup, hidden tiles and wall-sweep parts split over the waves
     const bool small = g_rollout_form == 1 || (g_rollout_form < 0 && e->N < 32768);
-    const size_t lds = small ? lds_small : lds_big;
+    size_t lds = small ? lds_small : lds_big;
     if (lds > 160 * 1024) return PC_ERR_UNSUPPORTED;
+    // the track's 1/den table rides along in LDS when it fits (big_track: 361 x 28 floats = 40 KB); else the sweep forms
+    // den and its reciprocal itself -- same bits either way
+    int rden_lds = 361 * e->hdr_host[0].nV;
+    if (g_rollout_rden == 0 || lds + (size_t)rden_lds * sizeof(float) > 160 * 1024) rden_lds = 0;
+    lds += (size_t)rden_lds * sizeof(float);
     const int rpl = small ? (e->R + 3) / 4 : (e->R + 1) / 2;  // 4 (x 4 sweep parts) or 2 lanes per env
     const int blocks = (int)(small ? (e->N + 31) / 32 : (e->N + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
@@ -2703,7 +2809,7 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
         }                                                                                                                \
         hipLaunchKernelGGL((rollout_kernel<KSV, RPLV, PRC>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, seed, \
                            offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs,  \
-                           next_term, next_trunc, dbg);                                                                  \
+                           next_term, next_trunc, rden_lds, dbg);                                                                  \
     } while (0)
 #define PC_ROLLS(KSV, RPLV, PRC)                                                                                         \
     do {                                                                                                                 \
@@ -2714,7 +2820,7 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
         }                                                                                                                \
         hipLaunchKernelGGL((rollout_small_kernel<KSV, RPLV, PRC>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, \
                            seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, \
-                           next_term, next_trunc, dbg);                                                                     \
+                           next_term, next_trunc, rden_lds, dbg);                                                                     \
     } while (0)
     if (small) {
         if (KS == 5 && rpl == 3) { if (prec == 2) PC_ROLLS(5, 3, 2); else if (prec) PC_ROLLS(5, 3, 1); else PC_ROLLS(5, 3, 0); }        // 12 rays

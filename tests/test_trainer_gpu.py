@@ -185,17 +185,18 @@ def test_fused_and_torch_updates_agree_inside_the_trainer():
     assert torch.allclose(outs[False][0], outs[True][0], atol=5e-3)
 
 
-@pytest.mark.parametrize("form", [0, 1])
+@pytest.mark.parametrize("form", [0, 1, 2, 3])
 @pytest.mark.parametrize("precision", [2, 1, 0])
 @pytest.mark.parametrize("num_rays,n_envs", [(16, 1000), (12, 512), (32, 300)])
 def test_persistent_rollout_kernel_is_bitwise_the_two_kernel_rollout(num_rays, n_envs, precision, form):
     """pc_rollout (one persistent launch, weights in LDS, env state in registers) must fill the buffer with exactly the
     bits of the per-step policy_kernel / env_step_kernel sequence, over several epochs (auto-resets included), in both
     of its forms: 0 = 256 envs per workgroup, every wave independent (the whole-tile policy kernel's summation order);
-    1 = 32 envs per workgroup, hidden tiles split over the waves (the split policy kernel's summation order)."""
+    1 = 32 envs per workgroup, hidden tiles split over the waves (the split policy kernel's summation order); 2 / 3 = the
+    same two without the 1/den table in LDS (the sweep forms den and its reciprocal itself: same bits by construction)."""
     from ppo_car_amd._capi import lib
     res = {}
-    lib.pc_policy_set_split(form)   # same fp32 summation order in the per-step policy kernel as in this rollout form
+    lib.pc_policy_set_split(form & 1)   # same fp32 summation order in the per-step policy kernel as in this rollout form
     lib.pc_policy_set_precision(precision)
     lib.pc_rollout_set_form(form)
     try:
@@ -208,7 +209,7 @@ def test_persistent_rollout_kernel_is_bitwise_the_two_kernel_rollout(num_rays, n
                 torch.cuda.synchronize()
                 # 32 -> 33 rays: weight image + a 256-env observation tile exceed 160 KB of LDS -> form 0 reports
                 # PC_ERR_UNSUPPORTED and the trainer falls back to the two-kernel loop; form 1 fits
-                mega_ok = mode == "mega" and (num_rays != 32 or form == 1)
+                mega_ok = mode == "mega" and (num_rays != 32 or form & 1)
                 assert tr.rollout_mode == ("mega" if mega_ok else "steps-eager")
                 b = tr.buffer
                 snaps.append([t.clone() for t in (b.obs_buf, b.act_buf, b.rew_buf, b.val_buf, b.logprob_buf, b.term_buf,
