@@ -432,28 +432,49 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
             for (int s = 0; s < 2 * NP; ++s) rrow[s] = (lds_row)(rdl + (s < RPL ? didx[s] : 360) * h.nV) + gbeg;
         }
         Vtx nxt = cload(vt + (gbeg < gend ? 4 * gbeg : 0));
-        for (int gq = gbeg; gq < gend; ++gq) {
-            f32x4 rd[2 * NP];
-            if constexpr (TAB) {
+        // groups in pairs: the table reads of the NEXT group are issued before this group's arithmetic (register sets
+        // rdA / rdB alternate), so their LDS latency -- gather reads, bank conflicts included -- hides under ~200 VALU ops
+        f32x4 rdA[2 * NP], rdB[2 * NP];
+        if constexpr (TAB) {
+            if (gbeg < gend) {
 #pragma unroll
-                for (int s = 0; s < 2 * NP; ++s) rd[s] = rrow[s][gq - gbeg];
+                for (int s = 0; s < 2 * NP; ++s) rdA[s] = rrow[s][0];
             }
-            const int k = 4 * gq;
-#define PC_VERTEX(I, PAX, PAY, PC, NAX, NAY, NC)                                                                         \
-            {                                                                                                            \
-                const Vtx v = nxt;                                                                                       \
-                nxt = cload(vt + (k + I + 1 < 4 * gend ? k + I + 1 : k + I));                                            \
-                side(v, NAX, NAY, NC);                                                                                   \
-                float rdv[2 * NP];                                                                                       \
-                _Pragma("unroll") for (int s = 0; s < 2 * NP; ++s) rdv[s] = TAB ? rd[s][I] : 0.0f;                      \
-                if (!v.brk) close(v, PAX, PAY, PC, NC, rdv);                                                             \
-            }
-            PC_VERTEX(0, axA, ayA, cA, axB, ayB, cB)
-            PC_VERTEX(1, axB, ayB, cB, axA, ayA, cA)
-            PC_VERTEX(2, axA, ayA, cA, axB, ayB, cB)
-            PC_VERTEX(3, axB, ayB, cB, axA, ayA, cA)
-#undef PC_VERTEX
         }
+#define PC_VERTEX(RD, I, PAX, PAY, PC, NAX, NAY, NC)                                                                     \
+        {                                                                                                                \
+            const Vtx v = nxt;                                                                                           \
+            nxt = cload(vt + (k + I + 1 < 4 * gend ? k + I + 1 : k + I));                                                \
+            side(v, NAX, NAY, NC);                                                                                       \
+            float rdv[2 * NP];                                                                                           \
+            _Pragma("unroll") for (int s = 0; s < 2 * NP; ++s) rdv[s] = TAB ? RD[s][I] : 0.0f;                          \
+            if (!v.brk) close(v, PAX, PAY, PC, NC, rdv);                                                                 \
+        }
+#define PC_GROUP(RD, RDN, GQ)                                                                                            \
+        {                                                                                                                \
+            if constexpr (TAB) {                                                                                         \
+                if ((GQ) + 1 < gend) {                                                                                   \
+                    _Pragma("unroll") for (int s = 0; s < 2 * NP; ++s) RDN[s] = rrow[s][(GQ) + 1 - gbeg];               \
+                }                                                                                                        \
+            }                                                                                                            \
+            const int k = 4 * (GQ);                                                                                      \
+            PC_VERTEX(RD, 0, axA, ayA, cA, axB, ayB, cB)                                                                 \
+            PC_VERTEX(RD, 1, axB, ayB, cB, axA, ayA, cA)                                                                 \
+            PC_VERTEX(RD, 2, axA, ayA, cA, axB, ayB, cB)                                                                 \
+            PC_VERTEX(RD, 3, axB, ayB, cB, axA, ayA, cA)                                                                 \
+        }
+        if constexpr (TAB) {
+            int gq = gbeg;
+            for (; gq + 1 < gend; gq += 2) {
+                PC_GROUP(rdA, rdB, gq)
+                PC_GROUP(rdB, rdA, gq + 1)
+            }
+            if (gq < gend) PC_GROUP(rdA, rdB, gq)
+        } else {  // nothing to prefetch: one group per trip (half the code; the 33-ray stand-alone kernel stays within 256 VGPRs)
+            for (int gq = gbeg; gq < gend; ++gq) PC_GROUP(rdA, rdB, gq)
+        }
+#undef PC_GROUP
+#undef PC_VERTEX
 #pragma unroll
         for (int s = 0; s < RPL; ++s) best[s] = __uint_as_float(bb[s]);
     } else {
@@ -905,7 +926,8 @@ __global__ __launch_bounds__(256) void policy_pack_kernel(const int KS, const in
     }
 }
 
-__device__ __forceinline__ float relu_f(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+// ReLU as ONE v_med3_f32 (with +inf as the upper bound the compiler rewrites it into canonicalize + max: two instructions)
+__device__ __forceinline__ float relu_f(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 3.4028234663852886e38f); }
 
 // One wave's MFMA work for 32 envs (2 column tiles) over hidden tiles [ht0, ht1) (an even count): layer 1,
 // ReLU, layer 2.  x[et][ks] = B operands of layer 1 (X^T), out[et] = the [16 outs x 16 envs] accumulators of
