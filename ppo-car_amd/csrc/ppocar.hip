@@ -335,13 +335,22 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
     bool gate_hit = false;
     uint64_t colmask = 0;  // which of my ray slots are collision rays
     const Seg gate = p.segs[h.gate_off + st.next];  // only gate[next] can fire (the oracle does the full scan)
+    // F32 lattice indices with adds only: ray * step_deg = g * step_deg + s * (G * step_deg), the second term wave-uniform;
+    // (m mod 360) for m < 720 as min_u32(m, m - 360)
+    const int rs0 = g * p.step_deg, gstep = G * p.step_deg;
+    int k5_new = 0, k5_old = 0;
+    if constexpr (sizeof(T) == 4) {
+        k5_new = 5 * Math<float>::mod72(k_new) + rs0;
+        k5_old = 5 * Math<float>::mod72(st.k) + rs0;
+    }
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
         const int ray = g + s * G;
         const bool valid = ray < p.R;
         const int rr = valid ? ray : 0;
         if constexpr (sizeof(T) == 4) {  // direction lattice: entry / row 360 = "no ray" (direction 0, 1/den = +inf)
-            didx[s] = valid ? Math<float>::dir_index(p, k_new, ray) : 360;
+            const unsigned m = (unsigned)(k5_new + s * gstep);
+            didx[s] = valid ? (int)min(m, m - 360u) : 360;
             const float2 cs = p.dirtab[h.dir_off + didx[s]];
             dx[s] = cs.x;
             dy[s] = cs.y;
@@ -359,7 +368,16 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
         colmask |= (uint64_t)is_col << s;
         if (is_col) {  // Car.get_passed_gate (:394-408) uses the rays of the PREVIOUS update
             T odx = dx[s], ody = dy[s];
-            if (turned) Math<T>::ray_dir(p, h, rr, st.k, rot_old, odx, ody);
+            if constexpr (sizeof(T) == 4) {
+                if (turned) {
+                    const unsigned m = (unsigned)(k5_old + s * gstep);
+                    const float2 cs = p.dirtab[h.dir_off + (int)min(m, m - 360u)];
+                    odx = cs.x;
+                    ody = cs.y;
+                }
+            } else {
+                if (turned) Math<T>::ray_dir(p, h, rr, st.k, rot_old, odx, ody);
+            }
             gate_hit |= Math<T>::cast(gate, opx, opy, odx, ody) < (T)10;  // :387,:390
         }
     }
@@ -429,7 +447,7 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
         lds_row rrow[2 * NP];
         if constexpr (TAB) {
 #pragma unroll
-            for (int s = 0; s < 2 * NP; ++s) rrow[s] = (lds_row)(rdl + (s < RPL ? didx[s] : 360) * h.nV) + gbeg;
+            for (int s = 0; s < 2 * NP; ++s) rrow[s] = (lds_row)(rdl + __umul24(s < RPL ? didx[s] : 360, h.nV)) + gbeg;  // full-rate 24-bit multiply
         }
         Vtx nxt = cload(vt + (gbeg < gend ? 4 * gbeg : 0));
         // groups in pairs: the table reads of the NEXT group are issued before this group's arithmetic (register sets
