@@ -212,6 +212,7 @@ int pc_ppo_minibatch(int device, const int64_t* idx, int B, int D, int H, int A,
                      double max_norm, double beta1, double beta2, double eps, float* metrics, float* workspace, int apply,
                      void* stream);
 
+
 const char* pc_strerror(int code);
 /* Last HIP error string seen by this thread (diagnostics for PC_ERR_HIP). */
 const char* pc_last_hip_error(void);

@@ -1898,52 +1898,101 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 template <int DMAX>
-__global__ __launch_bounds__(256) void ppo_fwdbwd_kernel(const int64_t* __restrict__ idx, const int B, const int D, const int A,
-                                                         const float* __restrict__ obs, const float* __restrict__ act,
-                                                         const float* __restrict__ old_lp, const float* __restrict__ adv,
-                                                         const float* __restrict__ ret, const float* __restrict__ param,
-                                                         const float clip, const float vf, const float ec,
-                                                         float* __restrict__ partial, float* __restrict__ metric_partial) {
-    constexpr int H = 256, S = FB_S;
+__device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __restrict__ idx, const int B, const int D, const int A,
+                                                const float* __restrict__ obs, const float* __restrict__ act,
+                                                const float* __restrict__ old_lp, const float* __restrict__ adv,
+                                                const float* __restrict__ ret, const float* __restrict__ param,
+                                                const float clip, const float vf, const float ec,
+                                                float* __restrict__ partial, float* __restrict__ metric_partial) {
+    constexpr int H = 256, S = FB_S, LDT = DMAX + 1, LDH = H + 1;
+    // Everything in this kernel is latency: a minibatch is 44 MFLOP.  So: every global access coalesced (the [H][D]
+    // weight matrices and their gradients go through an LDS tile, transposed there), all loads of a phase in flight
+    // together, and no cross-lane reduction chains (layer 2 is a small GEMV out of LDS).
     __shared__ float sh[16];
     __shared__ float sX[S][DMAX];
-    __shared__ float sPart[4][S][16];
     __shared__ float sOut[S][16];
     __shared__ float sDout[S][16];
     __shared__ float sMet[S][3];
-    const int u = threadIdx.x, lane = u & 63, wave = u >> 6;
+    __shared__ float sSmp[S][4];                                          // act, old_lp, adv, ret of my samples
+    __shared__ __attribute__((aligned(16))) float sT[H * LDT > 2 * S * LDH + 16 * LDH + 2 * S * 16 ? H * LDT : 2 * S * LDH + 16 * LDH + 2 * S * 16];
+    float* sHid = sT;                    // [2][S][LDH]  hidden activations (actor, critic)         } alias the transposition
+    float* sW2 = sT + 2 * S * LDH;       // [16][LDH]    output-layer weights, row A = the critic's  } tile: used between
+    float* sP2 = sW2 + 16 * LDH;         // [2][S][16]   the two k-halves of layer 2                 } the load and store phases
+    const int u = threadIdx.x;
+    __syncthreads();  // a previous pass's readers of the shared arrays are done (persistent epoch kernel)
     // flat parameter offsets
     const int o_aW1 = 0, o_ab1 = H * D, o_aW2 = o_ab1 + H, o_ab2 = o_aW2 + A * H, o_cW1 = o_ab2 + A, o_cb1 = o_cW1 + H * D,
               o_cW2 = o_cb1 + H, o_cb2 = o_cW2 + H, n_param = o_cb2 + 1;
 
-    // ---- my weights and my workgroup's samples first: their loads fly while the statistics are reduced
-    // ---- my weights
-    float w1a[DMAX], w1c[DMAX], w2a[16];
+    // ---- loads that do not depend on anything, all issued before the first wait
+    const int s0 = wg * S;
+    int64_t my_src = 0;                                                   // threads 0..S-1: my sample's row
+    if (u < S && s0 + u < B) my_src = idx[s0 + u];
+    int64_t a_src[4];
 #pragma unroll
-    for (int f = 0; f < DMAX; ++f) {
-        w1a[f] = f < D ? param[o_aW1 + u * D + f] : 0.0f;
-        w1c[f] = f < D ? param[o_cW1 + u * D + f] : 0.0f;
-    }
+    for (int j = 0; j < 4; ++j) a_src[j] = u + j * 256 < B ? idx[u + j * 256] : 0;
+    float w2a[16];
 #pragma unroll
     for (int o = 0; o < 16; ++o) w2a[o] = o < A ? param[o_aW2 + o * H + u] : 0.0f;
     const float w2c = param[o_cW2 + u], b1a = param[o_ab1 + u], b1c = param[o_cb1 + u];
-
-    // ---- gather my workgroup's samples (train.py:233-238)
-    const int s0 = blockIdx.x * S;
-    for (int i = u; i < S * DMAX; i += 256) {
+    const int ob = u & 15;                                                // my output index in the layer-2 epilogue
+    const float b2 = ob < A ? param[o_ab2 + ob] : (ob == A ? param[o_cb2] : 0.0f);
+    // W1 of both nets: element e = u + 256 j of the [H][D] block sits at (row, col) = (e / D, e % D), tracked incrementally
+    const int qD = 256 / D, rD = 256 - qD * D;
+    float w1raw[2][DMAX];
+    {
+        int e = u;
+#pragma unroll
+        for (int j = 0; j < DMAX; ++j) {
+            w1raw[0][j] = j < D ? param[o_aW1 + e] : 0.0f;
+            w1raw[1][j] = j < D ? param[o_cW1 + e] : 0.0f;
+            e += 256;
+        }
+    }
+    // ---- second-level loads (addresses came from idx)
+    float a_loc[4], a_sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a_loc[j] = u + j * 256 < B ? adv[a_src[j]] : 0.0f;
+        a_sum += a_loc[j];
+    }
+    if (u < S) {
+        const bool lv = s0 + u < B;
+        sSmp[u][0] = lv ? act[my_src] : 0.0f;
+        sSmp[u][1] = lv ? old_lp[my_src] : 0.0f;
+        sSmp[u][2] = lv ? adv[my_src] : 0.0f;
+        sSmp[u][3] = lv ? ret[my_src] : 0.0f;
+    }
+    for (int i = u; i < S * DMAX; i += 256) {                             // gather my workgroup's samples (train.py:233-238)
         const int sidx = i / DMAX, f = i - sidx * DMAX;
         const int b = s0 + sidx;
         sX[sidx][f] = (b < B && f < D) ? obs[idx[b] * D + f] : 0.0f;
     }
-
-    // ---- per-minibatch advantage statistics (train.py:238-240), recomputed identically by every workgroup
-    float a_loc[4], a_sum = 0.0f;
+    // ---- W1 rows into registers through the LDS tile (one net at a time: the tile holds [H][D] once)
+    float w1a[DMAX], w1c[DMAX];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = u + j * 256;
-        a_loc[j] = i < B ? adv[idx[i]] : 0.0f;
-        a_sum += a_loc[j];
+    for (int net = 0; net < 2; ++net) {
+        lds_barrier();  // LDS-only: __syncthreads() would also wait for every outstanding global access
+        int row = u / D, col = u - row * D;
+#pragma unroll
+        for (int j = 0; j < DMAX; ++j) {
+            if (j < D) sT[row * LDT + col] = w1raw[net][j];
+            row += qD;
+            col += rD;
+            if (col >= D) {
+                col -= D;
+                ++row;
+            }
+        }
+        lds_barrier();  // LDS-only: __syncthreads() would also wait for every outstanding global access
+#pragma unroll
+        for (int f = 0; f < DMAX; ++f) {
+            const float w = f < D ? sT[u * LDT + f] : 0.0f;
+            if (net == 0) w1a[f] = w;
+            else w1c[f] = w;
+        }
     }
+    // ---- per-minibatch advantage statistics (train.py:238-240), recomputed identically by every workgroup
     const float invB = 1.0f / (float)B;
     const float mean = block_sum(a_sum, sh) * invB;
     float d2 = 0.0f;
@@ -1954,8 +2003,7 @@ __global__ __launch_bounds__(256) void ppo_fwdbwd_kernel(const int64_t* __restri
         d2 += dv * dv;
     }
     const float sd = fmaxf(sqrtf(block_sum(d2, sh) / (float)(B - 1)), 1e-5f);
-
-    __syncthreads();
+    __syncthreads();   // (also: every thread has read its W1 row out of the tile, which sHid / sW2 alias)
 
     // ---- forward, layer 1 (Linear + ReLU), both nets
     float ha[S], hc[S];
@@ -1969,23 +2017,29 @@ __global__ __launch_bounds__(256) void ppo_fwdbwd_kernel(const int64_t* __restri
         }
         ha[sidx] = fmaxf(za, 0.0f);
         hc[sidx] = fmaxf(zc, 0.0f);
+        sHid[sidx * LDH + u] = ha[sidx];
+        sHid[(S + sidx) * LDH + u] = hc[sidx];
     }
-    // ---- forward, layer 2: sum over the 256 hidden units = over the threads (wave butterfly, then 4 partials)
 #pragma unroll
-    for (int sidx = 0; sidx < S; ++sidx) {
-#pragma unroll
-        for (int o = 0; o < 16; ++o) {
-            if (o <= A) {  // uniform
-                const float pv = o < A ? w2a[o] * ha[sidx] : w2c * hc[sidx];
-                const float r = wave_sum(pv);
-                if (lane == 0) sPart[wave][sidx][o] = r;
-            }
+    for (int o = 0; o < 16; ++o) sW2[o * LDH + u] = o < A ? w2a[o] : (o == A ? w2c : 0.0f);
+    __syncthreads();
+    // ---- forward, layer 2: out[s][o] = sum_u W2[o][u] h[s][u], one thread per (sample, output, half of the hidden units),
+    // sequential in u (fixed order: deterministic); LDH = 257 keeps the 16 rows a wave touches in distinct banks
+    {
+        const int sidx = u >> 5, o = (u >> 1) & 15, kh = u & 1;
+        float acc = 0.0f;
+        if (o <= A) {
+            const float* hrow = sHid + ((o < A ? 0 : S) + sidx) * LDH + kh * (H / 2);
+            const float* wrow = sW2 + o * LDH + kh * (H / 2);
+#pragma unroll 16
+            for (int k = 0; k < H / 2; ++k) acc = __builtin_fmaf(wrow[k], hrow[k], acc);
         }
+        sP2[(kh * S + sidx) * 16 + o] = acc;
     }
     __syncthreads();
     if (u < S * 16) {
         const int sidx = u >> 4, o = u & 15;
-        if (o <= A) sOut[sidx][o] = (o < A ? param[o_ab2 + o] : param[o_cb2]) + sPart[0][sidx][o] + sPart[1][sidx][o] + sPart[2][sidx][o] + sPart[3][sidx][o];
+        if (o <= A) sOut[sidx][o] = b2 + sP2[sidx * 16 + o] + sP2[(S + sidx) * 16 + o];
     }
     __syncthreads();
     // ---- loss and its gradient w.r.t. the outputs, one thread per sample (train.py:235-255; as ppo_loss_kernel)
@@ -1993,38 +2047,43 @@ __global__ __launch_bounds__(256) void ppo_fwdbwd_kernel(const int64_t* __restri
         const int b = s0 + u;
         float pl = 0.0f, vl = 0.0f, ent = 0.0f;
         if (b < B) {
-            const int64_t src = idx[b];
-            float l[16], mx = -INFINITY;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < A) mx = fmaxf(mx, sOut[u][k]);
+            float ex[16], sum = 0.0f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                l[k] = k < A ? sOut[u][k] : -INFINITY;
-                mx = fmaxf(mx, l[k]);
+                if (k >= A) break;
+                ex[k] = expf(sOut[u][k] - mx);
+                sum += ex[k];
             }
-            float sum = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) sum += k < A ? expf(l[k] - mx) : 0.0f;
-            const float lse = mx + logf(sum);
-            const int a = (int)act[src];
+            const float lse = mx + logf(sum), inv = 1.0f / sum;
+            const int a = (int)sSmp[u][0];
             float new_lp = 0.0f, pk[16], lpk[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                lpk[k] = k < A ? l[k] - lse : 0.0f;
-                pk[k] = k < A ? expf(lpk[k]) : 0.0f;
+                if (k >= A) break;
+                lpk[k] = sOut[u][k] - lse;
+                pk[k] = ex[k] * inv;                                          // softmax, one expf per action
                 ent -= pk[k] * lpk[k];
                 if (k == a) new_lp = lpk[k];
             }
-            const float r = expf(new_lp - old_lp[src]);                       // :235
-            const float An = (adv[src] - mean) / sd;                          // :238-240
+            const float r = expf(new_lp - sSmp[u][1]);                        // :235
+            const float An = (sSmp[u][2] - mean) / sd;                        // :238-240
             const float rc = fminf(fmaxf(r, 1.0f - clip), 1.0f + clip);
             const float pl1 = -An * r, pl2 = -An * rc;                        // :243-244
             pl = fmaxf(pl1, pl2);                                             // :245
-            const float dv = sOut[u][A] - ret[src];
+            const float dv = sOut[u][A] - sSmp[u][3];
             vl = 0.5f * dv * dv;                                              // :249
             const float g_lp = (pl1 >= pl2 ? -An : 0.0f) * r * invB;
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                sDout[u][k] = k < A ? g_lp * ((k == a ? 1.0f : 0.0f) - pk[k]) + ec * invB * pk[k] * (lpk[k] + ent)
-                                    : (k == A ? vf * dv * invB : 0.0f);
+            for (int k = 0; k < 16; ++k) {
+                float dk = 0.0f;
+                if (k < A) dk = g_lp * ((k == a ? 1.0f : 0.0f) - pk[k]) + ec * invB * pk[k] * (lpk[k] + ent);
+                else if (k == A) dk = vf * dv * invB;
+                sDout[u][k] = dk;
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < 16; ++k) sDout[u][k] = 0.0f;
@@ -2066,15 +2125,8 @@ __global__ __launch_bounds__(256) void ppo_fwdbwd_kernel(const int64_t* __restri
             g1c[f] = __builtin_fmaf(dhc, sX[sidx][f], g1c[f]);
         }
     }
-    // ---- this workgroup's gradient partial, in flat parameter order
-    float* __restrict__ P = partial + (size_t)blockIdx.x * n_param;
-#pragma unroll
-    for (int f = 0; f < DMAX; ++f) {
-        if (f < D) {
-            P[o_aW1 + u * D + f] = g1a[f];
-            P[o_cW1 + u * D + f] = g1c[f];
-        }
-    }
+    // ---- this workgroup's gradient partial, in flat parameter order; the [H][D] blocks through the tile again
+    float* __restrict__ P = partial + (size_t)wg * n_param;
     P[o_ab1 + u] = gb1a;
     P[o_cb1 + u] = gb1c;
 #pragma unroll
@@ -2092,22 +2144,61 @@ __global__ __launch_bounds__(256) void ppo_fwdbwd_kernel(const int64_t* __restri
         float t = 0.0f;
 #pragma unroll
         for (int sidx = 0; sidx < S; ++sidx) t += sMet[sidx][u];
-        metric_partial[blockIdx.x * 4 + u] = t;
+        metric_partial[wg * 4 + u] = t;
     }
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {
+        lds_barrier();  // (not __syncthreads(): that waits for the stores already in flight, ~2 us each time)
+#pragma unroll
+        for (int f = 0; f < DMAX; ++f)
+            if (f < D) sT[u * LDT + f] = net == 0 ? g1a[f] : g1c[f];
+        lds_barrier();  // (not __syncthreads(): that waits for the stores already in flight, ~2 us each time)
+        float* __restrict__ dst = P + (net == 0 ? o_aW1 : o_cW1);
+        int row = u / D, col = u - row * D, e = u;
+#pragma unroll
+        for (int j = 0; j < DMAX; ++j) {
+            if (j < D) dst[e] = sT[row * LDT + col];
+            e += 256;
+            row += qD;
+            col += rD;
+            if (col >= D) {
+                col -= D;
+                ++row;
+            }
+        }
+    }
+}
+
+template <int DMAX>
+__global__ __launch_bounds__(256) void ppo_fwdbwd_kernel(const int64_t* __restrict__ idx, const int B, const int D, const int A,
+                                                         const float* __restrict__ obs, const float* __restrict__ act,
+                                                         const float* __restrict__ old_lp, const float* __restrict__ adv,
+                                                         const float* __restrict__ ret, const float* __restrict__ param,
+                                                         const float clip, const float vf, const float ec,
+                                                         float* __restrict__ partial, float* __restrict__ metric_partial) {
+    ppo_fwdbwd_body<DMAX>(blockIdx.x, idx, B, D, A, obs, act, old_lp, adv, ret, param, clip, vf, ec, partial, metric_partial);
 }
 
 // K11: flat_grad[i] = sum_p partial[p][i] (fixed order: deterministic); block-wise squared-norm partials for the clip;
 // block 0 folds the metric partials into the running sums (train.py:263-266) and advances the Adam step counter.
-__global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restrict__ partial, const int n_part, const int n,
+__device__ __forceinline__ void grad_reduce_body(const int blk, const float* __restrict__ partial, const int n_part, const int n,
                                                           float* __restrict__ grad, float* __restrict__ norm_partial,
                                                           const float* __restrict__ metric_partial, const int B, const float vf,
                                                           const float ec, float* __restrict__ metrics, float* __restrict__ step_count) {
     __shared__ float sh[16];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __syncthreads();  // (shared scratch reuse when called in a loop)
+    const int i = blk * blockDim.x + threadIdx.x;
     float g = 0.0f;
     if (i < n) {
         int pidx = 0;
-        for (; pidx + 8 <= n_part; pidx += 8) {  // 8 independent loads in flight; summed in index order
+        for (; pidx + 32 <= n_part; pidx += 32) {  // 32 independent loads in flight (the partials were written by other
+            float t[32];                              // workgroups: every load is a cold miss); summed in index order
+#pragma unroll
+            for (int j = 0; j < 32; ++j) t[j] = partial[(size_t)(pidx + j) * n + i];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) g += t[j];
+        }
+        for (; pidx + 8 <= n_part; pidx += 8) {
             float t[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) t[j] = partial[(size_t)(pidx + j) * n + i];
@@ -2118,13 +2209,18 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restric
     }
     if (i < n) grad[i] = g;
     const float ss = block_sum(g * g, sh);
-    if (threadIdx.x == 0) norm_partial[blockIdx.x] = ss;
-    if (blockIdx.x == 0) {
-        if (threadIdx.x < 3) {
-            float t = 0.0f;
-            for (int pidx = 0; pidx < n_part; ++pidx) t += metric_partial[pidx * 4 + threadIdx.x];
-            sh[threadIdx.x] = t / (float)B;
+    if (threadIdx.x == 0) norm_partial[blk] = ss;
+    if (blk == 0) {
+        __shared__ float sMp[256];
+        float mt[3] = {0.0f, 0.0f, 0.0f};
+        for (int p0 = 0; p0 < n_part; p0 += 64) {  // 64 workgroups' (pl, vl, ent, -) at a time, one coalesced load
+            __syncthreads();
+            sMp[threadIdx.x] = p0 * 4 + (int)threadIdx.x < n_part * 4 ? metric_partial[p0 * 4 + threadIdx.x] : 0.0f;
+            __syncthreads();
+            if (threadIdx.x < 3)
+                for (int pidx = 0; pidx < 64 && p0 + pidx < n_part; ++pidx) mt[threadIdx.x] += sMp[pidx * 4 + threadIdx.x];
         }
+        if (threadIdx.x < 3) sh[threadIdx.x] = mt[threadIdx.x] / (float)B;
         __syncthreads();
         if (threadIdx.x == 0) {
             metrics[0] += sh[0];
@@ -2136,29 +2232,57 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restric
     }
 }
 
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restrict__ partial, const int n_part, const int n,
+                                                          float* __restrict__ grad, float* __restrict__ norm_partial,
+                                                          const float* __restrict__ metric_partial, const int B, const float vf,
+                                                          const float ec, float* __restrict__ metrics, float* __restrict__ step_count) {
+    grad_reduce_body(blockIdx.x, partial, n_part, n, grad, norm_partial, metric_partial, B, vf, ec, metrics, step_count);
+}
+
 // K12: clip_grad_norm_ + Adam, one element per thread; the squared norm arrives as per-block partials of K11 and
 // the step counter has already been advanced there.
+__device__ __forceinline__ void adam_body(const int blk, float* __restrict__ param, float* __restrict__ grad, float* __restrict__ exp_avg,
+                                                   float* __restrict__ exp_avg_sq, const float* __restrict__ step_count,
+                                                   const float* __restrict__ lr_dev, const float* __restrict__ norm_partial,
+                                                   const int n_norm, const int n, const float max_norm, const float beta1,
+                                                   const float beta2, const float eps) {
+    // all loads first (cold misses: the operands were written by other workgroups), the norm partials once per
+    // workgroup through LDS; every thread then sums them in index order
+    __shared__ float sNorm[256];
+    const int i = blk * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    const float g_raw = live ? grad[i] : 0.0f, m0 = live ? exp_avg[i] : 0.0f, v0 = live ? exp_avg_sq[i] : 0.0f;
+    const float p0 = live ? param[i] : 0.0f;
+    const float step = step_count[0], lr = lr_dev[0];
+    float ss = 0.0f;
+    for (int j0 = 0; j0 < n_norm; j0 += 256) {
+        __syncthreads();
+        if (j0 + (int)threadIdx.x < n_norm) sNorm[threadIdx.x] = norm_partial[j0 + threadIdx.x];
+        __syncthreads();
+        const int cnt = n_norm - j0 < 256 ? n_norm - j0 : 256;
+        for (int j = 0; j < cnt; ++j) ss += sNorm[j];
+    }
+    const float coef = fminf(max_norm / (sqrtf(ss) + 1e-6f), 1.0f);
+    const float bc1 = 1.0f - powf(beta1, step), bc2_sqrt = sqrtf(1.0f - powf(beta2, step));
+    const float step_size = lr / bc1;
+    if (!live) return;
+    const float g = g_raw * coef;
+    grad[i] = g;
+    const float m = m0 + (1.0f - beta1) * (g - m0);
+    const float v = beta2 * v0 + (1.0f - beta2) * g * g;
+    exp_avg[i] = m;
+    exp_avg_sq[i] = v;
+    param[i] = p0 - step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ exp_avg,
                                                    float* __restrict__ exp_avg_sq, const float* __restrict__ step_count,
                                                    const float* __restrict__ lr_dev, const float* __restrict__ norm_partial,
                                                    const int n_norm, const int n, const float max_norm, const float beta1,
                                                    const float beta2, const float eps) {
-    float ss = 0.0f;
-    for (int j = 0; j < n_norm; ++j) ss += norm_partial[j];  // same order in every thread
-    const float coef = fminf(max_norm / (sqrtf(ss) + 1e-6f), 1.0f);
-    const float step = step_count[0];
-    const float bc1 = 1.0f - powf(beta1, step), bc2_sqrt = sqrtf(1.0f - powf(beta2, step));
-    const float step_size = lr_dev[0] / bc1;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float g = grad[i] * coef;
-    grad[i] = g;
-    const float m = exp_avg[i] + (1.0f - beta1) * (g - exp_avg[i]);
-    const float v = beta2 * exp_avg_sq[i] + (1.0f - beta2) * g * g;
-    exp_avg[i] = m;
-    exp_avg_sq[i] = v;
-    param[i] -= step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
+    adam_body(blockIdx.x, param, grad, exp_avg, exp_avg_sq, step_count, lr_dev, norm_partial, n_norm, n, max_norm, beta1, beta2, eps);
 }
+
 
 // ------------------------------------------------------------------------------------------
 // host side
