@@ -142,7 +142,8 @@ int pc_policy_set_split(int mode);
  *   2 (default) = fp16x2: every fp32 operand v = h + 2^-11 l with h = fp16(v), l = fp16((v - h) 2^11) (22 significant
  *       bits at any magnitude); a product is a_h b_h plus the two cross terms in a second, scaled fp32 accumulator
  *       (v_mfma_f32_16x16x32_f16, three per K block).  Max error vs float64 on this MLP 1.3e-7 (a plain fp32 GEMM:
- *       0.8e-7).  Operands saturate at fp16's finite range (|v| <= 65504).  Used when D <= 24 and A <= 9, else form 0.
+ *       0.8e-7).  Operands saturate at fp16's finite range (|v| <= 65504).  Used when D <= 40 (two K blocks of 32
+ *       features above D = 24) and A <= 9, else form 0.
  *   1 = bf16x3: three bf16 pieces per operand, six piece products (v_mfma_f32_16x16x32_bf16); 1.0e-7; same shapes.
  *   0 = fp32-input MFMA (v_mfma_f32_16x16x4_f32), bit-for-bit an fp32 fmaf chain.
  * pc_policy_precision reports the form a (D, H, A) shape will actually get (negative: unsupported shape). */

@@ -1024,10 +1024,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Split forms: PREC 1 = three bf16 pieces per operand, PREC 2 = two fp16 pieces (the second scaled by 2^11, below).
 __host__ __device__ constexpr int pol_np(int PREC) { return PREC == 2 ? 2 : 3; }
-__host__ __device__ constexpr int polx_w1_dwords(int PREC) { return 32 * pol_np(PREC) * 48 * 4; }
+// Layer-1 K blocks of 32 features: one for D <= 24 (3 stored groups of 8 features), two for D <= 40 (5 groups: the second
+// block's groups 1..3 are zero padding and are not stored).
+__host__ __device__ constexpr int pol_ng(int KS) { return KS == 10 ? 5 : 3; }
+__host__ __device__ constexpr int pol_kb(int KS) { return KS == 10 ? 2 : 1; }
+__host__ __device__ constexpr int polx_w1_dwords(int PREC, int NG) { return 32 * pol_np(PREC) * NG * 16 * 4; }
 __host__ __device__ constexpr int polx_w2_dwords(int PREC) { return 8 * pol_np(PREC) * 4 * 10 * 4; }  // actor tile pairs only
 // [W1 records][W2 records (actor)][b1: 512][b2: 16][critic output weights, fp32: 256]
-__host__ __device__ constexpr int polx_image_dwords(int PREC) { return polx_w1_dwords(PREC) + polx_w2_dwords(PREC) + 512 + 16 + 256; }
+__host__ __device__ constexpr int polx_image_dwords(int PREC, int NG) { return polx_w1_dwords(PREC, NG) + polx_w2_dwords(PREC) + 512 + 16 + 256; }
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {  // low half = bf16(a), high half = bf16(b), round-to-nearest-even
     const f32x2 v = {a, b};
@@ -1103,22 +1107,22 @@ __device__ __forceinline__ void mfma3(const u32x4 (&a)[2], const Pieces<2>& b, f
 }
 
 // image builder of the split forms (one thread per 16-byte operand record / per bias float)
-template <int PREC>
+template <int PREC, int NG>
 __global__ __launch_bounds__(256) void policy_pack16_kernel(const int D, const int A, const float* __restrict__ aW1,
                                                             const float* __restrict__ ab1, const float* __restrict__ aW2,
                                                             const float* __restrict__ ab2, const float* __restrict__ cW1,
                                                             const float* __restrict__ cb1, const float* __restrict__ cW2,
                                                             const float* __restrict__ cb2, unsigned* __restrict__ image) {
     constexpr int HID = 256, NP = pol_np(PREC);
-    constexpr int n1 = 32 * NP * 48, n2 = 8 * NP * 4 * 10;
+    constexpr int n1 = 32 * NP * NG * 16, n2 = 8 * NP * 4 * 10;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2 + 512 + 16 + 256; i += gridDim.x * blockDim.x) {
         if (i < n1 + n2) {
             float v[8];
             int pc;
             if (i < n1) {
-                const int lc = i % 16, g = (i / 16) % 3;
-                pc = (i / 48) % NP;
-                const int ht = i / (48 * NP), r = 16 * ht + lc;
+                const int lc = i % 16, g = (i / 16) % NG;
+                pc = (i / (16 * NG)) % NP;
+                const int ht = i / (16 * NG * NP), r = 16 * ht + lc;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int f = 8 * g + j;
@@ -1160,12 +1164,11 @@ __global__ __launch_bounds__(256) void policy_pack16_kernel(const int D, const i
 // Pairs 0..7 are the actor: ReLU, split, layer 2 on the matrix cores into out[et] (rows 0..A-1).  Pairs 8..15 are
 // the critic, whose output layer is ONE dot product per env: it is taken in plain fp32 on the VALU straight from
 // the accumulator registers (val[et] = this lane's partial over its hidden rows; the caller sums the 4 lane groups).
-template <int PREC>
+template <int PREC, int KB>
 __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsigned* sW2p, const float* sB1, const float* sW2c,
-                                              const int tp0, const int tp1, const Pieces<PREC> (&x)[2], f32x4 (&out)[2],
+                                              const int tp0, const int tp1, const Pieces<PREC> (&x)[2][KB], f32x4 (&out)[2],
                                               float (&val)[2], const int lc, const int g) {
-    constexpr int NP = pol_np(PREC);
-    const int gA = g < 3 ? g : 2;     // group 3 is K padding: its B operand is all zeros, any finite A will do
+    constexpr int NP = pol_np(PREC), NG = KB == 2 ? 5 : 3;
     const int oA = lc < 10 ? lc : 9;  // output rows >= 10 are never read
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     f32x4 outlo[2] = {zero4, zero4};  // PREC 2: the scaled cross terms of layer 2
@@ -1175,18 +1178,27 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
         for (int j = 0; j < 2; ++j) {
             const int ht = 2 * tp + j;
             const f32x4 bias = *reinterpret_cast<const f32x4*>(sB1 + 16 * ht + 4 * g);
-            u32x4 a[NP];
+            f32x4 hi[2] = {bias, bias}, lo[2] = {zero4, zero4};
 #pragma unroll
-            for (int pc = 0; pc < NP; ++pc) a[pc] = *reinterpret_cast<const u32x4*>(sW1p + ((ht * NP + pc) * 48 + gA * 16 + lc) * 4);
+            for (int kb = 0; kb < KB; ++kb) {
+                // feature group 4 kb + g; groups >= NG are K padding (their B operand is all zeros): any finite A will do
+                const int gi = 4 * kb + g, gA = gi < NG ? gi : NG - 1;
+                u32x4 a[NP];
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc)
+                    a[pc] = *reinterpret_cast<const u32x4*>(sW1p + (((ht * NP + pc) * NG + gA) * 16 + lc) * 4);
+#pragma unroll
+                for (int et = 0; et < 2; ++et) {
+                    if constexpr (PREC == 2) mfma3(a, x[et][kb], hi[et], lo[et]);
+                    else hi[et] = mfma6(a, x[et][kb], hi[et]);
+                }
+            }
 #pragma unroll
             for (int et = 0; et < 2; ++et) {
-                if constexpr (PREC == 2) {
-                    f32x4 hi = bias, lo = zero4;
-                    mfma3(a, x[et], hi, lo);
-                    acc[j][et] = __builtin_elementwise_fma(lo, (f32x4){PC_H_UNSCALE, PC_H_UNSCALE, PC_H_UNSCALE, PC_H_UNSCALE}, hi);
-                } else {
-                    acc[j][et] = mfma6(a, x[et], bias);
-                }
+                if constexpr (PREC == 2)
+                    acc[j][et] = __builtin_elementwise_fma(lo[et], (f32x4){PC_H_UNSCALE, PC_H_UNSCALE, PC_H_UNSCALE, PC_H_UNSCALE}, hi[et]);
+                else
+                    acc[j][et] = hi[et];
             }
         }
         if (tp < 8) {  // actor (uniform branch)
@@ -1301,14 +1313,15 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
     constexpr int HID = 256, NT = 2 * HID / 16;  // 32 hidden tiles: 16 actor + 16 critic
     constexpr int LD1 = pol_ld1(KS), LDO = 17, ET = 2;
     constexpr int ENVS_PER_WG = SPLIT ? 32 : 256;
-    constexpr int IMG = PREC ? polx_image_dwords(PREC) : pol_image_padded(KS);
+    constexpr int NG = pol_ng(KS), KB = pol_kb(KS);
+    constexpr int IMG = PREC ? polx_image_dwords(PREC, NG) : pol_image_padded(KS);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sW1 = lds;                        // PREC 0: [512][LD1]
-    float* sB1 = PREC ? lds + polx_w1_dwords(PREC) + polx_w2_dwords(PREC) : sW1 + 2 * HID * LD1;  // [512]
+    float* sB1 = PREC ? lds + polx_w1_dwords(PREC, NG) + polx_w2_dwords(PREC) : sW1 + 2 * HID * LD1;  // [512]
     float* sW2 = sB1 + 2 * HID;              // PREC 0: [NT][4][64]
     float* sB2 = PREC ? sB1 + 512 : sW2 + NT * 4 * 64;  // [16]
     const unsigned* sW1p = reinterpret_cast<const unsigned*>(lds);                       // PREC 1 operand records
-    const unsigned* sW2p = sW1p + polx_w1_dwords(PREC ? PREC : 1);
+    const unsigned* sW2p = sW1p + polx_w1_dwords(PREC ? PREC : 1, NG);
     const float* sW2c = sB2 + 16;            // PREC 1: critic output weights [256]
     float* sOut = lds + IMG;                 // [8 waves][32 envs][LDO]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1339,21 +1352,24 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
             }
             policy_pass<KS>(sW1, sB1, sW2, ht0, ht1, x, out, lc, lk, lane);
         } else {
-            Pieces<PREC> x[ET];
+            Pieces<PREC> x[ET][KB];
 #pragma unroll
             for (int et = 0; et < ET; ++et) {
                 const int64_t e = env0 + 16 * et + lc;
-                float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int f = 8 * lk + j;
-                    v[j] = (e < N && f < D) ? obs[e * D + f] : 0.0f;
-                    if constexpr (PREC == 2) v[j] = clamp_h(v[j]);
+                for (int kb = 0; kb < KB; ++kb) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int f = 8 * (4 * kb + lk) + j;
+                        v[j] = (e < N && f < D) ? obs[e * D + f] : 0.0f;
+                        if constexpr (PREC == 2) v[j] = clamp_h(v[j]);
+                    }
+                    x[et][kb] = split8<PREC>(v);
                 }
-                x[et] = split8<PREC>(v);
             }
             float val[ET] = {0.0f, 0.0f};
-            policy_pass16<PREC>(sW1p, sW2p, sB1, sW2c, ht0 / 2, ht1 / 2, x, out, val, lc, lk);
+            policy_pass16<PREC, KB>(sW1p, sW2p, sB1, sW2c, ht0 / 2, ht1 / 2, x, out, val, lc, lk);
 #pragma unroll
             for (int et = 0; et < ET; ++et) {  // the env column's value: sum of the 4 lane groups' partials -> output row A
                 float t = val[et];
@@ -1450,17 +1466,17 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                                                       float* __restrict__ next_term, float* __restrict__ next_trunc,
                                                       const int rden_lds, const int dbg) {
     constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, LDX = 4 * KS + 1, ET = 2;
-    constexpr int IMG = PREC ? polx_image_dwords(PREC) : pol_image_padded(KS);
+    constexpr int NG = pol_ng(KS), KB = pol_kb(KS);
+    constexpr int IMG = PREC ? polx_image_dwords(PREC, NG) : pol_image_padded(KS);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sW1 = lds;
-    float* sB1 = PREC ? lds + polx_w1_dwords(PREC) + polx_w2_dwords(PREC) : sW1 + 2 * HID * LD1;
+    float* sB1 = PREC ? lds + polx_w1_dwords(PREC, NG) + polx_w2_dwords(PREC) : sW1 + 2 * HID * LD1;
     float* sW2 = sB1 + 2 * HID;
     float* sB2 = PREC ? sB1 + 512 : sW2 + NT * 4 * 64;
     const unsigned* sW1p = reinterpret_cast<const unsigned*>(lds);
-    const unsigned* sW2p = sW1p + polx_w1_dwords(PREC ? PREC : 1);
+    const unsigned* sW2p = sW1p + polx_w1_dwords(PREC ? PREC : 1, NG);
     const float* sW2c = sB2 + 16;                  // PREC 1: critic output weights [256]
-    float* sOut = lds + IMG;                       // [8 waves][32 envs][LDO]
-    float* sObs = sOut + 8 * 32 * LDO;             // [256 envs][LDX]   observation of the step in flight
+    float* sObs = lds + IMG;                       // [256 envs][LDX]   observation of the step in flight
     int* sAct = reinterpret_cast<int*>(sObs + 256 * LDX);
     float* sTab = reinterpret_cast<float*>(sAct + 256);    // staged per-track tables (stage_tables)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1486,7 +1502,10 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     EnvRegs st = {};
     if (e_valid) st = env_load<float>(p, e_env);
     for (int f = g; f < 4 * KS; f += 2) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
-    float* myOut = sOut + wave * 32 * LDO;
+    // this wave's output tile [32 envs][LDO] lives in its own observation rows: they are dead from the policy pass's
+    // operand load until the env step stores the next observation (32 * LDX >= 32 * LDO floats)
+    static_assert(4 * KS + 1 >= 17, "the output tile must fit the wave's observation rows");
+    float* myOut = sObs + wave * 32 * LDX;
     const uint64_t off0 = offset + (offset_dev ? *offset_dev : 0);
     PhiloxBlock rnd = {};  // the sampling lanes' current Philox block (4 steps' draws)
     __syncthreads();  // the weight image is in place; from here on the waves never synchronise again
@@ -1510,20 +1529,23 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                     for (int ks = 0; ks < KS; ++ks) x[et][ks] = sObs[(pbase + 16 * et + lc) * LDX + 4 * ks + lk];
                 if (!(dbg & 1)) policy_pass<KS>(sW1, sB1, sW2, 0, NT, x, out, lc, lk, lane);  // dbg: timing ablations only
             } else {
-                Pieces<PREC> x[ET];
+                Pieces<PREC> x[ET][KB];
 #pragma unroll
                 for (int et = 0; et < ET; ++et) {
-                    float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int f = 8 * lk + j;
-                        v[j] = f < D ? sObs[(pbase + 16 * et + lc) * LDX + f] : 0.0f;
-                        if constexpr (PREC == 2) v[j] = clamp_h(v[j]);
+                    for (int kb = 0; kb < KB; ++kb) {
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int f = 8 * (4 * kb + lk) + j;
+                            v[j] = f < D ? sObs[(pbase + 16 * et + lc) * LDX + f] : 0.0f;
+                            if constexpr (PREC == 2) v[j] = clamp_h(v[j]);
+                        }
+                        x[et][kb] = split8<PREC>(v);
                     }
-                    x[et] = split8<PREC>(v);
                 }
                 float val[ET] = {0.0f, 0.0f};
-                if (!(dbg & 1)) policy_pass16<PREC>(sW1p, sW2p, sB1, sW2c, 0, NT / 2, x, out, val, lc, lk);
+                if (!(dbg & 1)) policy_pass16<PREC, KB>(sW1p, sW2p, sB1, sW2c, 0, NT / 2, x, out, val, lc, lk);
 #pragma unroll
                 for (int et = 0; et < ET; ++et) {
                     float tv = val[et];
@@ -1599,14 +1621,15 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                                                             float* __restrict__ next_term, float* __restrict__ next_trunc,
                                                             const int rden_lds, const int dbg) {
     constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, LDX = 4 * KS + 1, ET = 2;
-    constexpr int IMG = PREC ? polx_image_dwords(PREC) : pol_image_padded(KS);
+    constexpr int NG = pol_ng(KS), KB = pol_kb(KS);
+    constexpr int IMG = PREC ? polx_image_dwords(PREC, NG) : pol_image_padded(KS);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sW1 = lds;
-    float* sB1 = PREC ? lds + polx_w1_dwords(PREC) + polx_w2_dwords(PREC) : sW1 + 2 * HID * LD1;
+    float* sB1 = PREC ? lds + polx_w1_dwords(PREC, NG) + polx_w2_dwords(PREC) : sW1 + 2 * HID * LD1;
     float* sW2 = sB1 + 2 * HID;
     float* sB2 = PREC ? sB1 + 512 : sW2 + NT * 4 * 64;
     const unsigned* sW1p = reinterpret_cast<const unsigned*>(lds);
-    const unsigned* sW2p = sW1p + polx_w1_dwords(PREC ? PREC : 1);
+    const unsigned* sW2p = sW1p + polx_w1_dwords(PREC ? PREC : 1, NG);
     const float* sW2c = sB2 + 16;
     float* sOut = lds + IMG;                       // [8 waves][32 envs][LDO] partial output tiles
     float* sObs = sOut + 8 * 32 * LDO;             // [32 envs][LDX]
@@ -1657,20 +1680,23 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 for (int ks = 0; ks < KS; ++ks) x[et][ks] = sObs[(16 * et + lc) * LDX + 4 * ks + lk];
             if (!(dbg & 1)) policy_pass<KS>(sW1, sB1, sW2, ht0, ht1, x, out, lc, lk, lane);  // dbg: timing ablations only
         } else {
-            Pieces<PREC> x[ET];
+            Pieces<PREC> x[ET][KB];
 #pragma unroll
             for (int et = 0; et < ET; ++et) {
-                float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int f = 8 * lk + j;
-                    v[j] = f < D ? sObs[(16 * et + lc) * LDX + f] : 0.0f;
-                    if constexpr (PREC == 2) v[j] = clamp_h(v[j]);
+                for (int kb = 0; kb < KB; ++kb) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int f = 8 * (4 * kb + lk) + j;
+                        v[j] = f < D ? sObs[(16 * et + lc) * LDX + f] : 0.0f;
+                        if constexpr (PREC == 2) v[j] = clamp_h(v[j]);
+                    }
+                    x[et][kb] = split8<PREC>(v);
                 }
-                x[et] = split8<PREC>(v);
             }
             float val[ET] = {0.0f, 0.0f};
-            if (!(dbg & 1)) policy_pass16<PREC>(sW1p, sW2p, sB1, sW2c, ht0 / 2, ht1 / 2, x, out, val, lc, lk);
+            if (!(dbg & 1)) policy_pass16<PREC, KB>(sW1p, sW2p, sB1, sW2c, ht0 / 2, ht1 / 2, x, out, val, lc, lk);
 #pragma unroll
             for (int et = 0; et < ET; ++et) {
                 float tv = val[et];
@@ -2799,7 +2825,7 @@ int pc_policy_set_precision(int mode) {
     return PC_OK;
 }
 
-static int policy_prec(int D, int A) { return (g_policy_precision >= 1 && D <= 24 && A <= 9) ? g_policy_precision : 0; }
+static int policy_prec(int D, int A) { return (g_policy_precision >= 1 && D <= 40 && A <= 9) ? g_policy_precision : 0; }
 int pc_policy_precision(int D, int H, int A) {
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
     return policy_prec(D, A);
@@ -2814,7 +2840,7 @@ int pc_policy_set_split(int mode) {
 int64_t pc_policy_image_floats(int D, int H, int A) {
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
     const int prec = policy_prec(D, A);
-    return prec ? polx_image_dwords(prec) : pol_image_padded(policy_ks(D));
+    return prec ? polx_image_dwords(prec, pol_ng(policy_ks(D))) : pol_image_padded(policy_ks(D));
 }
 
 int pc_policy_pack(int device, int D, int H, int A, const float* aW1, const float* ab1, const float* aW2, const float* ab2,
@@ -2826,12 +2852,13 @@ int pc_policy_pack(int device, int D, int H, int A, const float* aW1, const floa
     DeviceGuard guard(device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
     const int prec = policy_prec(D, A);
-    if (prec == 1)
-        hipLaunchKernelGGL(policy_pack16_kernel<1>, dim3(64), dim3(256), 0, (hipStream_t)stream, D, A, aW1, ab1, aW2, ab2, cW1, cb1,
-                           cW2, cb2, reinterpret_cast<unsigned*>(image));
-    else if (prec == 2)
-        hipLaunchKernelGGL(policy_pack16_kernel<2>, dim3(64), dim3(256), 0, (hipStream_t)stream, D, A, aW1, ab1, aW2, ab2, cW1, cb1,
-                           cW2, cb2, reinterpret_cast<unsigned*>(image));
+#define PC_PACK(PRC, NGV)                                                                                                \
+    hipLaunchKernelGGL((policy_pack16_kernel<PRC, NGV>), dim3(64), dim3(256), 0, (hipStream_t)stream, D, A, aW1, ab1, aW2, ab2, cW1, \
+                       cb1, cW2, cb2, reinterpret_cast<unsigned*>(image))
+    const int ng = pol_ng(policy_ks(D));
+    if (prec == 1) { if (ng == 5) PC_PACK(1, 5); else PC_PACK(1, 3); }
+    else if (prec == 2) { if (ng == 5) PC_PACK(2, 5); else PC_PACK(2, 3); }
+#undef PC_PACK
     else
         hipLaunchKernelGGL(policy_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, policy_ks(D), D, A, aW1, ab1, aW2, ab2,
                            cW1, cb1, cW2, cb2, image);
@@ -2850,7 +2877,7 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
     if (!guard.ok) return PC_ERR_NO_DEVICE;
     const int KS = policy_ks(D);
     const int prec = policy_prec(D, A);
-    const size_t lds = (size_t)((prec ? polx_image_dwords(prec) : pol_image_padded(KS)) + 8 * 32 * 17) * sizeof(float);
+    const size_t lds = (size_t)((prec ? polx_image_dwords(prec, pol_ng(KS)) : pol_image_padded(KS)) + 8 * 32 * 17) * sizeof(float);
     static int n_cu[64] = {0};
     if (device < 64 && n_cu[device] == 0) {
         hipDeviceProp_t prop;
@@ -2874,11 +2901,11 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
                            action, action_f32, logprob, value, logits_out);                                              \
     } while (0)
     if (prec == 1) {
-        if (split) { if (KS == 5) PC_POL(5, true, 1); else PC_POL(6, true, 1); }
-        else { if (KS == 5) PC_POL(5, false, 1); else PC_POL(6, false, 1); }
+        if (split) { if (KS == 5) PC_POL(5, true, 1); else if (KS == 6) PC_POL(6, true, 1); else PC_POL(10, true, 1); }
+        else { if (KS == 5) PC_POL(5, false, 1); else if (KS == 6) PC_POL(6, false, 1); else PC_POL(10, false, 1); }
     } else if (prec == 2) {
-        if (split) { if (KS == 5) PC_POL(5, true, 2); else PC_POL(6, true, 2); }
-        else { if (KS == 5) PC_POL(5, false, 2); else PC_POL(6, false, 2); }
+        if (split) { if (KS == 5) PC_POL(5, true, 2); else if (KS == 6) PC_POL(6, true, 2); else PC_POL(10, true, 2); }
+        else { if (KS == 5) PC_POL(5, false, 2); else if (KS == 6) PC_POL(6, false, 2); else PC_POL(10, false, 2); }
     } else if (split) {
         if (KS == 5) PC_POL(5, true, 0);
         else if (KS == 6) PC_POL(6, true, 0);
@@ -2943,8 +2970,10 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     DeviceGuard guard(e->device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
     const int prec = policy_prec(e->D, A);
-    const int img = prec ? polx_image_dwords(prec) : pol_image_padded(KS);
-    const size_t lds_big = (size_t)(img + 8 * 32 * 17 + 256 * (4 * KS + 1) + 256 + TAB_FLOATS) * sizeof(float);
+    const int img = prec ? polx_image_dwords(prec, pol_ng(KS)) : pol_image_padded(KS);
+    // (big form: each wave's output tile aliases its own 32 observation rows -- dead between the policy pass's operand
+    // load and the env step's store of the next observation)
+    const size_t lds_big = (size_t)(img + 256 * (4 * KS + 1) + 256 + TAB_FLOATS) * sizeof(float);
     const size_t lds_small = (size_t)(img + 8 * 32 * 17 + 32 * (4 * KS + 1) + 32 + TAB_FLOATS) * sizeof(float);
     // large batches: 256 envs per workgroup, every wave independent (at 33 rays the 256-env observation tile does not fit
     // LDS: PC_ERR_UNSUPPORTED, the per-step kernels are the faster choice there anyway); small batches: 32 envs per
@@ -2989,10 +3018,11 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     if (small) {
         if (KS == 5 && rpl == 3) { if (prec == 2) PC_ROLLS(5, 3, 2); else if (prec) PC_ROLLS(5, 3, 1); else PC_ROLLS(5, 3, 0); }        // 12 rays
         else if (KS == 6 && rpl == 5) { if (prec == 2) PC_ROLLS(6, 5, 2); else if (prec) PC_ROLLS(6, 5, 1); else PC_ROLLS(6, 5, 0); }   // 16 -> 17 rays
-        else if (KS == 10 && rpl == 9) PC_ROLLS(10, 9, 0);                                         // 32 -> 33 rays
+        else if (KS == 10 && rpl == 9) { if (prec == 2) PC_ROLLS(10, 9, 2); else if (prec) PC_ROLLS(10, 9, 1); else PC_ROLLS(10, 9, 0); }   // 32 -> 33 rays
         else return PC_ERR_UNSUPPORTED;
     } else if (KS == 5 && rpl == 6) { if (prec == 2) PC_ROLL(5, 6, 2); else if (prec) PC_ROLL(5, 6, 1); else PC_ROLL(5, 6, 0); }       // 12 rays, D = 18
     else if (KS == 6 && rpl == 9) { if (prec == 2) PC_ROLL(6, 9, 2); else if (prec) PC_ROLL(6, 9, 1); else PC_ROLL(6, 9, 0); }          // 16 -> 17 rays, D = 23
+    else if (KS == 10 && rpl == 17 && prec) { if (prec == 2) PC_ROLL(10, 17, 2); else PC_ROLL(10, 17, 1); }                               // 32 -> 33 rays, D = 39
     else return PC_ERR_UNSUPPORTED;
 #undef PC_ROLLS
 #undef PC_ROLL

@@ -159,11 +159,13 @@ def test_shape_menus_are_reported_without_a_gpu():
     assert lib.pc_policy_image_floats(23, 128, 9) == _capi.PC_ERR_UNSUPPORTED      # hidden size other than 256
     assert lib.pc_policy_image_floats(41, 256, 9) == _capi.PC_ERR_UNSUPPORTED
     assert lib.pc_policy_image_floats(23, 256, 16) == _capi.PC_ERR_UNSUPPORTED
-    assert lib.pc_policy_precision(23, 256, 9) == 2 and lib.pc_policy_precision(39, 256, 9) == 0   # the split forms cover D <= 24
+    assert lib.pc_policy_precision(23, 256, 9) == 2 and lib.pc_policy_precision(39, 256, 9) == 2   # the split forms cover D <= 40
+    assert lib.pc_policy_precision(23, 256, 12) == 0                                                 # ... and A <= 9
     assert lib.pc_policy_set_precision(0) == 0 and lib.pc_policy_precision(23, 256, 9) == 0
     assert lib.pc_policy_set_precision(1) == 0 and lib.pc_policy_precision(23, 256, 9) == 1
     assert lib.pc_policy_set_precision(7) == _capi.PC_ERR_INVALID_ARG and lib.pc_policy_set_precision(2) == 0
     assert lib.pc_policy_image_floats(23, 256, 9) == 32 * 2 * 48 * 4 + 8 * 2 * 4 * 10 * 4 + 512 + 16 + 256
+    assert lib.pc_policy_image_floats(39, 256, 9) == 32 * 2 * 80 * 4 + 8 * 2 * 4 * 10 * 4 + 512 + 16 + 256   # two K blocks, 5 stored groups
     assert lib.pc_policy_set_split(2) == _capi.PC_ERR_INVALID_ARG and lib.pc_policy_set_split(-1) == 0
     n = lib.pc_ppo_workspace_floats(512, 23, 256, 9)
     n_param = 2 * (256 * 23 + 256) + 9 * 256 + 9 + 256 + 1

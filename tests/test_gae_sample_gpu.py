@@ -163,7 +163,7 @@ def test_fused_policy_kernel_matches_torch_mlp(D, N, policy_precision):
     with torch.no_grad():
         ref_logits, ref_v = agent.actor(x), agent.critic(x).view(-1)
     from ppo_car_amd._capi import lib
-    assert lib.pc_policy_precision(D, 256, 9) == (policy_precision if D <= 24 else 0)   # the split forms cover D <= 24
+    assert lib.pc_policy_precision(D, 256, 9) == policy_precision   # the split forms cover D <= 40 (two K blocks above 24)
     assert torch.allclose(logits, ref_logits, atol=1e-5, rtol=1e-5)
     assert torch.allclose(v, ref_v, atol=1e-5, rtol=1e-5)
     # against float64: all three forms are fp32-class

@@ -207,9 +207,10 @@ def test_persistent_rollout_kernel_is_bitwise_the_two_kernel_rollout(num_rays, n
             for ep in range(3):
                 tr.rollout()
                 torch.cuda.synchronize()
-                # 32 -> 33 rays: weight image + a 256-env observation tile exceed 160 KB of LDS -> form 0 reports
-                # PC_ERR_UNSUPPORTED and the trainer falls back to the two-kernel loop; form 1 fits
-                mega_ok = mode == "mega" and (num_rays != 32 or form & 1)
+                # 32 -> 33 rays with the fp32 weight image: image + a 256-env observation tile exceed 160 KB of LDS -> form 0
+                # reports PC_ERR_UNSUPPORTED and the trainer falls back to the two-kernel loop; form 1 fits.  The 95 KB fp16x2
+                # image fits both forms, the 141 KB bf16x3 image (two K blocks at D = 39) neither.
+                mega_ok = mode == "mega" and (num_rays != 32 or precision == 2 or (precision == 0 and form & 1))
                 assert tr.rollout_mode == ("mega" if mega_ok else "steps-eager")
                 b = tr.buffer
                 snaps.append([t.clone() for t in (b.obs_buf, b.act_buf, b.rew_buf, b.val_buf, b.logprob_buf, b.term_buf,
