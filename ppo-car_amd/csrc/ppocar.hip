@@ -1277,6 +1277,43 @@ __device__ __forceinline__ void policy_tail(const float (&v)[16], const int A, c
     }
 }
 
+// The same draw with 16 lanes per env (the split forms, where the 32 envs of a workgroup would otherwise be drawn by half
+// of ONE wave while seven wait): lane i of a 16-lane row holds output i of its env (logits 0..A-1, the value at A).
+// Row-wide max / sum by DPP rotations, the CDF by a DPP scan, the action = number of bins the uniform has passed.  The
+// sums are tree-ordered, so the last bits differ from policy_tail's (the split forms differ from the whole-tile forms
+// in summation order anyway); the distribution is the same.  act / lp / val are returned in every lane of the row.
+#define PC_ROW_ROR(v, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n), 0xf, 0xf, false))
+#define PC_ROW_SHR0(v, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + (n), 0xf, 0xf, true))
+__device__ __forceinline__ void policy_tail_row(const float v, const int i, const int A, const float u, const int lane, int& act,
+                                                float& lp, float& val) {
+    const float l = i < A ? v : -INFINITY;
+    float mx = l;
+    mx = fmaxf(mx, PC_ROW_ROR(mx, 8));
+    mx = fmaxf(mx, PC_ROW_ROR(mx, 4));
+    mx = fmaxf(mx, PC_ROW_ROR(mx, 2));
+    mx = fmaxf(mx, PC_ROW_ROR(mx, 1));
+    const float ex = i < A ? expf(l - mx) : 0.0f;
+    float sum = ex;
+    sum += PC_ROW_ROR(sum, 8);
+    sum += PC_ROW_ROR(sum, 4);
+    sum += PC_ROW_ROR(sum, 2);
+    sum += PC_ROW_ROR(sum, 1);
+    const float lse = mx + logf(sum);  // Categorical(logits=...) normalises: logits - logsumexp
+    float cdf = ex * (1.0f / sum);     // inclusive scan over the row (lanes shifted in from outside the row read 0)
+    cdf += PC_ROW_SHR0(cdf, 1);
+    cdf += PC_ROW_SHR0(cdf, 2);
+    cdf += PC_ROW_SHR0(cdf, 4);
+    cdf += PC_ROW_SHR0(cdf, 8);
+    const unsigned long long passed = __ballot(i < A && !(u < cdf));       // inverse CDF: bins the uniform has passed
+    const int cnt = __popc((unsigned)(passed >> (lane & 48)) & 0xffffu);
+    act = cnt < A - 1 ? cnt : A - 1;                                       // last bin absorbs rounding
+    const int row0 = lane & 48;
+    lp = __shfl(l, row0 + act, 64) - lse;
+    val = __shfl(v, row0 + A, 64);
+}
+#undef PC_ROW_ROR
+#undef PC_ROW_SHR0
+
 template <int NDW> __device__ __forceinline__ void policy_stage_image(const float* __restrict__ image, float* lds, const int tid) {
     // 16-byte coalesced copies, all loads of a thread in flight together
     const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(image);
@@ -1385,27 +1422,40 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) myOut[(16 * et + lc) * LDO + 4 * lk + reg] = out[et][reg];
         __syncthreads();
-        const int64_t e = env0 + lane;
-        if (lane < 32 && e < N && (!SPLIT || wave == 0)) {
-            float v[16];
+        if constexpr (SPLIT) {
+            // every wave draws for 4 of the 32 envs, 16 lanes (= outputs) per env: sum the 8 waves' partial tiles in a fixed
+            // order, then the row-parallel draw
+            const int el = wave * 4 + lk, oi = lc;
+            const int64_t e = env0 + el;
+            float t = sB2[oi];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float t = sB2[i];
-                if constexpr (SPLIT) {   // sum the 8 waves' partial tiles, fixed order
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) t += sOut[(w * 32 + lane) * LDO + i];
-                } else {
-                    t += myOut[lane * LDO + i];
-                }
-                v[i] = t;
-            }
+            for (int w = 0; w < 8; ++w) t += sOut[(w * 32 + el) * LDO + oi];
             int act;
             float lp, val;
-            policy_tail(v, A, philox_uniform(seed, off, (uint64_t)e), act, lp, val, logits_out ? logits_out + e * A : nullptr);
-            action[e] = act;
-            if (action_f) action_f[e] = (float)act;
-            logprob[e] = lp;
-            value[e] = val;
+            policy_tail_row(t, oi, A, philox_uniform(seed, off, (uint64_t)e), lane, act, lp, val);
+            if (e < N) {
+                if (logits_out && oi < A) logits_out[e * A + oi] = t;
+                if (oi == 0) {
+                    action[e] = act;
+                    if (action_f) action_f[e] = (float)act;
+                    logprob[e] = lp;
+                    value[e] = val;
+                }
+            }
+        } else {
+            const int64_t e = env0 + lane;
+            if (lane < 32 && e < N) {
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = sB2[i] + myOut[lane * LDO + i];
+                int act;
+                float lp, val;
+                policy_tail(v, A, philox_uniform(seed, off, (uint64_t)e), act, lp, val, logits_out ? logits_out + e * A : nullptr);
+                action[e] = act;
+                if (action_f) action_f[e] = (float)act;
+                logprob[e] = lp;
+                value[e] = val;
+            }
         }
     }
 }
@@ -1710,27 +1760,25 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) myOut[(16 * et + lc) * LDO + 4 * lk + reg] = out[et][reg];
         lds_barrier();
-        const int64_t e = (int64_t)blockIdx.x * 32 + lane;
-        if (wave == 0 && lane < 32 && e < N) {
-            float v[16];
+        {   // every wave draws for 4 of the 32 envs, 16 lanes (= outputs) per env, exactly as policy_kernel<SPLIT>
+            const int dl = wave * 4 + lk, oi = lc;
+            const int64_t e = (int64_t)blockIdx.x * 32 + dl;
+            float tsum = sB2[oi];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float tsum = sB2[i];
-#pragma unroll
-                for (int w = 0; w < 8; ++w) tsum += sOut[(w * 32 + lane) * LDO + i];  // fixed order, as policy_kernel<SPLIT>
-                v[i] = tsum;
-            }
-            int act;
-            float lp, val;
+            for (int w = 0; w < 8; ++w) tsum += sOut[(w * 32 + dl) * LDO + oi];  // fixed order
             const uint64_t o = off0 + (uint64_t)t;
             if (t == 0 || (o & 3) == 0) rnd = philox_block(seed, o >> 2, (uint64_t)e);  // uniform: ten rounds per 4 steps
-            if (!(dbg & 4)) policy_tail(v, A, philox_word_uniform(rnd, (unsigned)(o & 3)), act, lp, val, nullptr);
-            else { act = 0; lp = v[0]; val = v[1]; }
-            sAct[lane] = act;
-            const int64_t row = (int64_t)t * N + e;
-            act_buf[row] = (float)act;
-            logprob_buf[row] = lp;
-            val_buf[row] = val;
+            int act;
+            float lp, val;
+            if (!(dbg & 4)) policy_tail_row(tsum, oi, A, philox_word_uniform(rnd, (unsigned)(o & 3)), lane, act, lp, val);
+            else { act = 0; lp = tsum; val = tsum; }
+            if (oi == 0 && e < N) {
+                sAct[dl] = act;
+                const int64_t row = (int64_t)t * N + e;
+                act_buf[row] = (float)act;
+                logprob_buf[row] = lp;
+                val_buf[row] = val;
+            }
         }
         lds_barrier();
         // ---------------- E(t): 4 waves x 4 lanes per env (one more barrier inside, where the sweep parts meet)
