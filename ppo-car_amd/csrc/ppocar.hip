@@ -338,10 +338,9 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
     // F32 lattice indices with adds only: ray * step_deg = g * step_deg + s * (G * step_deg), the second term wave-uniform;
     // (m mod 360) for m < 720 as min_u32(m, m - 360)
     const int rs0 = g * p.step_deg, gstep = G * p.step_deg;
-    int k5_new = 0, k5_old = 0;
+    int k5_new = 0;
     if constexpr (sizeof(T) == 4) {
         k5_new = 5 * Math<float>::mod72(k_new) + rs0;
-        k5_old = 5 * Math<float>::mod72(st.k) + rs0;
     }
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
@@ -366,19 +365,28 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
         // (host-built bitmask for rays < 64: a runtime modulo per ray slot costs ~20 VALU instructions)
         const bool is_col = valid & (ray < 64 ? (bool)((p.colbits >> ray) & 1) : ((ray < p.n_nominal) & (ray % p.q == 0)));
         colmask |= (uint64_t)is_col << s;
-        if (is_col) {  // Car.get_passed_gate (:394-408) uses the rays of the PREVIOUS update
-            T odx = dx[s], ody = dy[s];
-            if constexpr (sizeof(T) == 4) {
-                if (turned) {
-                    const unsigned m = (unsigned)(k5_old + s * gstep);
-                    const float2 cs = p.dirtab[h.dir_off + (int)min(m, m - 360u)];
-                    odx = cs.x;
-                    ody = cs.y;
-                }
-            } else {
+        if constexpr (sizeof(T) == 8) {
+            if (is_col) {  // Car.get_passed_gate (:394-408) uses the rays of the PREVIOUS update
+                T odx = dx[s], ody = dy[s];
                 if (turned) Math<T>::ray_dir(p, h, rr, st.k, rot_old, odx, ody);
+                gate_hit |= Math<T>::cast(gate, opx, opy, odx, ody) < (T)10;  // :387,:390
             }
-            gate_hit |= Math<T>::cast(gate, opx, opy, odx, ody) < (T)10;  // :387,:390
+        }
+    }
+    if constexpr (sizeof(T) == 4) {
+        // Car.get_passed_gate (:394-408): the four collision rays j * (n // 4) at the PREVIOUS pose against gate[next].  Any
+        // lane can cast any ray (directions come from the lattice table), so the four casts are dealt round-robin to the
+        // env's lanes instead of falling on whichever lane owns those rays (with rays strided over the lanes: all on lane 0).
+        const int k5o = 5 * Math<float>::mod72(st.k);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = g + jj * G;
+            if (jj * G < 4) {  // uniform
+                const unsigned m = (unsigned)(k5o + (j < 4 ? j : 0) * p.q * p.step_deg);
+                const float2 cs = p.dirtab[h.dir_off + (int)min(m, m - 360u)];
+                const bool hit = Math<float>::cast(gate, opx, opy, cs.x, cs.y) < 10.0f;  // :387,:390
+                gate_hit |= hit & (j < 4);
+            }
         }
     }
 
