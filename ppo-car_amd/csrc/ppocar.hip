@@ -2088,9 +2088,12 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
     __syncthreads();   // (also: every thread has read its W1 row out of the tile, which sHid / sW2 alias)
 
     // ---- forward, layer 1 (Linear + ReLU), both nets
-    float ha[S], hc[S];
+    // (DMAX = 40: the sample loops stay rolled and the activations are re-read from LDS in the backward pass -- fully
+    // unrolled, the compiler keeps all S x D sample values live at once and spills a hundred registers)
+    constexpr bool ROLLED = DMAX > 24;
+    float ha[ROLLED ? 1 : S], hc[ROLLED ? 1 : S];
 #pragma unroll
-    for (int sidx = 0; sidx < S; ++sidx) {
+    for (int sidx = 0; sidx < (ROLLED ? 0 : S); ++sidx) {
         float za = b1a, zc = b1c;
 #pragma unroll
         for (int f = 0; f < DMAX; ++f) {
@@ -2101,6 +2104,19 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
         hc[sidx] = fmaxf(zc, 0.0f);
         sHid[sidx * LDH + u] = ha[sidx];
         sHid[(S + sidx) * LDH + u] = hc[sidx];
+    }
+    if constexpr (ROLLED) {
+#pragma unroll 1
+        for (int sidx = 0; sidx < S; ++sidx) {
+            float za = b1a, zc = b1c;
+#pragma unroll
+            for (int f = 0; f < DMAX; ++f) {
+                za = __builtin_fmaf(w1a[f], sX[sidx][f], za);
+                zc = __builtin_fmaf(w1c[f], sX[sidx][f], zc);
+            }
+            sHid[sidx * LDH + u] = fmaxf(za, 0.0f);
+            sHid[(S + sidx) * LDH + u] = fmaxf(zc, 0.0f);
+        }
     }
 #pragma unroll
     for (int o = 0; o < 16; ++o) sW2[o * LDH + u] = o < A ? w2a[o] : (o == A ? w2c : 0.0f);
@@ -2184,21 +2200,20 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
     }
 #pragma unroll
     for (int o = 0; o < 16; ++o) g2a[o] = 0.0f;
-#pragma unroll
-    for (int sidx = 0; sidx < S; ++sidx) {
+    auto backward_sample = [&](const int sidx, const float h_a, const float h_c) {
         float dha = 0.0f;
 #pragma unroll
         for (int o = 0; o < 16; ++o) {
             if (o < A) {
                 const float d = sDout[sidx][o];
                 dha = __builtin_fmaf(w2a[o], d, dha);
-                g2a[o] = __builtin_fmaf(d, ha[sidx], g2a[o]);
+                g2a[o] = __builtin_fmaf(d, h_a, g2a[o]);
             }
         }
         const float dval = sDout[sidx][A];
-        g2c = __builtin_fmaf(dval, hc[sidx], g2c);
-        dha = ha[sidx] > 0.0f ? dha : 0.0f;                      // ReLU backward (threshold at 0)
-        const float dhc = hc[sidx] > 0.0f ? w2c * dval : 0.0f;
+        g2c = __builtin_fmaf(dval, h_c, g2c);
+        dha = h_a > 0.0f ? dha : 0.0f;                           // ReLU backward (threshold at 0)
+        const float dhc = h_c > 0.0f ? w2c * dval : 0.0f;
         gb1a += dha;
         gb1c += dhc;
 #pragma unroll
@@ -2206,6 +2221,13 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
             g1a[f] = __builtin_fmaf(dha, sX[sidx][f], g1a[f]);
             g1c[f] = __builtin_fmaf(dhc, sX[sidx][f], g1c[f]);
         }
+    };
+    if constexpr (ROLLED) {
+#pragma unroll 1
+        for (int sidx = 0; sidx < S; ++sidx) backward_sample(sidx, sHid[sidx * LDH + u], sHid[(S + sidx) * LDH + u]);
+    } else {
+#pragma unroll
+        for (int sidx = 0; sidx < S; ++sidx) backward_sample(sidx, ha[sidx], hc[sidx]);
     }
     // ---- this workgroup's gradient partial, in flat parameter order; the [H][D] blocks through the tile again
     float* __restrict__ P = partial + (size_t)wg * n_param;
