@@ -4,6 +4,7 @@ log_video (train.py:23-50) without the renderer: one env, actions from the agent
 (`done = terminated`, train.py:45 -- a truncation does not end the loop there; here the episode limit does).
 
     python evaluate.py --checkpoint checkpoints/<run>/model.dat --track tracks/big_track.json [--num-rays 12] [--episodes 5]
+                       [--frames DIR [--frame-every 5]]      # PNG frames of episode 0 (software rasteriser, no pygame)
 """
 import argparse
 import json
@@ -19,6 +20,8 @@ def main(argv=None):
     ap.add_argument("--episodes", type=int, default=5)
     ap.add_argument("--greedy", action="store_true", help="argmax instead of sampling (the reference samples)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--frames", default=None, help="directory for PNG frames of episode 0 (the role of log_video's frames)")
+    ap.add_argument("--frame-every", type=int, default=5)
     args = ap.parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("evaluate.py needs the GPU: the env has no CPU path")
@@ -34,8 +37,22 @@ def main(argv=None):
     steps = torch.zeros(N, dtype=torch.int64, device="cuda")
     gates = torch.zeros(N, dtype=torch.int32, device="cuda")
     gp = torch.empty(N, dtype=torch.int32, device="cuda")
+    frames = 0
+    if args.frames:
+        import os
+        from ppo_car_amd.env import Track
+        from ppo_car_amd.render import rasterise, write_png
+        os.makedirs(args.frames, exist_ok=True)
+        walls, gate_segs = Track(args.track).geometry()
     with torch.no_grad():
-        for _ in range(1000):               # CarEnv's own time limit (car_env.py:491)
+        for t in range(1000):               # CarEnv's own time limit (car_env.py:491)
+            if args.frames and bool(alive[0]) and t % args.frame_every == 0:
+                st = env.get_state()        # (synchronous test hook: fine for a viewer)
+                rot = float(st["rot"][0])
+                img = rasterise(walls, gate_segs, float(st["px"][0]), float(st["py"][0]), rot, obs[0, 6:].cpu().numpy(),
+                                next_gate=int(st["next_gate"][0]), num_rays_nominal=args.num_rays)
+                write_png(os.path.join(args.frames, f"frame_{frames:05d}.png"), img)
+                frames += 1
             if args.greedy:
                 action = agent.actor(obs).argmax(-1)
             else:
@@ -49,6 +66,8 @@ def main(argv=None):
                 break
     out = {"episodes": N, "mean_return": float(ret.mean()), "mean_steps": float(steps.float().mean()),
            "mean_gates_passed": float(gates.float().mean()), "returns": ret.tolist(), "gates_passed": gates.tolist()}
+    if args.frames:
+        out["frames"] = frames
     print(json.dumps(out))
     return out
 

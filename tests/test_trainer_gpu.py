@@ -369,3 +369,10 @@ def test_evaluate_entry_point(tmp_path):
     torch.save(agent.state_dict(), tmp_path / "model.dat")
     out = evaluate.main(["--checkpoint", str(tmp_path / "model.dat"), "--track", TRACKS["big_track"], "--episodes", "4"])
     assert out["episodes"] == 4 and 1 <= out["mean_steps"] <= 1000 and len(out["returns"]) == 4
+    # frame dump: PNG frames of episode 0 from the software rasteriser
+    out = evaluate.main(["--checkpoint", str(tmp_path / "model.dat"), "--track", TRACKS["big_track"], "--episodes", "2",
+                         "--frames", str(tmp_path / "frames"), "--frame-every", "3"])
+    files = sorted((tmp_path / "frames").glob("frame_*.png"))
+    assert out["frames"] == len(files) >= 1
+    head = files[0].read_bytes()[:24]
+    assert head[:8] == b"\x89PNG\r\n\x1a\n" and int.from_bytes(head[16:20], "big") == 640 and int.from_bytes(head[20:24], "big") == 360
