@@ -168,9 +168,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tr.run_epoch(sync=False)
-        run_probe()
     barrier()
     dt = time.perf_counter() - t0
+    for _ in range(args.steps):          # the stand-alone K1 probe, outside the timed region (it is not part of the path)
+        run_probe()
+    torch.cuda.synchronize()
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -191,7 +193,7 @@ def main():
         k1 = {"kernel": "env_step_kernel (K1), stand-alone", "launch_us": k1_us, "achieved": per_step_bytes * cfg.n_envs / (k1_us * 1e-6) / 1e9,
               "unit": "GB/s", "frac": per_step_bytes * cfg.n_envs / (k1_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
               "launch_us_method": f"{PROBE} back-to-back launches on an identical env batch between two HIP events on the launch stream, "
-                                  "once per timed epoch", "launch_us_bracketed_in_rollout": k1_bracketed_us}
+                                  "after the timed epochs", "launch_us_bracketed_in_rollout": k1_bracketed_us}
         if tr.mega_events:
             # the timed region's dominant kernel is the persistent rollout kernel: ONE launch does n_steps env steps (+ policy steps)
             # for every env; algorithmic bytes = SURVEY's per-env-step figure x n_envs x n_steps
