@@ -40,6 +40,8 @@ WORKLOADS = {
     "cfg1": dict(n_envs=4096, n_steps=1024, num_rays=16, batch_size=512, train_iters=40),
     # BASELINE.json configs[2] (ray-kernel stress: 32 -> 33 rays)
     "cfg2": dict(n_envs=65536, n_steps=128, num_rays=32, batch_size=512, train_iters=40),
+    # the per-GPU shard of BASELINE.json configs[4] (262144 envs on 8 GPUs, track.json and big_track.json in one batch)
+    "cfg4": dict(n_envs=32768, n_steps=1024, num_rays=16, batch_size=512, train_iters=40, mixed=True),
 }
 ALGO_BYTES = {12: 156, 16: 176, 32: 240}      # SURVEY 8(d) / BASELINE.md section 4, per env step
 ALGO_FLOPS = {12: 8200, 16: 11600, 32: 22400}  # ditto, big_track (24 wall segments)
@@ -128,7 +130,10 @@ def main():
         wl["n_envs"] = args.n_envs
     if args.n_steps:
         wl["n_steps"] = args.n_steps
-    cfg = PPOConfig(track=os.path.join(ROOT, "tracks", "big_track.json"), env_dtype=args.env_dtype, seed=0, policy=args.policy, use_graphs=not args.no_graphs, fused_update=not args.torch_update, custom_mlp=not args.torch_mlp,
+    mixed = wl.pop("mixed", False)
+    track = ([os.path.join(ROOT, "tracks", "track.json"), os.path.join(ROOT, "tracks", "big_track.json")] if mixed
+             else os.path.join(ROOT, "tracks", "big_track.json"))
+    cfg = PPOConfig(track=track, env_dtype=args.env_dtype, seed=0, policy=args.policy, use_graphs=not args.no_graphs, fused_update=not args.torch_update, custom_mlp=not args.torch_mlp,
                     rollout_kernel=args.rollout_kernel, **wl)
     tr = Trainer(cfg, device=dev, rank=rank, world_size=world)
     tr.profile_stride = 0
@@ -137,7 +142,7 @@ def main():
     # stepped PROBE times back to back between two events with the trainer's latest actions.
     from ppo_car_amd.env import VecCarEnv
     PROBE = 32
-    probe = VecCarEnv(cfg.n_envs, cfg.track, num_rays=cfg.num_rays, reward_scaling=cfg.reward_scaling, device=dev, dtype=cfg.env_dtype)
+    probe = VecCarEnv(cfg.n_envs, os.path.join(ROOT, "tracks", "big_track.json"), num_rays=cfg.num_rays, reward_scaling=cfg.reward_scaling, device=dev, dtype=cfg.env_dtype)
     p_obs, _ = probe.reset()
     p_out = (p_obs, torch.empty(cfg.n_envs, device=dev), torch.empty(cfg.n_envs, device=dev), torch.empty(cfg.n_envs, device=dev))
     probe_events = []
@@ -210,7 +215,7 @@ def main():
             "value": env_steps / dt, "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.env_dtype == "f32" else "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: big_track.json, num_rays={nr} ({tr.obs_dim[0] - 6} actual), "
+            "config": {"workload": f"{args.workload}: {'track.json + big_track.json (halves)' if mixed else 'big_track.json'}, num_rays={nr} ({tr.obs_dim[0] - 6} actual), "
                                    f"n_envs={cfg.n_envs}/GPU, n_steps={cfg.n_steps}, batch_size={cfg.batch_size}, "
                                    f"train_iters={cfg.train_iters}; one step = one PPO epoch (rollout + GAE + update)",
                        "n_envs_total": cfg.n_envs * world, "parallelism": f"env-sharded dp{world}, 1 flat grad all-reduce/minibatch",

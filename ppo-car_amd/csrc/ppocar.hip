@@ -1489,6 +1489,7 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
 constexpr int TAB_MAX_GATES = 128;
 constexpr int TAB_DIR = 72 * 4 + TAB_MAX_GATES * 8, TAB_RESET = TAB_DIR + 361 * 2 + 2, TAB_FLOATS = TAB_RESET + 40;
 __device__ __forceinline__ EnvParams<float> stage_tables(const EnvParams<float>& p, float* sTab, const int tid, const int nthreads) {
+    if (p.track_id) return p;  // mixed-track batch: the tables are read where they lie (global memory, L2-resident)
     const TrackHdr h0 = cload(p.hdr);
     int* dst = reinterpret_cast<int*>(sTab);
     EnvParams<float> q = p;
@@ -1559,6 +1560,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const bool e_valid = e_env < N;
     EnvRegs st = {};
     if (e_valid) st = env_load<float>(p, e_env);
+    // mixed-track batch: this wave's envs share one track (the host checked every aligned block of 32 envs)
+    const int trk = p.track_id ? (int)p.track_id[e_valid ? e_env : N - 1] : 0;
     for (int f = g; f < 4 * KS; f += 2) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
     // this wave's output tile [32 envs][LDO] lives in its own observation rows: they are dead from the policy pass's
     // operand load until the env step stores the next observation (32 * LDX >= 32 * LDO floats)
@@ -1645,10 +1648,10 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
             bool term, trunc;
             int passed;
             if (rden_lds)  // uniform
-                env_step_core<float, RPL, 1, true>(q, 0, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw,
+                env_step_core<float, RPL, 1, true>(q, trk, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw,
                                                    term, trunc, passed, 0, nullptr, rdl);
             else
-                env_step_core<float, RPL>(q, 0, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw, term,
+                env_step_core<float, RPL>(q, trk, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw, term,
                                           trunc, passed);
             if (g == 0) {
                 rew_buf[(int64_t)t * N + e_env] = rw;
@@ -1717,6 +1720,8 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     const bool e_valid = e_env < N;
     EnvRegs st = {};
     if (e_valid) st = env_load<float>(p, e_env);
+    // mixed-track batch: this wave's envs share one track (the host checked every aligned block of 32 envs)
+    const int trk = p.track_id ? (int)p.track_id[e_valid ? e_env : N - 1] : 0;
     for (int f = g + 4 * part; f < 4 * KS; f += 16) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
     float* myOut = sOut + wave * 32 * LDO;
     const int ht0 = wave * (NT / 8), ht1 = ht0 + NT / 8;
@@ -1797,11 +1802,11 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
             bool term, trunc;
             int passed;
             if (rden_lds)  // uniform
-                env_step_core<float, RPL, PARTS, true>(q, 0, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
+                env_step_core<float, RPL, PARTS, true>(q, trk, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
                                                        e_valid && part == 0 ? sObs + el * LDX : nullptr, rw, term, trunc, passed, part,
                                                        exch, rdl);
             else
-                env_step_core<float, RPL, PARTS>(q, 0, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
+                env_step_core<float, RPL, PARTS>(q, trk, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
                                                  e_valid && part == 0 ? sObs + el * LDX : nullptr, rw, term, trunc, passed, part, exch);
             if (e_valid && g == 0 && part == 0) {
                 rew_buf[(int64_t)t * N + e_env] = rw;
@@ -2441,6 +2446,7 @@ struct pc_env {
     int4* iv = nullptr;
     double* rot = nullptr;
     uint8_t* track_id = nullptr;
+    bool track_blocks32 = false;   // mixed tracks: every aligned block of 32 envs holds ONE track (what pc_rollout needs)
     TrackHdr* hdr = nullptr;
     Seg* segs = nullptr;
     Vtx* vtx = nullptr;
@@ -2653,6 +2659,12 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
     HIPCHK(hipMalloc((void**)&e->iv, N * sizeof(int4)));
     if (f64) HIPCHK(hipMalloc((void**)&e->rot, N * sizeof(double)));
     if (track_id) {
+        e->track_blocks32 = true;
+        for (size_t i = 0; i < N; ++i)
+            if (track_id[i] != track_id[i & ~(size_t)31]) {
+                e->track_blocks32 = false;
+                break;
+            }
         HIPCHK(hipMalloc((void**)&e->track_id, N));
         HIPCHK(hipMemcpy(e->track_id, track_id, N, hipMemcpyHostToDevice));
     }
@@ -3043,7 +3055,8 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     if (!e || !image || !obs_buf || !act_buf || !rew_buf || !val_buf || !term_buf || !trunc_buf || !logprob_buf || !next_obs ||
         !next_term || !next_trunc || T < 1 || T > (1 << 24))
         return PC_ERR_INVALID_ARG;
-    if (e->dtype != PC_DTYPE_F32 || e->track_id || A < 1 || A > 15) return PC_ERR_UNSUPPORTED;
+    // mixed tracks: a wave (big form) / a workgroup (small form) steps 32 consecutive envs, which must share one track
+    if (e->dtype != PC_DTYPE_F32 || (e->track_id && !e->track_blocks32) || A < 1 || A > 15) return PC_ERR_UNSUPPORTED;
     const int KS = policy_ks(e->D);
     DeviceGuard guard(e->device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
@@ -3062,7 +3075,7 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     // the track's 1/den table rides along in LDS when it fits (big_track: 361 x 28 floats = 40 KB); else the sweep forms
     // den and its reciprocal itself -- same bits either way
     int rden_lds = 361 * e->hdr_host[0].nV;
-    if (g_rollout_rden == 0 || lds + (size_t)rden_lds * sizeof(float) > 160 * 1024) rden_lds = 0;
+    if (g_rollout_rden == 0 || e->track_id || lds + (size_t)rden_lds * sizeof(float) > 160 * 1024) rden_lds = 0;
     lds += (size_t)rden_lds * sizeof(float);
     const int rpl = small ? (e->R + 3) / 4 : (e->R + 1) / 2;  // 4 (x 4 sweep parts) or 2 lanes per env
     const int blocks = (int)(small ? (e->N + 31) / 32 : (e->N + 255) / 256);

@@ -45,7 +45,10 @@ class PPOConfig:
     max_grad_norm: float = 1.0
     reward_scaling: float = 0.1
     # additions
-    track: str = "tracks/big_track.json"   # replaces the Tk file dialog (train.py:95-111,119)
+    track: str = "tracks/big_track.json"   # replaces the Tk file dialog (train.py:95-111,119).  A list / tuple of paths = a
+                                           # mixed-track batch (BASELINE configs[4]): env i runs track (i * n_tracks) // n_envs,
+                                           # rounded to blocks of 32 envs (the layout the persistent rollout kernel accepts)
+    track_interleave: bool = False         # mixed tracks env by env instead (i % n_tracks: every wave holds all tracks; per-step kernels only)
     num_rays: int = 12                     # Car(num_rays=...) (car_env.py:227); 16 -> 17 rays, 32 -> 33
     env_dtype: str = "f32"
     seed: int = 0
@@ -391,8 +394,14 @@ class Trainer:
         if self.device.type == "cuda" and self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         torch.manual_seed(cfg.seed)  # identical initial parameters on every rank (then broadcast anyway)
+        track_id = None
+        if isinstance(cfg.track, (list, tuple)) and len(cfg.track) > 1:
+            import numpy as np
+            i = np.arange(cfg.n_envs)
+            nt = len(cfg.track)
+            track_id = (i % nt if cfg.track_interleave else np.minimum((i // 32 * 32) * nt // cfg.n_envs, nt - 1)).astype(np.uint8)
         self.envs = VecCarEnv(cfg.n_envs, cfg.track, num_rays=cfg.num_rays, reward_scaling=cfg.reward_scaling,
-                              device=self.device, dtype=cfg.env_dtype)
+                              device=self.device, dtype=cfg.env_dtype, track_id=track_id)
         self.obs_dim = (self.envs.obs_dim,)          # train.py:141
         self.act_dim = self.envs.act_dim             # train.py:142
         self.agent = Agent(self.obs_dim[0], self.act_dim).to(self.device)   # train.py:145
@@ -405,7 +414,8 @@ class Trainer:
         self.next_term = torch.zeros(N, device=self.device)      # train.py:165-166
         self.next_trunc = torch.zeros(N, device=self.device)
         self.actions = torch.empty(N, dtype=torch.int64, device=self.device)
-        self.envs.reset(options={"track_path": cfg.track}, out=self.next_obs)   # train.py:159
+        mixed = isinstance(cfg.track, (list, tuple)) and len(cfg.track) > 1
+        self.envs.reset(options=None if mixed else {"track_path": cfg.track}, out=self.next_obs)   # train.py:159
         self.global_step_idx = 0
         self.epoch = 0
         self.start_time = time.time()

@@ -248,6 +248,46 @@ def test_rollout_forms_agree_with_default_dispatch():
         assert torch.equal(a, b), i
 
 
+@pytest.mark.parametrize("n_envs,form", [(4096, -1), (1000, 0), (65536, -1)])
+def test_mixed_track_batches_through_the_persistent_rollout_kernel(n_envs, form):
+    """BASELINE configs[4] (track.json and big_track.json in one batch): with every aligned block of 32 envs on one track
+    pc_rollout steps the batch (each wave / workgroup reads its own track's tables) bit-identically to the per-step
+    kernels; with the tracks interleaved env by env it reports PC_ERR_UNSUPPORTED and the trainer takes the per-step path."""
+    from ppo_car_amd._capi import lib
+    tracks = [TRACKS["track"], TRACKS["big_track"]]
+    res = {}
+    lib.pc_rollout_set_form(form)
+    lib.pc_policy_set_split(-1 if form < 0 else form & 1)
+    try:
+        for mode in ("steps", "mega"):
+            tr = Trainer(_cfg(track=tracks, rollout_kernel=mode, use_graphs=False, n_envs=n_envs, n_steps=48, num_rays=16), device="cuda")
+            for _ in range(2):
+                tr.rollout()
+                tr.buffer.ptr = 0
+            torch.cuda.synchronize()
+            assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
+            b = tr.buffer
+            res[mode] = [t.clone() for t in (b.obs_buf, b.act_buf, b.rew_buf, b.val_buf, b.logprob_buf, b.term_buf, tr.next_obs)]
+            res[mode + "_state"] = tr.envs.get_state()
+            tr.close()
+    finally:
+        lib.pc_rollout_set_form(-1)
+        lib.pc_policy_set_split(-1)
+    for i, (a, b) in enumerate(zip(res["steps"], res["mega"])):
+        assert torch.equal(a, b), i
+    for k in res["steps_state"]:
+        assert np.array_equal(res["steps_state"][k], res["mega_state"][k]), k
+    st = res["mega_state"]                                   # both tracks really ran: 45 vs 55 gates bound next_gate
+    half = n_envs // 2 // 32 * 32
+    assert st["next_gate"][:half].max() < 45 and float(res["mega"][5].sum()) > 0
+    tr = Trainer(_cfg(track=tracks, track_interleave=True, rollout_kernel="mega", use_graphs=False, n_envs=512, n_steps=8, num_rays=16),
+                 device="cuda")
+    tr.rollout()
+    assert tr.rollout_mode == "steps-eager"
+    tr.close()
+
+
+
 def _two_rank_worker(rank, world, port, out_dir, use_graphs):
     import os
     import torch.distributed as dist
