@@ -134,7 +134,7 @@ int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, 
  * logprob, value [N]; logits_out [N][A] or NULL.  PC_ERR_UNSUPPORTED unless H == 256, A <= 15, D <= 40
  * (the caller then uses its own GEMMs + pc_sample). */
 int64_t pc_policy_image_floats(int D, int H, int A);
-/* Work decomposition of pc_policy_act: -1 = automatic (hidden tiles split across the waves of a workgroup below 32768
+/* Work decomposition of pc_policy_act: -1 = automatic (hidden tiles split across the waves of a workgroup up to 16384
  * envs), 0 = never split, 1 = always.  The two forms differ in fp32 summation order (last-bit differences).  Tuning /
  * test knob, process-wide. */
 int pc_policy_set_split(int mode);
@@ -170,8 +170,8 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
                const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
                float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, void* stream);
 
-/* Work decomposition of pc_rollout: -1 = automatic (256 envs per workgroup with independent waves from 32768 envs up,
- * else 32 envs per workgroup with the policy's hidden tiles split over the waves -- also the only form that fits LDS
+/* Work decomposition of pc_rollout: -1 = automatic (independent waves of 32 envs, 256 envs per workgroup -- 128 up to
+ * 32768 envs -- above 16384 envs, else 32 envs per workgroup with the policy's hidden tiles split over the waves -- also the only form that fits LDS
  * at 33 rays), 0 / 1 force one form; 2 / 3 = forms 0 / 1 with the env step forming 1/den arithmetically instead of
  * reading the track's 1/den table from LDS (what happens anyway when the table does not fit).  All are bit-identical
  * to the per-step kernels.  Tuning / test knob. */

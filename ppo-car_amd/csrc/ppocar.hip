@@ -1523,7 +1523,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                                                       float* __restrict__ term_buf, float* __restrict__ trunc_buf,
                                                       float* __restrict__ logprob_buf, float* __restrict__ next_obs,
                                                       float* __restrict__ next_term, float* __restrict__ next_trunc,
-                                                      const int rden_lds, const int dbg) {
+                                                      const int rden_lds, const int epw, const int dbg) {
     constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, LDX = 4 * KS + 1, ET = 2;
     constexpr int NG = pol_ng(KS), KB = pol_kb(KS);
     constexpr int IMG = PREC ? polx_image_dwords(PREC, NG) : pol_image_padded(KS);
@@ -1556,7 +1556,9 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     // this wave's 32 envs: local rows [pbase, pbase + 32); env-step identity: 2 lanes per env
     const int pbase = wave * 32;
     const int el = pbase + (lane >> 1), g = lane & 1;
-    const int64_t e_env = (int64_t)blockIdx.x * 256 + el;
+    // epw = envs per workgroup: 256 (all 8 waves) or 128 (waves 4..7 only help to stage LDS and leave: at <= 32768 envs
+    // that doubles the workgroups, one wave per SIMD on all 256 CUs instead of two on half of them)
+    const int64_t e_env = (int64_t)blockIdx.x * epw + el;
     const bool e_valid = e_env < N;
     EnvRegs st = {};
     if (e_valid) st = env_load<float>(p, e_env);
@@ -1570,6 +1572,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const uint64_t off0 = offset + (offset_dev ? *offset_dev : 0);
     PhiloxBlock rnd = {};  // the sampling lanes' current Philox block (4 steps' draws)
     __syncthreads();  // the weight image is in place; from here on the waves never synchronise again
+    if (pbase >= epw) return;
     if (wave >= 4) {  // stagger: the second wave of each SIMD starts about half a step (~15 us) later (speed only)
 #pragma unroll 1
         for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);  // 4 x 127 x 64 cycles
@@ -1621,7 +1624,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 for (int reg = 0; reg < 4; ++reg) myOut[(16 * et + lc) * LDO + 4 * lk + reg] = out[et][reg];
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the tile is written and read by this wave only
             __builtin_amdgcn_wave_barrier();
-            const int64_t e = (int64_t)blockIdx.x * 256 + pbase + lane;
+            const int64_t e = (int64_t)blockIdx.x * epw + pbase + lane;
             if (lane < 32 && e < N) {
                 float v[16];
 #pragma unroll
@@ -2899,6 +2902,12 @@ int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, 
 static int policy_ks(int D) { return D <= 20 ? 5 : (D <= 24 ? 6 : 10); }
 static int g_policy_split_mode = -1;  // -1 auto (split below 32768 envs), 0 never, 1 always
 static int g_rollout_form = -1;       // pc_rollout: -1 auto, 0 = 256 envs per workgroup, 1 = 32 envs per workgroup
+// Batches up to this size take the forms that cut the work of 32 envs over a whole workgroup (policy_kernel<SPLIT>,
+// rollout_small_kernel): n_envs / 32 workgroups, so 16384 envs are two rounds of 256 -- about what the 128-env big form
+// needs for anything up to 32768 envs.  The same bound for both kernels keeps the default per-step and persistent paths
+// bit-identical.
+#define PC_SPLIT_MAX_ENVS 16384
+static int64_t g_rollout_epw128_max = 32768;  // big form at or below this many envs: 128 envs (4 waves) per workgroup
 static int g_rollout_rden = 1;        // pc_rollout: stage the 1/den table in LDS when it fits (0: never; test / tuning knob)
 static int g_policy_precision = 2;    // 0 = fp32-input MFMA; split forms on the 16-bit matrix cores (need D <= 24, A <= 9): 1 = bf16 x 3, 2 = fp16 x 2
 
@@ -2976,7 +2985,7 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
     }
     const int cus = device < 64 ? n_cu[device] : 256;
     // too few 256-env workgroups to fill the chip: split the hidden tiles over the waves instead
-    const bool split = g_policy_split_mode < 0 ? N < 32768 : g_policy_split_mode == 1;
+    const bool split = g_policy_split_mode < 0 ? N <= PC_SPLIT_MAX_ENVS : g_policy_split_mode == 1;
     const int64_t chunks = split ? (N + 31) / 32 : (N + 255) / 256;
     const int blocks = (int)(chunks < cus ? chunks : cus);  // one ~100-KB-LDS workgroup per CU, persistent over env chunks
     hipStream_t st = (hipStream_t)stream;
@@ -3069,7 +3078,7 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     // large batches: 256 envs per workgroup, every wave independent (at 33 rays the 256-env observation tile does not fit
     // LDS: PC_ERR_UNSUPPORTED, the per-step kernels are the faster choice there anyway); small batches: 32 envs per
     // workgroup, hidden tiles and wall-sweep parts split over the waves
-    const bool small = g_rollout_form == 1 || (g_rollout_form < 0 && e->N < 32768);
+    const bool small = g_rollout_form == 1 || (g_rollout_form < 0 && e->N <= PC_SPLIT_MAX_ENVS);
     size_t lds = small ? lds_small : lds_big;
     if (lds > 160 * 1024) return PC_ERR_UNSUPPORTED;
     // the track's 1/den table rides along in LDS when it fits (big_track: 361 x 28 floats = 40 KB); else the sweep forms
@@ -3078,7 +3087,8 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     if (g_rollout_rden == 0 || e->track_id || lds + (size_t)rden_lds * sizeof(float) > 160 * 1024) rden_lds = 0;
     lds += (size_t)rden_lds * sizeof(float);
     const int rpl = small ? (e->R + 3) / 4 : (e->R + 1) / 2;  // 4 (x 4 sweep parts) or 2 lanes per env
-    const int blocks = (int)(small ? (e->N + 31) / 32 : (e->N + 255) / 256);
+    const int epw = (!small && e->N <= g_rollout_epw128_max) ? 128 : 256;   // big form: envs per workgroup
+    const int blocks = (int)(small ? (e->N + 31) / 32 : (e->N + epw - 1) / epw);
     hipStream_t st = (hipStream_t)stream;
     EnvParams<float> prm = e->params<float>();
     prm.lg = small ? 2 : 1;
@@ -3093,7 +3103,7 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
         }                                                                                                                \
         hipLaunchKernelGGL((rollout_kernel<KSV, RPLV, PRC>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, seed, \
                            offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs,  \
-                           next_term, next_trunc, rden_lds, dbg);                                                                  \
+                           next_term, next_trunc, rden_lds, epw, dbg);                                                             \
     } while (0)
 #define PC_ROLLS(KSV, RPLV, PRC)                                                                                         \
     do {                                                                                                                 \
