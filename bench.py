@@ -79,8 +79,8 @@ def cpu_baseline(cfg, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3, help="timed epochs")
-    ap.add_argument("--warmup", type=int, default=1, help="untimed epochs")
+    ap.add_argument("--steps", type=int, default=10, help="timed epochs")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed epochs")
     ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
     ap.add_argument("--n-envs", type=int, default=None, help="override envs per GPU")
     ap.add_argument("--n-steps", type=int, default=None)
