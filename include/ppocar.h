@@ -213,6 +213,20 @@ int pc_ppo_minibatch(int device, const int64_t* idx, int B, int D, int H, int A,
                      double max_norm, double beta1, double beta2, double eps, float* metrics, float* workspace, int apply,
                      void* stream);
 
+/* The same step on a minibatch gathered beforehand.  pc_ppo_prepare gathers n_mb minibatches in ONE launch: minibatch m
+ * reads its B indices at idx[m * idx_ld ...] and writes, at prepared + m * pc_ppo_prepared_floats(B, D), the sample rows
+ * obs[idx] [B][D], then act / old_logprob / adv / ret [B] each, then (mean, max(unbiased std, 1e-5)) of its advantages and
+ * two pad floats -- what every workgroup of pc_ppo_minibatch otherwise fetches (an index load, then the dependent row
+ * loads: two cold misses at the head of its critical path) and reduces for itself.  pc_ppo_minibatch_prepared(one such
+ * block) == pc_ppo_minibatch on the same samples, bit for bit.  (train.py:225-240) */
+int64_t pc_ppo_prepared_floats(int B, int D);
+int pc_ppo_prepare(int device, const int64_t* idx, int64_t idx_ld, int n_mb, int B, int D, const float* obs, const float* act,
+                   const float* old_logprob, const float* adv, const float* ret, float* prepared, void* stream);
+int pc_ppo_minibatch_prepared(int device, const float* prepared_mb, int B, int D, int H, int A, float* param, float* grad, float* exp_avg,
+                              float* exp_avg_sq, float* step_count, const float* lr_dev, double clip_ratio, double vf_coef,
+                              double ent_coef, double max_norm, double beta1, double beta2, double eps, float* metrics,
+                              float* workspace, int apply, void* stream);
+
 
 const char* pc_strerror(int code);
 /* Last HIP error string seen by this thread (diagnostics for PC_ERR_HIP). */

@@ -82,6 +82,9 @@ _sig = {
     "pc_ppo_loss": (_i, [_i] + [_vp] * 6 + [_i, _i, _d, _d, _d, _vp, _vp, _vp, _vp]),
     "pc_clip_adam": (_i, [_i] + [_vp] * 6 + [_i64, _d, _d, _d, _d, _d, _vp]),
     "pc_ppo_workspace_floats": (_i64, [_i, _i, _i, _i]),
+    "pc_ppo_prepared_floats": (_i64, [_i, _i]),
+    "pc_ppo_prepare": (_i, [_i, _vp, _i64, _i, _i, _i] + [_vp] * 5 + [_vp, _vp]),
+    "pc_ppo_minibatch_prepared": (_i, [_i, _vp, _i, _i, _i, _i] + [_vp] * 6 + [_d] * 7 + [_vp, _vp, _i, _vp]),
     "pc_ppo_minibatch": (_i, [_i, _vp, _i, _i, _i, _i] + [_vp] * 5 + [_vp] * 6 + [_d] * 7 + [_vp, _vp, _i, _vp]),
     "pc_strerror": (C.c_char_p, [_i]),
     "pc_last_hip_error": (C.c_char_p, []),

@@ -1987,13 +1987,70 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// (mean, max(unbiased std, 1e-5)) of a minibatch's advantages (train.py:238-240) over a 256-thread workgroup, thread u
+// holding elements u, u + 256, ...  One code path for the minibatch kernel and the prepare kernel: same bits.
+__device__ __forceinline__ void adv_stats(const float (&a_loc)[4], const float a_sum, const int B, float* sh, float& mean, float& sd) {
+    const int u = threadIdx.x;
+    mean = block_sum(a_sum, sh) * (1.0f / (float)B);
+    float d2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = u + j * 256;
+        const float dv = i < B ? a_loc[j] - mean : 0.0f;
+        d2 += dv * dv;
+    }
+    sd = fmaxf(sqrtf(block_sum(d2, sh) / (float)(B - 1)), 1e-5f);
+}
+
+// K10p: gather n_mb minibatches in one launch (one workgroup each): sample rows, per-sample scalars, advantage statistics.
+// What every workgroup of K10 otherwise does for itself at the head of its critical path -- an index load, then the
+// dependent row loads (two cold misses in a row), then two workgroup reductions -- is done here once per epoch.
+__global__ __launch_bounds__(256) void ppo_prepare_kernel(const int64_t* __restrict__ idx, const int64_t idx_ld, const int B, const int D,
+                                                          const float* __restrict__ obs, const float* __restrict__ act,
+                                                          const float* __restrict__ old_lp, const float* __restrict__ adv,
+                                                          const float* __restrict__ ret, float* __restrict__ prepared,
+                                                          const int64_t prep_ld) {
+    __shared__ float sh[16];
+    const int u = threadIdx.x;
+    const int64_t* ix = idx + (int64_t)blockIdx.x * idx_ld;
+    float* out = prepared + (int64_t)blockIdx.x * prep_ld;
+    float* ps = out + (size_t)B * D;
+    float a_loc[4], a_sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = u + j * 256;
+        const int64_t src = i < B ? ix[i] : 0;
+        a_loc[j] = i < B ? adv[src] : 0.0f;
+        a_sum += a_loc[j];
+        if (i < B) {
+            ps[i] = act[src];
+            ps[B + i] = old_lp[src];
+            ps[2 * B + i] = a_loc[j];
+            ps[3 * B + i] = ret[src];
+        }
+    }
+    for (int i = u; i < B * D; i += 256) {
+        const int b = i / D, f = i - b * D;
+        out[i] = obs[ix[b] * D + f];
+    }
+    float mean, sd;
+    adv_stats(a_loc, a_sum, B, sh, mean, sd);
+    if (u == 0) {
+        ps[4 * B] = mean;
+        ps[4 * B + 1] = sd;
+        ps[4 * B + 2] = 0.0f;
+        ps[4 * B + 3] = 0.0f;
+    }
+}
+
 template <int DMAX>
 __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __restrict__ idx, const int B, const int D, const int A,
                                                 const float* __restrict__ obs, const float* __restrict__ act,
                                                 const float* __restrict__ old_lp, const float* __restrict__ adv,
                                                 const float* __restrict__ ret, const float* __restrict__ param,
                                                 const float clip, const float vf, const float ec,
-                                                float* __restrict__ partial, float* __restrict__ metric_partial) {
+                                                float* __restrict__ partial, float* __restrict__ metric_partial,
+                                                const float* __restrict__ prep) {
     constexpr int H = 256, S = FB_S, LDT = DMAX + 1, LDH = H + 1;
     // Everything in this kernel is latency: a minibatch is 44 MFLOP.  So: every global access coalesced (the [H][D]
     // weight matrices and their gradients go through an LDS tile, transposed there), all loads of a phase in flight
@@ -2015,12 +2072,16 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
               o_cW2 = o_cb1 + H, o_cb2 = o_cW2 + H, n_param = o_cb2 + 1;
 
     // ---- loads that do not depend on anything, all issued before the first wait
+    // prep != nullptr: this minibatch was gathered by ppo_prepare_kernel -- rows [B][D], act / old_lp / adv / ret [B] and
+    // (mean, std) of the advantages, contiguous -- so nothing here depends on an index load and no statistics are reduced
     const int s0 = wg * S;
     int64_t my_src = 0;                                                   // threads 0..S-1: my sample's row
-    if (u < S && s0 + u < B) my_src = idx[s0 + u];
-    int64_t a_src[4];
+    int64_t a_src[4] = {0, 0, 0, 0};
+    if (!prep) {
+        if (u < S && s0 + u < B) my_src = idx[s0 + u];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a_src[j] = u + j * 256 < B ? idx[u + j * 256] : 0;
+        for (int j = 0; j < 4; ++j) a_src[j] = u + j * 256 < B ? idx[u + j * 256] : 0;
+    }
     float w2a[16];
 #pragma unroll
     for (int o = 0; o < 16; ++o) w2a[o] = o < A ? param[o_aW2 + o * H + u] : 0.0f;
@@ -2040,23 +2101,40 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
         }
     }
     // ---- second-level loads (addresses came from idx)
-    float a_loc[4], a_sum = 0.0f;
+    float a_loc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, a_sum = 0.0f;
+    float pre_mean = 0.0f, pre_sd = 1.0f;
+    if (prep) {
+        const float* ps = prep + (size_t)B * D;                           // act | old_lp | adv | ret | (mean, std, -, -)
+        pre_mean = ps[4 * B];
+        pre_sd = ps[4 * B + 1];
+        if (u < S) {
+            const bool lv = s0 + u < B;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        a_loc[j] = u + j * 256 < B ? adv[a_src[j]] : 0.0f;
-        a_sum += a_loc[j];
-    }
-    if (u < S) {
-        const bool lv = s0 + u < B;
-        sSmp[u][0] = lv ? act[my_src] : 0.0f;
-        sSmp[u][1] = lv ? old_lp[my_src] : 0.0f;
-        sSmp[u][2] = lv ? adv[my_src] : 0.0f;
-        sSmp[u][3] = lv ? ret[my_src] : 0.0f;
-    }
-    for (int i = u; i < S * DMAX; i += 256) {                             // gather my workgroup's samples (train.py:233-238)
-        const int sidx = i / DMAX, f = i - sidx * DMAX;
-        const int b = s0 + sidx;
-        sX[sidx][f] = (b < B && f < D) ? obs[idx[b] * D + f] : 0.0f;
+            for (int c = 0; c < 4; ++c) sSmp[u][c] = lv ? ps[c * B + s0 + u] : 0.0f;
+        }
+        for (int i = u; i < S * DMAX; i += 256) {
+            const int sidx = i / DMAX, f = i - sidx * DMAX;
+            const int b = s0 + sidx;
+            sX[sidx][f] = (b < B && f < D) ? prep[(size_t)b * D + f] : 0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a_loc[j] = u + j * 256 < B ? adv[a_src[j]] : 0.0f;
+            a_sum += a_loc[j];
+        }
+        if (u < S) {
+            const bool lv = s0 + u < B;
+            sSmp[u][0] = lv ? act[my_src] : 0.0f;
+            sSmp[u][1] = lv ? old_lp[my_src] : 0.0f;
+            sSmp[u][2] = lv ? adv[my_src] : 0.0f;
+            sSmp[u][3] = lv ? ret[my_src] : 0.0f;
+        }
+        for (int i = u; i < S * DMAX; i += 256) {                         // gather my workgroup's samples (train.py:233-238)
+            const int sidx = i / DMAX, f = i - sidx * DMAX;
+            const int b = s0 + sidx;
+            sX[sidx][f] = (b < B && f < D) ? obs[idx[b] * D + f] : 0.0f;
+        }
     }
     // ---- W1 rows into registers through the LDS tile (one net at a time: the tile holds [H][D] once)
     float w1a[DMAX], w1c[DMAX];
@@ -2084,15 +2162,8 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
     }
     // ---- per-minibatch advantage statistics (train.py:238-240), recomputed identically by every workgroup
     const float invB = 1.0f / (float)B;
-    const float mean = block_sum(a_sum, sh) * invB;
-    float d2 = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = u + j * 256;
-        const float dv = i < B ? a_loc[j] - mean : 0.0f;
-        d2 += dv * dv;
-    }
-    const float sd = fmaxf(sqrtf(block_sum(d2, sh) / (float)(B - 1)), 1e-5f);
+    float mean = pre_mean, sd = pre_sd;
+    if (!prep) adv_stats(a_loc, a_sum, B, sh, mean, sd);   // (uniform branch)
     __syncthreads();   // (also: every thread has read its W1 row out of the tile, which sHid / sW2 alias)
 
     // ---- forward, layer 1 (Linear + ReLU), both nets
@@ -2287,8 +2358,9 @@ __global__ __launch_bounds__(256) void ppo_fwdbwd_kernel(const int64_t* __restri
                                                          const float* __restrict__ old_lp, const float* __restrict__ adv,
                                                          const float* __restrict__ ret, const float* __restrict__ param,
                                                          const float clip, const float vf, const float ec,
-                                                         float* __restrict__ partial, float* __restrict__ metric_partial) {
-    ppo_fwdbwd_body<DMAX>(blockIdx.x, idx, B, D, A, obs, act, old_lp, adv, ret, param, clip, vf, ec, partial, metric_partial);
+                                                         float* __restrict__ partial, float* __restrict__ metric_partial,
+                                                         const float* __restrict__ prep) {
+    ppo_fwdbwd_body<DMAX>(blockIdx.x, idx, B, D, A, obs, act, old_lp, adv, ret, param, clip, vf, ec, partial, metric_partial, prep);
 }
 
 // K11: flat_grad[i] = sum_p partial[p][i] (fixed order: deterministic); block-wise squared-norm partials for the clip;
@@ -3138,12 +3210,13 @@ int64_t pc_ppo_workspace_floats(int B, int D, int H, int A) {
     return n_part * n_param + n_part * 4 + (n_param + 255) / 256;
 }
 
-int pc_ppo_minibatch(int device, const int64_t* idx, int B, int D, int H, int A, const float* obs, const float* act,
-                     const float* old_logprob, const float* adv, const float* ret, float* param, float* grad, float* exp_avg,
-                     float* exp_avg_sq, float* step_count, const float* lr_dev, double clip_ratio, double vf_coef, double ent_coef,
-                     double max_norm, double beta1, double beta2, double eps, float* metrics, float* workspace, int apply,
-                     void* stream) {
-    if (!idx || !obs || !act || !old_logprob || !adv || !ret || !param || !grad || !metrics || !workspace) return PC_ERR_INVALID_ARG;
+static int ppo_minibatch_impl(int device, const int64_t* idx, const float* prep, int B, int D, int H, int A, const float* obs,
+                              const float* act, const float* old_logprob, const float* adv, const float* ret, float* param, float* grad,
+                              float* exp_avg, float* exp_avg_sq, float* step_count, const float* lr_dev, double clip_ratio,
+                              double vf_coef, double ent_coef, double max_norm, double beta1, double beta2, double eps, float* metrics,
+                              float* workspace, int apply, void* stream) {
+    if (!param || !grad || !metrics || !workspace) return PC_ERR_INVALID_ARG;
+    if (!prep && (!idx || !obs || !act || !old_logprob || !adv || !ret)) return PC_ERR_INVALID_ARG;
     if (apply && (!exp_avg || !exp_avg_sq || !step_count || !lr_dev)) return PC_ERR_INVALID_ARG;
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40 || B < 2 || B > 1024) return PC_ERR_UNSUPPORTED;
     DeviceGuard guard(device);
@@ -3157,10 +3230,10 @@ int pc_ppo_minibatch(int device, const int64_t* idx, int B, int D, int H, int A,
     hipStream_t st = (hipStream_t)stream;
     if (D <= 24)
         hipLaunchKernelGGL(ppo_fwdbwd_kernel<24>, dim3(n_part), dim3(256), 0, st, idx, B, D, A, obs, act, old_logprob, adv, ret, param,
-                           (float)clip_ratio, (float)vf_coef, (float)ent_coef, partial, metric_partial);
+                           (float)clip_ratio, (float)vf_coef, (float)ent_coef, partial, metric_partial, prep);
     else
         hipLaunchKernelGGL(ppo_fwdbwd_kernel<40>, dim3(n_part), dim3(256), 0, st, idx, B, D, A, obs, act, old_logprob, adv, ret, param,
-                           (float)clip_ratio, (float)vf_coef, (float)ent_coef, partial, metric_partial);
+                           (float)clip_ratio, (float)vf_coef, (float)ent_coef, partial, metric_partial, prep);
     hipLaunchKernelGGL(grad_reduce_kernel, dim3(n_blk), dim3(256), 0, st, partial, n_part, n_param, grad, norm_partial, metric_partial, B,
                        (float)vf_coef, (float)ent_coef, metrics, apply ? step_count : nullptr);
     if (apply)
@@ -3168,6 +3241,43 @@ int pc_ppo_minibatch(int device, const int64_t* idx, int B, int D, int H, int A,
                            n_blk, n_param, (float)max_norm, (float)beta1, (float)beta2, (float)eps);
     HIPCHK(hipGetLastError());
     return PC_OK;
+}
+
+int pc_ppo_minibatch(int device, const int64_t* idx, int B, int D, int H, int A, const float* obs, const float* act,
+                     const float* old_logprob, const float* adv, const float* ret, float* param, float* grad, float* exp_avg,
+                     float* exp_avg_sq, float* step_count, const float* lr_dev, double clip_ratio, double vf_coef, double ent_coef,
+                     double max_norm, double beta1, double beta2, double eps, float* metrics, float* workspace, int apply,
+                     void* stream) {
+    return ppo_minibatch_impl(device, idx, nullptr, B, D, H, A, obs, act, old_logprob, adv, ret, param, grad, exp_avg, exp_avg_sq,
+                              step_count, lr_dev, clip_ratio, vf_coef, ent_coef, max_norm, beta1, beta2, eps, metrics, workspace, apply,
+                              stream);
+}
+
+int64_t pc_ppo_prepared_floats(int B, int D) {
+    if (D < 1 || D > 40 || B < 2 || B > 1024) return PC_ERR_UNSUPPORTED;
+    return (int64_t)B * (D + 4) + 4;
+}
+
+int pc_ppo_prepare(int device, const int64_t* idx, int64_t idx_ld, int n_mb, int B, int D, const float* obs, const float* act,
+                   const float* old_logprob, const float* adv, const float* ret, float* prepared, void* stream) {
+    if (!idx || !obs || !act || !old_logprob || !adv || !ret || !prepared || n_mb < 1 || idx_ld < B) return PC_ERR_INVALID_ARG;
+    if (D < 1 || D > 40 || B < 2 || B > 1024) return PC_ERR_UNSUPPORTED;
+    DeviceGuard guard(device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    hipLaunchKernelGGL(ppo_prepare_kernel, dim3(n_mb), dim3(256), 0, (hipStream_t)stream, idx, idx_ld, B, D, obs, act, old_logprob, adv, ret,
+                       prepared, (int64_t)B * (D + 4) + 4);
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_ppo_minibatch_prepared(int device, const float* prepared_mb, int B, int D, int H, int A, float* param, float* grad, float* exp_avg,
+                              float* exp_avg_sq, float* step_count, const float* lr_dev, double clip_ratio, double vf_coef,
+                              double ent_coef, double max_norm, double beta1, double beta2, double eps, float* metrics,
+                              float* workspace, int apply, void* stream) {
+    if (!prepared_mb) return PC_ERR_INVALID_ARG;
+    return ppo_minibatch_impl(device, nullptr, prepared_mb, B, D, H, A, nullptr, nullptr, nullptr, nullptr, nullptr, param, grad, exp_avg,
+                              exp_avg_sq, step_count, lr_dev, clip_ratio, vf_coef, ent_coef, max_norm, beta1, beta2, eps, metrics,
+                              workspace, apply, stream);
 }
 
 }  // extern "C"

@@ -58,6 +58,7 @@ class PPOConfig:
                                            # (the MLP GEMMs stay torch autograd); False = the reference's torch ops throughout
     custom_mlp: bool = True                # with fused_update: the MLP forward/backward too are HIP kernels (pc_ppo_minibatch,
                                            # no library GEMM); False = torch autograd GEMMs between the fused loss / Adam kernels
+    prepared_minibatches: bool = True      # gather all minibatches of an epoch in one launch (pc_ppo_prepare) before the steps
     rollout_kernel: str = "auto"           # "mega": the whole rollout as one persistent launch (pc_rollout); "steps": two
                                            # kernels per step (HIP-graph replayed); "auto": mega whenever pc_rollout supports the shape
     policy: str = "fused"                  # rollout policy step: "fused" (one MFMA kernel: MLPs + draw),
@@ -217,12 +218,62 @@ class PPOLearner:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)     # the 1/W is folded into pc_clip_adam
             self._fused_apply()
 
+    def prepare_minibatches(self, idx_all, n_mb, obs, act, logprob, adv, ret):
+        """pc_ppo_prepare: gather all train_iters x n_mb minibatches of the epoch in one launch (sample rows, per-sample
+        scalars, advantage statistics), so that no minibatch step starts with dependent index -> row loads."""
+        cfg, a1 = self.cfg, self.agent.actor[0]
+        B, D = cfg.batch_size, a1.in_features
+        pf = lib.pc_ppo_prepared_floats(B, D)
+        total = idx_all.shape[0] * n_mb
+        if getattr(self, "_prep", None) is None or self._prep.numel() != total * pf:
+            self._prep = torch.empty(total * pf, device=self.device)
+        rows = idx_all if idx_all.is_contiguous() and idx_all.shape[1] == n_mb * B else None
+        if rows is not None:                      # minibatch m = it * n_mb + mb starts at element m * B
+            check(lib.pc_ppo_prepare(self._dev_index(), rows.data_ptr(), B, total, B, D, obs.data_ptr(), act.data_ptr(),
+                                     logprob.data_ptr(), adv.data_ptr(), ret.data_ptr(), self._prep.data_ptr(), self._stream()),
+                  "pc_ppo_prepare")
+        else:
+            for it in range(idx_all.shape[0]):
+                row = idx_all[it]
+                check(lib.pc_ppo_prepare(self._dev_index(), row.data_ptr(), B, n_mb, B, D, obs.data_ptr(), act.data_ptr(),
+                                         logprob.data_ptr(), adv.data_ptr(), ret.data_ptr(),
+                                         self._prep[it * n_mb * pf:].data_ptr(), self._stream()), "pc_ppo_prepare")
+        return pf
+
+    def prepared_minibatch_step(self, m, pf):
+        """pc_ppo_minibatch_prepared on block m of the prepared epoch (+ all-reduce and clip/Adam when multi-rank)."""
+        cfg, a1, a2 = self.cfg, self.agent.actor[0], self.agent.actor[2]
+        single = self.world_size == 1
+        check(lib.pc_ppo_minibatch_prepared(self._dev_index(), self._prep.data_ptr() + 4 * m * pf, cfg.batch_size, a1.in_features,
+                                            a1.out_features, a2.out_features, self.flat_param.data_ptr(), self.flat_grad.data_ptr(),
+                                            self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(),
+                                            self.lr_dev.data_ptr(), cfg.clip_ratio, cfg.vf_coef, cfg.ent_coef, cfg.max_grad_norm, 0.9,
+                                            0.999, 1e-5, self.metrics.data_ptr(), self._ws.data_ptr(), 1 if single else 0,
+                                            self._stream()), "pc_ppo_minibatch_prepared")
+        if not single:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)     # the 1/W is folded into pc_clip_adam
+            self._fused_apply()
+
     def fused_minibatch_step(self, idx, obs, act, logprob, adv, ret):
         self._fused_fwd_bwd(idx, obs, act, logprob, adv, ret)
         if self.world_size > 1:
             import torch.distributed as dist
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)     # the 1/W is folded into pc_clip_adam
         self._fused_apply()
+
+    def _epoch_body(self, idx_all, n_mb, args):
+        """All minibatch steps of one epoch's update (train.py:223-261) with the hand-written kernels."""
+        cfg = self.cfg
+        B = cfg.batch_size
+        if cfg.prepared_minibatches:
+            pf = self.prepare_minibatches(idx_all, n_mb, *args)
+            for m in range(cfg.train_iters * n_mb):
+                self.prepared_minibatch_step(m, pf)
+        else:
+            for it in range(cfg.train_iters):
+                for mb in range(n_mb):
+                    self.custom_minibatch_step(idx_all[it, mb * B:(mb + 1) * B], *args)
 
     def draw_indices(self, M):
         """train.py:225-230: per train iter a fresh shuffle of all M = n_steps*n_envs indices, of which only
@@ -344,16 +395,15 @@ class PPOLearner:
                         pass   # (capture does not execute: safe at any time)
                     torch.cuda.synchronize(self.device)
                     g = torch.cuda.CUDAGraph()
+                    if cfg.prepared_minibatches:
+                        self.prepare_minibatches(idx_all, n_mb, *args)      # (allocates outside the capture)
+                        torch.cuda.synchronize(self.device)
                     with torch.cuda.graph(g):
-                        for it in range(cfg.train_iters):
-                            for mb in range(n_mb):
-                                self.custom_minibatch_step(idx_all[it, mb * B:(mb + 1) * B], *args)
+                        self._epoch_body(idx_all, n_mb, args)
                     self._epoch_graph, self._epoch_key = g, key
                 self._epoch_graph.replay()
             else:
-                for it in range(cfg.train_iters):
-                    for mb in range(n_mb):
-                        self.custom_minibatch_step(idx_all[it, mb * B:(mb + 1) * B], *args)
+                self._epoch_body(idx_all, n_mb, args)
             self._opt_started = True
             self.lr_dev.mul_(cfg.learning_rate_decay)                                    # StepLR(step_size=1), :147,:269
             return

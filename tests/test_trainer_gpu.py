@@ -288,6 +288,28 @@ def test_mixed_track_batches_through_the_persistent_rollout_kernel(n_envs, form)
 
 
 
+@pytest.mark.parametrize("num_rays,batch,graphs", [(16, 512, True), (12, 100, False), (32, 64, False)])
+def test_prepared_minibatches_are_bitwise_the_in_kernel_gather(num_rays, batch, graphs):
+    """pc_ppo_prepare + pc_ppo_minibatch_prepared (samples, scalars and advantage statistics of all minibatches gathered
+    once per epoch) against pc_ppo_minibatch gathering for itself: identical parameters, Adam state and logged sums."""
+    res = {}
+    for prep in (False, True):
+        cfg = _cfg(prepared_minibatches=prep, use_graphs=graphs, n_envs=256, n_steps=64, batch_size=batch, train_iters=3,
+                   num_rays=num_rays, seed=7)
+        tr = Trainer(cfg, device="cuda")
+        scal = [tr.run_epoch() for _ in range(3)]
+        L = tr.learner
+        res[prep] = ([t.clone() for t in (L.flat_param, L.exp_avg, L.exp_avg_sq, L.step_count, L.metrics, L.flat_grad)], scal)
+        assert (getattr(L, "_prep", None) is not None) == prep
+        tr.close()
+    for i, (a, b) in enumerate(zip(res[False][0], res[True][0])):
+        assert torch.equal(a, b), i
+    for a, b in zip(res[False][1], res[True][1]):
+        for k in ("losses/policy_loss", "losses/value_loss", "losses/entropy", "losses/total_loss", "charts/avg_reward"):
+            assert a[k] == b[k], k
+
+
+
 def _two_rank_worker(rank, world, port, out_dir, use_graphs):
     import os
     import torch.distributed as dist
