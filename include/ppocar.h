@@ -159,20 +159,22 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
  *   (action, logprob, value) = Agent.get_action_and_value(obs_t)      [pc_policy_act's arithmetic and RNG, offset + t]
  *   obs_{t+1}, reward, terminated, truncated = envs.step(action)      [pc_env_step's arithmetic]
  *   Buffer.store(...)                                                 [rows written in place]
- * Inputs: the env handle (F32 handles on a single track), the policy weight image of pc_policy_pack, and next_obs /
+ * Inputs: the env handle (F32; single track, or mixed tracks with every aligned block of 32 envs on one track), the
+ * policy weight image of pc_policy_pack, and next_obs /
  * next_term / next_trunc [N] = observation and flags the rollout starts from (the caller has copied them into row 0 of
  * obs_buf / term_buf / trunc_buf, as Trainer does).  Outputs: obs_buf [T][N][D] rows 1..T-1, act_buf (float32, buffer.py:13),
  * rew_buf, val_buf, logprob_buf [T][N] rows 0..T-1, term_buf / trunc_buf rows 1..T-1, and next_obs / next_term / next_trunc
  * overwritten with the state after step T-1.  Bit-identical to T x (pc_policy_act; pc_env_step).
- * PC_ERR_UNSUPPORTED for F64 or mixed-track handles and ray counts other than 12 / 16 / 32 (callers fall back to the
- * two-kernel loop). */
+ * PC_ERR_UNSUPPORTED for F64 handles, mixed-track handles whose track ids change inside an aligned block of 32 envs, ray
+ * counts other than 12 / 16 / 32, and shapes whose LDS footprint exceeds 160 KB (33 rays with the fp32 or bf16x3 weight
+ * image): callers fall back to the two-kernel loop. */
 int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
                const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
                float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, void* stream);
 
-/* Work decomposition of pc_rollout: -1 = automatic (independent waves of 32 envs, 256 envs per workgroup -- 128 up to
- * 32768 envs -- above 16384 envs, else 32 envs per workgroup with the policy's hidden tiles split over the waves -- also the only form that fits LDS
- * at 33 rays), 0 / 1 force one form; 2 / 3 = forms 0 / 1 with the env step forming 1/den arithmetically instead of
+/* Work decomposition of pc_rollout: -1 = automatic (above 16384 envs: independent waves of 32 envs, 256 envs per workgroup
+ * -- 128 up to 32768 envs; else 32 envs per workgroup with the policy's hidden tiles and the wall sweep split over the
+ * waves), 0 / 1 force the first / second form; 2 / 3 = forms 0 / 1 with the env step forming 1/den arithmetically instead of
  * reading the track's 1/den table from LDS (what happens anyway when the table does not fit).  All are bit-identical
  * to the per-step kernels.  Tuning / test knob. */
 int pc_rollout_set_form(int form);
