@@ -310,6 +310,24 @@ def test_prepared_minibatches_are_bitwise_the_in_kernel_gather(num_rays, batch, 
 
 
 
+def test_reference_style_loop_runs_on_the_drop_in_surface():
+    """examples/dropin_loop.py is the reference's train.py loop written against VecCarEnv / Buffer / Agent only (plain torch
+    for the loss and Adam, torch.randperm minibatches, the reference's loop bounds): it must run unchanged and learn."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("dropin_loop", os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples",
+                                                                            "dropin_loop.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    agent, hist = mod.run(TRACKS["big_track"], n_envs=512, n_steps=128, n_epochs=12, batch_size=512, train_iters=20, num_rays=12,
+                          seed=1, log=lambda *_: None)
+    assert len(hist) == 12 and all(np.isfinite(list(h.values())).all() for h in hist)
+    first, last = np.mean([h["avg_reward"] for h in hist[:3]]), np.mean([h["avg_reward"] for h in hist[-3:]])
+    assert last > first + 0.01                                   # per-step reward goes up within a dozen epochs
+    assert set(agent.state_dict()) == {"actor.0.weight", "actor.0.bias", "actor.2.weight", "actor.2.bias",
+                                       "critic.0.weight", "critic.0.bias", "critic.2.weight", "critic.2.bias"}
+
+
+
 def _two_rank_worker(rank, world, port, out_dir, use_graphs):
     import os
     import torch.distributed as dist
