@@ -575,32 +575,50 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
     passed_out = passed;
 
     // ---- observation.  Auto-reset (gymnasium 0.29.1 AsyncVectorEnv): a done env returns its reset obs.
+    // All loads of the reset observation first (one branch: taken by the few lanes whose env just ended), then the stores
+    // back to back.  Interleaved, every conditional load put an `s_waitcnt vmcnt(0)` in front of the next store -- which on
+    // gfx9 also waits for the stores already in flight: fifteen store round trips in a row per step.
     const float* __restrict__ robs = p.reset_obs + (size_t)trk * p.D;
+    const bool out_here = store && orow != nullptr;
+    float vraw[RPL], vout[RPL], hd[6], hout[6];
 #pragma unroll
-    for (int s = 0; s < RPL; ++s) {
-        const int ray = g + s * G;
-        if (ray < p.R && store && orow) {
-            const float v = Math<T>::norm_dist(best[s]);  // :593
-            const float o = done ? robs[6 + ray] : v;
-            orow[6 + ray] = o;
-            if (lrow) lrow[6 + ray] = o;
-            if (frow) frow[6 + ray] = v;
+    for (int s = 0; s < RPL; ++s) vout[s] = vraw[s] = Math<T>::norm_dist(best[s]);  // :593
+    hd[0] = Math<T>::norm(npx, 1280.0);  // :578-581
+    hd[1] = Math<T>::norm(npy, 720.0);
+    hd[2] = Math<T>::norm(nvx, 10.0);
+    hd[3] = Math<T>::norm(nvy, 10.0);
+    hd[4] = (float)ch1;  // :584-588
+    hd[5] = (float)sh1;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) hout[i] = hd[i];
+    if (done && out_here) {
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const int ray = g + s * G;
+            vout[s] = robs[6 + (ray < p.R ? ray : 0)];
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) hout[i] = robs[i];
         }
     }
-    if (g == 0 && store && orow) {
-        float hd[6];
-        hd[0] = Math<T>::norm(npx, 1280.0);  // :578-581
-        hd[1] = Math<T>::norm(npy, 720.0);
-        hd[2] = Math<T>::norm(nvx, 10.0);
-        hd[3] = Math<T>::norm(nvy, 10.0);
-        hd[4] = (float)ch1;  // :584-588
-        hd[5] = (float)sh1;
+    if (out_here) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const float o = done ? robs[i] : hd[i];
-            orow[i] = o;
-            if (lrow) lrow[i] = o;
-            if (frow) frow[i] = hd[i];
+        for (int s = 0; s < RPL; ++s) {
+            const int ray = g + s * G;
+            if (ray < p.R) {
+                orow[6 + ray] = vout[s];
+                if (lrow) lrow[6 + ray] = vout[s];
+                if (frow) frow[6 + ray] = vraw[s];
+            }
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                orow[i] = hout[i];
+                if (lrow) lrow[i] = hout[i];
+                if (frow) frow[i] = hd[i];
+            }
         }
     }
     // ---- new state (every lane of the group keeps the same copy)
