@@ -42,7 +42,6 @@
 //               grazing rays (measured: DESIGN.md).
 //               Rewards are bit-exact with the reference's float32(r * reward_scaling).
 #include <hip/hip_runtime.h>
-#include <type_traits>
 
 #include <cmath>
 #include <cstdio>
@@ -411,31 +410,8 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
         }
         const unsigned sgn = sign_mask();
         const Vtx* vt = p.vtx + h.vtx_off;
-        // Vertex records: wave-uniform -> scalar loads (s_load_dwordx8, operands stay in SGPRs).  TAB: the persistent kernel
-        // staged them in LDS behind the 1/den table and they are read as (broadcast) ds_reads into VGPRs instead -- scalar
-        // loads return out of order, so every one of them needs `s_waitcnt lgkmcnt(0)`, which would also drain the 1/den
-        // gathers prefetched for the NEXT vertex group (LDS and scalar memory share that counter); LDS reads return in order.
-        struct VtxL { double x, y; float ex, ey; int brk; };
-        constexpr bool VLDS = TAB && PARTS == 1;   // (measured: a gain for the 32-env waves, a loss for the split form's short part loops)
-        using VT = std::conditional_t<VLDS, VtxL, Vtx>;
-        auto fetch = [&](const int k) -> VT {
-            if constexpr (VLDS) {
-                typedef const __attribute__((address_space(3))) f32x4* lds_q;
-                const lds_q vq = (lds_q)(rdl + 361 * h.nV) + 2 * k;
-                const f32x4 a = vq[0], b = vq[1];
-                VtxL v;
-                v.x = __builtin_bit_cast(double, (f32x2){a.x, a.y});
-                v.y = __builtin_bit_cast(double, (f32x2){a.z, a.w});
-                v.ex = b.x;
-                v.ey = b.y;
-                v.brk = __builtin_amdgcn_readfirstlane(__float_as_int(b.z));
-                return v;
-            } else {
-                return cload(vt + k);
-            }
-        };
         // side values of vertex k: a_k = p_k - pos (float64, then rounded), c_k = cross(a_k, dir) per ray
-        auto side = [&](const auto& v, float& ax, float& ay, f32x2 (&c)[NP]) {
+        auto side = [&](const Vtx& v, float& ax, float& ay, f32x2 (&c)[NP]) {
             ax = (float)(v.x - npx);
             ay = (float)(v.y - npy);
             const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay};
@@ -443,7 +419,7 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
             for (int j = 0; j < NP; ++j) c[j] = __builtin_elementwise_fma(ay2, dx2[j], -(ax2 * dy2[j]));
         };
         // vertex k closes the segment (k-1, k): (axp, ayp, cp) belong to k-1, c to k; rdv = the slots' 1/den (TAB)
-        auto close = [&](const auto& v, const float axp, const float ayp, const f32x2 (&cp)[NP], const f32x2 (&c)[NP],
+        auto close = [&](const Vtx& v, const float axp, const float ayp, const f32x2 (&cp)[NP], const f32x2 (&c)[NP],
                          const float (&rdv)[2 * NP]) {
             const float un = __builtin_fmaf(v.ey, axp, -(v.ex * ayp));
             const f32x2 un2 = {un, un}, ex2 = {v.ex, v.ex}, ey2 = {v.ey, v.ey};
@@ -473,7 +449,7 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
         f32x2 cA[NP], cB[NP];
 #pragma unroll
         for (int j = 0; j < NP; ++j) cA[j] = cB[j] = (f32x2){0.0f, 0.0f};
-        if (PARTS > 1 && gbeg > 0) side(fetch(4 * gbeg - 1), axA, ayA, cA);
+        if (PARTS > 1 && gbeg > 0) side(cload(vt + 4 * gbeg - 1), axA, ayA, cA);
         // TAB: one 16-byte LDS read per ray slot and group = the slot's 1/den for the group's four vertices
         typedef const __attribute__((address_space(3))) f32x4* lds_row;
         lds_row rrow[2 * NP];
@@ -481,7 +457,7 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
 #pragma unroll
             for (int s = 0; s < 2 * NP; ++s) rrow[s] = (lds_row)(rdl + __umul24(s < RPL ? didx[s] : 360, h.nV)) + gbeg;  // full-rate 24-bit multiply
         }
-        VT nxt = fetch(gbeg < gend ? 4 * gbeg : 0);
+        Vtx nxt = cload(vt + (gbeg < gend ? 4 * gbeg : 0));
         // groups in pairs: the table reads of the NEXT group are issued before this group's arithmetic (register sets
         // rdA / rdB alternate), so their LDS latency -- gather reads, bank conflicts included -- hides under ~200 VALU ops
         f32x4 rdA[2 * NP], rdB[2 * NP];
@@ -493,8 +469,8 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
         }
 #define PC_VERTEX(RD, I, PAX, PAY, PC, NAX, NAY, NC)                                                                     \
         {                                                                                                                \
-            const VT v = nxt;                                                                                            \
-            nxt = fetch(k + I + 1 < 4 * gend ? k + I + 1 : k + I);                                                       \
+            const Vtx v = nxt;                                                                                           \
+            nxt = cload(vt + (k + I + 1 < 4 * gend ? k + I + 1 : k + I));                                                \
             side(v, NAX, NAY, NC);                                                                                       \
             float rdv[2 * NP];                                                                                           \
             _Pragma("unroll") for (int s = 0; s < 2 * NP; ++s) rdv[s] = TAB ? RD[s][I] : 0.0f;                          \
@@ -599,50 +575,32 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
     passed_out = passed;
 
     // ---- observation.  Auto-reset (gymnasium 0.29.1 AsyncVectorEnv): a done env returns its reset obs.
-    // All loads of the reset observation first (one branch: taken by the few lanes whose env just ended), then the stores
-    // back to back.  Interleaved, every conditional load put an `s_waitcnt vmcnt(0)` in front of the next store -- which on
-    // gfx9 also waits for the stores already in flight: fifteen store round trips in a row per step.
     const float* __restrict__ robs = p.reset_obs + (size_t)trk * p.D;
-    const bool out_here = store && orow != nullptr;
-    float vraw[RPL], vout[RPL], hd[6], hout[6];
 #pragma unroll
-    for (int s = 0; s < RPL; ++s) vout[s] = vraw[s] = Math<T>::norm_dist(best[s]);  // :593
-    hd[0] = Math<T>::norm(npx, 1280.0);  // :578-581
-    hd[1] = Math<T>::norm(npy, 720.0);
-    hd[2] = Math<T>::norm(nvx, 10.0);
-    hd[3] = Math<T>::norm(nvy, 10.0);
-    hd[4] = (float)ch1;  // :584-588
-    hd[5] = (float)sh1;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) hout[i] = hd[i];
-    if (done && out_here) {
-#pragma unroll
-        for (int s = 0; s < RPL; ++s) {
-            const int ray = g + s * G;
-            vout[s] = robs[6 + (ray < p.R ? ray : 0)];
-        }
-        if (g == 0) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) hout[i] = robs[i];
+    for (int s = 0; s < RPL; ++s) {
+        const int ray = g + s * G;
+        if (ray < p.R && store && orow) {
+            const float v = Math<T>::norm_dist(best[s]);  // :593
+            const float o = done ? robs[6 + ray] : v;
+            orow[6 + ray] = o;
+            if (lrow) lrow[6 + ray] = o;
+            if (frow) frow[6 + ray] = v;
         }
     }
-    if (out_here) {
+    if (g == 0 && store && orow) {
+        float hd[6];
+        hd[0] = Math<T>::norm(npx, 1280.0);  // :578-581
+        hd[1] = Math<T>::norm(npy, 720.0);
+        hd[2] = Math<T>::norm(nvx, 10.0);
+        hd[3] = Math<T>::norm(nvy, 10.0);
+        hd[4] = (float)ch1;  // :584-588
+        hd[5] = (float)sh1;
 #pragma unroll
-        for (int s = 0; s < RPL; ++s) {
-            const int ray = g + s * G;
-            if (ray < p.R) {
-                orow[6 + ray] = vout[s];
-                if (lrow) lrow[6 + ray] = vout[s];
-                if (frow) frow[6 + ray] = vraw[s];
-            }
-        }
-        if (g == 0) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                orow[i] = hout[i];
-                if (lrow) lrow[i] = hout[i];
-                if (frow) frow[i] = hd[i];
-            }
+        for (int i = 0; i < 6; ++i) {
+            const float o = done ? robs[i] : hd[i];
+            orow[i] = o;
+            if (lrow) lrow[i] = o;
+            if (frow) frow[i] = hd[i];
         }
     }
     // ---- new state (every lane of the group keeps the same copy)
@@ -1592,10 +1550,6 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
         const TrackHdr h0 = cload(p.hdr);
         const f32x4* src = reinterpret_cast<const f32x4*>(p.rden + h0.rden_off);
         for (int i = tid; i < rden_lds / 4; i += 512) reinterpret_cast<f32x4*>(sRden)[i] = src[i];
-        if (rden_lds) {  // ... and the track's vertex records right behind it (env_step_core<TAB> reads both from LDS)
-            const f32x4* vsrc = reinterpret_cast<const f32x4*>(p.vtx + h0.vtx_off);
-            for (int i = tid; i < h0.nV * 2; i += 512) reinterpret_cast<f32x4*>(sRden + rden_lds)[i] = vsrc[i];
-        }
     }
     const lds_cfp rdl = (lds_cfp)sRden;
 
@@ -1757,10 +1711,6 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
         const TrackHdr h0 = cload(p.hdr);
         const f32x4* src = reinterpret_cast<const f32x4*>(p.rden + h0.rden_off);
         for (int i = tid; i < rden_lds / 4; i += 512) reinterpret_cast<f32x4*>(sRden)[i] = src[i];
-        if (rden_lds) {  // ... and the track's vertex records right behind it (env_step_core<TAB> reads both from LDS)
-            const f32x4* vsrc = reinterpret_cast<const f32x4*>(p.vtx + h0.vtx_off);
-            for (int i = tid; i < h0.nV * 2; i += 512) reinterpret_cast<f32x4*>(sRden + rden_lds)[i] = vsrc[i];
-        }
     }
     const lds_cfp rdl = (lds_cfp)sRden;
 
@@ -3206,9 +3156,8 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     // the track's 1/den table rides along in LDS when it fits (big_track: 361 x 28 floats = 40 KB); else the sweep forms
     // den and its reciprocal itself -- same bits either way
     int rden_lds = 361 * e->hdr_host[0].nV;
-    const size_t vtx_lds = (size_t)e->hdr_host[0].nV * sizeof(Vtx);   // the vertex records ride behind the table
-    if (g_rollout_rden == 0 || e->track_id || lds + (size_t)rden_lds * sizeof(float) + vtx_lds > 160 * 1024) rden_lds = 0;
-    lds += rden_lds ? (size_t)rden_lds * sizeof(float) + vtx_lds : 0;
+    if (g_rollout_rden == 0 || e->track_id || lds + (size_t)rden_lds * sizeof(float) > 160 * 1024) rden_lds = 0;
+    lds += (size_t)rden_lds * sizeof(float);
     const int rpl = small ? (e->R + 3) / 4 : (e->R + 1) / 2;  // 4 (x 4 sweep parts) or 2 lanes per env
     const int epw = (!small && e->N <= g_rollout_epw128_max) ? 128 : 256;   // big form: envs per workgroup
     const int blocks = (int)(small ? (e->N + 31) / 32 : (e->N + epw - 1) / epw);
