@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--eager-rollout", action="store_true", help="no rollout graph; bracket env-step launches with events instead")
     ap.add_argument("--rollout-kernel", default="auto", choices=["auto", "mega", "steps"], help="persistent rollout kernel or 2 kernels/step")
+    ap.add_argument("--rollout-form", type=int, default=-1, choices=[-1, 0, 1, 2, 3], help="pc_rollout_set_form: -1 auto; 0/1 force the 32-env-wave / split form; 2/3 the same without the 1/den table in LDS (A/B knob)")
     ap.add_argument("--no-graphs", action="store_true", help="eager update and rollout")
     ap.add_argument("--torch-mlp", action="store_true", help="torch autograd GEMMs for the MLPs inside the minibatch step (fused loss/Adam kernels only)")
     ap.add_argument("--torch-update", action="store_true", help="reference torch ops for the whole minibatch step (no fused loss/Adam kernels)")
@@ -122,6 +123,7 @@ def main():
     from ppo_car_amd.ppo import PPOConfig, Trainer
     from ppo_car_amd._capi import lib as _lib
     _lib.pc_policy_set_precision({"fp16x2": 2, "bf16x3": 1, "fp32": 0}[args.policy_arith])
+    _lib.pc_rollout_set_form(args.rollout_form)
     POLICY_ARITH = {"fp16x2": "fp16x2 split (v = h + 2^-11 l), 3 products, two fp32 accumulators on the fp16 matrix cores (fp32-class; DESIGN.md section 5)",
                     "bf16x3": "bf16x3 split, 6 products, fp32 accumulate on the bf16 matrix cores (fp32-equivalent; DESIGN.md section 5)",
                     "fp32": "fp32-input MFMA (exact fp32 fmaf chain)"}[args.policy_arith]
