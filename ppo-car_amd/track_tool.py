@@ -177,10 +177,11 @@ def make_oval(n_points=32, n_gates=24, rx=0.42, ry=0.40, width=0.13, wobble=0.0,
             sx = (rx if s > 1 else rx - width) * s
             sy = (ry if s > 1 else ry - width * WIDTH / HEIGHT * 0.6) * s
             gates.append([round(0.5 + sx * math.cos(a), 4), round(0.5 + sy * math.sin(a), 4)])
-    a0 = 2.0 * np.pi * 0.5 / n_gates + 0.37 * 2.0 * np.pi / n_points   # half a gate past the start line, heading along the tangent
+    a0 = -2.0 * np.pi * 0.5 / n_gates + 0.37 * 2.0 * np.pi / n_points  # half a gate spacing BEFORE gate 0 (the first gate to
+    #                                                                    pass: next_gate_index starts at 0), heading along the tangent
     mx, my = rx - width / 2, ry - width * WIDTH / HEIGHT * 0.3
     start = [round(0.5 + mx * math.cos(a0), 4), round(0.5 + my * math.sin(a0), 4)]
-    ang = math.atan2(my * HEIGHT * math.cos(a0), -mx * WIDTH * math.sin(a0))
+    ang = math.degrees(math.atan2(my * HEIGHT * math.cos(a0), -mx * WIDTH * math.sin(a0)))   # the heading is in degrees (car_env.py:426)
     return {"outer_track_points": outer, "inner_track_points": inner, "reward_gates": gates, "initial_position": start,
             "initial_angle": ang}
 

@@ -9,8 +9,9 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 TRACKS = {"big_track": os.path.join(ROOT, "tracks", "big_track.json"),
-          "track": os.path.join(ROOT, "tracks", "track.json")}
-ENV_CONFIGS = [(t, n) for t in ("big_track", "track") for n in (12, 16, 32)]
+          "track": os.path.join(ROOT, "tracks", "track.json"),
+          "oval64": os.path.join(ROOT, "tracks", "oval64.json")}    # generated (track_tool make-oval): 128 walls, 40 gates
+ENV_CONFIGS = [(t, n) for t in ("big_track", "track") for n in (12, 16, 32)] + [("oval64", 16)]
 
 
 def pytest_configure(config):

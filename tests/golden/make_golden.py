@@ -69,7 +69,10 @@ _inject_stubs()
 sys.path.insert(0, REF)
 from lib.car_env import Boundary, Car, CarEnv, Ray  # noqa: E402
 
-TRACKS = {"big_track": f"{REF}/tracks/big_track.json", "track": f"{REF}/tracks/track.json"}
+REPO = os.path.dirname(os.path.dirname(OUT))
+# the reference's two tracks, plus a generated 128-wall circuit of this repository (python -m ppo_car_amd.track_tool make-oval
+# tracks/oval64.json --points 64 --gates 40 --wobble 0.01 --seed 0): the reference runs it like any other track file
+TRACKS = {"big_track": f"{REF}/tracks/big_track.json", "track": f"{REF}/tracks/track.json", "oval64": f"{REPO}/tracks/oval64.json"}
 REWARD_SCALING = 0.1  # train.py:90 default
 
 
@@ -237,11 +240,15 @@ def gae_cases():
 
 def main():
     os.chdir(REF)  # the reference loads "lib/assets/car.png" relative to cwd (stubbed, but keep the cwd it expects)
-    np.savez_compressed(f"{OUT}/ray_cases.npz", **ray_unit_cases())
-    np.savez_compressed(f"{OUT}/gae_cases.npz", **gae_cases())
+    if not sys.argv[1:]:
+        np.savez_compressed(f"{OUT}/ray_cases.npz", **ray_unit_cases())
+        np.savez_compressed(f"{OUT}/gae_cases.npz", **gae_cases())
     const = [("const", a) for a in range(9)]
-    for track in ("big_track", "track"):
-        for n in (12, 16, 32):
+    only = sys.argv[1:]                       # e.g. `make_golden.py oval64` regenerates that track's fixtures only
+    for track in ("big_track", "track", "oval64"):
+        if only and track not in only:
+            continue
+        for n in ((16,) if track == "oval64" else (12, 16, 32)):
             main_cfg = (track == "big_track" and n == 16)
             env = make_env(track, n)
             reset_obs = env._get_obs()

@@ -35,7 +35,7 @@ def test_track_loader_matches_reference(track, n):
     t = pc.Track(TRACKS[track])
     walls, gates = t.geometry()
     assert np.array_equal(walls, g["walls"]) and np.array_equal(gates, g["gates"])   # bit-exact float64
-    assert (t.n_walls, t.n_gates) == ((24, 55) if track == "big_track" else (16, 45))
+    assert (t.n_walls, t.n_gates) == {"big_track": (24, 55), "track": (16, 45), "oval64": (128, 40)}[track]
     assert np.array_equal([t.start_x, t.start_y, t.start_angle], g["reset_state"][[0, 1, 4]])
 
 

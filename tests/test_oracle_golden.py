@@ -20,7 +20,7 @@ def test_track_loader_matches_reference_geometry(track, n):
     tr = oracle.Track(TRACKS[track])
     assert np.array_equal(tr.walls, g["walls"])      # outer-then-inner order, x*1280 / y*720
     assert np.array_equal(tr.gates, g["gates"])
-    assert (tr.S, tr.G) == ((24, 55) if track == "big_track" else (16, 45))
+    assert (tr.S, tr.G) == {"big_track": (24, 55), "track": (16, 45), "oval64": (128, 40)}[track]
     assert np.array_equal(np.array([tr.start_x, tr.start_y, 0.0, 0.0, tr.start_rot]), g["reset_state"])
 
 
