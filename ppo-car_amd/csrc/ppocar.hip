@@ -1591,14 +1591,14 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 for (int et = 0; et < ET; ++et)
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) x[et][ks] = sObs[(pbase + 16 * et + lc) * LDX + 4 * ks + lk];
-                // Wave priority: the policy pass (MFMA chains, whose results it waits for anyway) runs at the lowest priority,
-                // everything else -- the draw and the env step, dense dependent VALU work -- above it.  The two waves of a
+                // Wave priority: the policy pass (MFMA chains, whose results it waits for anyway) runs at the lowest priority (0),
+                // the env step -- dense dependent VALU work -- above it (2), the short serial draw in between highest (3).  The two waves of a
                 // SIMD are in opposite phases most of the time; with equal priorities the issue arbiter interleaves them
                 // instruction by instruction and both crawl, with the env-step wave preferred the matrix pipe still gets
-                // its instructions in the gaps.  Measured inside the benchmark's epochs: 20.5 -> 18.9 ms per rollout.
+                // its instructions in the gaps.  Measured inside the benchmark's epochs: 20.5 -> 18.7 ms per rollout.
                 __builtin_amdgcn_s_setprio(0);
                 if (!(dbg & 1)) policy_pass<KS>(sW1, sB1, sW2, 0, NT, x, out, lc, lk, lane);  // dbg: timing ablations only
-                __builtin_amdgcn_s_setprio(2);
+                __builtin_amdgcn_s_setprio(3);
             } else {
                 Pieces<PREC> x[ET][KB];
 #pragma unroll
@@ -1618,7 +1618,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 float val[ET] = {0.0f, 0.0f};
                 __builtin_amdgcn_s_setprio(0);
                 if (!(dbg & 1)) policy_pass16<PREC, KB>(sW1p, sW2p, sB1, sW2c, 0, NT / 2, x, out, val, lc, lk);
-                __builtin_amdgcn_s_setprio(2);
+                __builtin_amdgcn_s_setprio(3);
 #pragma unroll
                 for (int et = 0; et < ET; ++et) {
                     float tv = val[et];
@@ -1653,6 +1653,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
             __builtin_amdgcn_wave_barrier();
         }
         if (e_valid && !(dbg & 2)) {
+            __builtin_amdgcn_s_setprio(2);
             // ---------------- E(t)
             const bool last = t + 1 == T;
             float* orow = last ? next_obs + e_env * D : obs_buf + ((int64_t)(t + 1) * N + e_env) * D;
