@@ -1573,10 +1573,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     PhiloxBlock rnd = {};  // the sampling lanes' current Philox block (4 steps' draws)
     __syncthreads();  // the weight image is in place; from here on the waves never synchronise again
     if (pbase >= epw) return;
-    if (wave >= 4) {  // stagger: the second wave of each SIMD starts about half a step (~15 us) later (speed only)
-#pragma unroll 1
-        for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);  // 4 x 127 x 64 cycles
-    }
+    // (no deliberate phase offset between the two waves of a SIMD: with the priorities below they fall into opposite
+    // phases by themselves; a start-up stagger measured 1 % slower)
 
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
