@@ -1209,6 +1209,7 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
                     acc[j][et] = hi[et];
             }
         }
+        __builtin_amdgcn_s_setprio(1);  // the VALU epilogue one step above the MFMA issue (K9: below the env step's 2)
         if (tp < 8) {  // actor (uniform branch)
             u32x4 w2[NP];
 #pragma unroll
@@ -1240,6 +1241,7 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
                     for (int r = 0; r < 4; ++r) val[et] = __builtin_fmaf(w[r], relu_f(acc[j][et][r]), val[et]);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
     }
     if constexpr (PREC == 2) {
 #pragma unroll
