@@ -458,15 +458,8 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
             for (int s = 0; s < 2 * NP; ++s) rrow[s] = (lds_row)(rdl + __umul24(s < RPL ? didx[s] : 360, h.nV)) + gbeg;  // full-rate 24-bit multiply
         }
         Vtx nxt = cload(vt + (gbeg < gend ? 4 * gbeg : 0));
-        // groups in pairs: the table reads of the NEXT group are issued before this group's arithmetic (register sets
-        // rdA / rdB alternate), so their LDS latency -- gather reads, bank conflicts included -- hides under ~200 VALU ops
-        f32x4 rdA[2 * NP], rdB[2 * NP];
-        if constexpr (TAB) {
-            if (gbeg < gend) {
-#pragma unroll
-                for (int s = 0; s < 2 * NP; ++s) rdA[s] = rrow[s][0];
-            }
-        }
+        // (A one-group-ahead prefetch of the table rows into a second register set was measured and dropped: inside the
+        // benchmark, with the wave priorities, it is 1.5 % slower than loading each group's rows at its top.)
 #define PC_VERTEX(RD, I, PAX, PAY, PC, NAX, NAY, NC)                                                                     \
         {                                                                                                                \
             const Vtx v = nxt;                                                                                           \
@@ -476,30 +469,18 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
             _Pragma("unroll") for (int s = 0; s < 2 * NP; ++s) rdv[s] = TAB ? RD[s][I] : 0.0f;                          \
             if (!v.brk) close(v, PAX, PAY, PC, NC, rdv);                                                                 \
         }
-#define PC_GROUP(RD, RDN, GQ)                                                                                            \
-        {                                                                                                                \
-            if constexpr (TAB) {                                                                                         \
-                if ((GQ) + 1 < gend) {                                                                                   \
-                    _Pragma("unroll") for (int s = 0; s < 2 * NP; ++s) RDN[s] = rrow[s][(GQ) + 1 - gbeg];               \
-                }                                                                                                        \
-            }                                                                                                            \
-            const int k = 4 * (GQ);                                                                                      \
-            PC_VERTEX(RD, 0, axA, ayA, cA, axB, ayB, cB)                                                                 \
-            PC_VERTEX(RD, 1, axB, ayB, cB, axA, ayA, cA)                                                                 \
-            PC_VERTEX(RD, 2, axA, ayA, cA, axB, ayB, cB)                                                                 \
-            PC_VERTEX(RD, 3, axB, ayB, cB, axA, ayA, cA)                                                                 \
-        }
-        if constexpr (TAB) {
-            int gq = gbeg;
-            for (; gq + 1 < gend; gq += 2) {
-                PC_GROUP(rdA, rdB, gq)
-                PC_GROUP(rdB, rdA, gq + 1)
+        for (int gq = gbeg; gq < gend; ++gq) {
+            f32x4 rd[2 * NP];
+            if constexpr (TAB) {
+#pragma unroll
+                for (int s = 0; s < 2 * NP; ++s) rd[s] = rrow[s][gq - gbeg];
             }
-            if (gq < gend) PC_GROUP(rdA, rdB, gq)
-        } else {  // nothing to prefetch: one group per trip (half the code; the 33-ray stand-alone kernel stays within 256 VGPRs)
-            for (int gq = gbeg; gq < gend; ++gq) PC_GROUP(rdA, rdB, gq)
+            const int k = 4 * gq;
+            PC_VERTEX(rd, 0, axA, ayA, cA, axB, ayB, cB)
+            PC_VERTEX(rd, 1, axB, ayB, cB, axA, ayA, cA)
+            PC_VERTEX(rd, 2, axA, ayA, cA, axB, ayB, cB)
+            PC_VERTEX(rd, 3, axB, ayB, cB, axA, ayA, cA)
         }
-#undef PC_GROUP
 #undef PC_VERTEX
 #pragma unroll
         for (int s = 0; s < RPL; ++s) best[s] = __uint_as_float(bb[s]);
