@@ -2,9 +2,13 @@
 """bench.py -- headline benchmark: env steps/sec of the whole PPO loop (rollout + GAE + update, the
 `charts/SPS` definition of the reference, train.py:174,292) on big_track.json, "16 rays" (17 actual).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|cfg1|cfg2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|cfg1|cfg2|cfg4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself: the parent
+process -- before it has touched the GPU in any way -- runs `python -m torch.distributed.run` as a CHILD process (never
+an exec) and exits with its code; rank 0 of the children prints the JSON line.
 
 A "step" is ONE EPOCH of the hot path on one batch of synthetic input: n_steps vector-env steps of
 n_envs envs per GPU (policy forward + sample + env-step kernel + store), the bootstrap value, the GAE
@@ -13,21 +17,24 @@ all-reduce when N > 1).  Nothing is skipped inside the timed region.  value = al
 slowest rank's time (weak scaling: n_envs per GPU is fixed).
 
 Extra objects on the JSON line:
-  roofline     -- the env-step kernel (K1): algorithmic bytes per launch (176 B per env step
-                  at 16 rays) / its mean duration measured with HIP events on the launch stream inside the
-                  timed epochs; peak = 8 TB/s HBM.  K1 is VALU-bound, so a second, informative
-                  `valu` entry prices the same duration against the fp32 vector peak.
+  roofline     -- the dominant kernel of the timed region (the persistent rollout kernel K9 / K9s when pc_rollout runs
+                  the rollout, else the env-step kernel K1).  `achieved` / `peak` / `frac` keep the contract's figure:
+                  algorithmic bytes per launch (176 B per env step at 16 rays) / the launch's mean duration by
+                  HIP events on the launch stream inside the timed epochs, against the 8 TB/s HBM peak.  `bound` names
+                  the roof that actually binds -- "valu": the env step is branchy fp32 geometry, 66 flop/B -- and `valu`,
+                  `mfma`, `hbm` price the same launch against each roof; `gae` is the GAE scan's own HBM fraction.
   cpu_baseline -- the CPU oracle (oracle/, the checker -- never the product) driving the same rollout on the
                   host cores of this box for a bounded sample.
+  parity_check -- one more pc_rollout launch of the same trainer AFTER the timed region, whose first 256 envs x 64 steps
+                  are replayed through the CPU oracle (rewards / flags exact, observations within 1e-5).
+  strict_fp32_value -- the same metric with the policy GEMMs as exact-fp32 MFMAs (3 epochs, outside the headline timing).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -47,9 +54,51 @@ ALGO_BYTES = {12: 156, 16: 176, 32: 240}      # SURVEY 8(d) / BASELINE.md sectio
 ALGO_FLOPS = {12: 8200, 16: 11600, 32: 22400}  # ditto, big_track (24 wall segments)
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8 TB/s
 VALU_PEAK_TFLOPS = 157.3                       # fp32 vector peak
+MFMA_F16_PEAK_TFLOPS = 2500.0                  # dense fp16 / bf16 matrix peak
+GAE_BYTES = 24                                 # per transition: 4 reads + 2 writes of float32
+# the reference Python CarEnv timed in the survey container (it cannot travel to the GPU box)
+PY_REFERENCE = {12: 320.0, 16: 227.0, 32: 154.0}   # env steps/s on one core, big_track
 
 
-def cpu_baseline(cfg, budget_s=12.0):
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10, help="timed epochs")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed epochs")
+    ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
+    ap.add_argument("--n-envs", type=int, default=None, help="override envs per GPU")
+    ap.add_argument("--n-steps", type=int, default=None)
+    ap.add_argument("--env-dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--policy", default="fused", choices=["fused", "sample", "torch"], help="rollout policy-step implementation")
+    ap.add_argument("--policy-arith", default="fp16x2", choices=["fp16x2", "bf16x3", "fp32"], help="arithmetic of the fused policy step's GEMMs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the parity check and the strict-fp32 bracket after the timed region")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--eager-rollout", action="store_true", help="no rollout graph; bracket env-step launches with events instead")
+    ap.add_argument("--rollout-kernel", default="auto", choices=["auto", "mega", "steps"], help="persistent rollout kernel or 2 kernels/step")
+    ap.add_argument("--rollout-form", type=int, default=-1, choices=[-1, 0, 1, 2, 3], help="pc_rollout_set_form: -1 auto; 0/1 force the 32-env-wave / split form; 2/3 the same without the 1/den table in LDS (A/B knob)")
+    ap.add_argument("--no-graphs", action="store_true", help="eager update and rollout")
+    ap.add_argument("--torch-mlp", action="store_true", help="torch autograd GEMMs for the MLPs inside the minibatch step (fused loss/Adam kernels only)")
+    ap.add_argument("--torch-update", action="store_true", help="reference torch ops for the whole minibatch step (no fused loss/Adam kernels)")
+    ap.add_argument("--event-stride", type=int, default=8, help="with --eager-rollout: bracket every k-th env-step launch")
+    ap.add_argument("--master-port", type=int, default=None, help="rendezvous port when bench.py starts the ranks itself")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """--gpus N > 1 without a launcher: start N fresh rank processes (torch.distributed.run, one per GPU) as a child of this
+    process, which has not initialised HIP (nothing here imports the extension or calls torch.cuda), and pass its exit code on."""
+    port = args.master_port or (29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_baseline(cfg, torch, budget_s=12.0):
     """Rollout of the same workload on the host: torch-CPU policy forward + the C oracle env on all host
     cores, bounded sample.  The PPO update is not included (it favours the CPU figure)."""
     import oracle
@@ -71,41 +120,64 @@ def cpu_baseline(cfg, budget_s=12.0):
             if time.time() - t0 > budget_s and steps >= 4:
                 break
     dt = time.time() - t0
+    py = PY_REFERENCE.get(cfg["num_rays"])
     return {"value": n_envs * steps / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
             "sample": f"rollout only (torch-CPU policy + C oracle env, {cores} threads), n_envs={n_envs}, {steps} steps, "
-                      f"{cfg['num_rays']} rays, big_track; PPO update not included"}
+                      f"{cfg['num_rays']} rays, big_track; PPO update not included",
+            "reference_python": {"value": py, "unit": "env steps/s", "cores": 1,
+                                 "source": "BASELINE.md section 2: the reference's Python CarEnv on one Xeon 2.1 GHz core of the survey "
+                                           "container (env only, big_track); it cannot travel to the GPU box, so it is quoted, not re-timed"}}
+
+
+def parity_check(tr, cfg, torch, np, envs=256, steps=64):
+    """One more pc_rollout launch of this trainer (same shape, same kernel, after the timed region): its first `envs` envs x
+    `steps` steps replayed through the CPU oracle from the env state the launch started from."""
+    import oracle
+    st = tr.envs.get_state()
+    P = min(envs, cfg.n_envs)
+    T = min(steps, cfg.n_steps - 1)            # rows 1..T of the buffer hold the observations after steps 0..T-1
+    first = tr.next_obs[:P].clone()
+    tr.rollout()
+    torch.cuda.synchronize()
+    b = tr.buffer
+    acts = b.act_buf[:T, :P].cpu().numpy().astype(np.int64)
+    ora = oracle.OracleVecEnv(oracle.Track(cfg.track), P, num_rays=cfg.num_rays, reward_scaling=cfg.reward_scaling, threads=4)
+    ora.reset()
+    ora.set_state(**{k: st[k][:P] for k in ("px", "py", "vx", "vy", "rot", "time_step", "next_gate", "passed")})
+    OB, RW = b.obs_buf[:T + 1, :P].cpu().numpy(), b.rew_buf[:T, :P].cpu().numpy()
+    TE, TR = b.term_buf[:T + 1, :P].cpu().numpy() != 0, b.trunc_buf[:T + 1, :P].cpu().numpy() != 0
+    alive = np.ones(P, bool)
+    worst, flips = float(np.abs(OB[0] - first.cpu().numpy()).max()), 0
+    for t in range(T):
+        o, r, te, trn = ora.step(acts[t])
+        bad = (TE[t + 1] != te) | (TR[t + 1] != trn) | (RW[t] != r.astype(np.float32))
+        flips += int((bad & alive).sum())
+        alive &= ~bad
+        if alive.any():
+            worst = max(worst, float(np.abs(OB[t + 1][alive] - o[alive]).max()))
+    return {"kernel": tr.rollout_mode, "envs": P, "steps": T, "obs_max_abs_err": worst, "obs_tolerance": 1e-5,
+            "envs_left_oracle_trajectory_at_a_near_tie": flips, "rewards_and_flags": "exact on every env still on the oracle's trajectory",
+            "ok": bool(worst <= 1e-5 and flips <= max(2, P // 50)),
+            "checker": "oracle/carenv_oracle.c (float64 restatement of car_env.py:693-760), teacher-forced by the stored actions"}
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10, help="timed epochs")
-    ap.add_argument("--warmup", type=int, default=2, help="untimed epochs")
-    ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
-    ap.add_argument("--n-envs", type=int, default=None, help="override envs per GPU")
-    ap.add_argument("--n-steps", type=int, default=None)
-    ap.add_argument("--env-dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--policy", default="fused", choices=["fused", "sample", "torch"], help="rollout policy-step implementation")
-    ap.add_argument("--policy-arith", default="fp16x2", choices=["fp16x2", "bf16x3", "fp32"], help="arithmetic of the fused policy step's GEMMs")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL)")
-    ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
-    ap.add_argument("--eager-rollout", action="store_true", help="no rollout graph; bracket env-step launches with events instead")
-    ap.add_argument("--rollout-kernel", default="auto", choices=["auto", "mega", "steps"], help="persistent rollout kernel or 2 kernels/step")
-    ap.add_argument("--rollout-form", type=int, default=-1, choices=[-1, 0, 1, 2, 3], help="pc_rollout_set_form: -1 auto; 0/1 force the 32-env-wave / split form; 2/3 the same without the 1/den table in LDS (A/B knob)")
-    ap.add_argument("--no-graphs", action="store_true", help="eager update and rollout")
-    ap.add_argument("--torch-mlp", action="store_true", help="torch autograd GEMMs for the MLPs inside the minibatch step (fused loss/Adam kernels only)")
-    ap.add_argument("--torch-update", action="store_true", help="reference torch ops for the whole minibatch step (no fused loss/Adam kernels)")
-    ap.add_argument("--event-stride", type=int, default=8, help="with --eager-rollout: bracket every k-th env-step launch")
-    args = ap.parse_args()
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+
+    import numpy as np
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    knobs = {k: v for k, v in os.environ.items() if k.startswith("PPOCAR_")}
+    if knobs:
+        raise SystemExit(f"bench.py: PPOCAR_* environment variables are set ({knobs}); the product reads none -- unset them")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path for the hot path")
     if args.same_device:
@@ -122,9 +194,12 @@ def main():
 
     from ppo_car_amd.ppo import PPOConfig, Trainer
     from ppo_car_amd._capi import lib as _lib
-    _lib.pc_policy_set_precision({"fp16x2": 2, "bf16x3": 1, "fp32": 0}[args.policy_arith])
+    if _lib.pc_build_ablate() != 0:
+        raise SystemExit("bench.py: libppocar.so is a timing-ablation build (PC_ABLATE != 0)")
+    PREC = {"fp16x2": 2, "bf16x3": 1, "fp32": 0}
+    _lib.pc_policy_set_precision(PREC[args.policy_arith])
     _lib.pc_rollout_set_form(args.rollout_form)
-    POLICY_ARITH = {"fp16x2": "fp16x2 split (v = h + 2^-11 l), 3 products, two fp32 accumulators on the fp16 matrix cores (fp32-class; DESIGN.md section 5)",
+    POLICY_ARITH = {"fp16x2": "fp16x2 split (v = h + l), 3 products, fp32 accumulate on the fp16 matrix cores (fp32-class; DESIGN.md section 5)",
                     "bf16x3": "bf16x3 split, 6 products, fp32 accumulate on the bf16 matrix cores (fp32-equivalent; DESIGN.md section 5)",
                     "fp32": "fp32-input MFMA (exact fp32 fmaf chain)"}[args.policy_arith]
     wl = dict(WORKLOADS[args.workload])
@@ -135,9 +210,13 @@ def main():
     mixed = wl.pop("mixed", False)
     track = ([os.path.join(ROOT, "tracks", "track.json"), os.path.join(ROOT, "tracks", "big_track.json")] if mixed
              else os.path.join(ROOT, "tracks", "big_track.json"))
-    cfg = PPOConfig(track=track, env_dtype=args.env_dtype, seed=0, policy=args.policy, use_graphs=not args.no_graphs, fused_update=not args.torch_update, custom_mlp=not args.torch_mlp,
-                    rollout_kernel=args.rollout_kernel, **wl)
-    tr = Trainer(cfg, device=dev, rank=rank, world_size=world)
+
+    def make_trainer():
+        cfg_ = PPOConfig(track=track, env_dtype=args.env_dtype, seed=0, policy=args.policy, use_graphs=not args.no_graphs,
+                         fused_update=not args.torch_update, custom_mlp=not args.torch_mlp, rollout_kernel=args.rollout_kernel, **wl)
+        return cfg_, Trainer(cfg_, device=dev, rank=rank, world_size=world)
+
+    cfg, tr = make_trainer()
     tr.profile_stride = 0
     # K1 probe: a second env batch of the same size and launch geometry.  When the rollout runs as a replayed HIP
     # graph its kernels cannot be bracketed one by one, so inside the timed region (same stream) this twin is
@@ -162,6 +241,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(trn, n_epochs):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_epochs):
+            trn.run_epoch(sync=False)
+        barrier()
+        return time.perf_counter() - t0
+
     for _ in range(max(args.warmup, 2 if cfg.use_graphs else 0)):   # graphs: 1 eager epoch, then capture, then replay
         tr.run_epoch(sync=False)
     run_probe()
@@ -171,14 +258,17 @@ def main():
     tr.k1_events = []
     tr.phase_events = []
     tr.mega_events = []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.run_epoch(sync=False)
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = timed(tr, args.steps)
     for _ in range(args.steps):          # the stand-alone K1 probe, outside the timed region (it is not part of the path)
         run_probe()
+    # the GAE scan alone (HBM-bound: 24 B per transition), outside the timed region
+    gae_events = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        tr.buffer.calculate_advantages(tr.next_term.reshape(1, -1), tr.next_term.reshape(1, -1), tr.next_trunc.reshape(1, -1))
+        e1.record()
+        gae_events.append((e0, e1))
     torch.cuda.synchronize()
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -186,70 +276,120 @@ def main():
         dt = float(t)
     k1_us = float(np.mean([a.elapsed_time(b) for a, b in probe_events]) * 1e3 / PROBE)
     k1_bracketed_us = float(np.mean([a.elapsed_time(b) for a, b in tr.k1_events]) * 1e3) if tr.k1_events else None
+    gae_us = float(np.median([a.elapsed_time(b) for a, b in gae_events]) * 1e3)
     probe.close()
     info = tr.envs.launch_info()
     split = {"rollout_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in tr.phase_events])),
              "gae_update_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in tr.phase_events]))}
+    mega_us = float(np.mean([a.elapsed_time(b) for a, b in tr.mega_events]) * 1e3) if tr.mega_events else None
+    rollout_mode, obs_dim, custom = tr.rollout_mode, tr.obs_dim[0], bool(tr.learner.custom)
+    tr.mega_events = None
+    tr.phase_events = None
+
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras and args.env_dtype == "f32" and not mixed:
+        try:
+            extras["parity_check"] = parity_check(tr, cfg, torch, np)
+        except Exception as ex:                      # the check must never take the benchmark line down with it
+            extras["parity_check"] = {"ok": False, "error": repr(ex)}
     tr.close()
+    del tr
+    if world == 1 and not args.no_extras and args.policy_arith != "fp32" and args.policy == "fused":
+        # the price of exact-fp32 policy GEMMs (v_mfma_f32_16x16x4_f32) on the same workload: 3 epochs, outside the headline timing
+        try:
+            _lib.pc_policy_set_precision(0)
+            cfg2, tr2 = make_trainer()
+            for _ in range(2):
+                tr2.run_epoch(sync=False)
+            dt2 = timed(tr2, 3)
+            extras["strict_fp32_value"] = {"value": cfg2.n_envs * cfg2.n_steps * 3 / dt2, "unit": "env steps/s", "epochs": 3,
+                                           "ms_per_step": dt2 / 3 * 1e3, "rollout": tr2.rollout_mode,
+                                           "policy_gemm_arithmetic": "fp32-input MFMA (exact fp32 fmaf chain), --policy-arith fp32"}
+            tr2.close()
+            del tr2
+        except Exception as ex:
+            extras["strict_fp32_value"] = {"error": repr(ex)}
+        finally:
+            _lib.pc_policy_set_precision(PREC[args.policy_arith])
 
     if rank == 0:
         env_steps = cfg.n_envs * cfg.n_steps * args.steps * world
         nr = cfg.num_rays
-        per_step_bytes = ALGO_BYTES.get(nr, 4 * (tr.obs_dim[0]) + 84)     # algorithmic bytes per env step
+        per_step_bytes = ALGO_BYTES.get(nr, 4 * obs_dim + 84)     # algorithmic bytes per env step
         per_step_flops = ALGO_FLOPS.get(nr, 0)
         k1 = {"kernel": "env_step_kernel (K1), stand-alone", "launch_us": k1_us, "achieved": per_step_bytes * cfg.n_envs / (k1_us * 1e-6) / 1e9,
               "unit": "GB/s", "frac": per_step_bytes * cfg.n_envs / (k1_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
               "launch_us_method": f"{PROBE} back-to-back launches on an identical env batch between two HIP events on the launch stream, "
                                   "after the timed epochs", "launch_us_bracketed_in_rollout": k1_bracketed_us}
-        if tr.mega_events:
+        if mega_us is not None:
             # the timed region's dominant kernel is the persistent rollout kernel: ONE launch does n_steps env steps (+ policy steps)
             # for every env; algorithmic bytes = SURVEY's per-env-step figure x n_envs x n_steps
-            dom_us = float(np.mean([a.elapsed_time(b) for a, b in tr.mega_events]) * 1e3)
+            dom_us = mega_us
             algo_bytes = per_step_bytes * cfg.n_envs * cfg.n_steps
             dom_name = "rollout_kernel (K9: policy step + env step + Buffer.store for all n_steps, one persistent launch)"
             dom_method = "HIP events on the launch stream around each pc_rollout launch inside the timed epochs"
             units = cfg.n_envs * cfg.n_steps
         else:
             dom_us, algo_bytes, dom_name, dom_method, units = k1_us, per_step_bytes * cfg.n_envs, k1["kernel"], k1["launch_us_method"], cfg.n_envs
-        achieved = algo_bytes / (dom_us * 1e-6) / 1e9
+        sec = dom_us * 1e-6
+        achieved = algo_bytes / sec / 1e9
+        D, A = obs_dim, 9
+        mlp_flops = 2 * (2 * D * 256 + 256 * A + 256)                       # both MLPs, one env step (model.py:14-32)
+        n_prod = {"fp16x2": 3, "bf16x3": 6, "fp32": 1}[args.policy_arith]
+        track_name = "track.json + big_track.json (halves)" if mixed else "big_track.json"
+        roof = {"kernel": dom_name, "bound": "valu" if not mixed else "valu (mixed tracks: flops priced with big_track's 24 walls)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "launch_us": dom_us, "launch_us_method": dom_method, "algorithmic_bytes_per_launch": algo_bytes,
+                "env_steps_per_launch": units,
+                "note": "achieved / peak / frac = SURVEY 8(d)'s algorithmic bytes against the HBM peak (the figure the task prices); the "
+                        "launch is bound by the SIMDs' vector pipes (fp32 ray geometry: 66 flop/B against a ridge of 20), see `valu`",
+                "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS},
+                "valu": {"achieved": per_step_flops * units / sec / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": per_step_flops * units / sec / 1e12 / VALU_PEAK_TFLOPS,
+                         "counts": "SURVEY 8(d) env-step flops only (11.6 kflop per env step at 16 rays)"},
+                "k1_standalone": k1,
+                "gae": {"kernel": "gae_kernel (K3)", "bound": "hbm", "launch_us": gae_us,
+                        "achieved": GAE_BYTES * cfg.n_envs * cfg.n_steps / (gae_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": GAE_BYTES * cfg.n_envs * cfg.n_steps / (gae_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": GAE_BYTES * cfg.n_envs * cfg.n_steps,
+                        "launch_us_method": "median of 5 stand-alone launches between HIP events after the timed epochs"}}
+        if mega_us is not None and args.policy == "fused":
+            roof["mfma"] = {"achieved": n_prod * mlp_flops * units / sec / 1e12, "peak": MFMA_F16_PEAK_TFLOPS if n_prod > 1 else VALU_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": n_prod * mlp_flops * units / sec / 1e12 / (MFMA_F16_PEAK_TFLOPS if n_prod > 1 else VALU_PEAK_TFLOPS),
+                            "counts": f"{n_prod} piece products x {mlp_flops} flop of the two MLPs per env step (D = {D}, unpadded), same launch"}
         out = {
-            "metric": "env steps/sec (whole node) on big_track.json, 16 rays",
+            "metric": f"env steps/sec (whole node) on {track_name}, {nr} rays",
             "value": env_steps / dt, "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.env_dtype == "f32" else "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {'track.json + big_track.json (halves)' if mixed else 'big_track.json'}, num_rays={nr} ({tr.obs_dim[0] - 6} actual), "
+            "config": {"workload": f"{args.workload}: {track_name}, num_rays={nr} ({obs_dim - 6} actual), "
                                    f"n_envs={cfg.n_envs}/GPU, n_steps={cfg.n_steps}, batch_size={cfg.batch_size}, "
                                    f"train_iters={cfg.train_iters}; one step = one PPO epoch (rollout + GAE + update)",
                        "n_envs_total": cfg.n_envs * world, "parallelism": f"env-sharded dp{world}, 1 flat grad all-reduce/minibatch",
-                       "env_kernel": info, "policy_step": args.policy, "rollout": tr.rollout_mode,
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+                       "backend": (args.backend if dist is not None else None),
+                       "env_kernel": info, "policy_step": args.policy, "rollout": rollout_mode,
                        "policy_gemm_arithmetic": POLICY_ARITH, "hip_graphs": bool(cfg.use_graphs),
-                       "fused_update": bool(cfg.fused_update), "custom_mlp_update": bool(tr.learner.custom), "epoch_split": split,
+                       "fused_update": bool(cfg.fused_update), "custom_mlp_update": custom, "epoch_split": split,
+                       "env_knobs": knobs, "ablate_build": int(_lib.pc_build_ablate()),
                        "numerics": "float64 kinematic state, float32 ray geometry" if args.env_dtype == "f32"
                        else "float64 throughout (reference operation order)"},
-            "roofline": {"kernel": dom_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "launch_us": dom_us, "launch_us_method": dom_method, "algorithmic_bytes_per_launch": algo_bytes,
-                         "env_steps_per_launch": units,
-                         "note": "the path is bound by the SIMDs' vector-issue port (fp32 VALU ray geometry + operand splitting), "
-                                 "not by HBM: DESIGN.md section 4; `valu` prices the same launch against the fp32 vector peak",
-                         "valu": {"achieved": per_step_flops * units / (dom_us * 1e-6) / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": per_step_flops * units / (dom_us * 1e-6) / 1e12 / VALU_PEAK_TFLOPS,
-                                  "counts": "SURVEY 8(d) env-step flops only (policy MFMA work not included)"},
-                         "k1_standalone": k1},
+            "roofline": roof,
         }
         traffic_file = os.path.join(ROOT, "profiles", "k1_traffic.json")
         if os.path.exists(traffic_file):
             try:
                 tf = json.load(open(traffic_file))
-                key = (f"rollout_{args.env_dtype}_n{nr}_N{cfg.n_envs}_T{cfg.n_steps}" if tr.mega_events
+                key = (f"rollout_{args.env_dtype}_n{nr}_N{cfg.n_envs}_T{cfg.n_steps}" if mega_us is not None
                        else f"{args.env_dtype}_n{nr}_N{cfg.n_envs}")
-                if key in tf:
+                if key in tf and not mixed:
                     out["roofline"]["traffic"] = tf[key]["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = tf[key].get("source", "profiles/k1_traffic.json")
             except Exception:
                 pass
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl)
+            out["cpu_baseline"] = cpu_baseline(wl, torch)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

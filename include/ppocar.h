@@ -95,6 +95,11 @@ int pc_env_reset(pc_env* e, float* obs, void* stream);
 int pc_env_step(pc_env* e, const int64_t* actions, double reward_scale, float* obs, float* reward,
                 float* terminated, float* truncated, int32_t* gates_passed, float* final_obs, void* stream);
 
+/* CarEnv._get_info (car_env.py:599-603) of every env's CURRENT state: info["gates_passed"] and info["time_passed"]
+ * as the vector env's `infos` hold them after a step (an env auto-reset in that step reports its reset state, 0 / 0;
+ * the finished episode's count is pc_env_step's `gates_passed`).  [N] int32 device arrays, either may be NULL. */
+int pc_env_info(pc_env* e, int32_t* gates_passed, int32_t* time_passed, void* stream);
+
 /* Teacher forcing for parity tests: copy the env state from / to HOST arrays of length n_envs
  * (any pointer may be NULL).  `rot` is the heading in degrees.  Synchronous.
  * F32 handles store the heading as a count of 5-degree turns from the track's start angle
@@ -178,6 +183,9 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
  * reading the track's 1/den table from LDS (what happens anyway when the table does not fit).  All are bit-identical
  * to the per-step kernels.  Tuning / test knob. */
 int pc_rollout_set_form(int form);
+/* Test / tuning knob of pc_rollout's big form: envs per workgroup, 0 = automatic (128 up to 32768 envs, else 256), or
+ * 128 / 256 to force one -- so that the 256-env variant the benchmark size takes can be checked at small batches. */
+int pc_rollout_set_epw(int envs_per_workgroup);
 
 /* ---- the non-GEMM work of one PPO minibatch step (train.py:230-261), three launches:
  * pc_ppo_gather : traj_*[batch_indices] (train.py:233-238,249): idx [B] int64 into the flattened trajectories
@@ -233,6 +241,10 @@ int pc_ppo_minibatch_prepared(int device, const float* prepared_mb, int B, int D
 const char* pc_strerror(int code);
 /* Last HIP error string seen by this thread (diagnostics for PC_ERR_HIP). */
 const char* pc_last_hip_error(void);
+/* 0 in every shipped build.  Non-zero only in the separate developer library `make ablate` builds
+ * (libppocar_ablate.so, -DPC_ABLATE=n: timing ablations that skip parts of the rollout kernel); bench.py and the
+ * tests refuse to run on such a build.  There is no run-time switch that makes a kernel do less work. */
+int pc_build_ablate(void);
 /* Kernel-launch geometry of the last pc_env_step on this handle (lanes per env, rays per lane,
  * blocks, threads) -- for bench.py / DESIGN.md; any pointer may be NULL. */
 int pc_env_launch_info(const pc_env* e, int* lanes_per_env, int* rays_per_lane, int* blocks, int* threads);

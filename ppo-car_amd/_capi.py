@@ -66,6 +66,8 @@ _sig = {
     "pc_env_num_envs": (_i64, [_vp]),
     "pc_env_reset": (_i, [_vp, _vp, _vp]),
     "pc_env_step": (_i, [_vp, _vp, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pc_env_info": (_i, [_vp, _vp, _vp, _vp]),
+    "pc_build_ablate": (_i, []),
     "pc_env_get_state": (_i, [_vp] * 9),
     "pc_env_set_state": (_i, [_vp] * 9),
     "pc_gae": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _i64, _i64, _vp, _vp, _vp]),
@@ -78,6 +80,7 @@ _sig = {
     "pc_policy_act": (_i, [_i, _vp, _i64, _i, _i, _i, _vp, C.c_uint64, C.c_uint64, _vp] + [_vp] * 5 + [_vp]),
     "pc_rollout": (_i, [_vp, _vp, _i, _i64, _d, C.c_uint64, C.c_uint64, _vp] + [_vp] * 10 + [_vp]),
     "pc_rollout_set_form": (_i, [_i]),
+    "pc_rollout_set_epw": (_i, [_i]),
     "pc_ppo_gather": (_i, [_i, _vp, _i, _i] + [_vp] * 10 + [_vp]),
     "pc_ppo_loss": (_i, [_i] + [_vp] * 6 + [_i, _i, _d, _d, _d, _vp, _vp, _vp, _vp]),
     "pc_clip_adam": (_i, [_i] + [_vp] * 6 + [_i64, _d, _d, _d, _d, _d, _vp]),
@@ -96,6 +99,10 @@ for _name, (_res, _args) in _sig.items():
     _f.restype, _f.argtypes = _res, _args
 
 EXPORTS = tuple(_sig)
+
+if lib.pc_build_ablate() != 0:
+    raise ImportError(f"{_LIB_PATH} is a developer timing-ablation build (PC_ABLATE={lib.pc_build_ablate()}): "
+                      "its rollout kernel skips work. Rebuild the product library with `make -C ppo-car_amd/csrc`.")
 
 
 def check(code, what):

@@ -721,6 +721,18 @@ __global__ __launch_bounds__(256) void env_reset_kernel(const EnvParams<T> p, fl
     }
 }
 
+// CarEnv._get_info (car_env.py:599-603) of every env's CURRENT state: what the vector env's `infos` holds after a step
+// (for an env that was auto-reset in that step: the reset state's counters, 0 / 0 -- gymnasium 0.29.1 moves the
+// finished episode's info to "final_info"; its gates_passed is pc_env_step's `gates_passed` output).
+__global__ __launch_bounds__(256) void env_info_kernel(const int4* __restrict__ iv, const int64_t N, int32_t* __restrict__ gates_passed,
+                                                       int32_t* __restrict__ time_passed) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const int4 s = iv[e];
+    if (gates_passed) gates_passed[e] = s.w;
+    if (time_passed) time_passed[e] = s.y;
+}
+
 // ------------------------------------------------------------------------------------------
 // K3: GAE(lambda), buffer.py:36-64.  One lane per env, serial in t (the recurrence), rows
 // coalesced across envs.  Operation order = torch's, one float32 rounding per op (no FMA):
@@ -1452,6 +1464,12 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
 }
 
 // ------------------------------------------------------------------------------------------
+// Developer-only timing ablation of the persistent rollout kernels: a SEPARATE build (make ABLATE=n -> libppocar_ablate.so,
+// never loaded by the product or the tests) compiled with -DPC_ABLATE=n skips the policy MFMAs (1), the env step (2) or
+// the draw (4).  The shipped library is built with PC_ABLATE = 0: there is no run-time switch that makes a kernel do less.
+#ifndef PC_ABLATE
+#define PC_ABLATE 0
+#endif
 // K9: the whole rollout (train.py:173-195) as ONE persistent launch.
 // A workgroup (8 waves) owns 256 envs for all T steps: the policy weights stay in LDS, the env state in
 // registers, the observation of step t passes from the env step to the policy step through LDS; per step an
@@ -1506,7 +1524,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                                                       float* __restrict__ term_buf, float* __restrict__ trunc_buf,
                                                       float* __restrict__ logprob_buf, float* __restrict__ next_obs,
                                                       float* __restrict__ next_term, float* __restrict__ next_trunc,
-                                                      const int rden_lds, const int epw, const int dbg) {
+                                                      const int rden_lds, const int epw) {
+    constexpr int dbg = PC_ABLATE;  // 0 in the product build (see PC_ABLATE)
     constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, LDX = 4 * KS + 1, ET = 2;
     constexpr int NG = pol_ng(KS), KB = pol_kb(KS);
     constexpr int IMG = PREC ? polx_image_dwords(PREC, NG) : pol_image_padded(KS);
@@ -1674,7 +1693,8 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                                                             float* __restrict__ term_buf, float* __restrict__ trunc_buf,
                                                             float* __restrict__ logprob_buf, float* __restrict__ next_obs,
                                                             float* __restrict__ next_term, float* __restrict__ next_trunc,
-                                                            const int rden_lds, const int dbg) {
+                                                            const int rden_lds) {
+    constexpr int dbg = PC_ABLATE;  // 0 in the product build (see PC_ABLATE)
     constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, LDX = 4 * KS + 1, ET = 2;
     constexpr int NG = pol_ng(KS), KB = pol_kb(KS);
     constexpr int IMG = PREC ? polx_image_dwords(PREC, NG) : pol_image_padded(KS);
@@ -2868,6 +2888,18 @@ int pc_env_step(pc_env* e, const int64_t* actions, double reward_scale, float* o
     return PC_OK;
 }
 
+int pc_env_info(pc_env* e, int32_t* gates_passed, int32_t* time_passed, void* stream) {
+    if (!e) return PC_ERR_INVALID_ARG;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    hipLaunchKernelGGL(env_info_kernel, dim3((unsigned)((e->N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, e->iv, e->N, gates_passed,
+                       time_passed);
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_build_ablate(void) { return PC_ABLATE; }
+
 int pc_env_get_state(pc_env* e, double* px, double* py, double* vx, double* vy, double* rot, int64_t* time_step,
                      int64_t* next_gate, int64_t* passed) {
     if (!e) return PC_ERR_INVALID_ARG;
@@ -2971,6 +3003,7 @@ static int g_rollout_form = -1;       // pc_rollout: -1 auto, 0 = 256 envs per w
 // bit-identical.
 #define PC_SPLIT_MAX_ENVS 16384
 static int64_t g_rollout_epw128_max = 32768;  // big form at or below this many envs: 128 envs (4 waves) per workgroup
+static int g_rollout_epw_override = 0;  // pc_rollout_set_epw: 0 = automatic, 128 / 256 = force (test knob)
 static int g_rollout_rden = 1;        // pc_rollout: stage the 1/den table in LDS when it fits (0: never; test / tuning knob)
 static int g_policy_precision = 2;    // 0 = fp32-input MFMA; split forms on the 16-bit matrix cores (need D <= 24, A <= 9): 1 = bf16 x 3, 2 = fp16 x 2
 
@@ -2978,6 +3011,12 @@ int pc_rollout_set_form(int form) {
     if (form < -1 || form > 3) return PC_ERR_INVALID_ARG;
     g_rollout_rden = form >= 2 ? 0 : 1;              // forms 2 / 3 = forms 0 / 1 without the LDS 1/den table
     g_rollout_form = form >= 2 ? form - 2 : form;
+    return PC_OK;
+}
+
+int pc_rollout_set_epw(int envs_per_workgroup) {
+    if (envs_per_workgroup != 0 && envs_per_workgroup != 128 && envs_per_workgroup != 256) return PC_ERR_INVALID_ARG;
+    g_rollout_epw_override = envs_per_workgroup;
     return PC_OK;
 }
 
@@ -3150,13 +3189,12 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     if (g_rollout_rden == 0 || e->track_id || lds + (size_t)rden_lds * sizeof(float) > 160 * 1024) rden_lds = 0;
     lds += (size_t)rden_lds * sizeof(float);
     const int rpl = small ? (e->R + 3) / 4 : (e->R + 1) / 2;  // 4 (x 4 sweep parts) or 2 lanes per env
-    const int epw = (!small && e->N <= g_rollout_epw128_max) ? 128 : 256;   // big form: envs per workgroup
+    const int epw = g_rollout_epw_override ? g_rollout_epw_override
+                                           : ((!small && e->N <= g_rollout_epw128_max) ? 128 : 256);   // big form: envs per workgroup
     const int blocks = (int)(small ? (e->N + 31) / 32 : (e->N + epw - 1) / epw);
     hipStream_t st = (hipStream_t)stream;
     EnvParams<float> prm = e->params<float>();
     prm.lg = small ? 2 : 1;
-    const char* dbg_env = getenv("PPOCAR_ROLLOUT_ABLATE");  // developer timing ablation: 1 = skip policy MFMAs, 2 = skip env step, 4 = skip sampling
-    const int dbg = dbg_env ? atoi(dbg_env) : 0;
 #define PC_ROLL(KSV, RPLV, PRC)                                                                                          \
     do {                                                                                                                 \
         static bool attr_set[64] = {false};                                                                              \
@@ -3166,7 +3204,7 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
         }                                                                                                                \
         hipLaunchKernelGGL((rollout_kernel<KSV, RPLV, PRC>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, seed, \
                            offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs,  \
-                           next_term, next_trunc, rden_lds, epw, dbg);                                                             \
+                           next_term, next_trunc, rden_lds, epw);                                                                  \
     } while (0)
 #define PC_ROLLS(KSV, RPLV, PRC)                                                                                         \
     do {                                                                                                                 \
@@ -3177,7 +3215,7 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
         }                                                                                                                \
         hipLaunchKernelGGL((rollout_small_kernel<KSV, RPLV, PRC>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, \
                            seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, \
-                           next_term, next_trunc, rden_lds, dbg);                                                                     \
+                           next_term, next_trunc, rden_lds);                                                                          \
     } while (0)
     if (small) {
         if (KS == 5 && rpl == 3) { if (prec == 2) PC_ROLLS(5, 3, 2); else if (prec) PC_ROLLS(5, 3, 1); else PC_ROLLS(5, 3, 0); }        // 12 rays

@@ -51,6 +51,17 @@ def ray_count(num_rays):
     return r
 
 
+class _Space:
+    """The two attributes of gymnasium's spaces that train.py reads (train.py:141-142): `.shape` of the Box observation
+    space (car_env.py:522-524) and `.n` of Discrete(9) (car_env.py:525)."""
+
+    def __init__(self, shape=None, n=None, dtype=np.float32):
+        self.shape, self.n, self.dtype = shape, n, dtype
+
+    def __repr__(self):
+        return f"Discrete({self.n})" if self.n is not None else f"Box(-inf, inf, {self.shape}, float32)"
+
+
 def _device_index(device):
     device = torch.device(device)
     if device.type != "cuda":
@@ -101,8 +112,12 @@ class VecCarEnv:
         self._h, self._tracks = h, tr
         self.obs_dim = lib.pc_env_obs_dim(h)
         self.act_dim = lib.pc_env_num_actions(h)
-        # what train.py:141-142 reads
-        self.single_observation_space_shape = (self.obs_dim,)
+        # what train.py:141-142 reads: envs.single_observation_space.shape, envs.single_action_space.n
+        self.single_observation_space = _Space(shape=(self.obs_dim,))
+        self.single_action_space = _Space(n=self.act_dim, dtype=np.int64)
+        self.observation_space = _Space(shape=(self.num_envs, self.obs_dim))
+        self.action_space = _Space(shape=(self.num_envs,), dtype=np.int64)
+        self.single_observation_space_shape = (self.obs_dim,)     # (round-1 spellings, kept)
         self.single_action_space_n = self.act_dim
 
     def _stream(self):
@@ -131,9 +146,18 @@ class VecCarEnv:
               "pc_env_reset")
         return obs, {}
 
-    def step(self, actions, out=None, gates_passed=None, final_obs=None):
+    def infos(self):
+        """CarEnv._get_info() (car_env.py:599-603) of every env's current state, as device tensors."""
+        gp, tp = self._new(self.num_envs, dtype=torch.int32), self._new(self.num_envs, dtype=torch.int32)
+        check(lib.pc_env_info(self._h, gp.data_ptr(), tp.data_ptr(), self._stream()), "pc_env_info")
+        return {"gates_passed": gp, "time_passed": tp}
+
+    def step(self, actions, out=None, gates_passed=None, final_obs=None, info=False):
         """out = (obs, rewards, terminateds, truncateds) preallocated tensors (e.g. rows of the rollout
-        buffer) or None to allocate.  Flags are float32 0/1, what train.py:191-192 builds."""
+        buffer) or None to allocate.  Flags are float32 0/1, what train.py:191-192 builds.
+        info=True fills `infos` with CarEnv._get_info()'s keys (car_env.py:599-603) as device tensors:
+        "gates_passed" / "time_passed" of every env's current state (0 / 0 for an env auto-reset in this step, whose
+        finished episode's count is "final_gates_passed" -- gymnasium's final_info["gates_passed"])."""
         N, D = self.num_envs, self.obs_dim
         if actions.dtype != torch.int64 or not actions.is_cuda:
             actions = actions.to(device=self.device, dtype=torch.int64)
@@ -141,13 +165,20 @@ class VecCarEnv:
         if out is None:
             out = (self._new(N, D), self._new(N), self._new(N), self._new(N))
         obs, rew, term, trunc = out
+        if info and gates_passed is None:
+            gates_passed = self._new(N, dtype=torch.int32)
         check(lib.pc_env_step(self._h, self._ptr(actions, torch.int64, N, "actions"), self.reward_scaling,
                               self._ptr(obs, torch.float32, N * D, "obs"), self._ptr(rew, torch.float32, N, "rewards"),
                               self._ptr(term, torch.float32, N, "terminateds"), self._ptr(trunc, torch.float32, N, "truncateds"),
                               self._ptr(gates_passed, torch.int32, N, "gates_passed"),
                               self._ptr(final_obs, torch.float32, N * D, "final_obs"), self._stream()), "pc_env_step")
         infos = {}
-        if gates_passed is not None:
+        if info:
+            gp, tp = self._new(N, dtype=torch.int32), self._new(N, dtype=torch.int32)
+            check(lib.pc_env_info(self._h, gp.data_ptr(), tp.data_ptr(), self._stream()), "pc_env_info")
+            infos["gates_passed"], infos["time_passed"] = gp, tp
+            infos["final_gates_passed"] = gates_passed
+        elif gates_passed is not None:
             infos["gates_passed"] = gates_passed
         if final_obs is not None:
             infos["final_observation"] = final_obs

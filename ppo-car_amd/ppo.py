@@ -63,6 +63,10 @@ class PPOConfig:
                                            # kernels per step (HIP-graph replayed); "auto": mega whenever pc_rollout supports the shape
     policy: str = "fused"                  # rollout policy step: "fused" (one MFMA kernel: MLPs + draw),
                                            # "sample" (torch GEMMs + sampling kernel), "torch" (reference ops)
+    capture_collectives: bool = True       # multi-rank + backend nccl (RCCL): the per-minibatch gradient all-reduce is captured INSIDE
+                                           # the epoch's update graph (one replay per epoch, as on a single rank); False / gloo: the
+                                           # minibatch steps are enqueued eagerly around an eager all-reduce
+    force_collective: bool = False         # test knob: take the multi-rank update path (all-reduce + pc_clip_adam) on ONE rank
 
 
 def flatten_parameters(module):
@@ -129,6 +133,8 @@ class PPOLearner:
             import torch.distributed as dist
             dist.broadcast(self.flat_param, src=0)       # every rank starts from rank 0's parameters
         self.exchange = GradExchange(self.flat_grad, world_size)
+        self.collective = world_size > 1 or bool(cfg.force_collective)     # the update has an exchange step
+        self._capture_failed = False
         self.graphs = bool(cfg.use_graphs) and self.device.type == "cuda"
         self.fused = bool(cfg.fused_update) and self.device.type == "cuda" and 2 <= cfg.batch_size <= 1024
         if self.fused:    # Adam state of the fused clip+Adam kernel (pc_clip_adam): flat, on the device
@@ -206,7 +212,7 @@ class PPOLearner:
     def custom_minibatch_step(self, idx, obs, act, logprob, adv, ret):
         """pc_ppo_minibatch: gather + forward + loss + backward (+ clip + Adam when single-rank) with no library GEMM."""
         cfg, a1, a2 = self.cfg, self.agent.actor[0], self.agent.actor[2]
-        single = self.world_size == 1
+        single = not self.collective
         check(lib.pc_ppo_minibatch(self._dev_index(), idx.data_ptr(), cfg.batch_size, a1.in_features, a1.out_features, a2.out_features,
                                    obs.data_ptr(), act.data_ptr(), logprob.data_ptr(), adv.data_ptr(), ret.data_ptr(),
                                    self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
@@ -243,7 +249,7 @@ class PPOLearner:
     def prepared_minibatch_step(self, m, pf):
         """pc_ppo_minibatch_prepared on block m of the prepared epoch (+ all-reduce and clip/Adam when multi-rank)."""
         cfg, a1, a2 = self.cfg, self.agent.actor[0], self.agent.actor[2]
-        single = self.world_size == 1
+        single = not self.collective
         check(lib.pc_ppo_minibatch_prepared(self._dev_index(), self._prep.data_ptr() + 4 * m * pf, cfg.batch_size, a1.in_features,
                                             a1.out_features, a2.out_features, self.flat_param.data_ptr(), self.flat_grad.data_ptr(),
                                             self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(),
@@ -274,6 +280,43 @@ class PPOLearner:
             for it in range(cfg.train_iters):
                 for mb in range(n_mb):
                     self.custom_minibatch_step(idx_all[it, mb * B:(mb + 1) * B], *args)
+
+    def _can_capture_update(self):
+        """The whole epoch's update as ONE graph: always on a single rank; with an exchange step only when the all-reduce
+        itself can be captured -- backend nccl (RCCL records its kernels into the capturing stream), not gloo."""
+        if not self.collective:
+            return True
+        if self._capture_failed or not self.cfg.capture_collectives:
+            return False
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+
+    def _capture_epoch(self, idx_all, n_mb, args):
+        """Capture _epoch_body.  With an exchange step the graph contains 80 x (K10, K11, RCCL all-reduce, clip+Adam): a replay
+        then costs the host one call, as on a single rank.  If this RCCL / driver refuses to capture a collective, say so once
+        and fall back to eager enqueueing (identical results)."""
+        g = torch.cuda.CUDAGraph()
+        if not self.collective:
+            with torch.cuda.graph(g):
+                self._epoch_body(idx_all, n_mb, args)
+            return g
+        import torch.distributed as dist
+        saved = [t.clone() for t in (self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.metrics)]
+        try:
+            dist.all_reduce(torch.zeros(1, device=self.device))       # the communicator exists before the capture starts
+            torch.cuda.synchronize(self.device)
+            with torch.cuda.graph(g):
+                self._epoch_body(idx_all, n_mb, args)
+            return g
+        except Exception as ex:      # noqa: BLE001 -- whatever the runtime raises, the eager path is the answer
+            import sys
+            print(f"[ppo_car_amd] rank {self.rank}: capturing the gradient all-reduce into the update graph failed ({ex!r}); "
+                  "running the update eagerly", file=sys.stderr, flush=True)
+            self._capture_failed = True
+            torch.cuda.synchronize(self.device)
+            for t, v in zip((self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.metrics), saved):
+                t.copy_(v)           # (a capture executes nothing; restored anyway in case a partial eager launch slipped through)
+            return None
 
     def draw_indices(self, M):
         """train.py:225-230: per train iter a fresh shuffle of all M = n_steps*n_envs indices, of which only
@@ -320,8 +363,6 @@ class PPOLearner:
         B = self.cfg.batch_size
         self._g_idx = torch.zeros(B, dtype=torch.int64, device=self.device)
         self._g_terms = torch.zeros(4, device=self.device)
-        if getattr(self, "_opt_started", False):
-            raise RuntimeError("PPOLearner graphs must be built before the first real optimizer step")
 
         def half_a():
             i = self._g_idx
@@ -336,9 +377,19 @@ class PPOLearner:
             else:
                 self._apply(self._g_terms)
 
-        # warm-up on a side stream (allocator / lazy optimizer-state initialisation), then undo its effect
+        # Warm-up on a side stream (allocator / lazy optimizer-state initialisation), then undo its effect: the optimizer
+        # state is SAVED before and RESTORED after, so the graphs can be (re)built at any time -- also on a Trainer whose
+        # state was just loaded from a checkpoint (train.py --resume), where the state is not "never stepped".
         saved_param, saved_metrics = self.flat_param.clone(), self.metrics.clone()
-        saved_lr = self.lr_dev.clone() if self.fused else self.optimizer.param_groups[0]["lr"].clone()
+        if self.fused:
+            saved_opt = {k: getattr(self, k).clone() for k in ("exp_avg", "exp_avg_sq", "step_count", "lr_dev")}
+        else:
+            if not self.optimizer.state:      # lazy state: one throw-away step creates it (undone below)
+                saved_opt = None
+            else:
+                saved_opt = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.optimizer.state[p_].items()}
+                             for p_ in self.agent.parameters()]
+            saved_lr = self.optimizer.param_groups[0]["lr"].clone()
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -347,14 +398,17 @@ class PPOLearner:
                 half_b()
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
-        if self.fused:   # the warm-up steps were the optimizer's first: return its state to "never stepped"
-            self.exp_avg.zero_(); self.exp_avg_sq.zero_(); self.step_count.zero_()
-            self.lr_dev.copy_(saved_lr)
+        if self.fused:
+            for k, v in saved_opt.items():
+                getattr(self, k).copy_(v)
         else:
-            for st in self.optimizer.state.values():
-                for v in st.values():
+            for n_, p_ in enumerate(self.agent.parameters()):
+                for k, v in self.optimizer.state[p_].items():
                     if torch.is_tensor(v):
-                        v.zero_()
+                        if saved_opt is None:
+                            v.zero_()          # the warm-up steps were the optimizer's first: back to "never stepped"
+                        else:
+                            v.copy_(saved_opt[n_][k])
             self.optimizer.param_groups[0]["lr"].copy_(saved_lr)
         self.flat_param.copy_(saved_param)
         self.metrics.copy_(saved_metrics)
@@ -388,20 +442,19 @@ class PPOLearner:
             # three tiny launches per minibatch, indices read in place from the epoch's index block; single rank +
             # graphs: the whole epoch's update (train_iters x n_mb minibatches) is ONE captured graph
             args = (obs, act, logprob, adv, ret)
-            if self.graphs and self.world_size == 1:
+            if self.graphs and self._can_capture_update():
                 key = tuple(t.data_ptr() for t in args) + (M, idx_all.data_ptr())
                 if self._epoch_graph is None or self._epoch_key != key:
-                    if getattr(self, "_opt_started", False) and self._epoch_graph is None:
-                        pass   # (capture does not execute: safe at any time)
                     torch.cuda.synchronize(self.device)
-                    g = torch.cuda.CUDAGraph()
                     if cfg.prepared_minibatches:
                         self.prepare_minibatches(idx_all, n_mb, *args)      # (allocates outside the capture)
                         torch.cuda.synchronize(self.device)
-                    with torch.cuda.graph(g):
-                        self._epoch_body(idx_all, n_mb, args)
-                    self._epoch_graph, self._epoch_key = g, key
-                self._epoch_graph.replay()
+                    self._epoch_graph = self._capture_epoch(idx_all, n_mb, args)
+                    self._epoch_key = key
+                if self._epoch_graph is not None:
+                    self._epoch_graph.replay()
+                else:                                  # the capture of the collective was refused: eager from now on
+                    self._epoch_body(idx_all, n_mb, args)
             else:
                 self._epoch_body(idx_all, n_mb, args)
             self._opt_started = True
@@ -623,7 +676,7 @@ class Trainer:
                 "next_obs": self.next_obs, "next_term": self.next_term, "next_trunc": self.next_trunc,
                 "rng_base": self.rng_base, "np_rng": L._np_rng.bit_generator.state, "epoch": self.epoch,
                 "global_step_idx": self.global_step_idx, "agent_rng_offset": self.agent._rng_offset,
-                "config": dataclasses.asdict(self.cfg)}
+                "elapsed": time.time() - self.start_time, "config": dataclasses.asdict(self.cfg)}
 
     def load_state_dict(self, sd):
         L = self.learner
@@ -643,6 +696,7 @@ class Trainer:
         L._np_rng.bit_generator.state = sd["np_rng"]
         L._opt_started = True
         self.epoch, self.global_step_idx = sd["epoch"], sd["global_step_idx"]
+        self.start_time = time.time() - float(sd.get("elapsed", 0.0))     # charts/SPS = global_step / elapsed (train.py:292)
         self.agent._rng_offset = sd["agent_rng_offset"]
 
     def close(self):

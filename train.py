@@ -65,7 +65,12 @@ def main(argv=None):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    folder = f"{datetime.datetime.now().strftime('%Y-%m-%d_%H-%M-%S')}_{args.run_name}"
+    folder = f"{datetime.datetime.now().strftime('%Y-%m-%d_%H-%M-%S')}_{args.run_name}"       # train.py:118-123
+    if world > 1:   # ONE folder name for the job: the ranks' clocks may straddle a second boundary
+        import torch.distributed as dist
+        box = [folder]
+        dist.broadcast_object_list(box, src=0)
+        folder = box[0]
     ckpt_dir = os.path.join(args.out_dir, "checkpoints", folder)
     log_dir = os.path.join(args.out_dir, "logs", folder)
     if rank == 0:
@@ -86,7 +91,7 @@ def main(argv=None):
     if args.resume:
         path = args.resume if world == 1 else args.resume.replace(".pt", f".rank{rank}.pt")
         trainer.load_state_dict(torch.load(path, map_location=trainer.device, weights_only=False))
-        first_epoch = trainer.epoch + 1
+        first_epoch = trainer.epoch + 1             # (charts/SPS keeps counting from the checkpoint's elapsed time)
     if rank == 0:
         print(trainer.agent.actor)      # train.py:148-149
         print(trainer.agent.critic)
