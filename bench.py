@@ -263,6 +263,7 @@ def main():
         run_probe()
     # the GAE scan alone (HBM-bound: 24 B per transition), outside the timed region
     gae_events = []
+    tr.buffer.ptr = tr.buffer.capacity          # (Buffer.get() rewinds it; the rows of the last epoch are still there)
     for _ in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -186,6 +186,10 @@ int pc_rollout_set_form(int form);
 /* Test / tuning knob of pc_rollout's big form: envs per workgroup, 0 = automatic (128 up to 32768 envs, else 256), or
  * 128 / 256 to force one -- so that the 256-env variant the benchmark size takes can be checked at small batches. */
 int pc_rollout_set_epw(int envs_per_workgroup);
+/* A/B / test knob of pc_rollout's big form: 1 (default) = single-track batches take the mode whose gather tables sit in LDS
+ * behind LDS pointers, with a branch-free env step and the wave copying its observation rows out in 16-byte stores;
+ * 0 = always the generic mode (what mixed-track batches take).  Bit-identical buffers either way. */
+int pc_rollout_set_fast(int on);
 
 /* ---- the non-GEMM work of one PPO minibatch step (train.py:230-261), three launches:
  * pc_ppo_gather : traj_*[batch_indices] (train.py:233-238,249): idx [B] int64 into the flattened trajectories

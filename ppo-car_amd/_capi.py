@@ -81,6 +81,7 @@ _sig = {
     "pc_rollout": (_i, [_vp, _vp, _i, _i64, _d, C.c_uint64, C.c_uint64, _vp] + [_vp] * 10 + [_vp]),
     "pc_rollout_set_form": (_i, [_i]),
     "pc_rollout_set_epw": (_i, [_i]),
+    "pc_rollout_set_fast": (_i, [_i]),
     "pc_ppo_gather": (_i, [_i, _vp, _i, _i] + [_vp] * 10 + [_vp]),
     "pc_ppo_loss": (_i, [_i] + [_vp] * 6 + [_i, _i, _d, _d, _d, _vp, _vp, _vp, _vp]),
     "pc_clip_adam": (_i, [_i] + [_vp] * 6 + [_i64, _d, _d, _d, _d, _d, _vp]),

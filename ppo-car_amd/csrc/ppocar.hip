@@ -270,6 +270,103 @@ __device__ __forceinline__ unsigned and_or(unsigned a, unsigned m, unsigned c) {
 // global stores (__syncthreads() waits vmcnt(0) too: ~1 us of store latency per barrier in the rollout loop).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ---- the float32 wall sweep: Car.get_distances (car_env.py:360-374) for the RPL ray slots of one lane against the vertex
+// chain `vt` (nV vertices, a multiple of 4), part `part` of PARTS.  dx / dy = the slots' directions, didx = their lattice
+// indices (TAB: rows of the 1/den table `rdl` in LDS).  bb = the slots' minimum distances as float bit patterns.
+template <int RPL, int PARTS, bool TAB>
+__device__ __forceinline__ void wall_sweep_f32(const Vtx* vt, const int nV, const int part, const double npx, const double npy,
+                                               const float (&dx)[RPL], const float (&dy)[RPL], const int (&didx)[RPL], lds_cfp rdl,
+                                               unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
+    // Ray slots in PAIRS (packed fp32: one v_pk_* per two rays); an odd last slot is padded with a direction-0 ray that
+    // never hits.  The running minimum is kept as the float's bit pattern: for non-negative floats unsigned order is
+    // value order, so   best = min_u32(best, u_bits | sign(-(c1*c2)))   accepts u exactly when the endpoints lie
+    // on strictly opposite sides of the ray line (c1*c2 < 0) AND 0 <= u < best -- a rejected candidate (same side,
+    // u negative, u NaN) has its sign or all exponent bits set and compares above any finite best.  Two VALU
+    // instructions per ray after the products instead of two compares and a select.
+    // (u == +0 passes where the reference's u > 0 rejects: the ray origin exactly on a wall line.)
+    constexpr int NP = (RPL + 1) / 2;
+    f32x2 dx2[NP], dy2[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        dx2[j] = (f32x2){dx[2 * j], 2 * j + 1 < RPL ? dx[2 * j + 1] : 0.0f};
+        dy2[j] = (f32x2){dy[2 * j], 2 * j + 1 < RPL ? dy[2 * j + 1] : 0.0f};
+        bb[2 * j] = bb[2 * j + 1] = 0x447a0000u;  // 1000.0f, Ray.get_distance :198
+    }
+    const unsigned sgn = sign_mask();
+    // side values of vertex k: a_k = p_k - pos (float64, then rounded), c_k = cross(a_k, dir) per ray
+    auto side = [&](const Vtx& v, float& ax, float& ay, f32x2 (&c)[NP]) {
+        ax = (float)(v.x - npx);
+        ay = (float)(v.y - npy);
+        const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay};
+#pragma unroll
+        for (int j = 0; j < NP; ++j) c[j] = __builtin_elementwise_fma(ay2, dx2[j], -(ax2 * dy2[j]));
+    };
+    // vertex k closes the segment (k-1, k): (axp, ayp, cp) belong to k-1, c to k; rdv = the slots' 1/den (TAB)
+    auto close = [&](const Vtx& v, const float axp, const float ayp, const f32x2 (&cp)[NP], const f32x2 (&c)[NP],
+                     const float (&rdv)[2 * NP]) {
+        const float un = __builtin_fmaf(v.ey, axp, -(v.ex * ayp));
+        const f32x2 un2 = {un, un}, ex2 = {v.ex, v.ex}, ey2 = {v.ey, v.ey};
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            f32x2 u;
+            if constexpr (TAB) {
+                u = (f32x2){un * rdv[2 * j], un * rdv[2 * j + 1]};
+            } else {
+                const f32x2 den = __builtin_elementwise_fma(ey2, dx2[j], -(ex2 * dy2[j]));  // = rden_build_kernel's
+                const f32x2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                u = un2 * rc;
+            }
+            const f32x2 t = cp[j] * (-c[j]);  // sign clear <=> strictly opposite sides
+            bb[2 * j] = min(bb[2 * j], and_or(__float_as_uint(t.x), sgn, __float_as_uint(u.x)));
+            bb[2 * j + 1] = min(bb[2 * j + 1], and_or(__float_as_uint(t.y), sgn, __float_as_uint(u.y)));
+        }
+    };
+    // Vertex GROUPS of four (the host pads every track's chain to a multiple of 4 with chain-break sentinels);
+    // this part's groups [gbeg, gend).  The vertex before the range supplies the chain's previous side values.
+    const int ngrp = nV >> 2;
+    const int gbeg = PARTS > 1 ? ngrp * part / PARTS : 0;
+    const int gend = PARTS > 1 ? ngrp * (part + 1) / PARTS : ngrp;
+    // The "previous vertex" registers alternate between sets A and B (no copies); wave-uniform vertex records ->
+    // s_load_dwordx8, prefetched one vertex ahead under the VALU work.
+    float axA = 0.0f, ayA = 0.0f, axB = 0.0f, ayB = 0.0f;
+    f32x2 cA[NP], cB[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) cA[j] = cB[j] = (f32x2){0.0f, 0.0f};
+    if (PARTS > 1 && gbeg > 0) side(cload(vt + 4 * gbeg - 1), axA, ayA, cA);
+    // TAB: one 16-byte LDS read per ray slot and group = the slot's 1/den for the group's four vertices
+    typedef const __attribute__((address_space(3))) f32x4* lds_row;
+    lds_row rrow[2 * NP];
+    if constexpr (TAB) {
+#pragma unroll
+        for (int s = 0; s < 2 * NP; ++s) rrow[s] = (lds_row)(rdl + __umul24(s < RPL ? didx[s] : 360, nV)) + gbeg;  // full-rate 24-bit multiply
+    }
+    Vtx nxt = cload(vt + (gbeg < gend ? 4 * gbeg : 0));
+    // (A one-group-ahead prefetch of the table rows into a second register set was measured and dropped: inside the
+    // benchmark, with the wave priorities, it is 1.5 % slower than loading each group's rows at its top.)
+#define PC_VERTEX(RD, I, PAX, PAY, PC, NAX, NAY, NC)                                                                     \
+    {                                                                                                                \
+        const Vtx v = nxt;                                                                                           \
+        nxt = cload(vt + (k + I + 1 < 4 * gend ? k + I + 1 : k + I));                                                \
+        side(v, NAX, NAY, NC);                                                                                       \
+        float rdv[2 * NP];                                                                                           \
+        _Pragma("unroll") for (int s = 0; s < 2 * NP; ++s) rdv[s] = TAB ? RD[s][I] : 0.0f;                          \
+        if (!v.brk) close(v, PAX, PAY, PC, NC, rdv);                                                                 \
+    }
+    for (int gq = gbeg; gq < gend; ++gq) {
+        f32x4 rd[2 * NP];
+        if constexpr (TAB) {
+#pragma unroll
+            for (int s = 0; s < 2 * NP; ++s) rd[s] = rrow[s][gq - gbeg];
+        }
+        const int k = 4 * gq;
+        PC_VERTEX(rd, 0, axA, ayA, cA, axB, ayB, cB)
+        PC_VERTEX(rd, 1, axB, ayB, cB, axA, ayA, cA)
+        PC_VERTEX(rd, 2, axA, ayA, cA, axB, ayB, cB)
+        PC_VERTEX(rd, 3, axB, ayB, cB, axA, ayA, cA)
+    }
+#undef PC_VERTEX
+}
+
 // One CarEnv.step (car_env.py:693-760) + TransformReward + same-step auto-reset for the env whose state the
 // 2^lg lanes of this group hold in `st` (updated in place, identically in every lane).  Lane g sweeps rays
 // g, g + G, ...  Observation entries go to orow (global row), frow (pre-reset obs, optional) and lrow (an LDS
@@ -392,96 +489,8 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
 
     // ---- wall sweep: Car.get_distances (:360-374) -- also serves Car.check_collision (E2)
     if constexpr (sizeof(T) == 4) {
-        // Ray slots in PAIRS (packed fp32: one v_pk_* per two rays); an odd last slot is padded with a direction-0 ray that
-        // never hits.  The running minimum is kept as the float's bit pattern: for non-negative floats unsigned order is
-        // value order, so   best = min_u32(best, u_bits | sign(-(c1*c2)))   accepts u exactly when the endpoints lie
-        // on strictly opposite sides of the ray line (c1*c2 < 0) AND 0 <= u < best -- a rejected candidate (same side,
-        // u negative, u NaN) has its sign or all exponent bits set and compares above any finite best.  Two VALU
-        // instructions per ray after the products instead of two compares and a select.
-        // (u == +0 passes where the reference's u > 0 rejects: the ray origin exactly on a wall line.)
-        constexpr int NP = (RPL + 1) / 2;
-        f32x2 dx2[NP], dy2[NP];
-        unsigned bb[2 * NP];
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            dx2[j] = (f32x2){dx[2 * j], 2 * j + 1 < RPL ? dx[2 * j + 1] : 0.0f};
-            dy2[j] = (f32x2){dy[2 * j], 2 * j + 1 < RPL ? dy[2 * j + 1] : 0.0f};
-            bb[2 * j] = bb[2 * j + 1] = 0x447a0000u;  // 1000.0f, Ray.get_distance :198
-        }
-        const unsigned sgn = sign_mask();
-        const Vtx* vt = p.vtx + h.vtx_off;
-        // side values of vertex k: a_k = p_k - pos (float64, then rounded), c_k = cross(a_k, dir) per ray
-        auto side = [&](const Vtx& v, float& ax, float& ay, f32x2 (&c)[NP]) {
-            ax = (float)(v.x - npx);
-            ay = (float)(v.y - npy);
-            const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay};
-#pragma unroll
-            for (int j = 0; j < NP; ++j) c[j] = __builtin_elementwise_fma(ay2, dx2[j], -(ax2 * dy2[j]));
-        };
-        // vertex k closes the segment (k-1, k): (axp, ayp, cp) belong to k-1, c to k; rdv = the slots' 1/den (TAB)
-        auto close = [&](const Vtx& v, const float axp, const float ayp, const f32x2 (&cp)[NP], const f32x2 (&c)[NP],
-                         const float (&rdv)[2 * NP]) {
-            const float un = __builtin_fmaf(v.ey, axp, -(v.ex * ayp));
-            const f32x2 un2 = {un, un}, ex2 = {v.ex, v.ex}, ey2 = {v.ey, v.ey};
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                f32x2 u;
-                if constexpr (TAB) {
-                    u = (f32x2){un * rdv[2 * j], un * rdv[2 * j + 1]};
-                } else {
-                    const f32x2 den = __builtin_elementwise_fma(ey2, dx2[j], -(ex2 * dy2[j]));  // = rden_build_kernel's
-                    const f32x2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                    u = un2 * rc;
-                }
-                const f32x2 t = cp[j] * (-c[j]);  // sign clear <=> strictly opposite sides
-                bb[2 * j] = min(bb[2 * j], and_or(__float_as_uint(t.x), sgn, __float_as_uint(u.x)));
-                bb[2 * j + 1] = min(bb[2 * j + 1], and_or(__float_as_uint(t.y), sgn, __float_as_uint(u.y)));
-            }
-        };
-        // Vertex GROUPS of four (the host pads every track's chain to a multiple of 4 with chain-break sentinels);
-        // this part's groups [gbeg, gend).  The vertex before the range supplies the chain's previous side values.
-        const int ngrp = h.nV >> 2;
-        const int gbeg = PARTS > 1 ? ngrp * part / PARTS : 0;
-        const int gend = PARTS > 1 ? ngrp * (part + 1) / PARTS : ngrp;
-        // The "previous vertex" registers alternate between sets A and B (no copies); wave-uniform vertex records ->
-        // s_load_dwordx8, prefetched one vertex ahead under the VALU work.
-        float axA = 0.0f, ayA = 0.0f, axB = 0.0f, ayB = 0.0f;
-        f32x2 cA[NP], cB[NP];
-#pragma unroll
-        for (int j = 0; j < NP; ++j) cA[j] = cB[j] = (f32x2){0.0f, 0.0f};
-        if (PARTS > 1 && gbeg > 0) side(cload(vt + 4 * gbeg - 1), axA, ayA, cA);
-        // TAB: one 16-byte LDS read per ray slot and group = the slot's 1/den for the group's four vertices
-        typedef const __attribute__((address_space(3))) f32x4* lds_row;
-        lds_row rrow[2 * NP];
-        if constexpr (TAB) {
-#pragma unroll
-            for (int s = 0; s < 2 * NP; ++s) rrow[s] = (lds_row)(rdl + __umul24(s < RPL ? didx[s] : 360, h.nV)) + gbeg;  // full-rate 24-bit multiply
-        }
-        Vtx nxt = cload(vt + (gbeg < gend ? 4 * gbeg : 0));
-        // (A one-group-ahead prefetch of the table rows into a second register set was measured and dropped: inside the
-        // benchmark, with the wave priorities, it is 1.5 % slower than loading each group's rows at its top.)
-#define PC_VERTEX(RD, I, PAX, PAY, PC, NAX, NAY, NC)                                                                     \
-        {                                                                                                                \
-            const Vtx v = nxt;                                                                                           \
-            nxt = cload(vt + (k + I + 1 < 4 * gend ? k + I + 1 : k + I));                                                \
-            side(v, NAX, NAY, NC);                                                                                       \
-            float rdv[2 * NP];                                                                                           \
-            _Pragma("unroll") for (int s = 0; s < 2 * NP; ++s) rdv[s] = TAB ? RD[s][I] : 0.0f;                          \
-            if (!v.brk) close(v, PAX, PAY, PC, NC, rdv);                                                                 \
-        }
-        for (int gq = gbeg; gq < gend; ++gq) {
-            f32x4 rd[2 * NP];
-            if constexpr (TAB) {
-#pragma unroll
-                for (int s = 0; s < 2 * NP; ++s) rd[s] = rrow[s][gq - gbeg];
-            }
-            const int k = 4 * gq;
-            PC_VERTEX(rd, 0, axA, ayA, cA, axB, ayB, cB)
-            PC_VERTEX(rd, 1, axB, ayB, cB, axA, ayA, cA)
-            PC_VERTEX(rd, 2, axA, ayA, cA, axB, ayB, cB)
-            PC_VERTEX(rd, 3, axB, ayB, cB, axA, ayA, cA)
-        }
-#undef PC_VERTEX
+        unsigned bb[2 * ((RPL + 1) / 2)];
+        wall_sweep_f32<RPL, PARTS, TAB>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dx, dy, didx, rdl, bb);
 #pragma unroll
         for (int s = 0; s < RPL; ++s) best[s] = __uint_as_float(bb[s]);
     } else {
@@ -1244,10 +1253,15 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
 }
 
 // Softmax / Philox draw / log_prob for one env given its 16 output values (logits 0..A-1, value at A).
-__device__ __forceinline__ void policy_tail(const float (&v)[16], const int A, const float u, int& act, float& lp, float& val,
+// AC > 0: the action count as a compile-time constant (the persistent rollout kernel: CarEnv has Discrete(9), car_env.py:525) --
+// the same operations in the same order as with the run-time count, but fully unrolled over registers (with a run-time count
+// the compiler walks the 16-slot arrays by register indexing, s_set_gpr_idx: several times the instructions).
+template <int AC = 0>
+__device__ __forceinline__ void policy_tail(const float (&v)[16], const int A_rt, const float u, int& act, float& lp, float& val,
                                             float* __restrict__ logits_row) {
     // A is wave-uniform: the loops leave at i == A with a scalar branch instead of predicating all 16 slots, and the
     // inverse CDF reuses the exponentials of the log-sum-exp pass (p_i = e_i / sum) -- one expf per action in all.
+    const int A = AC > 0 ? AC : A_rt;
     float mx = -INFINITY;
     val = 0.0f;
 #pragma unroll
@@ -1464,6 +1478,182 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
 }
 
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// The env step of the persistent big-form rollout (K9), single track, every gather table in LDS.
+// Same arithmetic as env_step_core<float> -- its buffers are compared bit for bit with the per-step kernels' -- but laid out
+// for a wave that owns its 32 envs outright (2 lanes per env) and whose cost is VALU issue slots, not latency:
+//   * no branches: the action is decoded through a 16-entry table (thrust factor, friction factor, turn, forward bonus),
+//     rewards / counters / the reset are selects;
+//   * every table access is an explicit LDS read (ds_read), never a generic (flat) load -- those count on vmcnt AND lgkmcnt,
+//     so each one used to wait for every global store the wave had in flight;
+//   * the heading index is kept reduced mod 72 through a 74-entry wrap table instead of an integer division per step;
+//   * an unused ray slot (17 rays on 2 lanes: 9 + 8) repeats the lane's last ray instead of being predicated off;
+//   * the observation row goes to LDS only; the wave then copies its 32 rows -- contiguous in the rollout buffer -- to
+//     global memory with 16-byte stores (three per lane instead of 23 scattered dword stores), and an env that finished its
+//     episode gets its reset observation in a rarely taken, wave-uniformly skipped fix-up.
+// ------------------------------------------------------------------------------------------
+constexpr int TAB_MAX_GATES = 128;  // reward gates of a track staged in LDS (32 bytes each)
+struct ActLut {          // one per action 0..15 (9..15: no-op, car_env.py:721), 32 bytes
+    double thrust;       // acc = heading * thrust: +0.8 forward, -0.8 backward, 0 none (car_env.py:423-438)
+    double fric;         // velocity factor after the thrust: 1 - 0.2 without thrust, 1 with (car_env.py:454-455)
+    int dk;              // turn in 5-degree steps: -1 left, +1 right (car_env.py:440-442)
+    int fwd;             // 1: the +0.01 forward bonus (car_env.py:700,710,714)
+    int pad0, pad1;
+};
+// (plain ext_vector element types: a struct cannot be copied out of an address-space-qualified pointer in C++)
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) f64x2* lds_cd2;
+typedef const __attribute__((address_space(3))) f64x4* lds_cd4;
+typedef const __attribute__((address_space(3))) f32x2* lds_cf2;
+typedef const __attribute__((address_space(3))) i32x2* lds_ci2;
+typedef const __attribute__((address_space(3))) int* lds_ci;
+typedef __attribute__((address_space(3))) float* lds_fp;
+
+struct FastTabs {        // LDS addresses of the staged tables (wave-uniform)
+    lds_cd2 head;        // [72] (cos, sin) of radians(start_rot + 5 j), float64
+    lds_ci wrap;         // [74] j - 1 reduced mod 72, j = 0..73
+    lds_cd2 act;         // [16] ActLut records, 32 bytes each: (thrust, fric) then (dk, fwd)
+    lds_cd4 gates;       // [G] (x1, y1, x2, y2)
+    lds_cf2 dir;         // [361] direction lattice
+    lds_cfp reset;       // [D] the track's reset observation
+    lds_cfp rden;        // [361][nV] or unused
+};
+constexpr int FT_HEAD = 0, FT_WRAP = FT_HEAD + 72 * 4, FT_ACT = FT_WRAP + 76, FT_GATES = FT_ACT + 16 * 8,
+              FT_DIR = FT_GATES + TAB_MAX_GATES * 8, FT_RESET = FT_DIR + 361 * 2 + 2, FT_FLOATS = FT_RESET + 40;
+static_assert(FT_ACT % 4 == 0 && FT_GATES % 4 == 0 && FT_DIR % 2 == 0, "16-byte / 8-byte aligned records");
+
+__device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p, const TrackHdr& h0, float* sTab, const int tid,
+                                                      const int nthreads) {
+    int* dst = reinterpret_cast<int*>(sTab);
+    const int* head = reinterpret_cast<const int*>(p.headtab + h0.head_off);
+    for (int i = tid; i < 72 * 4; i += nthreads) dst[FT_HEAD + i] = head[i];
+    for (int i = tid; i < 74; i += nthreads) dst[FT_WRAP + i] = i == 0 ? 71 : (i == 73 ? 0 : i - 1);
+    if (tid < 16) {
+        const int a = tid;
+        const bool fwd = (a == 0) | (a == 4) | (a == 5), bwd = (a == 1) | (a == 6) | (a == 7);     // car_env.py:698-722
+        const bool left = (a == 2) | (a == 4) | (a == 6), right = (a == 3) | (a == 5) | (a == 7);
+        ActLut L;
+        L.thrust = fwd ? 0.8 : (bwd ? -0.8 : 0.0);
+        L.fric = (fwd | bwd) ? 1.0 : 1 - 0.2;
+        L.dk = (left ? -1 : 0) + (right ? 1 : 0);
+        L.fwd = fwd ? 1 : 0;
+        L.pad0 = L.pad1 = 0;
+        *reinterpret_cast<ActLut*>(sTab + FT_ACT + 8 * a) = L;
+    }
+    const int* gates = reinterpret_cast<const int*>(p.segs + h0.gate_off);
+    for (int i = tid; i < h0.G * 8; i += nthreads) dst[FT_GATES + i] = gates[i];
+    const int* dir = reinterpret_cast<const int*>(p.dirtab + h0.dir_off);
+    for (int i = tid; i < 361 * 2; i += nthreads) dst[FT_DIR + i] = dir[i];
+    const int* ro = reinterpret_cast<const int*>(p.reset_obs);
+    for (int i = tid; i < p.D; i += nthreads) dst[FT_RESET + i] = ro[i];
+    FastTabs ft;
+    ft.head = (lds_cd2)(sTab + FT_HEAD);
+    ft.wrap = (lds_ci)(sTab + FT_WRAP);
+    ft.act = (lds_cd2)(sTab + FT_ACT);
+    ft.gates = (lds_cd4)(sTab + FT_GATES);
+    ft.dir = (lds_cf2)(sTab + FT_DIR);
+    ft.reset = (lds_cfp)(sTab + FT_RESET);
+    ft.rden = (lds_cfp)(sTab + FT_FLOATS);
+    return ft;
+}
+
+// exchange with the neighbouring lane (the other lane of the env): DPP quad_perm [1, 0, 3, 2], one VALU instruction
+__device__ __forceinline__ int swap_pair(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false); }
+
+template <int RPL, bool TAB>
+__device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const TrackHdr& h, const FastTabs& ft, const int (&rsd)[RPL],
+                                              const unsigned (&noncol)[RPL], const int (&col)[RPL], const int (&gq)[2], const int g,
+                                              EnvRegs& st, int& k72, const int a, const double reward_scale, lds_fp lrow,
+                                              float& reward_f, float& term_f, float& trunc_f) {
+    // ---- action, heading before and after the turn (car_env.py:698-722, :440-442)
+    const f64x2 Lf = ft.act[2 * a];                                     // (thrust, fric)
+    const i32x2 Li = *(lds_ci2)(ft.act + 2 * a + 1);                    // (dk, fwd)
+    struct { double thrust, fric; int dk, fwd; } L = {Lf.x, Lf.y, Li.x, Li.y};
+    const f64x2 cs0 = ft.head[k72];
+    const int k72n = ft.wrap[k72 + L.dk + 1];
+    const f64x2 cs1 = ft.head[k72n];
+    // ---- Car.update physics (car_env.py:452-461), float64: thrust with the PRE-turn heading, friction without thrust, clip
+    double nvx = (st.vx + cs0.x * L.thrust) * L.fric, nvy = (st.vy + cs0.y * L.thrust) * L.fric;
+    nvx = nvx < -10.0 ? -10.0 : (nvx > 10.0 ? 10.0 : nvx);
+    nvy = nvy < -10.0 ? -10.0 : (nvy > 10.0 ? 10.0 : nvy);
+    const double opx = st.px, opy = st.py;
+    const double npx = opx + nvx, npy = opy + nvy;
+
+    // ---- ray directions at the new heading: lattice index (5 k + step_deg * ray) mod 360
+    float dx[RPL], dy[RPL];
+    int didx[RPL];
+    const int k5n = 5 * k72n;
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) {
+        const unsigned m = (unsigned)(k5n + rsd[s]);
+        didx[s] = (int)min(m, m - 360u);
+        const f32x2 cs = ft.dir[didx[s]];
+        dx[s] = cs.x;
+        dy[s] = cs.y;
+    }
+    // ---- Car.get_passed_gate (:394-408): the four collision rays at the PREVIOUS pose against gate[next], two per lane
+    const f64x4 gv = ft.gates[st.next];
+    const Seg gate = {gv.x, gv.y, gv.z, gv.w};
+    const int k5o = 5 * k72;
+    bool gate_hit = false;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const unsigned m = (unsigned)(k5o + gq[jj]);
+        const f32x2 cs = ft.dir[(int)min(m, m - 360u)];
+        gate_hit |= Math<float>::cast(gate, opx, opy, cs.x, cs.y) < 10.0f;  // :387,:390
+    }
+    // ---- wall sweep
+    unsigned bb[2 * ((RPL + 1) / 2)];
+    wall_sweep_f32<RPL, 1, TAB>(p.vtx + h.vtx_off, h.nV, 0, npx, npy, dx, dy, didx, ft.rden, bb);
+    // Car.check_collision (:376-392): any collision ray closer than 10 px.  Distances are non-negative floats, so the
+    // smallest one is the unsigned minimum of the bit patterns; a slot that is not a collision ray is masked to +inf.
+    unsigned hm = 0x7f800000u;
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) hm = min(hm, bb[s] | noncol[s]);
+    int flags = (gate_hit ? 1 : 0) | (hm < 0x41200000u ? 2 : 0);       // 0x41200000 = 10.0f
+    flags |= swap_pair(flags);
+    gate_hit = flags & 1;
+    const bool destroyed = ((flags & 2) != 0) | (h.start_collides != 0);
+    // ---- bookkeeping (car_env.py:694-750): float64 reward in the reference's order of accumulation
+    double rw = L.fwd ? 0.01 : 0.0;                                     // 0.0 + 0.01
+    const bool lap = gate_hit & (st.next == h.G - 1);                   // :730 remaining == 0
+    rw = rw + (gate_hit ? 1.0 : 0.0);                                   // :727
+    rw = rw + (lap ? 10.0 : 0.0);                                       // :732
+    const int passed = st.passed + (gate_hit ? 1 : 0);
+    const int next = gate_hit ? (lap ? 0 : st.next + 1) : st.next;      // :734-741
+    const int time = st.time + 1;                                       // :745
+    rw = rw + (destroyed ? -3.0 : 0.0);                                 // :748
+    const bool trunc = !destroyed & (time >= 1000);                     // :749-750
+    const bool done = destroyed | trunc;
+    reward_f = (float)(rw * reward_scale);
+    term_f = destroyed ? 1.0f : 0.0f;
+    trunc_f = trunc ? 1.0f : 0.0f;
+    // ---- observation row -> LDS (the reset observation of a finished env is written by the caller's fix-up)
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) lrow[col[s]] = Math<float>::norm_dist(__uint_as_float(bb[s]));     // :593
+    if (g == 0) {
+        lrow[0] = Math<float>::norm(npx, 1280.0);  // :578-581
+        lrow[1] = Math<float>::norm(npy, 720.0);
+        lrow[2] = Math<float>::norm(nvx, 10.0);
+        lrow[3] = Math<float>::norm(nvy, 10.0);
+        lrow[4] = (float)cs1.x;                    // :584-588
+        lrow[5] = (float)cs1.y;
+    }
+    // ---- new state; CarEnv.reset (:677-686) for a finished env
+    st.px = done ? h.start_x : npx;
+    st.py = done ? h.start_y : npy;
+    st.vx = done ? 0.0 : nvx;
+    st.vy = done ? 0.0 : nvy;
+    st.k = done ? 0 : st.k + L.dk;
+    k72 = done ? 0 : k72n;
+    st.time = done ? 0 : time;
+    st.next = done ? 0 : next;
+    st.passed = done ? 0 : passed;
+    return done;
+}
+
 // Developer-only timing ablation of the persistent rollout kernels: a SEPARATE build (make ABLATE=n -> libppocar_ablate.so,
 // never loaded by the product or the tests) compiled with -DPC_ABLATE=n skips the policy MFMAs (1), the env step (2) or
 // the draw (4).  The shipped library is built with PC_ABLATE = 0: there is no run-time switch that makes a kernel do less.
@@ -1487,7 +1677,6 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
 // table, reset observation) are copied into LDS once and the EnvParams pointers redirected, so that a gather on the
 // step's critical path costs an LDS access instead of a global-memory round trip.  Single-track batches only (the
 // kernels' precondition).  The caller synchronises the workgroup before the first use.
-constexpr int TAB_MAX_GATES = 128;
 constexpr int TAB_DIR = 72 * 4 + TAB_MAX_GATES * 8, TAB_RESET = TAB_DIR + 361 * 2 + 2, TAB_FLOATS = TAB_RESET + 40;
 __device__ __forceinline__ EnvParams<float> stage_tables(const EnvParams<float>& p, float* sTab, const int tid, const int nthreads) {
     if (p.track_id) return p;  // mixed-track batch: the tables are read where they lie (global memory, L2-resident)
@@ -1515,7 +1704,10 @@ __device__ __forceinline__ EnvParams<float> stage_tables(const EnvParams<float>&
     return q;
 }
 
-template <int KS, int RPL, int PREC>
+// MODE 0: the gather tables where stage_tables puts them (generic pointers; mixed-track batches read them from global
+//         memory), env step = env_step_core.  MODE 1 / 2: single track, A = 9, every table in LDS behind explicit LDS
+//         pointers, env step = env_step_fast (2: with the 1/den table), observation rows copied out by the wave.
+template <int KS, int RPL, int PREC, int MODE>
 __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, const float* __restrict__ image, const int A,
                                                       const int T, const double reward_scale, const uint64_t seed,
                                                       const uint64_t offset, const uint64_t* __restrict__ offset_dev,
@@ -1524,11 +1716,12 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                                                       float* __restrict__ term_buf, float* __restrict__ trunc_buf,
                                                       float* __restrict__ logprob_buf, float* __restrict__ next_obs,
                                                       float* __restrict__ next_term, float* __restrict__ next_trunc,
-                                                      const int rden_lds, const int epw) {
+                                                      const int rden_lds, const int epw, const int vec_ok) {
     constexpr int dbg = PC_ABLATE;  // 0 in the product build (see PC_ABLATE)
-    constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, LDX = 4 * KS + 1, ET = 2;
+    constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, ET = 2;
     constexpr int NG = pol_ng(KS), KB = pol_kb(KS);
     constexpr int IMG = PREC ? polx_image_dwords(PREC, NG) : pol_image_padded(KS);
+    constexpr bool FAST = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sW1 = lds;
     float* sB1 = PREC ? lds + polx_w1_dwords(PREC, NG) + polx_w2_dwords(PREC) : sW1 + 2 * HID * LD1;
@@ -1537,19 +1730,25 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const unsigned* sW1p = reinterpret_cast<const unsigned*>(lds);
     const unsigned* sW2p = sW1p + polx_w1_dwords(PREC ? PREC : 1, NG);
     const float* sW2c = sB2 + 16;                  // PREC 1: critic output weights [256]
-    float* sObs = lds + IMG;                       // [256 envs][LDX]   observation of the step in flight
-    int* sAct = reinterpret_cast<int*>(sObs + 256 * LDX);
-    float* sTab = reinterpret_cast<float*>(sAct + 256);    // staged per-track tables (stage_tables)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lc = lane & 15, lk = lane >> 4;
     const int64_t N = p.N;
     const int D = p.D;
+    // observation of the step in flight, [256 envs][LDX]: FAST keeps the rows dense (LDX = D, exactly the rollout buffer's
+    // layout: a wave's 32 rows are one contiguous block there and here)
+    const int LDX = FAST ? D : 4 * KS + 1;
+    float* sObs = lds + IMG;
+    int* sAct = reinterpret_cast<int*>(sObs + 256 * LDX);
+    float* sTab = reinterpret_cast<float*>(sAct + 256);    // staged per-track tables
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lc = lane & 15, lk = lane >> 4;
     policy_stage_image<IMG>(image, lds, tid);
-    const EnvParams<float> q = stage_tables(p, sTab, tid, 512);
+    const TrackHdr h0 = cload(p.hdr);
+    EnvParams<float> q = p;
+    FastTabs ft = {};
+    if constexpr (FAST) ft = stage_fast_tables(p, h0, sTab, tid, 512);
+    else q = stage_tables(p, sTab, tid, 512);
     // the track's 1/den table, when the host found room for it: rden_lds = its size in floats (else 0)
-    float* sRden = sTab + TAB_FLOATS;
+    float* sRden = sTab + (FAST ? FT_FLOATS : TAB_FLOATS);
     {
-        const TrackHdr h0 = cload(p.hdr);
         const f32x4* src = reinterpret_cast<const f32x4*>(p.rden + h0.rden_off);
         for (int i = tid; i < rden_lds / 4; i += 512) reinterpret_cast<f32x4*>(sRden)[i] = src[i];
     }
@@ -1560,23 +1759,47 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const int el = pbase + (lane >> 1), g = lane & 1;
     // epw = envs per workgroup: 256 (all 8 waves) or 128 (waves 4..7 only help to stage LDS and leave: at <= 32768 envs
     // that doubles the workgroups, one wave per SIMD on all 256 CUs instead of two on half of them)
-    const int64_t e_env = (int64_t)blockIdx.x * epw + el;
+    const int64_t e_wave = (int64_t)blockIdx.x * epw + pbase;      // first env of this wave
+    const int64_t e_env = e_wave + (lane >> 1);
     const bool e_valid = e_env < N;
     EnvRegs st = {};
     if (e_valid) st = env_load<float>(p, e_env);
     // mixed-track batch: this wave's envs share one track (the host checked every aligned block of 32 envs)
     const int trk = p.track_id ? (int)p.track_id[e_valid ? e_env : N - 1] : 0;
-    for (int f = g; f < 4 * KS; f += 2) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
+    for (int f = g; f < (FAST ? D : 4 * KS); f += 2) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
     // this wave's output tile [32 envs][LDO] lives in its own observation rows: they are dead from the policy pass's
-    // operand load until the env step stores the next observation (32 * LDX >= 32 * LDO floats)
+    // operand load until the env step stores the next observation (32 * LDX >= 32 * LDO floats: D >= 17 on the host's menu)
     static_assert(4 * KS + 1 >= 17, "the output tile must fit the wave's observation rows");
     float* myOut = sObs + wave * 32 * LDX;
     const uint64_t off0 = offset + (offset_dev ? *offset_dev : 0);
     PhiloxBlock rnd = {};  // the sampling lanes' current Philox block (4 steps' draws)
+    // FAST: per-lane invariants of the env step.  Ray slot s of lane g is ray min(g + 2 s, R - 1): the odd slot that 17 or
+    // 33 rays leave over on lane 1 repeats that lane pair's last ray (same value, same address) instead of being masked.
+    int rsd[RPL], col[RPL], gq[2] = {0, 0}, k72 = 0;
+    unsigned noncol[RPL];
+    if constexpr (FAST) {
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const int ray = min(g + 2 * s, p.R - 1);
+            rsd[s] = ray * p.step_deg;
+            col[s] = 6 + ray;
+            // Car.check_collision's rays: r in range(0, n, n // 4) (:389) -- nominal n, not R
+            const bool is_col = ray < 64 ? (bool)((p.colbits >> ray) & 1) : ((ray < p.n_nominal) & (ray % p.q == 0));
+            noncol[s] = is_col ? 0u : 0x7f800000u;
+        }
+        gq[0] = g * p.q * p.step_deg;            // Car.get_passed_gate's rays j * (n // 4), j = g and g + 2
+        gq[1] = (g + 2) * p.q * p.step_deg;
+        k72 = Math<float>::mod72(st.k);
+    }
+    const lds_fp lrow = (lds_fp)(sObs + el * LDX);
     __syncthreads();  // the weight image is in place; from here on the waves never synchronise again
     if (pbase >= epw) return;
     // (no deliberate phase offset between the two waves of a SIMD: with the priorities below they fall into opposite
     // phases by themselves; a start-up stagger measured 1 % slower)
+    // The loop-carried env state came from global loads.  Passed through an empty asm it is, for the compiler's s_waitcnt
+    // insertion, a fresh register value: waited for HERE, once -- otherwise the first use inside the loop carries a
+    // conservative `s_waitcnt vmcnt(1)` on every iteration, i.e. a wait for the wave's own global stores of the step before.
+    asm volatile("" : "+v"(st.px), "+v"(st.py), "+v"(st.vx), "+v"(st.vy), "+v"(st.k), "+v"(st.time), "+v"(st.next), "+v"(st.passed), "+v"(k72));
 
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
@@ -1590,7 +1813,10 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
 #pragma unroll
                 for (int et = 0; et < ET; ++et)
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) x[et][ks] = sObs[(pbase + 16 * et + lc) * LDX + 4 * ks + lk];
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const int f = 4 * ks + lk;
+                        x[et][ks] = (!FAST || f < D) ? sObs[(pbase + 16 * et + lc) * LDX + f] : 0.0f;
+                    }
                 // Wave priority: the policy pass (MFMA chains, whose results it waits for anyway) runs at the lowest priority (0),
                 // the env step -- dense dependent VALU work -- above it (2), the short serial draw in between highest (3).  The two waves of a
                 // SIMD are in opposite phases most of the time; with equal priorities the issue arbiter interleaves them
@@ -1633,7 +1859,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 for (int reg = 0; reg < 4; ++reg) myOut[(16 * et + lc) * LDO + 4 * lk + reg] = out[et][reg];
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the tile is written and read by this wave only
             __builtin_amdgcn_wave_barrier();
-            const int64_t e = (int64_t)blockIdx.x * epw + pbase + lane;
+            const int64_t e = e_wave + lane;
             if (lane < 32 && e < N) {
                 float v[16];
 #pragma unroll
@@ -1642,7 +1868,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 float lp, val;
                 const uint64_t o = off0 + (uint64_t)t;
                 if (t == 0 || (o & 3) == 0) rnd = philox_block(seed, o >> 2, (uint64_t)e);  // uniform: ten rounds per 4 steps
-                policy_tail(v, A, philox_word_uniform(rnd, (unsigned)(o & 3)), act, lp, val, nullptr);
+                if constexpr (FAST) policy_tail<9>(v, 9, philox_word_uniform(rnd, (unsigned)(o & 3)), act, lp, val, nullptr);
+                else policy_tail(v, A, philox_word_uniform(rnd, (unsigned)(o & 3)), act, lp, val, nullptr);
                 sAct[pbase + lane] = act;
                 const int64_t row = (int64_t)t * N + e;
                 act_buf[row] = (float)act;     // stored as float32 like the reference (buffer.py:13)
@@ -1652,10 +1879,42 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        if (e_valid && !(dbg & 2)) {
+        const bool last = t + 1 == T;
+        if constexpr (FAST) {
+            if (!(dbg & 2)) {
+                __builtin_amdgcn_s_setprio(2);
+                // ---------------- E(t)
+                float rw, tf, cf;
+                const int a = e_valid ? sAct[el] : 8;
+                const bool done = env_step_fast<RPL, MODE == 2>(p, h0, ft, rsd, noncol, col, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf);
+                // gymnasium 0.29.1 same-step auto-reset: a finished env returns its reset observation
+                if (__builtin_amdgcn_ballot_w64(done) != 0) {   // wave-uniform: ~1.5 % of env steps end an episode
+                    if (done)
+                        for (int f = g; f < D; f += 2) lrow[f] = ft.reset[f];
+                }
+                if (g == 0 && e_valid) {
+                    rew_buf[(int64_t)t * N + e_env] = rw;
+                    float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;    // flags that precede obs t+1
+                    float* tc = last ? next_trunc : trunc_buf + (int64_t)(t + 1) * N;  // (train.py:176-177,195)
+                    tr[e_env] = tf;
+                    tc[e_env] = cf;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the rows are complete (this wave wrote them all)
+                __builtin_amdgcn_wave_barrier();
+                // rows -> rollout buffer: the wave's 32 rows are contiguous there (32 * D floats), 16-byte stores when aligned
+                float* dstg = (last ? next_obs : obs_buf + (int64_t)(t + 1) * N * D) + e_wave * D;
+                const int64_t left = N - e_wave;                       // valid envs from this wave's first on
+                const int n_rows = left >= 32 ? 32 : (int)left;
+                const float* srcl = sObs + pbase * LDX;
+                if (vec_ok && n_rows == 32) {
+                    for (int i = lane; i < 8 * D; i += 64) reinterpret_cast<f32x4*>(dstg)[i] = reinterpret_cast<const f32x4*>(srcl)[i];
+                } else {
+                    for (int i = lane; i < n_rows * D; i += 64) dstg[i] = srcl[i];
+                }
+            }
+        } else if (e_valid && !(dbg & 2)) {
             __builtin_amdgcn_s_setprio(2);
             // ---------------- E(t)
-            const bool last = t + 1 == T;
             float* orow = last ? next_obs + e_env * D : obs_buf + ((int64_t)(t + 1) * N + e_env) * D;
             float rw;
             bool term, trunc;
@@ -3004,6 +3263,7 @@ static int g_rollout_form = -1;       // pc_rollout: -1 auto, 0 = 256 envs per w
 #define PC_SPLIT_MAX_ENVS 16384
 static int64_t g_rollout_epw128_max = 32768;  // big form at or below this many envs: 128 envs (4 waves) per workgroup
 static int g_rollout_epw_override = 0;  // pc_rollout_set_epw: 0 = automatic, 128 / 256 = force (test knob)
+static int g_rollout_fast = 1;        // pc_rollout: the big form's fast mode (LDS tables behind LDS pointers) when the shape allows it (0: never; A/B knob)
 static int g_rollout_rden = 1;        // pc_rollout: stage the 1/den table in LDS when it fits (0: never; test / tuning knob)
 static int g_policy_precision = 2;    // 0 = fp32-input MFMA; split forms on the 16-bit matrix cores (need D <= 24, A <= 9): 1 = bf16 x 3, 2 = fp16 x 2
 
@@ -3011,6 +3271,12 @@ int pc_rollout_set_form(int form) {
     if (form < -1 || form > 3) return PC_ERR_INVALID_ARG;
     g_rollout_rden = form >= 2 ? 0 : 1;              // forms 2 / 3 = forms 0 / 1 without the LDS 1/den table
     g_rollout_form = form >= 2 ? form - 2 : form;
+    return PC_OK;
+}
+
+int pc_rollout_set_fast(int on) {
+    if (on != 0 && on != 1) return PC_ERR_INVALID_ARG;
+    g_rollout_fast = on;
     return PC_OK;
 }
 
@@ -3173,14 +3439,16 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     if (!guard.ok) return PC_ERR_NO_DEVICE;
     const int prec = policy_prec(e->D, A);
     const int img = prec ? polx_image_dwords(prec, pol_ng(KS)) : pol_image_padded(KS);
-    // (big form: each wave's output tile aliases its own 32 observation rows -- dead between the policy pass's operand
-    // load and the env step's store of the next observation)
-    const size_t lds_big = (size_t)(img + 256 * (4 * KS + 1) + 256 + TAB_FLOATS) * sizeof(float);
-    const size_t lds_small = (size_t)(img + 8 * 32 * 17 + 32 * (4 * KS + 1) + 32 + TAB_FLOATS) * sizeof(float);
-    // large batches: 256 envs per workgroup, every wave independent (at 33 rays the 256-env observation tile does not fit
-    // LDS: PC_ERR_UNSUPPORTED, the per-step kernels are the faster choice there anyway); small batches: 32 envs per
-    // workgroup, hidden tiles and wall-sweep parts split over the waves
+    // large batches: 256 envs per workgroup, every wave independent; small batches: 32 envs per workgroup, hidden tiles and
+    // wall-sweep parts split over the waves
     const bool small = g_rollout_form == 1 || (g_rollout_form < 0 && e->N <= PC_SPLIT_MAX_ENVS);
+    // big form, fast mode: single track, Discrete(9), every gather table in LDS behind LDS pointers, dense observation rows
+    // (each wave's output tile aliases its own 32 observation rows -- dead between the policy pass's operand load and the env
+    // step's store of the next observation: needs D >= 17)
+    const bool fast = !small && !e->track_id && A == 9 && e->D >= 17 && e->D <= 40 && e->hdr_host[0].G <= TAB_MAX_GATES && g_rollout_fast;
+    const size_t lds_big = fast ? (size_t)(img + 256 * e->D + 256 + FT_FLOATS) * sizeof(float)
+                                : (size_t)(img + 256 * (4 * KS + 1) + 256 + TAB_FLOATS) * sizeof(float);
+    const size_t lds_small = (size_t)(img + 8 * 32 * 17 + 32 * (4 * KS + 1) + 32 + TAB_FLOATS) * sizeof(float);
     size_t lds = small ? lds_small : lds_big;
     if (lds > 160 * 1024) return PC_ERR_UNSUPPORTED;
     // the track's 1/den table rides along in LDS when it fits (big_track: 361 x 28 floats = 40 KB); else the sweep forms
@@ -3192,19 +3460,27 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     const int epw = g_rollout_epw_override ? g_rollout_epw_override
                                            : ((!small && e->N <= g_rollout_epw128_max) ? 128 : 256);   // big form: envs per workgroup
     const int blocks = (int)(small ? (e->N + 31) / 32 : (e->N + epw - 1) / epw);
+    const int vec_ok = ((e->N * e->D) % 4 == 0) ? 1 : 0;      // the waves' 32-row blocks are 16-byte aligned in the buffers
+    const int mode = fast ? (rden_lds ? 2 : 1) : 0;
     hipStream_t st = (hipStream_t)stream;
     EnvParams<float> prm = e->params<float>();
     prm.lg = small ? 2 : 1;
-#define PC_ROLL(KSV, RPLV, PRC)                                                                                          \
+#define PC_ROLL_M(KSV, RPLV, PRC, MD)                                                                                    \
     do {                                                                                                                 \
         static bool attr_set[64] = {false};                                                                              \
         if (e->device < 64 && !attr_set[e->device]) {                                                                    \
-            HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<KSV, RPLV, PRC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<KSV, RPLV, PRC, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_set[e->device] = true;                                                                                  \
         }                                                                                                                \
-        hipLaunchKernelGGL((rollout_kernel<KSV, RPLV, PRC>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, seed, \
+        hipLaunchKernelGGL((rollout_kernel<KSV, RPLV, PRC, MD>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, seed, \
                            offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs,  \
-                           next_term, next_trunc, rden_lds, epw);                                                                  \
+                           next_term, next_trunc, rden_lds, epw, vec_ok);                                                \
+    } while (0)
+#define PC_ROLL(KSV, RPLV, PRC)                                                                                          \
+    do {                                                                                                                 \
+        if (mode == 2) PC_ROLL_M(KSV, RPLV, PRC, 2);                                                                     \
+        else if (mode == 1) PC_ROLL_M(KSV, RPLV, PRC, 1);                                                                \
+        else PC_ROLL_M(KSV, RPLV, PRC, 0);                                                                               \
     } while (0)
 #define PC_ROLLS(KSV, RPLV, PRC)                                                                                         \
     do {                                                                                                                 \
@@ -3215,7 +3491,7 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
         }                                                                                                                \
         hipLaunchKernelGGL((rollout_small_kernel<KSV, RPLV, PRC>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, \
                            seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, \
-                           next_term, next_trunc, rden_lds);                                                                          \
+                           next_term, next_trunc, rden_lds);                                                                     \
     } while (0)
     if (small) {
         if (KS == 5 && rpl == 3) { if (prec == 2) PC_ROLLS(5, 3, 2); else if (prec) PC_ROLLS(5, 3, 1); else PC_ROLLS(5, 3, 0); }        // 12 rays
@@ -3226,6 +3502,7 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     else if (KS == 6 && rpl == 9) { if (prec == 2) PC_ROLL(6, 9, 2); else if (prec) PC_ROLL(6, 9, 1); else PC_ROLL(6, 9, 0); }          // 16 -> 17 rays, D = 23
     else if (KS == 10 && rpl == 17 && prec) { if (prec == 2) PC_ROLL(10, 17, 2); else PC_ROLL(10, 17, 1); }                               // 32 -> 33 rays, D = 39
     else return PC_ERR_UNSUPPORTED;
+#undef PC_ROLL_M
 #undef PC_ROLLS
 #undef PC_ROLL
     HIPCHK(hipGetLastError());

@@ -200,20 +200,22 @@ def test_ray_segment_unit_cases_through_the_hip_kernels(dtype):
 
 
 def test_f32_ray_origin_on_a_wall_line_is_the_documented_deviation():
-    """u == +0 (the ray origin exactly on the wall, strictly between its endpoints): the reference's `u > 0`
-    (car_env.py:178) rejects the hit, the float32 sweep's unsigned-minimum trick accepts it with distance 0.  A car there
-    has crashed on the previous step (d < 10 px), so no trajectory of the env reaches this state; the float64 kernel
-    follows the reference.  Pinned here so that a change of either behaviour is noticed."""
+    """u == 0 (the ray origin exactly on the wall, strictly between its endpoints): the reference's `u > 0`
+    (car_env.py:178) rejects the hit.  The float32 sweep keeps the running minimum as an unsigned bit pattern: u == -0.0 is
+    rejected like the reference, u == +0.0 -- which of the two the arithmetic produces depends on the wall's orientation -- is
+    accepted with distance 0.  A car there has crashed on the previous step (d < 10 px), so no trajectory of the env reaches
+    this state; the float64 kernel follows the reference.  Pinned here so that a change of either behaviour is noticed."""
     far_gate = np.array([[-5000.0, -5000.0, -5001.0, -5000.0]])
-    wall = [[100.0, 50.0, 100.0, 150.0]]                     # vertical wall through the origin of a horizontal ray
     out = {}
-    for dtype in ("f64", "f32"):
-        env = pc.VecCarEnv(1, pc.Track(walls=wall, gates=far_gate, start=(100.0, 100.0, 0.0)), num_rays=12, dtype=dtype)
-        obs, _ = env.reset()
-        fin = torch.empty(1, env.obs_dim, device="cuda")
-        env.step(torch.full((1,), 8, dtype=torch.int64, device="cuda"), final_obs=fin)
-        out[dtype] = (float(obs[0, 6]), float(fin[0, 6]))
-        env.close()
-    assert oracle.ray_distance(100.0, 100.0, 0.0, wall[0]) == 1000.0
-    assert out["f64"] == (1.0, 1.0)
-    assert out["f32"] == (0.0, 0.0)
+    for name, wall in (("down", [[100.0, 50.0, 100.0, 150.0]]), ("up", [[100.0, 150.0, 100.0, 50.0]])):   # through the ray origin
+        assert oracle.ray_distance(100.0, 100.0, 0.0, wall[0]) == 1000.0
+        for dtype in ("f64", "f32"):
+            env = pc.VecCarEnv(1, pc.Track(walls=wall, gates=far_gate, start=(100.0, 100.0, 0.0)), num_rays=12, dtype=dtype)
+            obs, _ = env.reset()
+            fin = torch.empty(1, env.obs_dim, device="cuda")
+            env.step(torch.full((1,), 8, dtype=torch.int64, device="cuda"), final_obs=fin)
+            out[name, dtype] = (float(obs[0, 6]), float(fin[0, 6]))
+            env.close()
+    assert out["down", "f64"] == (1.0, 1.0) and out["up", "f64"] == (1.0, 1.0)
+    assert out["down", "f32"] == (1.0, 1.0)          # u == -0.0: rejected, as the reference
+    assert out["up", "f32"][1] == 0.0                # u == +0.0 in the wall sweep: accepted (the deviation)
