@@ -65,6 +65,7 @@ struct TrackHdr {        // one per track, read with scalar loads
     int vtx_off, nV;     // F32: the walls again as vertex chains, vtx[vtx_off .. vtx_off+nV); nV is padded to a multiple of 4
     int dir_off;         // F32: ray direction table [361] of this track in dirtab (entry 360 = (0, 0): no ray)
     int rden_off;        // F32: 1/den table [361][nV] of this track in rden (row 360 = +inf: never hits)
+    int n_chain, pad_;   // F32: chain vertices before the padding to a multiple of 4 (vtx[n_chain .. nV) are sentinels)
     double start_x, start_y, start_rot;
 };
 
@@ -365,6 +366,90 @@ __device__ __forceinline__ void wall_sweep_f32(const Vtx* vt, const int nV, cons
         PC_VERTEX(rd, 3, axB, ayB, cB, axA, ayA, cA)
     }
 #undef PC_VERTEX
+}
+
+// The same sweep for a track whose chain has exactly NGRP groups of four vertices, fully unrolled and WITHOUT a branch per
+// vertex (persistent big-form kernel: big_track has 24 walls in 2 loops = 26 chain vertices, padded to 28):
+//   * the 1/den rows are read with immediate offsets (no address arithmetic per group);
+//   * two consecutive vertices share one v_min3_u32 per ray slot instead of two v_min_u32;
+//   * a chain-break vertex is not skipped but computed: its edge (ex, ey) is (0, 0), so un = 0 and 1/den = +-inf (what
+//     rden_build_kernel's v_rcp_f32 of 0 stores, too), u = 0 * inf = NaN, whose bit pattern lies above every finite distance:
+//     the candidate can never win the unsigned minimum.  Only the trailing padding pair(s) are skipped (n_chain).
+// The minimum is exact, so the result is the very same bits as wall_sweep_f32's.
+template <int RPL, bool TAB, int NGRP>
+__device__ __forceinline__ void wall_sweep_unrolled(const Vtx* vt, const int n_chain, const double npx, const double npy,
+                                                    const float (&dx)[RPL], const float (&dy)[RPL], const int (&didx)[RPL], lds_cfp rdl,
+                                                    unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
+    constexpr int NP = (RPL + 1) / 2, nV = 4 * NGRP;
+    f32x2 dx2[NP], dy2[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        dx2[j] = (f32x2){dx[2 * j], 2 * j + 1 < RPL ? dx[2 * j + 1] : 0.0f};
+        dy2[j] = (f32x2){dy[2 * j], 2 * j + 1 < RPL ? dy[2 * j + 1] : 0.0f};
+        bb[2 * j] = bb[2 * j + 1] = 0x447a0000u;  // 1000.0f, Ray.get_distance :198
+    }
+    const unsigned sgn = sign_mask();
+    auto side = [&](const Vtx& v, float& ax, float& ay, f32x2 (&c)[NP]) {
+        ax = (float)(v.x - npx);
+        ay = (float)(v.y - npy);
+        const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay};
+#pragma unroll
+        for (int j = 0; j < NP; ++j) c[j] = __builtin_elementwise_fma(ay2, dx2[j], -(ax2 * dy2[j]));
+    };
+    // candidates of the segment that vertex v closes: the hit distance's bits, with the sign bit set unless the segment's
+    // endpoints lie on strictly opposite sides of the ray line (as wall_sweep_f32's `close`)
+    auto cand = [&](const Vtx& v, const float axp, const float ayp, const f32x2 (&cp)[NP], const f32x2 (&c)[NP], const f32x4 (&rd)[2 * NP],
+                    const int I, unsigned (&q)[2 * NP]) {
+        const float un = __builtin_fmaf(v.ey, axp, -(v.ex * ayp));
+        const f32x2 un2 = {un, un}, ex2 = {v.ex, v.ex}, ey2 = {v.ey, v.ey};
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            f32x2 u;
+            if constexpr (TAB) {
+                u = (f32x2){un * rd[2 * j][I], un * rd[2 * j + 1][I]};
+            } else {
+                const f32x2 den = __builtin_elementwise_fma(ey2, dx2[j], -(ex2 * dy2[j]));
+                const f32x2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                u = un2 * rc;
+            }
+            const f32x2 t = cp[j] * (-c[j]);
+            q[2 * j] = and_or(__float_as_uint(t.x), sgn, __float_as_uint(u.x));
+            q[2 * j + 1] = and_or(__float_as_uint(t.y), sgn, __float_as_uint(u.y));
+        }
+    };
+    float axA = 0.0f, ayA = 0.0f, axB = 0.0f, ayB = 0.0f;
+    f32x2 cA[NP], cB[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) cA[j] = cB[j] = (f32x2){0.0f, 0.0f};
+    typedef const __attribute__((address_space(3))) f32x4* lds_row;
+    lds_row rrow[2 * NP];
+    if constexpr (TAB) {
+#pragma unroll
+        for (int s = 0; s < 2 * NP; ++s) rrow[s] = (lds_row)(rdl + __umul24(s < RPL ? didx[s] : 360, nV));
+    }
+#pragma unroll
+    for (int gq = 0; gq < NGRP; ++gq) {
+        f32x4 rd[2 * NP];
+        if constexpr (TAB) {
+#pragma unroll
+            for (int s = 0; s < 2 * NP; ++s) rd[s] = rrow[s][gq];
+        }
+#pragma unroll
+        for (int I = 0; I < 4; I += 2) {
+            if (gq == NGRP - 1 && 4 * gq + I >= n_chain) break;   // (wave-uniform; only the last group can hold a padding pair)
+            const Vtx v0 = cload(vt + 4 * gq + I), v1 = cload(vt + 4 * gq + I + 1);
+            unsigned q0[2 * NP], q1[2 * NP];
+            side(v0, axB, ayB, cB);
+            cand(v0, axA, ayA, cA, cB, rd, I, q0);
+            side(v1, axA, ayA, cA);
+            cand(v1, axB, ayB, cB, cA, rd, I + 1, q1);
+#pragma unroll
+            for (int s = 0; s < 2 * NP; ++s) bb[s] = min(min(bb[s], q0[s]), q1[s]);   // v_min3_u32
+        }
+        // one scheduling region per group: left alone, the scheduler hoists every group's table rows and vertex records
+        // to the top of the 1300-instruction block and spills
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // One CarEnv.step (car_env.py:693-760) + TransformReward + same-step auto-reset for the env whose state the
@@ -1059,18 +1144,30 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsig
 
 template <int PREC> struct Pieces { u32x4 p[pol_np(PREC)]; };  // eight fp32 values as pol_np x (8 halves)
 
-// ---- PREC 2: fp16 x 2.  v = h + 2^-11 * l with h = fp16(v) and l = fp16((v - h) * 2^11): the residual is exact in
-// fp32 and the scaling keeps it out of fp16's subnormal range, so the pair carries 22 significant bits of v whatever
-// its magnitude.  A product a*b is taken as a_h*b_h (into one fp32 accumulator) and a_h*b_l + a_l*b_h (into a
-// second one, folded in as acc_hi + 2^-11 * acc_lo); the dropped a_l*b_l is <= 2^-22 relative.  Three MFMAs per
-// K block instead of six and two conversions per operand instead of three; against float64 this MLP's error is
-// 1.3e-7 (plain fp32 GEMM 0.8e-7, bf16x3 1.0e-7; emulation in DESIGN.md section 5).  Operands are clamped to fp16's
-// finite range at their sources (observations, weights, ReLU as med3(x, 0, 65504)).
+// ---- PREC 2: fp16 x 2 in SCALED DOMAINS.  Every operand v is written v = h + l with h = fp16(v) and l = fp16(v - h): the
+// residual is exact in fp32, and l carries 11 more significant bits of v as long as it is a NORMAL fp16 number, i.e. for
+// |v| >= 2^-3.  So that this holds for every operand whose magnitude matters, the GEMMs run on power-of-two multiples of the
+// data (exact rescalings): observations x 16, first-layer weights x 16 -> hidden pre-activations, biases and ReLU outputs
+// x 256, output-layer weights x 64 -> logits and the value x 16384, undone by one fused multiply-add where the output bias
+// is added.  An operand below 2^-3 in its scaled domain (an observation under 0.008, a hidden activation under 5e-4, an
+// output weight under 0.002) keeps an ABSOLUTE error of at most 2^-25 scaled, i.e. <= 2e-9 / 1e-10 / 5e-10 unscaled; all
+// others 22 significant bits.  A product a*b is a_h*b_l + a_l*b_h + a_h*b_h, the three fp16 MFMAs accumulating into ONE
+// fp32 accumulator, small terms first (each piece product is exact in fp32; the dropped a_l*b_l is <= 2^-22 relative).
+// Against float64 this MLP's error is 1.3e-7 (plain fp32 GEMM 0.8e-7, bf16x3 1.0e-7; tools/emu_policy_split.py).  Operands
+// saturate at fp16's finite range in their scaled domain: |obs| <= 4094, |W1| <= 4094, hidden activations <= 255.9,
+// |W2| <= 1023 (observations are O(1), the reference's weights O(0.1 - 1)).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
-#define PC_H_SCALE 2048.0f
-#define PC_H_UNSCALE 4.8828125e-4f
 #define PC_H_MAX 65504.0f
+#define PC_SX 16.0f          /* observations */
+#define PC_S1 16.0f          /* first-layer weights */
+#define PC_SH 256.0f         /* hidden layer = PC_SX * PC_S1 */
+#define PC_S2 64.0f          /* output-layer weights (actor: the split operands; critic: its fp32 weights) */
+#define PC_SO_INV 6.103515625e-05f   /* 1 / (PC_SH * PC_S2) = 2^-14 */
+template <int PREC> struct PolScale {   // the scaled domains exist for PREC 2 only
+    static constexpr float sx = PREC == 2 ? PC_SX : 1.0f, s1 = PREC == 2 ? PC_S1 : 1.0f, sh = PREC == 2 ? PC_SH : 1.0f,
+                           s2 = PREC == 2 ? PC_S2 : 1.0f, so_inv = PREC == 2 ? PC_SO_INV : 1.0f;
+};
 __device__ __forceinline__ float clamp_h(float v) { return __builtin_amdgcn_fmed3f(v, -PC_H_MAX, PC_H_MAX); }
 __device__ __forceinline__ unsigned pk_f16(float a, float b) {  // low half = fp16(a), high half = fp16(b), round-to-nearest-even
     const f32x2 v = {a, b};
@@ -1079,7 +1176,7 @@ __device__ __forceinline__ unsigned pk_f16(float a, float b) {  // low half = fp
 __device__ __forceinline__ void split_pair_h(float a, float b, unsigned& p0, unsigned& p1) {
     p0 = pk_f16(a, b);
     const f16x2v h = __builtin_bit_cast(f16x2v, p0);
-    const f32x2 r = ((f32x2){a, b} - (f32x2){(float)h.x, (float)h.y}) * (f32x2){PC_H_SCALE, PC_H_SCALE};
+    const f32x2 r = (f32x2){a, b} - (f32x2){(float)h.x, (float)h.y};
     p1 = pk_f16(r.x, r.y);
 }
 
@@ -1109,11 +1206,12 @@ __device__ __forceinline__ f32x4 mfma6(const u32x4 (&a)[3], const Pieces<1>& b, 
 #undef PC_MF
     return acc;
 }
-// fp16 x 2: hi += a_h*b_h, lo += a_h*b_l + a_l*b_h (two independent accumulator chains)
-__device__ __forceinline__ void mfma3(const u32x4 (&a)[2], const Pieces<2>& b, f32x4& hi, f32x4& lo) {
-#define PC_MF(acc, i, j) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[i]), __builtin_bit_cast(f16x8, b.p[j]), acc, 0, 0, 0)
-    PC_MF(lo, 0, 1); PC_MF(hi, 0, 0); PC_MF(lo, 1, 0);
+// fp16 x 2: acc += a_h*b_l + a_l*b_h + a_h*b_h, small terms first, one accumulator chain
+__device__ __forceinline__ f32x4 mfma3(const u32x4 (&a)[2], const Pieces<2>& b, f32x4 acc) {
+#define PC_MF(i, j) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[i]), __builtin_bit_cast(f16x8, b.p[j]), acc, 0, 0, 0)
+    PC_MF(0, 1); PC_MF(1, 0); PC_MF(0, 0);
 #undef PC_MF
+    return acc;
 }
 
 // image builder of the split forms (one thread per 16-byte operand record / per bias float)
@@ -1136,7 +1234,7 @@ __global__ __launch_bounds__(256) void policy_pack16_kernel(const int D, const i
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int f = 8 * g + j;
-                    v[j] = f < D ? (r < HID ? aW1[r * D + f] : cW1[(r - HID) * D + f]) : 0.0f;
+                    v[j] = f < D ? (r < HID ? aW1[r * D + f] : cW1[(r - HID) * D + f]) * PolScale<PREC>::s1 : 0.0f;
                 }
             } else {
                 const int k = i - n1;
@@ -1146,7 +1244,7 @@ __global__ __launch_bounds__(256) void policy_pack16_kernel(const int D, const i
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int h = 16 * (2 * tp + (j >> 2)) + 4 * g + (j & 3);   // actor hidden unit (tp < 8)
-                    v[j] = o < A ? aW2[o * HID + h] : 0.0f;
+                    v[j] = o < A ? aW2[o * HID + h] * PolScale<PREC>::s2 : 0.0f;
                 }
             }
             if constexpr (PREC == 2) {
@@ -1158,12 +1256,12 @@ __global__ __launch_bounds__(256) void policy_pack16_kernel(const int D, const i
         } else {
             const int b = i - n1 - n2;
             float v;
-            if (b < 512) v = b < HID ? ab1[b] : cb1[b - HID];
+            if (b < 512) v = (b < HID ? ab1[b] : cb1[b - HID]) * PolScale<PREC>::sh;   // hidden layer's scaled domain
             else if (b < 528) {
                 const int o = b - 512;
-                v = o < A ? ab2[o] : (o == A ? cb2[0] : 0.0f);
+                v = o < A ? ab2[o] : (o == A ? cb2[0] : 0.0f);   // added after the outputs are scaled back
             } else {
-                v = cW2[b - 528];   // critic output layer, plain fp32
+                v = cW2[b - 528] * PolScale<PREC>::s2;   // critic output layer, plain fp32, in the outputs' scaled domain
             }
             image[(n1 + n2) * 4 + b] = __float_as_uint(v);
         }
@@ -1180,15 +1278,13 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
                                               float (&val)[2], const int lc, const int g) {
     constexpr int NP = pol_np(PREC), NG = KB == 2 ? 5 : 3;
     const int oA = lc < 10 ? lc : 9;  // output rows >= 10 are never read
-    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    f32x4 outlo[2] = {zero4, zero4};  // PREC 2: the scaled cross terms of layer 2
-    for (int tp = tp0; tp < tp1; ++tp) {
-        f32x4 acc[2][2];
+    // layer 1 of tile pair tp: acc[j][et] = b1 + W1[16 rows of tile 2 tp + j] x^T[et] (in the hidden layer's scaled domain)
+    auto layer1 = [&](const int tp, f32x4 (&acc)[2][2]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int ht = 2 * tp + j;
             const f32x4 bias = *reinterpret_cast<const f32x4*>(sB1 + 16 * ht + 4 * g);
-            f32x4 hi[2] = {bias, bias}, lo[2] = {zero4, zero4};
+            f32x4 hi[2] = {bias, bias};
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 // feature group 4 kb + g; groups >= NG are K padding (their B operand is all zeros): any finite A will do
@@ -1199,56 +1295,77 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
                     a[pc] = *reinterpret_cast<const u32x4*>(sW1p + (((ht * NP + pc) * NG + gA) * 16 + lc) * 4);
 #pragma unroll
                 for (int et = 0; et < 2; ++et) {
-                    if constexpr (PREC == 2) mfma3(a, x[et][kb], hi[et], lo[et]);
+                    if constexpr (PREC == 2) hi[et] = mfma3(a, x[et][kb], hi[et]);
                     else hi[et] = mfma6(a, x[et][kb], hi[et]);
                 }
             }
 #pragma unroll
-            for (int et = 0; et < 2; ++et) {
-                if constexpr (PREC == 2)
-                    acc[j][et] = __builtin_elementwise_fma(lo[et], (f32x4){PC_H_UNSCALE, PC_H_UNSCALE, PC_H_UNSCALE, PC_H_UNSCALE}, hi[et]);
-                else
-                    acc[j][et] = hi[et];
-            }
+            for (int et = 0; et < 2; ++et) acc[j][et] = hi[et];
         }
-        __builtin_amdgcn_s_setprio(1);  // the VALU epilogue one step above the MFMA issue (K9: below the env step's 2)
-        if (tp < 8) {  // actor (uniform branch)
-            u32x4 w2[NP];
+    };
+    // what follows layer 1 for an ACTOR tile pair (tp < 8): ReLU, operand split, layer 2 on the matrix cores
+    auto epilogue_actor = [&](const int tp, const f32x4 (&acc)[2][2]) {
+        u32x4 w2[NP];
 #pragma unroll
-            for (int pc = 0; pc < NP; ++pc) w2[pc] = *reinterpret_cast<const u32x4*>(sW2p + (((tp * NP + pc) * 4 + g) * 10 + oA) * 4);
+        for (int pc = 0; pc < NP; ++pc) w2[pc] = *reinterpret_cast<const u32x4*>(sW2p + (((tp * NP + pc) * 4 + g) * 10 + oA) * 4);
 #pragma unroll
-            for (int et = 0; et < 2; ++et) {
-                float hv[8];
+        for (int et = 0; et < 2; ++et) {
+            float hv[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if constexpr (PREC == 2) {
-                        hv[r] = __builtin_amdgcn_fmed3f(acc[0][et][r], 0.0f, PC_H_MAX);  // ReLU, saturating at fp16's range
-                        hv[4 + r] = __builtin_amdgcn_fmed3f(acc[1][et][r], 0.0f, PC_H_MAX);
-                    } else {
-                        hv[r] = relu_f(acc[0][et][r]);
-                        hv[4 + r] = relu_f(acc[1][et][r]);
-                    }
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (PREC == 2) {
+                    hv[r] = __builtin_amdgcn_fmed3f(acc[0][et][r], 0.0f, PC_H_MAX);  // ReLU, saturating at fp16's range
+                    hv[4 + r] = __builtin_amdgcn_fmed3f(acc[1][et][r], 0.0f, PC_H_MAX);
+                } else {
+                    hv[r] = relu_f(acc[0][et][r]);
+                    hv[4 + r] = relu_f(acc[1][et][r]);
                 }
-                const Pieces<PREC> h3 = split8<PREC>(hv);
-                if constexpr (PREC == 2) mfma3(w2, h3, out[et], outlo[et]);
-                else out[et] = mfma6(w2, h3, out[et]);
             }
-        } else {       // critic
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(sW2c + 16 * (2 * tp + j - 16) + 4 * g);
-#pragma unroll
-                for (int et = 0; et < 2; ++et)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) val[et] = __builtin_fmaf(w[r], relu_f(acc[j][et][r]), val[et]);
-            }
+            const Pieces<PREC> h3 = split8<PREC>(hv);
+            if constexpr (PREC == 2) out[et] = mfma3(w2, h3, out[et]);
+            else out[et] = mfma6(w2, h3, out[et]);
         }
-        __builtin_amdgcn_s_setprio(0);
-    }
-    if constexpr (PREC == 2) {
+    };
+    // ... and for a CRITIC tile pair (tp >= 8): the output layer's dot product on the VALU
+    auto epilogue_critic = [&](const int tp, const f32x4 (&acc)[2][2]) {
 #pragma unroll
-        for (int et = 0; et < 2; ++et)
-            out[et] = __builtin_elementwise_fma(outlo[et], (f32x4){PC_H_UNSCALE, PC_H_UNSCALE, PC_H_UNSCALE, PC_H_UNSCALE}, out[et]);
+        for (int j = 0; j < 2; ++j) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(sW2c + 16 * (2 * tp + j - 16) + 4 * g);
+#pragma unroll
+            for (int et = 0; et < 2; ++et)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) val[et] = __builtin_fmaf(w[r], relu_f(acc[j][et][r]), val[et]);
+        }
+    };
+    // Software pipeline over the tile pairs [tp0, tp1) (an even count, actor pairs first): the NEXT pair's layer-1 MFMAs stand
+    // in the instruction stream before THIS pair's VALU epilogue, in one branch-free block, so the scheduler can interleave
+    // them and the matrix pipe works under the vector work instead of the wave waiting first for its MFMA results and then
+    // for its own epilogue.  Two accumulator sets, alternating (no copies); the arithmetic per accumulator is unchanged.
+    f32x4 accA[2][2], accB[2][2];
+    const int ta1 = tp1 < 8 ? tp1 : 8;
+    int tp = tp0;
+    layer1(tp, accA);
+#pragma unroll 1
+    for (; tp < ta1 && tp + 2 < tp1; tp += 2) {
+        layer1(tp + 1, accB);
+        epilogue_actor(tp, accA);
+        layer1(tp + 2, accA);
+        epilogue_actor(tp + 1, accB);
+    }
+#pragma unroll 1
+    for (; tp + 2 < tp1; tp += 2) {
+        layer1(tp + 1, accB);
+        epilogue_critic(tp, accA);
+        layer1(tp + 2, accA);
+        epilogue_critic(tp + 1, accB);
+    }
+    layer1(tp + 1, accB);      // the last two pairs
+    if (tp < 8) {              // (uniform)
+        epilogue_actor(tp, accA);
+        epilogue_actor(tp + 1, accB);
+    } else {
+        epilogue_critic(tp, accA);
+        epilogue_critic(tp + 1, accB);
     }
 }
 
@@ -1417,7 +1534,7 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
                     for (int j = 0; j < 8; ++j) {
                         const int f = 8 * (4 * kb + lk) + j;
                         v[j] = (e < N && f < D) ? obs[e * D + f] : 0.0f;
-                        if constexpr (PREC == 2) v[j] = clamp_h(v[j]);
+                        if constexpr (PREC == 2) v[j] = clamp_h(v[j] * PolScale<PREC>::sx);   // the observations' scaled domain
                     }
                     x[et][kb] = split8<PREC>(v);
                 }
@@ -1444,9 +1561,10 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
             // order, then the row-parallel draw
             const int el = wave * 4 + lk, oi = lc;
             const int64_t e = env0 + el;
-            float t = sB2[oi];
+            float ps = 0.0f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) t += sOut[(w * 32 + el) * LDO + oi];
+            for (int w = 0; w < 8; ++w) ps += sOut[(w * 32 + el) * LDO + oi];
+            const float t = __builtin_fmaf(ps, PolScale<PREC>::so_inv, sB2[oi]);   // outputs back from their scaled domain
             int act;
             float lp, val;
             policy_tail_row(t, oi, A, philox_uniform(seed, off, (uint64_t)e), lane, act, lp, val);
@@ -1464,7 +1582,7 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
             if (lane < 32 && e < N) {
                 float v[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = sB2[i] + myOut[lane * LDO + i];
+                for (int i = 0; i < 16; ++i) v[i] = __builtin_fmaf(myOut[lane * LDO + i], PolScale<PREC>::so_inv, sB2[i]);   // outputs back from their scaled domain
                 int act;
                 float lp, val;
                 policy_tail(v, A, philox_uniform(seed, off, (uint64_t)e), act, lp, val, logits_out ? logits_out + e * A : nullptr);
@@ -1478,6 +1596,18 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
 }
 
 // ------------------------------------------------------------------------------------------
+// Developer-only phase timeline of the big-form rollout kernel (make stamps -> libppocar_stamps.so, -DPC_STAMPS): workgroup 0's
+// eight waves write s_memtime at every phase boundary of steps 64..71 into a device array that tools/k9_timeline.py reads back.
+// The product build contains none of this.
+#ifdef PC_STAMPS
+constexpr int STAMP_T0 = 64, STAMP_NT = 8, STAMP_NPH = 8;
+__device__ unsigned long long g_stamps[8 * STAMP_NT * STAMP_NPH];
+#define PC_STAMP(ph)                                                                                                      \
+    if (blockIdx.x == 0 && t >= STAMP_T0 && t < STAMP_T0 + STAMP_NT && lane == 0)                                        \
+        g_stamps[((wave * STAMP_NT) + (t - STAMP_T0)) * STAMP_NPH + (ph)] = __builtin_amdgcn_s_memtime();
+#else
+#define PC_STAMP(ph)
+#endif
 // ------------------------------------------------------------------------------------------
 // The env step of the persistent big-form rollout (K9), single track, every gather table in LDS.
 // Same arithmetic as env_step_core<float> -- its buffers are compared bit for bit with the per-step kernels' -- but laid out
@@ -1566,7 +1696,8 @@ template <int RPL, bool TAB>
 __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const TrackHdr& h, const FastTabs& ft, const int (&rsd)[RPL],
                                               const unsigned (&noncol)[RPL], const int (&col)[RPL], const int (&gq)[2], const int g,
                                               EnvRegs& st, int& k72, const int a, const double reward_scale, lds_fp lrow,
-                                              float& reward_f, float& term_f, float& trunc_f) {
+                                              float& reward_f, float& term_f, float& trunc_f, const int t = 0, const int lane = 0,
+                                              const int wave = 0) {
     // ---- action, heading before and after the turn (car_env.py:698-722, :440-442)
     const f64x2 Lf = ft.act[2 * a];                                     // (thrust, fric)
     const i32x2 Li = *(lds_ci2)(ft.act + 2 * a + 1);                    // (dk, fwd)
@@ -1606,7 +1737,12 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     }
     // ---- wall sweep
     unsigned bb[2 * ((RPL + 1) / 2)];
-    wall_sweep_f32<RPL, 1, TAB>(p.vtx + h.vtx_off, h.nV, 0, npx, npy, dx, dy, didx, ft.rden, bb);
+    PC_STAMP(4)
+    if (h.nV == 28)   // (wave-uniform) big_track's chain: the unrolled sweep
+        wall_sweep_unrolled<RPL, TAB, 7>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dx, dy, didx, ft.rden, bb);
+    else
+        wall_sweep_f32<RPL, 1, TAB>(p.vtx + h.vtx_off, h.nV, 0, npx, npy, dx, dy, didx, ft.rden, bb);
+    PC_STAMP(5)
     // Car.check_collision (:376-392): any collision ray closer than 10 px.  Distances are non-negative floats, so the
     // smallest one is the unsigned minimum of the bit patterns; a slot that is not a collision ray is masked to +inf.
     unsigned hm = 0x7f800000u;
@@ -1731,7 +1867,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const unsigned* sW2p = sW1p + polx_w1_dwords(PREC ? PREC : 1, NG);
     const float* sW2c = sB2 + 16;                  // PREC 1: critic output weights [256]
     const int64_t N = p.N;
-    const int D = p.D;
+    constexpr int DC = RPL == 6 ? 18 : (RPL == 9 ? 23 : 39);   // FAST: 6 + the ray count the 2-lanes-per-env menu implies (12 / 17 / 33)
+    const int D = FAST ? DC : p.D;
     // observation of the step in flight, [256 envs][LDX]: FAST keeps the rows dense (LDX = D, exactly the rollout buffer's
     // layout: a wave's 32 rows are one contiguous block there and here)
     const int LDX = FAST ? D : 4 * KS + 1;
@@ -1803,6 +1940,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
 
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
+        PC_STAMP(0)
         {
             // ---------------- P(t)
             f32x4 out[ET];
@@ -1836,14 +1974,16 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                         for (int j = 0; j < 8; ++j) {
                             const int f = 8 * (4 * kb + lk) + j;
                             v[j] = f < D ? sObs[(pbase + 16 * et + lc) * LDX + f] : 0.0f;
-                            if constexpr (PREC == 2) v[j] = clamp_h(v[j]);
+                            if constexpr (PREC == 2) v[j] = clamp_h(v[j] * PolScale<PREC>::sx);   // the observations' scaled domain
                         }
                         x[et][kb] = split8<PREC>(v);
                     }
                 }
                 float val[ET] = {0.0f, 0.0f};
                 __builtin_amdgcn_s_setprio(0);
+                PC_STAMP(1)
                 if (!(dbg & 1)) policy_pass16<PREC, KB>(sW1p, sW2p, sB1, sW2c, 0, NT / 2, x, out, val, lc, lk);
+                PC_STAMP(2)
                 __builtin_amdgcn_s_setprio(3);
 #pragma unroll
                 for (int et = 0; et < ET; ++et) {
@@ -1863,7 +2003,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
             if (lane < 32 && e < N) {
                 float v[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = sB2[i] + myOut[lane * LDO + i];
+                for (int i = 0; i < 16; ++i) v[i] = __builtin_fmaf(myOut[lane * LDO + i], PolScale<PREC>::so_inv, sB2[i]);   // outputs back from their scaled domain
                 int act;
                 float lp, val;
                 const uint64_t o = off0 + (uint64_t)t;
@@ -1880,13 +2020,15 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
             __builtin_amdgcn_wave_barrier();
         }
         const bool last = t + 1 == T;
+        PC_STAMP(3)
         if constexpr (FAST) {
             if (!(dbg & 2)) {
                 __builtin_amdgcn_s_setprio(2);
                 // ---------------- E(t)
                 float rw, tf, cf;
                 const int a = e_valid ? sAct[el] : 8;
-                const bool done = env_step_fast<RPL, MODE == 2>(p, h0, ft, rsd, noncol, col, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf);
+                const bool done = env_step_fast<RPL, MODE == 2>(p, h0, ft, rsd, noncol, col, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave);
+                PC_STAMP(6)
                 // gymnasium 0.29.1 same-step auto-reset: a finished env returns its reset observation
                 if (__builtin_amdgcn_ballot_w64(done) != 0) {   // wave-uniform: ~1.5 % of env steps end an episode
                     if (done)
@@ -1907,10 +2049,15 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 const int n_rows = left >= 32 ? 32 : (int)left;
                 const float* srcl = sObs + pbase * LDX;
                 if (vec_ok && n_rows == 32) {
-                    for (int i = lane; i < 8 * D; i += 64) reinterpret_cast<f32x4*>(dstg)[i] = reinterpret_cast<const f32x4*>(srcl)[i];
+#pragma unroll
+                    for (int j = 0; j < (8 * DC + 63) / 64; ++j) {      // 8 * D float4s: 3 (D = 18, 23) or 5 (D = 39) stores per lane
+                        const int i = lane + 64 * j;
+                        if (64 * j + 63 < 8 * DC || i < 8 * DC) reinterpret_cast<f32x4*>(dstg)[i] = reinterpret_cast<const f32x4*>(srcl)[i];
+                    }
                 } else {
                     for (int i = lane; i < n_rows * D; i += 64) dstg[i] = srcl[i];
                 }
+                PC_STAMP(7)
             }
         } else if (e_valid && !(dbg & 2)) {
             __builtin_amdgcn_s_setprio(2);
@@ -2026,7 +2173,7 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                     for (int j = 0; j < 8; ++j) {
                         const int f = 8 * (4 * kb + lk) + j;
                         v[j] = f < D ? sObs[(16 * et + lc) * LDX + f] : 0.0f;
-                        if constexpr (PREC == 2) v[j] = clamp_h(v[j]);
+                        if constexpr (PREC == 2) v[j] = clamp_h(v[j] * PolScale<PREC>::sx);   // the observations' scaled domain
                     }
                     x[et][kb] = split8<PREC>(v);
                 }
@@ -2049,9 +2196,10 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
         {   // every wave draws for 4 of the 32 envs, 16 lanes (= outputs) per env, exactly as policy_kernel<SPLIT>
             const int dl = wave * 4 + lk, oi = lc;
             const int64_t e = (int64_t)blockIdx.x * 32 + dl;
-            float tsum = sB2[oi];
+            float ps = 0.0f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) tsum += sOut[(w * 32 + dl) * LDO + oi];  // fixed order
+            for (int w = 0; w < 8; ++w) ps += sOut[(w * 32 + dl) * LDO + oi];  // fixed order
+            const float tsum = __builtin_fmaf(ps, PolScale<PREC>::so_inv, sB2[oi]);   // outputs back from their scaled domain
             const uint64_t o = off0 + (uint64_t)t;
             if (t == 0 || (o & 3) == 0) rnd = philox_block(seed, o >> 2, (uint64_t)e);  // uniform: ten rounds per 4 steps
             int act;
@@ -2977,6 +3125,8 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
             if (!cont) vtx.push_back(Vtx{sg.x1, sg.y1, 0.f, 0.f, 1, 0});
             vtx.push_back(Vtx{sg.x2, sg.y2, (float)(sg.x1 - sg.x2), (float)(sg.y1 - sg.y2), 0, 0});
         }
+        h.n_chain = (int)vtx.size() - h.vtx_off;
+        h.pad_ = 0;
         while ((vtx.size() - h.vtx_off) % 4)  // the sweep walks vertex groups of four: pad with chain-break sentinels
             vtx.push_back(Vtx{vtx.back().x, vtx.back().y, 0.f, 0.f, 1, 0});
         h.nV = (int)vtx.size() - h.vtx_off;
@@ -3158,6 +3308,17 @@ int pc_env_info(pc_env* e, int32_t* gates_passed, int32_t* time_passed, void* st
 }
 
 int pc_build_ablate(void) { return PC_ABLATE; }
+
+#ifdef PC_STAMPS
+// developer build only (not declared in ppocar.h): copy the phase stamps of the last pc_rollout launch to the host
+int pc_debug_read_stamps(unsigned long long* out, int n) {
+    const int total = 8 * STAMP_NT * STAMP_NPH;
+    if (n < total) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), total * sizeof(unsigned long long)) != hipSuccess) return -3;
+    return total;
+}
+#endif
 
 int pc_env_get_state(pc_env* e, double* px, double* py, double* vx, double* vy, double* rot, int64_t* time_step,
                      int64_t* next_gate, int64_t* passed) {

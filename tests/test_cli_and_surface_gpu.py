@@ -1,0 +1,220 @@
+"""GPU tests of the drop-in surface around the hot path: the train.py CLI end to end (reference train.py:72-92,280-292,301),
+checkpoint / resume on every update path, the gymnasium-shaped attributes train.py reads (train.py:141-142) and the info keys
+(car_env.py:599-603), and the multi-rank update with the gradient all-reduce captured inside the epoch graph (RCCL)."""
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import ppo_car_amd as pc
+from ppo_car_amd.ppo import PPOConfig, Trainer
+from conftest import ROOT, TRACKS
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------------------------
+# train.py as a user runs it
+# ------------------------------------------------------------------------------------------------
+def _run_dirs(out_dir):
+    ck = sorted(os.listdir(os.path.join(out_dir, "checkpoints")))
+    lg = sorted(os.listdir(os.path.join(out_dir, "logs")))
+    return ck, lg
+
+
+def test_train_cli_end_to_end_and_resume(tmp_path):
+    import train
+    out = str(tmp_path)
+    base = ["--cuda", "--track", TRACKS["big_track"], "--n-envs", "256", "--n-steps", "64", "--batch-size", "64", "--train-iters", "2",
+            "--num-rays", "16", "--out-dir", out]
+    train.main(["--run-name", "t1", "--n-epochs", "10"] + base)
+    ck, lg = _run_dirs(out)
+    assert len(ck) == 1 and ck == lg and ck[0].endswith("_t1")                       # train.py:118-123: <timestamp>_<run-name>
+    files = sorted(os.listdir(os.path.join(out, "checkpoints", ck[0])))
+    assert files == ["checkpoint_10.dat", "model.dat", "trainer_10.pt"]              # train.py:283,301 (+ the resumable state)
+    sd = torch.load(os.path.join(out, "checkpoints", ck[0], "model.dat"), weights_only=True)
+    assert set(sd) == {"actor.0.weight", "actor.0.bias", "actor.2.weight", "actor.2.bias",
+                       "critic.0.weight", "critic.0.bias", "critic.2.weight", "critic.2.bias"}
+    assert sd["actor.0.weight"].shape == (256, 23)
+    hp = open(os.path.join(out, "logs", ck[0], "hyperparameters.md")).read()         # train.py:132-135
+    assert hp.startswith("|param|value|\n|-|-|\n") and "|n_envs|256|" in hp and "|learning_rate|0.0003|" in hp
+    rows = [json.loads(l) for l in open(os.path.join(out, "logs", ck[0], "scalars.jsonl"))]
+    assert len(rows) == 10
+    for tag in ("losses/policy_loss", "losses/value_loss", "losses/entropy", "losses/total_loss", "charts/avg_reward",
+                "charts/learning_rate", "charts/SPS"):                               # train.py:286-292
+        assert all(np.isfinite(r[tag]) for r in rows), tag
+    assert rows[-1]["global_step"] == 10 * 256 * 64
+    assert rows[-1]["charts/learning_rate"] == pytest.approx(3e-4 * 0.99 ** 10, rel=1e-5)
+    # --resume through the CLI: 2 more epochs continue the run (epoch counter, step counter, lr schedule)
+    resume = os.path.join(out, "checkpoints", ck[0], "trainer_10.pt")
+    train.main(["--run-name", "t2", "--n-epochs", "12", "--resume", resume] + base)
+    ck2, _ = _run_dirs(out)
+    new = [d for d in ck2 if d.endswith("_t2")]
+    assert len(new) == 1
+    rows2 = [json.loads(l) for l in open(os.path.join(out, "logs", new[0], "scalars.jsonl"))]
+    assert len(rows2) == 2 and rows2[-1]["global_step"] == 12 * 256 * 64
+    assert rows2[-1]["charts/learning_rate"] == pytest.approx(3e-4 * 0.99 ** 12, rel=1e-5)
+    # ... and equals an uninterrupted 12-epoch run, bit for bit
+    train.main(["--run-name", "t3", "--n-epochs", "12"] + base)
+    ck3, _ = _run_dirs(out)
+    full = [d for d in ck3 if d.endswith("_t3")][0]
+    a = torch.load(os.path.join(out, "checkpoints", new[0], "model.dat"), weights_only=True)
+    b = torch.load(os.path.join(out, "checkpoints", full, "model.dat"), weights_only=True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(custom_mlp=False), dict(fused_update=False), dict(use_graphs=False),
+                                dict(custom_mlp=False, use_graphs=False)],
+                         ids=["custom-epoch-graph", "torch-mlp-graphs", "torch-update-graphs", "custom-eager", "torch-mlp-eager"])
+def test_checkpoint_resume_on_every_update_path(tmp_path, kw):
+    """3 epochs in one go == 2 epochs, save, fresh trainer, load, 1 more -- also on the paths that build their graphs lazily
+    (torch MLPs between the fused kernels, capturable torch Adam): the warm-up of the graph capture must not disturb a
+    restored optimizer state."""
+    cfg = PPOConfig(n_envs=256, n_steps=48, batch_size=64, train_iters=3, track=TRACKS["big_track"], num_rays=16, seed=5, **kw)
+    a = Trainer(cfg, device="cuda")
+    for _ in range(3):
+        a.run_epoch(sync=False)
+    b = Trainer(cfg, device="cuda")
+    for _ in range(2):
+        b.run_epoch(sync=False)
+    torch.cuda.synchronize()
+    torch.save(b.state_dict(), tmp_path / "t.pt")
+    b.close()
+    c = Trainer(cfg, device="cuda")
+    c.load_state_dict(torch.load(tmp_path / "t.pt", map_location="cuda", weights_only=False))
+    c.run_epoch(sync=False)
+    torch.cuda.synchronize()
+    exact = kw.get("fused_update", True)      # torch's capturable Adam recomputes its bias correction on the device: 1e-6 slack
+    if exact:
+        assert torch.equal(a.learner.flat_param, c.learner.flat_param)
+    else:
+        assert torch.allclose(a.learner.flat_param, c.learner.flat_param, atol=2e-6, rtol=1e-5)
+    assert torch.equal(a.buffer.act_buf, c.buffer.act_buf) if exact else True
+    a.close(); c.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# gymnasium-shaped surface
+# ------------------------------------------------------------------------------------------------
+def test_spaces_and_info_keys():
+    env = pc.VecCarEnv(64, TRACKS["big_track"], num_rays=16, reward_scaling=0.1)
+    assert env.single_observation_space.shape == (23,) and env.single_action_space.n == 9      # train.py:141-142
+    assert env.observation_space.shape == (64, 23) and env.num_envs == 64
+    obs, info = env.reset()
+    assert info == {} and obs.shape == (64, 23)
+    ora = oracle.OracleVecEnv(oracle.Track(TRACKS["big_track"]), 64, num_rays=16, reward_scaling=0.1)
+    ora.reset()
+    rng = np.random.default_rng(0)
+    saw_reset = False
+    for t in range(120):
+        a = rng.choice([0, 4, 5, 2], size=64).astype(np.int64)
+        _, _, term, trunc, info = env.step(torch.from_numpy(a).cuda(), info=True)
+        _, _, TE, TR = ora.step(a)
+        # CarEnv._get_info() (car_env.py:599-603) of every env's state after the step (auto-reset envs: 0 / 0)
+        assert np.array_equal(info["time_passed"].cpu().numpy(), ora.time_step)
+        assert np.array_equal(info["gates_passed"].cpu().numpy(), ora.passed)
+        done = (term.cpu().numpy() != 0) | (trunc.cpu().numpy() != 0)
+        assert np.array_equal(done, TE | TR)
+        if done.any():
+            saw_reset = True
+            assert np.all(info["time_passed"].cpu().numpy()[done] == 0)
+    assert saw_reset
+    i2 = env.infos()
+    assert np.array_equal(i2["time_passed"].cpu().numpy(), ora.time_step)
+    env.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-rank update: the all-reduce inside the epoch graph
+# ------------------------------------------------------------------------------------------------
+def _one_rank_collective_worker(rank, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    res = {}
+    for name, kw in (("captured", dict(capture_collectives=True)), ("eager", dict(capture_collectives=False))):
+        cfg = PPOConfig(n_envs=512, n_steps=64, batch_size=32, train_iters=3, track=TRACKS["big_track"], num_rays=16, seed=11,
+                        force_collective=True, **kw)
+        tr = Trainer(cfg, device="cuda:0")
+        for _ in range(3):
+            tr.run_epoch(sync=False)
+        torch.cuda.synchronize()
+        res[name] = (tr.learner.flat_param.cpu(), tr.learner.metrics.cpu(), tr.learner._epoch_graph is not None,
+                     tr.learner._capture_failed)
+        tr.close()
+    cfg = PPOConfig(n_envs=512, n_steps=64, batch_size=32, train_iters=3, track=TRACKS["big_track"], num_rays=16, seed=11)
+    tr = Trainer(cfg, device="cuda:0")
+    for _ in range(3):
+        tr.run_epoch(sync=False)
+    torch.cuda.synchronize()
+    res["single"] = (tr.learner.flat_param.cpu(),)
+    tr.close()
+    torch.save(res, os.path.join(out_dir, "res.pt"))
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_is_captured_into_the_update_graph(tmp_path):
+    """The multi-rank update path (K10, K11, RCCL all-reduce, clip + Adam per minibatch) on a ONE-rank RCCL communicator:
+    with capture_collectives the whole epoch's update -- collectives included -- is one HIP graph replay; it must give the
+    bits of the eagerly enqueued sequence, and agree with the single-rank kernels (different norm summation: 1e-6)."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_one_rank_collective_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    res = torch.load(tmp_path / "res.pt")
+    assert res["captured"][2] and not res["captured"][3], "the RCCL all-reduce was not captured into the epoch graph"
+    assert not res["eager"][2]
+    assert torch.equal(res["captured"][0], res["eager"][0]) and torch.equal(res["captured"][1], res["eager"][1])
+    assert torch.allclose(res["captured"][0], res["single"][0], atol=2e-6, rtol=1e-5)
+
+
+def _two_rank_nccl_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    cfg = PPOConfig(n_envs=512, n_steps=64, batch_size=32, train_iters=2, track=TRACKS["big_track"], num_rays=16, seed=11)
+    tr = Trainer(cfg, device=f"cuda:{rank}", rank=rank, world_size=world)
+    tr.run_epoch()
+    s2 = tr.run_epoch()
+    torch.cuda.synchronize()
+    torch.save({"param": tr.learner.flat_param.cpu(), "acts": tr.buffer.act_buf.cpu(), "scalars": s2,
+                "captured": tr.learner._epoch_graph is not None}, os.path.join(out_dir, f"r{rank}.pt"))
+    tr.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (one RCCL rank per GPU)")
+def test_two_rccl_ranks_keep_replicas_identical(tmp_path):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_two_rank_nccl_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["param"], r1["param"]) and not torch.equal(r0["acts"], r1["acts"])
+    assert r0["scalars"]["charts/avg_reward"] == pytest.approx(r1["scalars"]["charts/avg_reward"])
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher: the parent spawns the ranks as child processes before touching the GPU.
+    On a 1-GPU box the two ranks share cuda:0 over gloo (--same-device); the JSON line must come from rank 0 of the children."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--workload",
+                        "cfg1", "--n-steps", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["n_envs_total"] == 8192
+    assert d["value"] > 0 and d["scaling"] == "weak"

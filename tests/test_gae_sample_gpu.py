@@ -183,3 +183,35 @@ def test_fused_policy_kernel_matches_torch_mlp(D, N, policy_precision):
         p = torch.softmax(ref_logits.double(), -1).mean(0).cpu().numpy()
         counts = torch.bincount(a, minlength=9).double().cpu().numpy()
         assert np.abs(counts / N - p).max() < 0.01
+
+
+@pytest.mark.parametrize("policy_precision", [2, 1, 0], indirect=True)
+def test_fused_policy_kernel_on_trained_weights_and_harvested_observations(policy_precision):
+    """The precision claim of the fused policy kernel on REAL data rather than random weights: tests/golden/policy_trained.npz
+    holds the weights after 150 PPO epochs on big_track (tools/make_policy_fixture.py, this repository's own run) and 4096
+    observations of its last rollout -- among them reset rows (velocity exactly 0), rows with |velocity / 10| < 1e-3 and rays
+    saturated at 1000 px.  Logits and values of every arithmetic form must stay within 4e-6 of float64 (north_star: 1e-5)."""
+    import os
+    from conftest import GOLDEN
+    f = np.load(os.path.join(GOLDEN, "policy_trained.npz"))
+    obs = f["obs"]
+    assert obs.shape == (4096, 23) and float(f["avg_reward"]) > 0.15                      # a trained policy (reference curve: 0.11 -> 0.25)
+    assert (np.abs(obs[:, 2:4]).max(1) == 0).sum() > 50 and (np.abs(obs[:, 2:4]).max(1) < 1e-3).sum() > 200
+    agent = pc.Agent(23, 9)
+    agent.load_state_dict({k: torch.from_numpy(f[k.replace(".", "_")]) for k in agent.state_dict()})
+    agent = agent.cuda()
+    x = torch.from_numpy(obs).cuda()
+    logits = torch.empty(4096, 9, device="cuda")
+    agent.rng_seed = 5
+    a, lp, v = agent.act(x, out_logits=logits)
+    W = {k: f[k.replace(".", "_")].astype(np.float64) for k in agent.state_dict()}
+    x64 = obs.astype(np.float64)
+    ref_logits = np.maximum(x64 @ W["actor.0.weight"].T + W["actor.0.bias"], 0) @ W["actor.2.weight"].T + W["actor.2.bias"]
+    ref_v = (np.maximum(x64 @ W["critic.0.weight"].T + W["critic.0.bias"], 0) @ W["critic.2.weight"].T + W["critic.2.bias"]).reshape(-1)
+    err_l = np.abs(logits.cpu().numpy().astype(np.float64) - ref_logits).max()
+    err_v = np.abs(v.cpu().numpy().astype(np.float64) - ref_v).max()
+    print(f"precision form {policy_precision}: max |logit err| {err_l:.2e}, max |value err| {err_v:.2e}, max |logit| {np.abs(ref_logits).max():.2f}, "
+          f"max |value| {np.abs(ref_v).max():.2f}")
+    assert err_l < 4e-6 and err_v < 4e-6
+    lp_ref = ref_logits - np.log(np.exp(ref_logits - ref_logits.max(1, keepdims=True)).sum(1, keepdims=True)) - ref_logits.max(1, keepdims=True)
+    assert np.abs(lp.cpu().numpy() - lp_ref[np.arange(4096), a.cpu().numpy()]).max() < 4e-6

@@ -85,24 +85,29 @@ def test_generated_circuit_steps_like_the_oracle_and_through_the_persistent_kern
     a[fwd] = rng.choice([0, 4, 5], size=int(fwd.sum()))
     a = a.astype(np.int64)
     oenv = oracle.OracleVecEnv(oracle.Track(path), N, num_rays=n, reward_scaling=0.1, threads=8)
-    oenv.reset()
     acts = torch.from_numpy(a).cuda()
     for dtype in ("f64", "f32"):
         env = pc.VecCarEnv(N, path, num_rays=n, reward_scaling=0.1, dtype=dtype)
         env.reset()
-        if dtype == "f64":
-            oenv.reset()
+        oenv.reset()
         worst, n_gate, n_term = 0.0, 0, 0
+        alive = np.ones(N, bool)                             # f32: env still on the oracle's trajectory (no near-tie flipped)
         for t in range(T):
-            if dtype == "f64":
-                O, R, TE, TR = oenv.step(a[t])
+            O, R, TE, TR = oenv.step(a[t])
             obs, rew, term, trunc, _ = env.step(acts[t])
+            o, r, te, tr_ = obs.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy() != 0, trunc.cpu().numpy() != 0
             if dtype == "f64":                               # the reference's own arithmetic: bit-exact
-                assert np.array_equal(obs.cpu().numpy(), O) and np.array_equal(rew.cpu().numpy(), R.astype(np.float32))
-                assert np.array_equal(term.cpu().numpy() != 0, TE)
+                assert np.array_equal(o, O) and np.array_equal(r, R.astype(np.float32))
+                assert np.array_equal(te, TE) and np.array_equal(tr_, TR)
                 n_gate += int((R > 0.09).sum()); n_term += int(TE.sum())
+            else:                                            # float32 ray geometry: free-running, compared until a threshold near-tie flips
+                alive &= ~((te != TE) | (tr_ != TR) | (r != R.astype(np.float32)))
+                worst = max(worst, float(np.abs(o - O)[alive].max()) if alive.any() else 0.0)
         if dtype == "f64":
             assert n_term > 20 and n_gate > 20               # walls were hit and gates passed on the generated circuit
+        else:
+            assert worst <= 1e-5, worst                      # observations within the north-star tolerance
+            assert alive.mean() > 0.95, alive.mean()         # and (nearly) every env's events identical over 300 steps
         env.close()
     # the persistent rollout kernel on this track (1/den table too large for LDS above ~90 walls: arithmetic path)
     res = {}

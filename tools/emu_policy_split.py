@@ -1,5 +1,7 @@
-"""Emulation (numpy, CPU) of the policy MLP under the three operand forms against float64: plain fp32, bf16 x 3 (six
-products), fp16 x 2 scaled (three products, two accumulators) -- with and without fp16 denormal flushing.  Developer tool."""
+"""Emulation (numpy, CPU) of the policy MLP under the operand forms against float64: plain fp32, bf16 x 3 (six products),
+fp16 x 2 with the residual scaled by 2^11 into a second accumulator (round 1's form), and fp16 x 2 in scaled domains with ONE
+accumulator (the shipped form: observations x 16, W1 x 16, hidden x 256, W2 x 64, outputs x 16384 -- DESIGN.md section 5) --
+with and without fp16 denormal flushing, and the unscaled single-accumulator form for comparison.  Developer tool."""
 import numpy as np
 rng = np.random.default_rng(0)
 def bf16(x):
@@ -42,6 +44,28 @@ def h2(flush=False):
         hi = mm32(ah, bh); lo = mm32(ah, bl) + mm32(al, bh)
         return (hi + lo * np.float32(2.0**-11)).astype(np.float32)
     h = np.maximum(mm(X, W1.T) + b1, 0).astype(np.float32); return mm(h, W2.T) + b2
+def split_h2u(x, flush=False):   # unscaled residual
+    x = x.astype(np.float32); h = x.astype(np.float16)
+    if flush: h = np.where(np.abs(h.astype(np.float32)) < 6.1035e-5, np.float16(0), h)
+    l = (x - h.astype(np.float32)).astype(np.float16)
+    if flush: l = np.where(np.abs(l.astype(np.float32)) < 6.1035e-5, np.float16(0), l)
+    return h.astype(np.float32), l.astype(np.float32)
+def h2_domains(sx=16.0, s1=16.0, s2=64.0, flush=False):
+    def mm(a, b, c0):   # one accumulator chain: small terms first, starting from the (scaled) bias
+        ah, al = split_h2u(a, flush); bh, bl = split_h2u(b, flush)
+        acc = np.broadcast_to(c0, (a.shape[0], b.shape[1])).astype(np.float32)
+        for u, v in ((ah, bl), (al, bh), (ah, bh)):
+            for k0 in range(0, a.shape[1], 32):
+                acc = (acc.astype(np.float64) + u[:, k0:k0+32].astype(np.float64) @ v[k0:k0+32].astype(np.float64)).astype(np.float32)
+        return acc
+    clamp = lambda v: np.clip(v, -65504.0, 65504.0).astype(np.float32)
+    xs, w1s, w2s = clamp(X * np.float32(sx)), clamp(W1 * np.float32(s1)), clamp(W2 * np.float32(s2))
+    h = np.clip(mm(xs, w1s.T, b1 * np.float32(sx * s1)), 0, 65504.0).astype(np.float32)
+    o = mm(h, w2s.T, np.float32(0))
+    return (o * np.float32(1.0 / (sx * s1 * s2)) + b2).astype(np.float32)
 t = truth()
-for name, f in [("plain fp32", plain32), ("bf16x3", bf3), ("fp16x2 scaled", h2), ("fp16x2 scaled, denormals flushed", lambda: h2(True))]:
-    o = f(); print(f"{name:36s} max abs err {np.abs(o - t).max():.3e}  rms {np.sqrt(((o-t)**2).mean()):.3e}   max|logit| {np.abs(t).max():.2f}")
+for name, f in [("plain fp32", plain32), ("bf16x3", bf3), ("fp16x2, residual x 2^11, 2 accumulators", h2),
+                ("  the same, denormals flushed", lambda: h2(True)),
+                ("fp16x2, scaled domains, 1 accumulator", h2_domains), ("  the same, denormals flushed", lambda: h2_domains(flush=True)),
+                ("fp16x2, unscaled, 1 accumulator", lambda: h2_domains(1.0, 1.0, 1.0))]:
+    o = f(); print(f"{name:44s} max abs err {np.abs(o - t).max():.3e}  rms {np.sqrt(((o-t)**2).mean()):.3e}   max|logit| {np.abs(t).max():.2f}")
