@@ -1689,12 +1689,17 @@ __device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p,
     return ft;
 }
 
+struct FastLane {        // per-lane invariants of the env step (a handful of registers instead of three per ray slot)
+    int rs0, rstep, rs_last;  // ray slot s of lane g is ray min(g + 2 s, R - 1): angle offsets step_deg * ray
+    int colmask;              // bit s: slot s is one of Car.check_collision's rays
+    lds_fp lray, llast;       // this lane's first ray column of its observation row (slot s: + 2 s floats), and the last slot's
+};
 // exchange with the neighbouring lane (the other lane of the env): DPP quad_perm [1, 0, 3, 2], one VALU instruction
 __device__ __forceinline__ int swap_pair(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false); }
 
 template <int RPL, bool TAB>
-__device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const TrackHdr& h, const FastTabs& ft, const int (&rsd)[RPL],
-                                              const unsigned (&noncol)[RPL], const int (&col)[RPL], const int (&gq)[2], const int g,
+__device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const TrackHdr& h, const FastTabs& ft, const FastLane& fl,
+                                              const int (&gq)[2], const int g,
                                               EnvRegs& st, int& k72, const int a, const double reward_scale, lds_fp lrow,
                                               float& reward_f, float& term_f, float& trunc_f, const int t = 0, const int lane = 0,
                                               const int wave = 0) {
@@ -1716,9 +1721,11 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     float dx[RPL], dy[RPL];
     int didx[RPL];
     const int k5n = 5 * k72n;
+    const int m0 = k5n + fl.rs0, m_last = k5n + fl.rs_last;
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
-        const unsigned m = (unsigned)(k5n + rsd[s]);
+        // ray(s) = min(g + 2 s, R - 1): its angle offset min(rs0 + s * rstep, rs_last), with k5n folded into both bounds
+        const unsigned m = s + 1 < RPL ? (unsigned)(m0 + s * fl.rstep) : (unsigned)min(m0 + s * fl.rstep, m_last);
         didx[s] = (int)min(m, m - 360u);
         const f32x2 cs = ft.dir[didx[s]];
         dx[s] = cs.x;
@@ -1735,19 +1742,47 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         const f32x2 cs = ft.dir[(int)min(m, m - 360u)];
         gate_hit |= Math<float>::cast(gate, opx, opy, cs.x, cs.y) < 10.0f;  // :387,:390
     }
-    // ---- wall sweep
-    unsigned bb[2 * ((RPL + 1) / 2)];
+    // ---- wall sweep.  More than 12 ray slots per lane (33 rays: 17) are swept in TWO passes over the vertex chain, 9 + 8
+    // slots: one pass would need ~40 more registers than the 256 a wave has at two waves per SIMD (it spilled 67 of them
+    // to scratch); the second pass repeats only the per-vertex position arithmetic (4 of ~50 instructions per vertex and pass).
+    constexpr int R1 = RPL > 12 ? (RPL + 1) / 2 : RPL, R2 = RPL - R1;
+    unsigned bb[RPL + 2];
     PC_STAMP(4)
-    if (h.nV == 28)   // (wave-uniform) big_track's chain: the unrolled sweep
-        wall_sweep_unrolled<RPL, TAB, 7>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dx, dy, didx, ft.rden, bb);
-    else
-        wall_sweep_f32<RPL, 1, TAB>(p.vtx + h.vtx_off, h.nV, 0, npx, npy, dx, dy, didx, ft.rden, bb);
+    {
+        const float(&dxa)[R1] = *reinterpret_cast<const float(*)[R1]>(&dx[0]);
+        const float(&dya)[R1] = *reinterpret_cast<const float(*)[R1]>(&dy[0]);
+        const int(&dia)[R1] = *reinterpret_cast<const int(*)[R1]>(&didx[0]);
+        unsigned ba[2 * ((R1 + 1) / 2)];
+        if (h.nV == 28)   // (wave-uniform) big_track's chain: the unrolled sweep
+            wall_sweep_unrolled<R1, TAB, 7>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxa, dya, dia, ft.rden, ba);
+        else
+            wall_sweep_f32<R1, 1, TAB>(p.vtx + h.vtx_off, h.nV, 0, npx, npy, dxa, dya, dia, ft.rden, ba);
+#pragma unroll
+        for (int s = 0; s < R1; ++s) bb[s] = ba[s];
+    }
+    if constexpr (R2 > 0) {
+        __builtin_amdgcn_sched_barrier(0);   // the passes one after the other
+        const float(&dxb)[R2] = *reinterpret_cast<const float(*)[R2]>(&dx[R1]);
+        const float(&dyb)[R2] = *reinterpret_cast<const float(*)[R2]>(&dy[R1]);
+        const int(&dib)[R2] = *reinterpret_cast<const int(*)[R2]>(&didx[R1]);
+        unsigned bc[2 * ((R2 + 1) / 2)];
+        if (h.nV == 28)
+            wall_sweep_unrolled<R2, TAB, 7>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxb, dyb, dib, ft.rden, bc);
+        else
+            wall_sweep_f32<R2, 1, TAB>(p.vtx + h.vtx_off, h.nV, 0, npx, npy, dxb, dyb, dib, ft.rden, bc);
+#pragma unroll
+        for (int s = 0; s < R2; ++s) bb[R1 + s] = bc[s];
+    }
     PC_STAMP(5)
     // Car.check_collision (:376-392): any collision ray closer than 10 px.  Distances are non-negative floats, so the
     // smallest one is the unsigned minimum of the bit patterns; a slot that is not a collision ray is masked to +inf.
     unsigned hm = 0x7f800000u;
 #pragma unroll
-    for (int s = 0; s < RPL; ++s) hm = min(hm, bb[s] | noncol[s]);
+    for (int s = 0; s < RPL; ++s) {
+        // bit s of colmask: slot s is one of Car.check_collision's rays; (bit ? 0 : 0x7f800000) without a register per slot
+        const unsigned nc = ((unsigned)__builtin_amdgcn_sbfe(fl.colmask, s, 1) & 0x7f800000u) ^ 0x7f800000u;
+        hm = min(hm, bb[s] | nc);
+    }
     int flags = (gate_hit ? 1 : 0) | (hm < 0x41200000u ? 2 : 0);       // 0x41200000 = 10.0f
     flags |= swap_pair(flags);
     gate_hit = flags & 1;
@@ -1768,7 +1803,11 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     trunc_f = trunc ? 1.0f : 0.0f;
     // ---- observation row -> LDS (the reset observation of a finished env is written by the caller's fix-up)
 #pragma unroll
-    for (int s = 0; s < RPL; ++s) lrow[col[s]] = Math<float>::norm_dist(__uint_as_float(bb[s]));     // :593
+    for (int s = 0; s < RPL; ++s) {   // ray slot s -> column 6 + ray(s): 8 bytes apart from the lane's first; the clamped last slot apart
+        const float o = Math<float>::norm_dist(__uint_as_float(bb[s]));     // :593
+        if (s + 1 < RPL) fl.lray[2 * s] = o;
+        else fl.llast[0] = o;
+    }
     if (g == 0) {
         lrow[0] = Math<float>::norm(npx, 1280.0);  // :578-581
         lrow[1] = Math<float>::norm(npy, 720.0);
@@ -1912,18 +1951,22 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     PhiloxBlock rnd = {};  // the sampling lanes' current Philox block (4 steps' draws)
     // FAST: per-lane invariants of the env step.  Ray slot s of lane g is ray min(g + 2 s, R - 1): the odd slot that 17 or
     // 33 rays leave over on lane 1 repeats that lane pair's last ray (same value, same address) instead of being masked.
-    int rsd[RPL], col[RPL], gq[2] = {0, 0}, k72 = 0;
-    unsigned noncol[RPL];
+    int gq[2] = {0, 0}, k72 = 0;
+    FastLane fl = {};
     if constexpr (FAST) {
+        fl.rs0 = g * p.step_deg;
+        fl.rstep = 2 * p.step_deg;
+        fl.rs_last = (p.R - 1) * p.step_deg;
+        fl.colmask = 0;
 #pragma unroll
         for (int s = 0; s < RPL; ++s) {
             const int ray = min(g + 2 * s, p.R - 1);
-            rsd[s] = ray * p.step_deg;
-            col[s] = 6 + ray;
             // Car.check_collision's rays: r in range(0, n, n // 4) (:389) -- nominal n, not R
             const bool is_col = ray < 64 ? (bool)((p.colbits >> ray) & 1) : ((ray < p.n_nominal) & (ray % p.q == 0));
-            noncol[s] = is_col ? 0u : 0x7f800000u;
+            fl.colmask |= (is_col ? 1 : 0) << s;
         }
+        fl.lray = (lds_fp)(sObs + el * LDX + 6 + g);
+        fl.llast = (lds_fp)(sObs + el * LDX + 6 + min(g + 2 * (RPL - 1), p.R - 1));
         gq[0] = g * p.q * p.step_deg;            // Car.get_passed_gate's rays j * (n // 4), j = g and g + 2
         gq[1] = (g + 2) * p.q * p.step_deg;
         k72 = Math<float>::mod72(st.k);
@@ -2027,7 +2070,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 // ---------------- E(t)
                 float rw, tf, cf;
                 const int a = e_valid ? sAct[el] : 8;
-                const bool done = env_step_fast<RPL, MODE == 2>(p, h0, ft, rsd, noncol, col, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave);
+                const bool done = env_step_fast<RPL, MODE == 2>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave);
                 PC_STAMP(6)
                 // gymnasium 0.29.1 same-step auto-reset: a finished env returns its reset observation
                 if (__builtin_amdgcn_ballot_w64(done) != 0) {   // wave-uniform: ~1.5 % of env steps end an episode

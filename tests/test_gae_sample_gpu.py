@@ -188,20 +188,21 @@ def test_fused_policy_kernel_matches_torch_mlp(D, N, policy_precision):
 @pytest.mark.parametrize("policy_precision", [2, 1, 0], indirect=True)
 def test_fused_policy_kernel_on_trained_weights_and_harvested_observations(policy_precision):
     """The precision claim of the fused policy kernel on REAL data rather than random weights: tests/golden/policy_trained.npz
-    holds the weights after 150 PPO epochs on big_track (tools/make_policy_fixture.py, this repository's own run) and 4096
-    observations of its last rollout -- among them reset rows (velocity exactly 0), rows with |velocity / 10| < 1e-3 and rays
-    saturated at 1000 px.  Logits and values of every arithmetic form must stay within 4e-6 of float64 (north_star: 1e-5)."""
+    holds the weights after 150 PPO epochs on big_track (tools/make_policy_fixture.py, this repository's own run) and ~3900
+    observations of its last rollout -- among them 300 reset rows (velocity exactly 0: operands below fp16's normal range in
+    every scaled domain).  Logits and values of every arithmetic form must stay within 4e-6 of float64 (north_star: 1e-5)."""
     import os
     from conftest import GOLDEN
     f = np.load(os.path.join(GOLDEN, "policy_trained.npz"))
     obs = f["obs"]
-    assert obs.shape == (4096, 23) and float(f["avg_reward"]) > 0.15                      # a trained policy (reference curve: 0.11 -> 0.25)
+    n = len(obs)
+    assert obs.shape == (n, 23) and n >= 3000 and float(f["avg_reward"]) > 0.15             # a trained policy (reference curve: 0.11 -> 0.25)
     assert (np.abs(obs[:, 2:4]).max(1) == 0).sum() > 50 and (np.abs(obs[:, 2:4]).max(1) < 1e-3).sum() > 200
     agent = pc.Agent(23, 9)
     agent.load_state_dict({k: torch.from_numpy(f[k.replace(".", "_")]) for k in agent.state_dict()})
     agent = agent.cuda()
     x = torch.from_numpy(obs).cuda()
-    logits = torch.empty(4096, 9, device="cuda")
+    logits = torch.empty(n, 9, device="cuda")
     agent.rng_seed = 5
     a, lp, v = agent.act(x, out_logits=logits)
     W = {k: f[k.replace(".", "_")].astype(np.float64) for k in agent.state_dict()}
@@ -214,4 +215,4 @@ def test_fused_policy_kernel_on_trained_weights_and_harvested_observations(polic
           f"max |value| {np.abs(ref_v).max():.2f}")
     assert err_l < 4e-6 and err_v < 4e-6
     lp_ref = ref_logits - np.log(np.exp(ref_logits - ref_logits.max(1, keepdims=True)).sum(1, keepdims=True)) - ref_logits.max(1, keepdims=True)
-    assert np.abs(lp.cpu().numpy() - lp_ref[np.arange(4096), a.cpu().numpy()]).max() < 4e-6
+    assert np.abs(lp.cpu().numpy() - lp_ref[np.arange(n), a.cpu().numpy()]).max() < 4e-6

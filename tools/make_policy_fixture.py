@@ -1,6 +1,6 @@
 """Developer tool (GPU): train the policy for 150 epochs on big_track (the run DESIGN.md section 8 describes) and write
-tests/golden/policy_trained.npz -- the trained weights plus 4096 observations harvested from its last rollout (incl. rows with
-1e-6-sized velocities right after a reset and saturated 1000-px rays) -- for tests/test_gae_sample_gpu.py's precision test of
+tests/golden/policy_trained.npz -- the trained weights plus ~3900 observations harvested from its last rollout (incl. the rows
+right after a reset: velocity exactly 0) -- for tests/test_gae_sample_gpu.py's precision test of
 the fused policy kernel on REAL weights and inputs.  Output goes to gpurun_out/ on the GPU box; copy it to tests/golden/."""
 import os
 import sys
