@@ -83,6 +83,9 @@ def parse_args():
     ap.add_argument("--torch-update", action="store_true", help="reference torch ops for the whole minibatch step (no fused loss/Adam kernels)")
     ap.add_argument("--event-stride", type=int, default=8, help="with --eager-rollout: bracket every k-th env-step launch")
     ap.add_argument("--master-port", type=int, default=None, help="rendezvous port when bench.py starts the ranks itself")
+    ap.add_argument("--force-collective", action="store_true", help="1 GPU: take the MULTI-RANK update path (K10, K11, RCCL all-reduce on a 1-rank "
+                    "communicator, clip+Adam) -- the multi-GPU update's cost minus the xGMI transport")
+    ap.add_argument("--no-capture-collectives", action="store_true", help="multi-rank: enqueue the update eagerly instead of capturing the all-reduce into the epoch graph")
     return ap.parse_args()
 
 
@@ -185,9 +188,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist
-        if args.backend == "nccl":
+        if world == 1:       # --force-collective: a one-rank communicator
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(args.master_port or (29500 + os.getpid() % 2000)))
+            dist.init_process_group(args.backend, rank=0, world_size=1, **({"device_id": dev} if args.backend == "nccl" else {}))
+        elif args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
@@ -213,7 +220,8 @@ def main():
 
     def make_trainer():
         cfg_ = PPOConfig(track=track, env_dtype=args.env_dtype, seed=0, policy=args.policy, use_graphs=not args.no_graphs,
-                         fused_update=not args.torch_update, custom_mlp=not args.torch_mlp, rollout_kernel=args.rollout_kernel, **wl)
+                         fused_update=not args.torch_update, custom_mlp=not args.torch_mlp, rollout_kernel=args.rollout_kernel,
+                         force_collective=args.force_collective, capture_collectives=not args.no_capture_collectives, **wl)
         return cfg_, Trainer(cfg_, device=dev, rank=rank, world_size=world)
 
     cfg, tr = make_trainer()
@@ -284,6 +292,7 @@ def main():
              "gae_update_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in tr.phase_events]))}
     mega_us = float(np.mean([a.elapsed_time(b) for a, b in tr.mega_events]) * 1e3) if tr.mega_events else None
     rollout_mode, obs_dim, custom = tr.rollout_mode, tr.obs_dim[0], bool(tr.learner.custom)
+    captured = tr.learner._epoch_graph is not None
     tr.mega_events = None
     tr.phase_events = None
 
@@ -295,7 +304,7 @@ def main():
             extras["parity_check"] = {"ok": False, "error": repr(ex)}
     tr.close()
     del tr
-    if world == 1 and not args.no_extras and args.policy_arith != "fp32" and args.policy == "fused":
+    if world == 1 and not args.no_extras and args.policy_arith != "fp32" and args.policy == "fused" and not args.force_collective:
         # the price of exact-fp32 policy GEMMs (v_mfma_f32_16x16x4_f32) on the same workload: 3 epochs, outside the headline timing
         try:
             _lib.pc_policy_set_precision(0)
@@ -368,6 +377,8 @@ def main():
                                    f"train_iters={cfg.train_iters}; one step = one PPO epoch (rollout + GAE + update)",
                        "n_envs_total": cfg.n_envs * world, "parallelism": f"env-sharded dp{world}, 1 flat grad all-reduce/minibatch",
                        "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+                       "update_path": ("multi-rank (all-reduce + clip/Adam per minibatch), " + ("captured in the epoch graph" if captured else "enqueued eagerly"))
+                       if (world > 1 or args.force_collective) else "single-rank epoch graph",
                        "backend": (args.backend if dist is not None else None),
                        "env_kernel": info, "policy_step": args.policy, "rollout": rollout_mode,
                        "policy_gemm_arithmetic": POLICY_ARITH, "hip_graphs": bool(cfg.use_graphs),

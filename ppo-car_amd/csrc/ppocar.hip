@@ -1690,19 +1690,42 @@ __device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p,
 }
 
 struct FastLane {        // per-lane invariants of the env step (a handful of registers instead of three per ray slot)
-    int rs0, rstep, rs_last;  // ray slot s of lane g is ray min(g + 2 s, R - 1): angle offsets step_deg * ray
+    int rs0, rstep, rs_last;  // ray slot s of lane g (of G per env) is ray min(g + G s, R - 1): angle offsets step_deg * ray
     int colmask;              // bit s: slot s is one of Car.check_collision's rays
-    lds_fp lray, llast;       // this lane's first ray column of its observation row (slot s: + 2 s floats), and the last slot's
+    lds_fp lray, llast;       // this lane's first ray column of its observation row (slot s: + G s floats), and the last slot's
 };
+template <int RPL, int G>
+__device__ __forceinline__ FastLane fast_lane(const EnvParams<float>& p, const int g, float* row) {
+    FastLane fl;
+    fl.rs0 = g * p.step_deg;
+    fl.rstep = G * p.step_deg;
+    fl.rs_last = (p.R - 1) * p.step_deg;
+    fl.colmask = 0;
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) {
+        const int ray = min(g + G * s, p.R - 1);
+        // Car.check_collision's rays: r in range(0, n, n // 4) (:389) -- nominal n, not R
+        const bool is_col = ray < 64 ? (bool)((p.colbits >> ray) & 1) : ((ray < p.n_nominal) & (ray % p.q == 0));
+        fl.colmask |= (is_col ? 1 : 0) << s;
+    }
+    fl.lray = (lds_fp)(row + 6 + g);
+    fl.llast = (lds_fp)(row + 6 + min(g + G * (RPL - 1), p.R - 1));
+    return fl;
+}
 // exchange with the neighbouring lane (the other lane of the env): DPP quad_perm [1, 0, 3, 2], one VALU instruction
 __device__ __forceinline__ int swap_pair(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false); }
 
-template <int RPL, bool TAB>
+// LG = log2 of the lanes per env (1: K9, a wave owns 32 envs; 2: K9s, 16 envs per wave).  PARTS > 1 (K9s): the wall sweep is split
+// over PARTS waves of the workgroup -- this wave sweeps vertex part `part`, the per-ray minima meet in LDS (`exch`: the env's
+// [rays][PARTS] floats) across ONE workgroup barrier (every thread of the workgroup must make the call), and all waves finish
+// the step on identical values; only `write_row` waves store the observation row.
+template <int RPL, bool TAB, int LG = 1, int PARTS = 1>
 __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const TrackHdr& h, const FastTabs& ft, const FastLane& fl,
                                               const int (&gq)[2], const int g,
                                               EnvRegs& st, int& k72, const int a, const double reward_scale, lds_fp lrow,
                                               float& reward_f, float& term_f, float& trunc_f, const int t = 0, const int lane = 0,
-                                              const int wave = 0) {
+                                              const int wave = 0, const int part = 0, float* exch = nullptr, const bool write_row = true) {
+    constexpr int G = 1 << LG;
     // ---- action, heading before and after the turn (car_env.py:698-722, :440-442)
     const f64x2 Lf = ft.act[2 * a];                                     // (thrust, fric)
     const i32x2 Li = *(lds_ci2)(ft.act + 2 * a + 1);                    // (dk, fwd)
@@ -1724,20 +1747,20 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     const int m0 = k5n + fl.rs0, m_last = k5n + fl.rs_last;
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
-        // ray(s) = min(g + 2 s, R - 1): its angle offset min(rs0 + s * rstep, rs_last), with k5n folded into both bounds
+        // ray(s) = min(g + G s, R - 1): its angle offset min(rs0 + s * rstep, rs_last), with k5n folded into both bounds
         const unsigned m = s + 1 < RPL ? (unsigned)(m0 + s * fl.rstep) : (unsigned)min(m0 + s * fl.rstep, m_last);
         didx[s] = (int)min(m, m - 360u);
         const f32x2 cs = ft.dir[didx[s]];
         dx[s] = cs.x;
         dy[s] = cs.y;
     }
-    // ---- Car.get_passed_gate (:394-408): the four collision rays at the PREVIOUS pose against gate[next], two per lane
+    // ---- Car.get_passed_gate (:394-408): the four collision rays at the PREVIOUS pose against gate[next], dealt over the lanes
     const f64x4 gv = ft.gates[st.next];
     const Seg gate = {gv.x, gv.y, gv.z, gv.w};
     const int k5o = 5 * k72;
     bool gate_hit = false;
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
+    for (int jj = 0; jj < 4 / G; ++jj) {
         const unsigned m = (unsigned)(k5o + gq[jj]);
         const f32x2 cs = ft.dir[(int)min(m, m - 360u)];
         gate_hit |= Math<float>::cast(gate, opx, opy, cs.x, cs.y) < 10.0f;  // :387,:390
@@ -1753,10 +1776,10 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         const float(&dya)[R1] = *reinterpret_cast<const float(*)[R1]>(&dy[0]);
         const int(&dia)[R1] = *reinterpret_cast<const int(*)[R1]>(&didx[0]);
         unsigned ba[2 * ((R1 + 1) / 2)];
-        if (h.nV == 28)   // (wave-uniform) big_track's chain: the unrolled sweep
+        if (PARTS == 1 && h.nV == 28)   // (wave-uniform) big_track's chain: the unrolled sweep
             wall_sweep_unrolled<R1, TAB, 7>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxa, dya, dia, ft.rden, ba);
         else
-            wall_sweep_f32<R1, 1, TAB>(p.vtx + h.vtx_off, h.nV, 0, npx, npy, dxa, dya, dia, ft.rden, ba);
+            wall_sweep_f32<R1, PARTS, TAB>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dxa, dya, dia, ft.rden, ba);
 #pragma unroll
         for (int s = 0; s < R1; ++s) bb[s] = ba[s];
     }
@@ -1766,12 +1789,33 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         const float(&dyb)[R2] = *reinterpret_cast<const float(*)[R2]>(&dy[R1]);
         const int(&dib)[R2] = *reinterpret_cast<const int(*)[R2]>(&didx[R1]);
         unsigned bc[2 * ((R2 + 1) / 2)];
-        if (h.nV == 28)
+        if (PARTS == 1 && h.nV == 28)
             wall_sweep_unrolled<R2, TAB, 7>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxb, dyb, dib, ft.rden, bc);
         else
-            wall_sweep_f32<R2, 1, TAB>(p.vtx + h.vtx_off, h.nV, 0, npx, npy, dxb, dyb, dib, ft.rden, bc);
+            wall_sweep_f32<R2, PARTS, TAB>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dxb, dyb, dib, ft.rden, bc);
 #pragma unroll
         for (int s = 0; s < R2; ++s) bb[R1 + s] = bc[s];
+    }
+    if constexpr (PARTS > 1) {   // the parts' minima meet in LDS (min is exact: the same bits as one wave sweeping everything)
+        unsigned* ex = reinterpret_cast<unsigned*>(exch);
+        int ray = g;
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const int r = s + 1 < RPL ? ray : min(ray, p.R - 1);
+            ex[r * PARTS + part] = bb[s];
+            ray += G;
+        }
+        lds_barrier();
+        ray = g;
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const int r = s + 1 < RPL ? ray : min(ray, p.R - 1);
+            unsigned m = ex[r * PARTS];
+#pragma unroll
+            for (int q = 1; q < PARTS; ++q) m = min(m, ex[r * PARTS + q]);
+            bb[s] = m;
+            ray += G;
+        }
     }
     PC_STAMP(5)
     // Car.check_collision (:376-392): any collision ray closer than 10 px.  Distances are non-negative floats, so the
@@ -1784,7 +1828,9 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         hm = min(hm, bb[s] | nc);
     }
     int flags = (gate_hit ? 1 : 0) | (hm < 0x41200000u ? 2 : 0);       // 0x41200000 = 10.0f
-    flags |= swap_pair(flags);
+    flags |= swap_pair(flags);                                          // any() over the env's G lanes
+    if constexpr (G == 4) flags |= __builtin_amdgcn_update_dpp(0, flags, 0x4e, 0xf, 0xf, false);   // quad_perm [2, 3, 0, 1]
+    static_assert(G == 2 || G == 4, "2 or 4 lanes per env");
     gate_hit = flags & 1;
     const bool destroyed = ((flags & 2) != 0) | (h.start_collides != 0);
     // ---- bookkeeping (car_env.py:694-750): float64 reward in the reference's order of accumulation
@@ -1803,12 +1849,14 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     trunc_f = trunc ? 1.0f : 0.0f;
     // ---- observation row -> LDS (the reset observation of a finished env is written by the caller's fix-up)
 #pragma unroll
-    for (int s = 0; s < RPL; ++s) {   // ray slot s -> column 6 + ray(s): 8 bytes apart from the lane's first; the clamped last slot apart
+    for (int s = 0; s < RPL; ++s) {   // ray slot s -> column 6 + ray(s): G floats apart from the lane's first; the clamped last slot apart
         const float o = Math<float>::norm_dist(__uint_as_float(bb[s]));     // :593
-        if (s + 1 < RPL) fl.lray[2 * s] = o;
-        else fl.llast[0] = o;
+        if (write_row) {
+            if (s + 1 < RPL) fl.lray[G * s] = o;
+            else fl.llast[0] = o;
+        }
     }
-    if (g == 0) {
+    if (g == 0 && write_row) {
         lrow[0] = Math<float>::norm(npx, 1280.0);  // :578-581
         lrow[1] = Math<float>::norm(npy, 720.0);
         lrow[2] = Math<float>::norm(nvx, 10.0);
@@ -1954,19 +2002,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     int gq[2] = {0, 0}, k72 = 0;
     FastLane fl = {};
     if constexpr (FAST) {
-        fl.rs0 = g * p.step_deg;
-        fl.rstep = 2 * p.step_deg;
-        fl.rs_last = (p.R - 1) * p.step_deg;
-        fl.colmask = 0;
-#pragma unroll
-        for (int s = 0; s < RPL; ++s) {
-            const int ray = min(g + 2 * s, p.R - 1);
-            // Car.check_collision's rays: r in range(0, n, n // 4) (:389) -- nominal n, not R
-            const bool is_col = ray < 64 ? (bool)((p.colbits >> ray) & 1) : ((ray < p.n_nominal) & (ray % p.q == 0));
-            fl.colmask |= (is_col ? 1 : 0) << s;
-        }
-        fl.lray = (lds_fp)(sObs + el * LDX + 6 + g);
-        fl.llast = (lds_fp)(sObs + el * LDX + 6 + min(g + 2 * (RPL - 1), p.R - 1));
+        fl = fast_lane<RPL, 2>(p, g, sObs + el * LDX);
         gq[0] = g * p.q * p.step_deg;            // Car.get_passed_gate's rays j * (n // 4), j = g and g + 2
         gq[1] = (g + 2) * p.q * p.step_deg;
         k72 = Math<float>::mod72(st.k);
@@ -2133,7 +2169,9 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
 // n_envs / 32 workgroups fill the chip.  Per step: the 8 waves split the policy's hidden tiles exactly as
 // policy_kernel<SPLIT> does (partial output tiles summed through LDS, same order: bit-identical), wave 0 draws the
 // 32 actions, then all 512 lanes run the env step with 16 lanes per env.  Three workgroup barriers per step.
-template <int KS, int RPL, int PREC>
+// MODE as in rollout_kernel: 0 = generic tables, env_step_core; 1 / 2 = single track, A = 9, every table in LDS behind LDS
+// pointers, env_step_fast (2: with the 1/den table), dense observation rows copied out by three waves in 16-byte stores.
+template <int KS, int RPL, int PREC, int MODE>
 __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<float> p, const float* __restrict__ image, const int A,
                                                             const int T, const double reward_scale, const uint64_t seed,
                                                             const uint64_t offset, const uint64_t* __restrict__ offset_dev,
@@ -2142,11 +2180,13 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                                                             float* __restrict__ term_buf, float* __restrict__ trunc_buf,
                                                             float* __restrict__ logprob_buf, float* __restrict__ next_obs,
                                                             float* __restrict__ next_term, float* __restrict__ next_trunc,
-                                                            const int rden_lds) {
+                                                            const int rden_lds, const int vec_ok) {
     constexpr int dbg = PC_ABLATE;  // 0 in the product build (see PC_ABLATE)
-    constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, LDX = 4 * KS + 1, ET = 2;
+    constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, ET = 2;
     constexpr int NG = pol_ng(KS), KB = pol_kb(KS);
     constexpr int IMG = PREC ? polx_image_dwords(PREC, NG) : pol_image_padded(KS);
+    constexpr bool FAST = MODE != 0;
+    constexpr int DC = RPL == 3 ? 18 : (RPL == 5 ? 23 : 39);   // FAST: 6 + the ray count the 4-lanes-per-env menu implies (12 / 17 / 33)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sW1 = lds;
     float* sB1 = PREC ? lds + polx_w1_dwords(PREC, NG) + polx_w2_dwords(PREC) : sW1 + 2 * HID * LD1;
@@ -2155,20 +2195,24 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     const unsigned* sW1p = reinterpret_cast<const unsigned*>(lds);
     const unsigned* sW2p = sW1p + polx_w1_dwords(PREC ? PREC : 1, NG);
     const float* sW2c = sB2 + 16;
+    const int64_t N = p.N;
+    const int D = FAST ? DC : p.D;
+    const int LDX = FAST ? D : 4 * KS + 1;
     float* sOut = lds + IMG;                       // [8 waves][32 envs][LDO] partial output tiles
     float* sObs = sOut + 8 * 32 * LDO;             // [32 envs][LDX]
-    int* sAct = reinterpret_cast<int*>(sObs + 32 * LDX);
-    float* sTab = reinterpret_cast<float*>(sAct + 32);     // staged per-track tables (stage_tables)
+    int* sAct = reinterpret_cast<int*>(sObs + 32 * (FAST ? 40 : LDX));   // (FAST: room for the widest row, so the tables stay 16-byte aligned)
+    float* sTab = reinterpret_cast<float*>(sAct + 32);     // staged per-track tables
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, lk = lane >> 4;
-    const int64_t N = p.N;
-    const int D = p.D;
     policy_stage_image<IMG>(image, lds, tid);
-    const EnvParams<float> q = stage_tables(p, sTab, tid, 512);
+    const TrackHdr h0 = cload(p.hdr);
+    EnvParams<float> q = p;
+    FastTabs ft = {};
+    if constexpr (FAST) ft = stage_fast_tables(p, h0, sTab, tid, 512);
+    else q = stage_tables(p, sTab, tid, 512);
     // the track's 1/den table, when the host found room for it: rden_lds = its size in floats (else 0)
-    float* sRden = sTab + TAB_FLOATS;
+    float* sRden = sTab + (FAST ? FT_FLOATS : TAB_FLOATS);
     {
-        const TrackHdr h0 = cload(p.hdr);
         const f32x4* src = reinterpret_cast<const f32x4*>(p.rden + h0.rden_off);
         for (int i = tid; i < rden_lds / 4; i += 512) reinterpret_cast<f32x4*>(sRden)[i] = src[i];
     }
@@ -2179,18 +2223,28 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     const int part = __builtin_amdgcn_readfirstlane(wave & 3);
     const int el = (wave >> 2) * 16 + (lane >> 2), g = lane & 3;
     float* exch = sOut + el * (PARTS * 34);        // [rays][PARTS] of this env; aliases the partial output tiles (idle now)
-    const int64_t e_env = (int64_t)blockIdx.x * 32 + el;
+    const int64_t e_wg = (int64_t)blockIdx.x * 32;
+    const int64_t e_env = e_wg + el;
     const bool e_valid = e_env < N;
     EnvRegs st = {};
     if (e_valid) st = env_load<float>(p, e_env);
     // mixed-track batch: this wave's envs share one track (the host checked every aligned block of 32 envs)
     const int trk = p.track_id ? (int)p.track_id[e_valid ? e_env : N - 1] : 0;
-    for (int f = g + 4 * part; f < 4 * KS; f += 16) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
+    for (int f = g + 4 * part; f < (FAST ? D : 4 * KS); f += 16) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
     float* myOut = sOut + wave * 32 * LDO;
     const int ht0 = wave * (NT / 8), ht1 = ht0 + NT / 8;
     const uint64_t off0 = offset + (offset_dev ? *offset_dev : 0);
     PhiloxBlock rnd = {};  // the sampling lanes' current Philox block (4 steps' draws)
+    int gq[2] = {0, 0}, k72 = 0;
+    FastLane fl = {};
+    if constexpr (FAST) {
+        fl = fast_lane<RPL, 4>(p, g, sObs + el * LDX);
+        gq[0] = g * p.q * p.step_deg;            // Car.get_passed_gate's ray j * (n // 4), j = g
+        k72 = Math<float>::mod72(st.k);
+    }
+    const lds_fp lrow = (lds_fp)(sObs + el * LDX);
     __syncthreads();
+    asm volatile("" : "+v"(st.px), "+v"(st.py), "+v"(st.vx), "+v"(st.vy), "+v"(st.k), "+v"(st.time), "+v"(st.next), "+v"(st.passed), "+v"(k72));
 
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
@@ -2203,7 +2257,10 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
 #pragma unroll
             for (int et = 0; et < ET; ++et)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) x[et][ks] = sObs[(16 * et + lc) * LDX + 4 * ks + lk];
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int f = 4 * ks + lk;
+                    x[et][ks] = (!FAST || f < D) ? sObs[(16 * et + lc) * LDX + f] : 0.0f;
+                }
             if (!(dbg & 1)) policy_pass<KS>(sW1, sB1, sW2, ht0, ht1, x, out, lc, lk, lane);  // dbg: timing ablations only
         } else {
             Pieces<PREC> x[ET][KB];
@@ -2238,7 +2295,7 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
         lds_barrier();
         {   // every wave draws for 4 of the 32 envs, 16 lanes (= outputs) per env, exactly as policy_kernel<SPLIT>
             const int dl = wave * 4 + lk, oi = lc;
-            const int64_t e = (int64_t)blockIdx.x * 32 + dl;
+            const int64_t e = e_wg + dl;
             float ps = 0.0f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) ps += sOut[(w * 32 + dl) * LDO + oi];  // fixed order
@@ -2259,28 +2316,64 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
         }
         lds_barrier();
         // ---------------- E(t): 4 waves x 4 lanes per env (one more barrier inside, where the sweep parts meet)
-        if (!(dbg & 2)) {
-            const bool last = t + 1 == T;
-            float* orow = !e_valid ? nullptr : (last ? next_obs + e_env * D : obs_buf + ((int64_t)(t + 1) * N + e_env) * D);
-            float rw;
-            bool term, trunc;
-            int passed;
-            if (rden_lds)  // uniform
-                env_step_core<float, RPL, PARTS, true>(q, trk, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
-                                                       e_valid && part == 0 ? sObs + el * LDX : nullptr, rw, term, trunc, passed, part,
-                                                       exch, rdl);
-            else
-                env_step_core<float, RPL, PARTS>(q, trk, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
-                                                 e_valid && part == 0 ? sObs + el * LDX : nullptr, rw, term, trunc, passed, part, exch);
-            if (e_valid && g == 0 && part == 0) {
-                rew_buf[(int64_t)t * N + e_env] = rw;
-                float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;
-                float* tc = last ? next_trunc : trunc_buf + (int64_t)(t + 1) * N;
-                tr[e_env] = term ? 1.0f : 0.0f;
-                tc[e_env] = trunc ? 1.0f : 0.0f;
+        const bool last = t + 1 == T;
+        if constexpr (FAST) {
+            if (!(dbg & 2)) {
+                float rw, tf, cf;
+                const int a = e_valid ? sAct[el] : 8;
+                const bool done = rden_lds   // (uniform)
+                    ? env_step_fast<RPL, true, 2, PARTS>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0)
+                    : env_step_fast<RPL, false, 2, PARTS>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0);
+                if (part == 0) {   // (uniform) the row-writing wave: reset observation of finished envs, per-env scalars
+                    if (__builtin_amdgcn_ballot_w64(done) != 0) {
+                        if (done)
+                            for (int f = g; f < D; f += 4) lrow[f] = ft.reset[f];
+                    }
+                    if (g == 0 && e_valid) {
+                        rew_buf[(int64_t)t * N + e_env] = rw;
+                        float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;
+                        float* tc = last ? next_trunc : trunc_buf + (int64_t)(t + 1) * N;
+                        tr[e_env] = tf;
+                        tc[e_env] = cf;
+                    }
+                }
             }
+            lds_barrier();
+            // rows -> rollout buffer: the workgroup's 32 rows are contiguous there (32 * D floats): waves 0 .. 2 (.. 4) store 64 float4 each
+            {
+                float* dstg = (last ? next_obs : obs_buf + (int64_t)(t + 1) * N * D) + e_wg * D;
+                const int64_t left = N - e_wg;
+                const int n_rows = left >= 32 ? 32 : (int)left;
+                if (vec_ok && n_rows == 32) {
+                    const int i = lane + 64 * wave;
+                    if (i < 8 * DC) reinterpret_cast<f32x4*>(dstg)[i] = reinterpret_cast<const f32x4*>(sObs)[i];
+                } else {
+                    for (int i = tid; i < n_rows * D; i += 512) dstg[i] = sObs[i];
+                }
+            }
+        } else {
+            if (!(dbg & 2)) {
+                float* orow = !e_valid ? nullptr : (last ? next_obs + e_env * D : obs_buf + ((int64_t)(t + 1) * N + e_env) * D);
+                float rw;
+                bool term, trunc;
+                int passed;
+                if (rden_lds)  // uniform
+                    env_step_core<float, RPL, PARTS, true>(q, trk, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
+                                                           e_valid && part == 0 ? sObs + el * LDX : nullptr, rw, term, trunc, passed, part,
+                                                           exch, rdl);
+                else
+                    env_step_core<float, RPL, PARTS>(q, trk, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
+                                                     e_valid && part == 0 ? sObs + el * LDX : nullptr, rw, term, trunc, passed, part, exch);
+                if (e_valid && g == 0 && part == 0) {
+                    rew_buf[(int64_t)t * N + e_env] = rw;
+                    float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;
+                    float* tc = last ? next_trunc : trunc_buf + (int64_t)(t + 1) * N;
+                    tr[e_env] = term ? 1.0f : 0.0f;
+                    tc[e_env] = trunc ? 1.0f : 0.0f;
+                }
+            }
+            lds_barrier();
         }
-        lds_barrier();
     }
     if (e_valid && g == 0 && part == 0) env_store<float>(p, e_env, st);
 }
@@ -3652,7 +3745,9 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     const bool fast = !small && !e->track_id && A == 9 && e->D >= 17 && e->D <= 40 && e->hdr_host[0].G <= TAB_MAX_GATES && g_rollout_fast;
     const size_t lds_big = fast ? (size_t)(img + 256 * e->D + 256 + FT_FLOATS) * sizeof(float)
                                 : (size_t)(img + 256 * (4 * KS + 1) + 256 + TAB_FLOATS) * sizeof(float);
-    const size_t lds_small = (size_t)(img + 8 * 32 * 17 + 32 * (4 * KS + 1) + 32 + TAB_FLOATS) * sizeof(float);
+    const bool fast_small = small && !e->track_id && A == 9 && e->D >= 17 && e->D <= 40 && e->hdr_host[0].G <= TAB_MAX_GATES && g_rollout_fast;
+    const size_t lds_small = fast_small ? (size_t)(img + 8 * 32 * 17 + 32 * 40 + 32 + FT_FLOATS) * sizeof(float)
+                                        : (size_t)(img + 8 * 32 * 17 + 32 * (4 * KS + 1) + 32 + TAB_FLOATS) * sizeof(float);
     size_t lds = small ? lds_small : lds_big;
     if (lds > 160 * 1024) return PC_ERR_UNSUPPORTED;
     // the track's 1/den table rides along in LDS when it fits (big_track: 361 x 28 floats = 40 KB); else the sweep forms
@@ -3665,7 +3760,7 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
                                            : ((!small && e->N <= g_rollout_epw128_max) ? 128 : 256);   // big form: envs per workgroup
     const int blocks = (int)(small ? (e->N + 31) / 32 : (e->N + epw - 1) / epw);
     const int vec_ok = ((e->N * e->D) % 4 == 0) ? 1 : 0;      // the waves' 32-row blocks are 16-byte aligned in the buffers
-    const int mode = fast ? (rden_lds ? 2 : 1) : 0;
+    const int mode = (fast || fast_small) ? (rden_lds ? 2 : 1) : 0;
     hipStream_t st = (hipStream_t)stream;
     EnvParams<float> prm = e->params<float>();
     prm.lg = small ? 2 : 1;
@@ -3686,16 +3781,21 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
         else if (mode == 1) PC_ROLL_M(KSV, RPLV, PRC, 1);                                                                \
         else PC_ROLL_M(KSV, RPLV, PRC, 0);                                                                               \
     } while (0)
-#define PC_ROLLS(KSV, RPLV, PRC)                                                                                         \
+#define PC_ROLLS_M(KSV, RPLV, PRC, MD)                                                                                   \
     do {                                                                                                                 \
         static bool attr_set[64] = {false};                                                                              \
         if (e->device < 64 && !attr_set[e->device]) {                                                                    \
-            HIPCHK(hipFuncSetAttribute((const void*)rollout_small_kernel<KSV, RPLV, PRC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HIPCHK(hipFuncSetAttribute((const void*)rollout_small_kernel<KSV, RPLV, PRC, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_set[e->device] = true;                                                                                  \
         }                                                                                                                \
-        hipLaunchKernelGGL((rollout_small_kernel<KSV, RPLV, PRC>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, \
+        hipLaunchKernelGGL((rollout_small_kernel<KSV, RPLV, PRC, MD>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, \
                            seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, \
-                           next_term, next_trunc, rden_lds);                                                                     \
+                           next_term, next_trunc, rden_lds, vec_ok);                                                             \
+    } while (0)
+#define PC_ROLLS(KSV, RPLV, PRC)                                                                                         \
+    do {                                                                                                                 \
+        if (mode) PC_ROLLS_M(KSV, RPLV, PRC, 1);    /* (the small form takes the 1/den table as a run-time branch) */   \
+        else PC_ROLLS_M(KSV, RPLV, PRC, 0);                                                                              \
     } while (0)
     if (small) {
         if (KS == 5 && rpl == 3) { if (prec == 2) PC_ROLLS(5, 3, 2); else if (prec) PC_ROLLS(5, 3, 1); else PC_ROLLS(5, 3, 0); }        // 12 rays
@@ -3707,6 +3807,7 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     else if (KS == 10 && rpl == 17 && prec) { if (prec == 2) PC_ROLL(10, 17, 2); else PC_ROLL(10, 17, 1); }                               // 32 -> 33 rays, D = 39
     else return PC_ERR_UNSUPPORTED;
 #undef PC_ROLL_M
+#undef PC_ROLLS_M
 #undef PC_ROLLS
 #undef PC_ROLL
     HIPCHK(hipGetLastError());
