@@ -183,8 +183,9 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
  * reading the track's 1/den table from LDS (what happens anyway when the table does not fit).  All are bit-identical
  * to the per-step kernels.  Tuning / test knob. */
 int pc_rollout_set_form(int form);
-/* Test / tuning knob of pc_rollout's big form: envs per workgroup, 0 = automatic (128 up to 32768 envs, else 256), or
- * 128 / 256 to force one -- so that the 256-env variant the benchmark size takes can be checked at small batches. */
+/* Test / tuning knob of pc_rollout: envs per workgroup, 0 = automatic (big form: 128 up to 32768 envs, else 256; small
+ * form: 16 up to 4096 envs, else 32); 128 / 256 force the big form's choice, 16 / 32 the small form's -- so that the variant a
+ * benchmark size takes can be checked at other batch sizes. */
 int pc_rollout_set_epw(int envs_per_workgroup);
 /* A/B / test knob of pc_rollout's big form: 1 (default) = single-track batches take the mode whose gather tables sit in LDS
  * behind LDS pointers, with a branch-free env step and the wave copying its observation rows out in 16-byte stores;

@@ -274,7 +274,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // ---- the float32 wall sweep: Car.get_distances (car_env.py:360-374) for the RPL ray slots of one lane against the vertex
 // chain `vt` (nV vertices, a multiple of 4), part `part` of PARTS.  dx / dy = the slots' directions, didx = their lattice
 // indices (TAB: rows of the 1/den table `rdl` in LDS).  bb = the slots' minimum distances as float bit patterns.
-template <int RPL, int PARTS, bool TAB>
+// ADDR: didx holds the LDS BYTE ADDRESSES of the slots' 1/den rows (env_step_fast's direction table delivers them) instead of
+// lattice indices.
+template <int RPL, int PARTS, bool TAB, bool ADDR = false>
 __device__ __forceinline__ void wall_sweep_f32(const Vtx* vt, const int nV, const int part, const double npx, const double npy,
                                                const float (&dx)[RPL], const float (&dy)[RPL], const int (&didx)[RPL], lds_cfp rdl,
                                                unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
@@ -339,7 +341,10 @@ __device__ __forceinline__ void wall_sweep_f32(const Vtx* vt, const int nV, cons
     lds_row rrow[2 * NP];
     if constexpr (TAB) {
 #pragma unroll
-        for (int s = 0; s < 2 * NP; ++s) rrow[s] = (lds_row)(rdl + __umul24(s < RPL ? didx[s] : 360, nV)) + gbeg;  // full-rate 24-bit multiply
+        for (int s = 0; s < 2 * NP; ++s) {
+            if constexpr (ADDR) rrow[s] = (lds_row)(size_t)(s < RPL ? (unsigned)didx[s] : (unsigned)(size_t)rdl + 1440u * (unsigned)nV) + gbeg;
+            else rrow[s] = (lds_row)(rdl + __umul24(s < RPL ? didx[s] : 360, nV)) + gbeg;  // full-rate 24-bit multiply
+        }
     }
     Vtx nxt = cload(vt + (gbeg < gend ? 4 * gbeg : 0));
     // (A one-group-ahead prefetch of the table rows into a second register set was measured and dropped: inside the
@@ -376,7 +381,7 @@ __device__ __forceinline__ void wall_sweep_f32(const Vtx* vt, const int nV, cons
 //     rden_build_kernel's v_rcp_f32 of 0 stores, too), u = 0 * inf = NaN, whose bit pattern lies above every finite distance:
 //     the candidate can never win the unsigned minimum.  Only the trailing padding pair(s) are skipped (n_chain).
 // The minimum is exact, so the result is the very same bits as wall_sweep_f32's.
-template <int RPL, bool TAB, int NGRP>
+template <int RPL, bool TAB, int NGRP, bool ADDR = false>
 __device__ __forceinline__ void wall_sweep_unrolled(const Vtx* vt, const int n_chain, const double npx, const double npy,
                                                     const float (&dx)[RPL], const float (&dy)[RPL], const int (&didx)[RPL], lds_cfp rdl,
                                                     unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
@@ -425,7 +430,10 @@ __device__ __forceinline__ void wall_sweep_unrolled(const Vtx* vt, const int n_c
     lds_row rrow[2 * NP];
     if constexpr (TAB) {
 #pragma unroll
-        for (int s = 0; s < 2 * NP; ++s) rrow[s] = (lds_row)(rdl + __umul24(s < RPL ? didx[s] : 360, nV));
+        for (int s = 0; s < 2 * NP; ++s) {
+            if constexpr (ADDR) rrow[s] = (lds_row)(size_t)(s < RPL ? (unsigned)didx[s] : (unsigned)(size_t)rdl + 1440u * (unsigned)nV);
+            else rrow[s] = (lds_row)(rdl + __umul24(s < RPL ? didx[s] : 360, nV));
+        }
     }
 #pragma unroll
     for (int gq = 0; gq < NGRP; ++gq) {
@@ -1272,19 +1280,21 @@ __global__ __launch_bounds__(256) void policy_pack16_kernel(const int D, const i
 // Pairs 0..7 are the actor: ReLU, split, layer 2 on the matrix cores into out[et] (rows 0..A-1).  Pairs 8..15 are
 // the critic, whose output layer is ONE dot product per env: it is taken in plain fp32 on the VALU straight from
 // the accumulator registers (val[et] = this lane's partial over its hidden rows; the caller sums the 4 lane groups).
-template <int PREC, int KB>
+template <int PREC, int KB, int ET = 2>
 __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsigned* sW2p, const float* sB1, const float* sW2c,
-                                              const int tp0, const int tp1, const Pieces<PREC> (&x)[2][KB], f32x4 (&out)[2],
-                                              float (&val)[2], const int lc, const int g) {
+                                              const int tp0, const int tp1, const Pieces<PREC> (&x)[ET][KB], f32x4 (&out)[ET],
+                                              float (&val)[ET], const int lc, const int g) {
     constexpr int NP = pol_np(PREC), NG = KB == 2 ? 5 : 3;
     const int oA = lc < 10 ? lc : 9;  // output rows >= 10 are never read
     // layer 1 of tile pair tp: acc[j][et] = b1 + W1[16 rows of tile 2 tp + j] x^T[et] (in the hidden layer's scaled domain)
-    auto layer1 = [&](const int tp, f32x4 (&acc)[2][2]) {
+    auto layer1 = [&](const int tp, f32x4 (&acc)[2][ET]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int ht = 2 * tp + j;
             const f32x4 bias = *reinterpret_cast<const f32x4*>(sB1 + 16 * ht + 4 * g);
-            f32x4 hi[2] = {bias, bias};
+            f32x4 hi[ET];
+#pragma unroll
+            for (int et = 0; et < ET; ++et) hi[et] = bias;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 // feature group 4 kb + g; groups >= NG are K padding (their B operand is all zeros): any finite A will do
@@ -1294,22 +1304,22 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
                 for (int pc = 0; pc < NP; ++pc)
                     a[pc] = *reinterpret_cast<const u32x4*>(sW1p + (((ht * NP + pc) * NG + gA) * 16 + lc) * 4);
 #pragma unroll
-                for (int et = 0; et < 2; ++et) {
+                for (int et = 0; et < ET; ++et) {
                     if constexpr (PREC == 2) hi[et] = mfma3(a, x[et][kb], hi[et]);
                     else hi[et] = mfma6(a, x[et][kb], hi[et]);
                 }
             }
 #pragma unroll
-            for (int et = 0; et < 2; ++et) acc[j][et] = hi[et];
+            for (int et = 0; et < ET; ++et) acc[j][et] = hi[et];
         }
     };
     // what follows layer 1 for an ACTOR tile pair (tp < 8): ReLU, operand split, layer 2 on the matrix cores
-    auto epilogue_actor = [&](const int tp, const f32x4 (&acc)[2][2]) {
+    auto epilogue_actor = [&](const int tp, const f32x4 (&acc)[2][ET]) {
         u32x4 w2[NP];
 #pragma unroll
         for (int pc = 0; pc < NP; ++pc) w2[pc] = *reinterpret_cast<const u32x4*>(sW2p + (((tp * NP + pc) * 4 + g) * 10 + oA) * 4);
 #pragma unroll
-        for (int et = 0; et < 2; ++et) {
+        for (int et = 0; et < ET; ++et) {
             float hv[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1327,12 +1337,12 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
         }
     };
     // ... and for a CRITIC tile pair (tp >= 8): the output layer's dot product on the VALU
-    auto epilogue_critic = [&](const int tp, const f32x4 (&acc)[2][2]) {
+    auto epilogue_critic = [&](const int tp, const f32x4 (&acc)[2][ET]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const f32x4 w = *reinterpret_cast<const f32x4*>(sW2c + 16 * (2 * tp + j - 16) + 4 * g);
 #pragma unroll
-            for (int et = 0; et < 2; ++et)
+            for (int et = 0; et < ET; ++et)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) val[et] = __builtin_fmaf(w[r], relu_f(acc[j][et][r]), val[et]);
         }
@@ -1341,7 +1351,17 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
     // in the instruction stream before THIS pair's VALU epilogue, in one branch-free block, so the scheduler can interleave
     // them and the matrix pipe works under the vector work instead of the wave waiting first for its MFMA results and then
     // for its own epilogue.  Two accumulator sets, alternating (no copies); the arithmetic per accumulator is unchanged.
-    f32x4 accA[2][2], accB[2][2];
+    f32x4 accA[2][ET], accB[2][ET];
+    if (tp1 < 0) {
+        // SPLIT forms (policy_kernel<SPLIT>, rollout_small_kernel): the eight waves of a workgroup share 32 envs; wave tp0 takes
+        // ACTOR pair tp0 and CRITIC pair 8 + tp0 -- the same work on every wave (with pairs 2 w, 2 w + 1 the four actor waves
+        // carried both operand splits while the critic waves waited at the barrier)
+        layer1(tp0, accA);
+        layer1(8 + tp0, accB);
+        epilogue_actor(tp0, accA);
+        epilogue_critic(8 + tp0, accB);
+        return;
+    }
     const int ta1 = tp1 < 8 ? tp1 : 8;
     int tp = tp0;
     layer1(tp, accA);
@@ -1540,7 +1560,7 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
                 }
             }
             float val[ET] = {0.0f, 0.0f};
-            policy_pass16<PREC, KB>(sW1p, sW2p, sB1, sW2c, ht0 / 2, ht1 / 2, x, out, val, lc, lk);
+            policy_pass16<PREC, KB>(sW1p, sW2p, sB1, sW2c, SPLIT ? wave : 0, SPLIT ? -1 : NT / 2, x, out, val, lc, lk);
 #pragma unroll
             for (int et = 0; et < ET; ++et) {  // the env column's value: sum of the 4 lane groups' partials -> output row A
                 float t = val[et];
@@ -1639,6 +1659,7 @@ typedef const __attribute__((address_space(3))) f64x4* lds_cd4;
 typedef const __attribute__((address_space(3))) f32x2* lds_cf2;
 typedef const __attribute__((address_space(3))) i32x2* lds_ci2;
 typedef const __attribute__((address_space(3))) int* lds_ci;
+typedef const __attribute__((address_space(3))) f32x4* lds_f4c;
 typedef __attribute__((address_space(3))) float* lds_fp;
 
 struct FastTabs {        // LDS addresses of the staged tables (wave-uniform)
@@ -1646,13 +1667,15 @@ struct FastTabs {        // LDS addresses of the staged tables (wave-uniform)
     lds_ci wrap;         // [74] j - 1 reduced mod 72, j = 0..73
     lds_cd2 act;         // [16] ActLut records, 32 bytes each: (thrust, fric) then (dk, fwd)
     lds_cd4 gates;       // [G] (x1, y1, x2, y2)
-    lds_cf2 dir;         // [361] direction lattice
+    lds_f4c dir;         // [720] direction lattice, twice around: (cos, sin, LDS byte address of the direction's 1/den row, -)
     lds_cfp reset;       // [D] the track's reset observation
+    lds_cd2 vtx;         // [nV] the wall vertex chain, 32 bytes each: (x, y) float64 then (ex, ey, brk, -) -- small form only (nV <= 64)
     lds_cfp rden;        // [361][nV] or unused
 };
 constexpr int FT_HEAD = 0, FT_WRAP = FT_HEAD + 72 * 4, FT_ACT = FT_WRAP + 76, FT_GATES = FT_ACT + 16 * 8,
-              FT_DIR = FT_GATES + TAB_MAX_GATES * 8, FT_RESET = FT_DIR + 361 * 2 + 2, FT_FLOATS = FT_RESET + 40;
-static_assert(FT_ACT % 4 == 0 && FT_GATES % 4 == 0 && FT_DIR % 2 == 0, "16-byte / 8-byte aligned records");
+              FT_DIR = FT_GATES + TAB_MAX_GATES * 8, FT_RESET = FT_DIR + 720 * 4, FT_VTX = FT_RESET + 40,
+              FT_VTX_MAX = 64, FT_FLOATS = FT_VTX + FT_VTX_MAX * 8;
+static_assert(FT_ACT % 4 == 0 && FT_GATES % 4 == 0 && FT_DIR % 4 == 0 && FT_VTX % 4 == 0, "16-byte aligned records");
 
 __device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p, const TrackHdr& h0, float* sTab, const int tid,
                                                       const int nthreads) {
@@ -1674,32 +1697,46 @@ __device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p,
     }
     const int* gates = reinterpret_cast<const int*>(p.segs + h0.gate_off);
     for (int i = tid; i < h0.G * 8; i += nthreads) dst[FT_GATES + i] = gates[i];
-    const int* dir = reinterpret_cast<const int*>(p.dirtab + h0.dir_off);
-    for (int i = tid; i < 361 * 2; i += nthreads) dst[FT_DIR + i] = dir[i];
+    // The direction lattice twice around (a ray's index 5 k + step_deg * ray < 720 needs no reduction mod 360), each entry
+    // with the LDS byte address of its row of the 1/den table: one 16-byte read per ray slot replaces the index arithmetic.
+    const float2* dir = p.dirtab + h0.dir_off;
+    const unsigned rden_base = (unsigned)(size_t)(lds_cfp)(sTab + FT_FLOATS);
+    for (int i = tid; i < 720; i += nthreads) {
+        const int j = i < 360 ? i : i - 360;
+        const float2 cs = dir[j];
+        *reinterpret_cast<f32x4*>(sTab + FT_DIR + 4 * i) = (f32x4){cs.x, cs.y, __uint_as_float(rden_base + (unsigned)(j * h0.nV) * 4u), 0.0f};
+    }
     const int* ro = reinterpret_cast<const int*>(p.reset_obs);
     for (int i = tid; i < p.D; i += nthreads) dst[FT_RESET + i] = ro[i];
+    if (h0.nV <= FT_VTX_MAX) {
+        const int* vs = reinterpret_cast<const int*>(p.vtx + h0.vtx_off);
+        for (int i = tid; i < h0.nV * 8; i += nthreads) dst[FT_VTX + i] = vs[i];
+    }
     FastTabs ft;
     ft.head = (lds_cd2)(sTab + FT_HEAD);
     ft.wrap = (lds_ci)(sTab + FT_WRAP);
     ft.act = (lds_cd2)(sTab + FT_ACT);
     ft.gates = (lds_cd4)(sTab + FT_GATES);
-    ft.dir = (lds_cf2)(sTab + FT_DIR);
+    ft.dir = (lds_f4c)(sTab + FT_DIR);
     ft.reset = (lds_cfp)(sTab + FT_RESET);
+    ft.vtx = (lds_cd2)(sTab + FT_VTX);
     ft.rden = (lds_cfp)(sTab + FT_FLOATS);
     return ft;
 }
 
 struct FastLane {        // per-lane invariants of the env step (a handful of registers instead of three per ray slot)
-    int rs0, rstep, rs_last;  // ray slot s of lane g (of G per env) is ray min(g + G s, R - 1): angle offsets step_deg * ray
+    int rs0, rstep, rs_last;  // ray slot s of lane g (of G per env) is ray min(g + G s, R - 1): angle offsets step_deg * ray, x 16 (bytes
+                              // of the direction table), the table's LDS address folded into rs0 / rs_last
     int colmask;              // bit s: slot s is one of Car.check_collision's rays
     lds_fp lray, llast;       // this lane's first ray column of its observation row (slot s: + G s floats), and the last slot's
 };
 template <int RPL, int G>
-__device__ __forceinline__ FastLane fast_lane(const EnvParams<float>& p, const int g, float* row) {
+__device__ __forceinline__ FastLane fast_lane(const EnvParams<float>& p, const FastTabs& ft, const int g, float* row) {
     FastLane fl;
-    fl.rs0 = g * p.step_deg;
-    fl.rstep = G * p.step_deg;
-    fl.rs_last = (p.R - 1) * p.step_deg;
+    const int dir_base = (int)(size_t)ft.dir;
+    fl.rs0 = dir_base + 16 * g * p.step_deg;
+    fl.rstep = 16 * G * p.step_deg;
+    fl.rs_last = dir_base + 16 * (p.R - 1) * p.step_deg;
     fl.colmask = 0;
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
@@ -1714,6 +1751,93 @@ __device__ __forceinline__ FastLane fast_lane(const EnvParams<float>& p, const i
 }
 // exchange with the neighbouring lane (the other lane of the env): DPP quad_perm [1, 0, 3, 2], one VALU instruction
 __device__ __forceinline__ int swap_pair(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false); }
+
+// The float32 wall sweep of the SMALL persistent form: part `part` of PARTS of the vertex chain, read from its LDS copy
+// (ft.vtx) instead of through scalar loads.  A part is only one or two groups of four vertices, so what counts is latency, not
+// issue slots: a group's vertex records and 1/den rows are all requested at its top, the four vertices' side values are
+// independent instruction chains, chain-break vertices are computed rather than branched around (their candidates are NaN: see
+// wall_sweep_unrolled), and two vertices share a v_min3_u32.  Same bits as wall_sweep_f32<RPL, PARTS, TAB>.
+template <int RPL, int PARTS, bool TAB, bool ADDR = false>
+__device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const int part, const double npx, const double npy,
+                                               const float (&dx)[RPL], const float (&dy)[RPL], const int (&didx)[RPL], lds_cfp rdl,
+                                               unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
+    constexpr int NP = (RPL + 1) / 2;
+    typedef const __attribute__((address_space(3))) f32x4* lds_f4;
+    f32x2 dx2[NP], dy2[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        dx2[j] = (f32x2){dx[2 * j], 2 * j + 1 < RPL ? dx[2 * j + 1] : 0.0f};
+        dy2[j] = (f32x2){dy[2 * j], 2 * j + 1 < RPL ? dy[2 * j + 1] : 0.0f};
+        bb[2 * j] = bb[2 * j + 1] = 0x447a0000u;  // 1000.0f, Ray.get_distance :198
+    }
+    const unsigned sgn = sign_mask();
+    auto side = [&](const f64x2 xy, float& ax, float& ay, f32x2 (&c)[NP]) {
+        ax = (float)(xy.x - npx);
+        ay = (float)(xy.y - npy);
+        const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay};
+#pragma unroll
+        for (int j = 0; j < NP; ++j) c[j] = __builtin_elementwise_fma(ay2, dx2[j], -(ax2 * dy2[j]));
+    };
+    auto cand = [&](const float ex, const float ey, const float axp, const float ayp, const f32x2 (&cp)[NP], const f32x2 (&c)[NP],
+                    const f32x4 (&rd)[2 * NP], const int I, unsigned (&q)[2 * NP]) {
+        const float un = __builtin_fmaf(ey, axp, -(ex * ayp));
+        const f32x2 un2 = {un, un}, ex2 = {ex, ex}, ey2 = {ey, ey};
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            f32x2 u;
+            if constexpr (TAB) {
+                u = (f32x2){un * rd[2 * j][I], un * rd[2 * j + 1][I]};
+            } else {
+                const f32x2 den = __builtin_elementwise_fma(ey2, dx2[j], -(ex2 * dy2[j]));
+                const f32x2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                u = un2 * rc;
+            }
+            const f32x2 t = cp[j] * (-c[j]);
+            q[2 * j] = and_or(__float_as_uint(t.x), sgn, __float_as_uint(u.x));
+            q[2 * j + 1] = and_or(__float_as_uint(t.y), sgn, __float_as_uint(u.y));
+        }
+    };
+    const int ngrp = nV >> 2;
+    const int gbeg = PARTS > 1 ? ngrp * part / PARTS : 0;
+    const int gend = PARTS > 1 ? ngrp * (part + 1) / PARTS : ngrp;
+    float axA = 0.0f, ayA = 0.0f, axB = 0.0f, ayB = 0.0f;
+    f32x2 cA[NP], cB[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) cA[j] = cB[j] = (f32x2){0.0f, 0.0f};
+    if (PARTS > 1 && gbeg > 0) side(vt[2 * (4 * gbeg - 1)], axA, ayA, cA);   // the vertex before the range: the chain's previous side values
+    lds_f4 rrow[2 * NP];
+    if constexpr (TAB) {
+#pragma unroll
+        for (int s = 0; s < 2 * NP; ++s) {
+            if constexpr (ADDR) rrow[s] = (lds_f4)(size_t)(s < RPL ? (unsigned)didx[s] : (unsigned)(size_t)rdl + 1440u * (unsigned)nV);
+            else rrow[s] = (lds_f4)(rdl + __umul24(s < RPL ? didx[s] : 360, nV));
+        }
+    }
+    for (int gq = gbeg; gq < gend; ++gq) {
+        f32x4 rd[2 * NP];
+        if constexpr (TAB) {
+#pragma unroll
+            for (int s = 0; s < 2 * NP; ++s) rd[s] = rrow[s][gq];
+        }
+        f64x2 xy[4];
+        f32x4 ee[4];
+#pragma unroll
+        for (int I = 0; I < 4; ++I) {
+            xy[I] = vt[2 * (4 * gq + I)];
+            ee[I] = *(lds_f4)(vt + 2 * (4 * gq + I) + 1);
+        }
+#pragma unroll
+        for (int I = 0; I < 4; I += 2) {
+            unsigned q0[2 * NP], q1[2 * NP];
+            side(xy[I], axB, ayB, cB);
+            cand(ee[I].x, ee[I].y, axA, ayA, cA, cB, rd, I, q0);
+            side(xy[I + 1], axA, ayA, cA);
+            cand(ee[I + 1].x, ee[I + 1].y, axB, ayB, cB, cA, rd, I + 1, q1);
+#pragma unroll
+            for (int s = 0; s < 2 * NP; ++s) bb[s] = min(min(bb[s], q0[s]), q1[s]);   // v_min3_u32
+        }
+    }
+}
 
 // LG = log2 of the lanes per env (1: K9, a wave owns 32 envs; 2: K9s, 16 envs per wave).  PARTS > 1 (K9s): the wall sweep is split
 // over PARTS waves of the workgroup -- this wave sweeps vertex part `part`, the per-ray minima meet in LDS (`exch`: the env's
@@ -1735,34 +1859,37 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     const f64x2 cs1 = ft.head[k72n];
     // ---- Car.update physics (car_env.py:452-461), float64: thrust with the PRE-turn heading, friction without thrust, clip
     double nvx = (st.vx + cs0.x * L.thrust) * L.fric, nvy = (st.vy + cs0.y * L.thrust) * L.fric;
-    nvx = nvx < -10.0 ? -10.0 : (nvx > 10.0 ? 10.0 : nvx);
-    nvy = nvy < -10.0 ? -10.0 : (nvy > 10.0 ? 10.0 : nvy);
+    nvx = fmin(fmax(nvx, -10.0), 10.0);      // np.clip per component (:457); the velocity is never NaN
+    nvy = fmin(fmax(nvy, -10.0), 10.0);
     const double opx = st.px, opy = st.py;
     const double npx = opx + nvx, npy = opy + nvy;
 
-    // ---- ray directions at the new heading: lattice index (5 k + step_deg * ray) mod 360
+    // ---- ray directions at the new heading: lattice entry 5 k + step_deg * ray (< 720: the table goes twice around), read as
+    // (cos, sin, LDS address of the direction's 1/den row) through a byte address that costs one add per slot
     float dx[RPL], dy[RPL];
-    int didx[RPL];
-    const int k5n = 5 * k72n;
-    const int m0 = k5n + fl.rs0, m_last = k5n + fl.rs_last;
+    int didx[RPL];    // TAB: the LDS byte address of the slot's 1/den row
+    const int k80n = 80 * k72n;                                         // 16 bytes x 5 entries per turn step
+    const int m0 = k80n + fl.rs0, m_last = k80n + fl.rs_last;
+    {
+        int m = m0;
 #pragma unroll
-    for (int s = 0; s < RPL; ++s) {
-        // ray(s) = min(g + G s, R - 1): its angle offset min(rs0 + s * rstep, rs_last), with k5n folded into both bounds
-        const unsigned m = s + 1 < RPL ? (unsigned)(m0 + s * fl.rstep) : (unsigned)min(m0 + s * fl.rstep, m_last);
-        didx[s] = (int)min(m, m - 360u);
-        const f32x2 cs = ft.dir[didx[s]];
-        dx[s] = cs.x;
-        dy[s] = cs.y;
+        for (int s = 0; s < RPL; ++s) {
+            // ray(s) = min(g + G s, R - 1): only the last slot can exceed the ray count
+            const f32x4 cs = *(lds_f4c)(size_t)(unsigned)(s + 1 < RPL ? m : min(m, m_last));
+            dx[s] = cs.x;
+            dy[s] = cs.y;
+            didx[s] = (int)__float_as_uint(cs.z);
+            m += fl.rstep;
+        }
     }
     // ---- Car.get_passed_gate (:394-408): the four collision rays at the PREVIOUS pose against gate[next], dealt over the lanes
     const f64x4 gv = ft.gates[st.next];
     const Seg gate = {gv.x, gv.y, gv.z, gv.w};
-    const int k5o = 5 * k72;
+    const int k80o = 80 * k72;
     bool gate_hit = false;
 #pragma unroll
     for (int jj = 0; jj < 4 / G; ++jj) {
-        const unsigned m = (unsigned)(k5o + gq[jj]);
-        const f32x2 cs = ft.dir[(int)min(m, m - 360u)];
+        const f32x4 cs = *(lds_f4c)(size_t)(unsigned)(k80o + gq[jj]);
         gate_hit |= Math<float>::cast(gate, opx, opy, cs.x, cs.y) < 10.0f;  // :387,:390
     }
     // ---- wall sweep.  More than 12 ray slots per lane (33 rays: 17) are swept in TWO passes over the vertex chain, 9 + 8
@@ -1776,10 +1903,12 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         const float(&dya)[R1] = *reinterpret_cast<const float(*)[R1]>(&dy[0]);
         const int(&dia)[R1] = *reinterpret_cast<const int(*)[R1]>(&didx[0]);
         unsigned ba[2 * ((R1 + 1) / 2)];
-        if (PARTS == 1 && h.nV == 28)   // (wave-uniform) big_track's chain: the unrolled sweep
-            wall_sweep_unrolled<R1, TAB, 7>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxa, dya, dia, ft.rden, ba);
+        if (PARTS > 1)                  // small form: latency-oriented sweep over the LDS copy of the chain
+            wall_sweep_lds<R1, PARTS, TAB, true>(ft.vtx, h.nV, part, npx, npy, dxa, dya, dia, ft.rden, ba);
+        else if (h.nV == 28)            // (wave-uniform) big_track's chain: the unrolled sweep
+            wall_sweep_unrolled<R1, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxa, dya, dia, ft.rden, ba);
         else
-            wall_sweep_f32<R1, PARTS, TAB>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dxa, dya, dia, ft.rden, ba);
+            wall_sweep_f32<R1, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dxa, dya, dia, ft.rden, ba);
 #pragma unroll
         for (int s = 0; s < R1; ++s) bb[s] = ba[s];
     }
@@ -1789,10 +1918,12 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         const float(&dyb)[R2] = *reinterpret_cast<const float(*)[R2]>(&dy[R1]);
         const int(&dib)[R2] = *reinterpret_cast<const int(*)[R2]>(&didx[R1]);
         unsigned bc[2 * ((R2 + 1) / 2)];
-        if (PARTS == 1 && h.nV == 28)
-            wall_sweep_unrolled<R2, TAB, 7>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxb, dyb, dib, ft.rden, bc);
+        if (PARTS > 1)
+            wall_sweep_lds<R2, PARTS, TAB, true>(ft.vtx, h.nV, part, npx, npy, dxb, dyb, dib, ft.rden, bc);
+        else if (h.nV == 28)
+            wall_sweep_unrolled<R2, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxb, dyb, dib, ft.rden, bc);
         else
-            wall_sweep_f32<R2, PARTS, TAB>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dxb, dyb, dib, ft.rden, bc);
+            wall_sweep_f32<R2, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dxb, dyb, dib, ft.rden, bc);
 #pragma unroll
         for (int s = 0; s < R2; ++s) bb[R1 + s] = bc[s];
     }
@@ -1864,17 +1995,24 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         lrow[4] = (float)cs1.x;                    // :584-588
         lrow[5] = (float)cs1.y;
     }
-    // ---- new state; CarEnv.reset (:677-686) for a finished env
-    st.px = done ? h.start_x : npx;
-    st.py = done ? h.start_y : npy;
-    st.vx = done ? 0.0 : nvx;
-    st.vy = done ? 0.0 : nvy;
-    st.k = done ? 0 : st.k + L.dk;
-    k72 = done ? 0 : k72n;
-    st.time = done ? 0 : time;
-    st.next = done ? 0 : next;
-    st.passed = done ? 0 : passed;
+    // ---- new state (CarEnv.reset for a finished env, :677-686, is the caller's rarely taken fix-up: env_reset_fast)
+    st.px = npx;
+    st.py = npy;
+    st.vx = nvx;
+    st.vy = nvy;
+    st.k += L.dk;
+    k72 = k72n;
+    st.time = time;
+    st.next = next;
+    st.passed = passed;
     return done;
+}
+
+// CarEnv.reset (car_env.py:677-686) of a finished env's registers
+__device__ __forceinline__ void env_reset_fast(const TrackHdr& h, EnvRegs& st, int& k72) {
+    st.px = h.start_x; st.py = h.start_y; st.vx = 0.0; st.vy = 0.0;
+    st.k = 0; st.time = 0; st.next = 0; st.passed = 0;
+    k72 = 0;
 }
 
 // Developer-only timing ablation of the persistent rollout kernels: a SEPARATE build (make ABLATE=n -> libppocar_ablate.so,
@@ -2002,9 +2140,9 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     int gq[2] = {0, 0}, k72 = 0;
     FastLane fl = {};
     if constexpr (FAST) {
-        fl = fast_lane<RPL, 2>(p, g, sObs + el * LDX);
-        gq[0] = g * p.q * p.step_deg;            // Car.get_passed_gate's rays j * (n // 4), j = g and g + 2
-        gq[1] = (g + 2) * p.q * p.step_deg;
+        fl = fast_lane<RPL, 2>(p, ft, g, sObs + el * LDX);
+        gq[0] = (int)(size_t)ft.dir + 16 * g * p.q * p.step_deg;            // Car.get_passed_gate's rays j * (n // 4), j = g and g + 2,
+        gq[1] = (int)(size_t)ft.dir + 16 * (g + 2) * p.q * p.step_deg;      // as byte addresses into the direction table
         k72 = Math<float>::mod72(st.k);
     }
     const lds_fp lrow = (lds_fp)(sObs + el * LDX);
@@ -2110,8 +2248,10 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 PC_STAMP(6)
                 // gymnasium 0.29.1 same-step auto-reset: a finished env returns its reset observation
                 if (__builtin_amdgcn_ballot_w64(done) != 0) {   // wave-uniform: ~1.5 % of env steps end an episode
-                    if (done)
+                    if (done) {
                         for (int f = g; f < D; f += 2) lrow[f] = ft.reset[f];
+                        env_reset_fast(h0, st, k72);
+                    }
                 }
                 if (g == 0 && e_valid) {
                     rew_buf[(int64_t)t * N + e_env] = rw;
@@ -2171,7 +2311,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
 // 32 actions, then all 512 lanes run the env step with 16 lanes per env.  Three workgroup barriers per step.
 // MODE as in rollout_kernel: 0 = generic tables, env_step_core; 1 / 2 = single track, A = 9, every table in LDS behind LDS
 // pointers, env_step_fast (2: with the 1/den table), dense observation rows copied out by three waves in 16-byte stores.
-template <int KS, int RPL, int PREC, int MODE>
+template <int KS, int RPL, int PREC, int MODE, int EPW>
 __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<float> p, const float* __restrict__ image, const int A,
                                                             const int T, const double reward_scale, const uint64_t seed,
                                                             const uint64_t offset, const uint64_t* __restrict__ offset_dev,
@@ -2182,11 +2322,15 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                                                             float* __restrict__ next_term, float* __restrict__ next_trunc,
                                                             const int rden_lds, const int vec_ok) {
     constexpr int dbg = PC_ABLATE;  // 0 in the product build (see PC_ABLATE)
-    constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, ET = 2;
+    // EPW = envs per workgroup: 32 (two groups of 4 waves = 4 sweep parts for 16 envs each; each wave 2 env tiles of the policy
+    // pass) or 16 (up to 4096 envs: twice the workgroups -- all 256 CUs at BASELINE configs[1] -- and every phase of the step
+    // half as long: all 8 waves = 8 sweep parts of the same 16 envs, one env tile per wave).
+    constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, ET = EPW / 16;
     constexpr int NG = pol_ng(KS), KB = pol_kb(KS);
     constexpr int IMG = PREC ? polx_image_dwords(PREC, NG) : pol_image_padded(KS);
     constexpr bool FAST = MODE != 0;
     constexpr int DC = RPL == 3 ? 18 : (RPL == 5 ? 23 : 39);   // FAST: 6 + the ray count the 4-lanes-per-env menu implies (12 / 17 / 33)
+    static_assert(EPW == 32 || (EPW == 16 && FAST && PREC != 0 && DC <= 23), "16 envs per workgroup: fast mode, split operand forms, <= 17 rays");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sW1 = lds;
     float* sB1 = PREC ? lds + polx_w1_dwords(PREC, NG) + polx_w2_dwords(PREC) : sW1 + 2 * HID * LD1;
@@ -2198,9 +2342,9 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     const int64_t N = p.N;
     const int D = FAST ? DC : p.D;
     const int LDX = FAST ? D : 4 * KS + 1;
-    float* sOut = lds + IMG;                       // [8 waves][32 envs][LDO] partial output tiles
-    float* sObs = sOut + 8 * 32 * LDO;             // [32 envs][LDX]
-    int* sAct = reinterpret_cast<int*>(sObs + 32 * (FAST ? 40 : LDX));   // (FAST: room for the widest row, so the tables stay 16-byte aligned)
+    float* sOut = lds + IMG;                       // [8 waves][EPW envs][LDO] partial output tiles
+    float* sObs = sOut + 8 * EPW * LDO;            // [EPW envs][LDX]
+    int* sAct = reinterpret_cast<int*>(sObs + EPW * (FAST ? 40 : LDX));   // (FAST: room for the widest row, so the tables stay 16-byte aligned)
     float* sTab = reinterpret_cast<float*>(sAct + 32);     // staged per-track tables
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, lk = lane >> 4;
@@ -2218,28 +2362,30 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     }
     const lds_cfp rdl = (lds_cfp)sRden;
 
-    // env step: wave w sweeps quarter (w & 3) of the wall vertices for 16 envs, 4 lanes (ray groups) per env
-    constexpr int PARTS = 4;
-    const int part = __builtin_amdgcn_readfirstlane(wave & 3);
-    const int el = (wave >> 2) * 16 + (lane >> 2), g = lane & 3;
-    float* exch = sOut + el * (PARTS * 34);        // [rays][PARTS] of this env; aliases the partial output tiles (idle now)
-    const int64_t e_wg = (int64_t)blockIdx.x * 32;
+    // env step: wave w sweeps part (w % PARTS) of the wall vertices for 16 envs, 4 lanes (ray groups) per env
+    constexpr int PARTS = 128 / EPW;
+    const int part = __builtin_amdgcn_readfirstlane(wave % PARTS);
+    const int el = (wave / PARTS) * 16 + (lane >> 2), g = lane & 3;
+    constexpr int EXS = EPW == 16 ? PARTS * (DC - 6) : PARTS * 34;   // floats per env: [rays][PARTS]
+    static_assert(EPW * EXS <= 8 * EPW * LDO, "the exchange area aliases the partial output tiles");
+    float* exch = sOut + el * EXS;                 // [rays][PARTS] of this env; aliases the partial output tiles (idle now)
+    const int64_t e_wg = (int64_t)blockIdx.x * EPW;
     const int64_t e_env = e_wg + el;
     const bool e_valid = e_env < N;
     EnvRegs st = {};
     if (e_valid) st = env_load<float>(p, e_env);
     // mixed-track batch: this wave's envs share one track (the host checked every aligned block of 32 envs)
     const int trk = p.track_id ? (int)p.track_id[e_valid ? e_env : N - 1] : 0;
-    for (int f = g + 4 * part; f < (FAST ? D : 4 * KS); f += 16) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
-    float* myOut = sOut + wave * 32 * LDO;
+    for (int f = g + 4 * part; f < (FAST ? D : 4 * KS); f += 4 * PARTS) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
+    float* myOut = sOut + wave * EPW * LDO;
     const int ht0 = wave * (NT / 8), ht1 = ht0 + NT / 8;
     const uint64_t off0 = offset + (offset_dev ? *offset_dev : 0);
     PhiloxBlock rnd = {};  // the sampling lanes' current Philox block (4 steps' draws)
     int gq[2] = {0, 0}, k72 = 0;
     FastLane fl = {};
     if constexpr (FAST) {
-        fl = fast_lane<RPL, 4>(p, g, sObs + el * LDX);
-        gq[0] = g * p.q * p.step_deg;            // Car.get_passed_gate's ray j * (n // 4), j = g
+        fl = fast_lane<RPL, 4>(p, ft, g, sObs + el * LDX);
+        gq[0] = (int)(size_t)ft.dir + 16 * g * p.q * p.step_deg;            // Car.get_passed_gate's ray j * (n // 4), j = g (byte address)
         k72 = Math<float>::mod72(st.k);
     }
     const lds_fp lrow = (lds_fp)(sObs + el * LDX);
@@ -2248,6 +2394,7 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
 
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
+        PC_STAMP(0)
         // ---------------- P(t), hidden tiles [ht0, ht1) of this wave, all 32 envs
         f32x4 out[ET];
 #pragma unroll
@@ -2261,7 +2408,9 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                     const int f = 4 * ks + lk;
                     x[et][ks] = (!FAST || f < D) ? sObs[(16 * et + lc) * LDX + f] : 0.0f;
                 }
-            if (!(dbg & 1)) policy_pass<KS>(sW1, sB1, sW2, ht0, ht1, x, out, lc, lk, lane);  // dbg: timing ablations only
+            if constexpr (ET == 2) {
+                if (!(dbg & 1)) policy_pass<KS>(sW1, sB1, sW2, ht0, ht1, x, out, lc, lk, lane);  // dbg: timing ablations only
+            }
         } else {
             Pieces<PREC> x[ET][KB];
 #pragma unroll
@@ -2278,8 +2427,8 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                     x[et][kb] = split8<PREC>(v);
                 }
             }
-            float val[ET] = {0.0f, 0.0f};
-            if (!(dbg & 1)) policy_pass16<PREC, KB>(sW1p, sW2p, sB1, sW2c, ht0 / 2, ht1 / 2, x, out, val, lc, lk);
+            float val[ET] = {};
+            if (!(dbg & 1)) policy_pass16<PREC, KB, ET>(sW1p, sW2p, sB1, sW2c, wave, -1, x, out, val, lc, lk);
 #pragma unroll
             for (int et = 0; et < ET; ++et) {
                 float tv = val[et];
@@ -2292,13 +2441,15 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
         for (int et = 0; et < ET; ++et)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) myOut[(16 * et + lc) * LDO + 4 * lk + reg] = out[et][reg];
+        PC_STAMP(1)
         lds_barrier();
-        {   // every wave draws for 4 of the 32 envs, 16 lanes (= outputs) per env, exactly as policy_kernel<SPLIT>
-            const int dl = wave * 4 + lk, oi = lc;
+        PC_STAMP(2)
+        if (lk < EPW / 8) {   // every wave draws for EPW / 8 of the envs, 16 lanes (= outputs) per env, exactly as policy_kernel<SPLIT>
+            const int dl = wave * (EPW / 8) + lk, oi = lc;
             const int64_t e = e_wg + dl;
             float ps = 0.0f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) ps += sOut[(w * 32 + dl) * LDO + oi];  // fixed order
+            for (int w = 0; w < 8; ++w) ps += sOut[(w * EPW + dl) * LDO + oi];  // fixed order
             const float tsum = __builtin_fmaf(ps, PolScale<PREC>::so_inv, sB2[oi]);   // outputs back from their scaled domain
             const uint64_t o = off0 + (uint64_t)t;
             if (t == 0 || (o & 3) == 0) rnd = philox_block(seed, o >> 2, (uint64_t)e);  // uniform: ten rounds per 4 steps
@@ -2315,6 +2466,7 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
             }
         }
         lds_barrier();
+        PC_STAMP(3)
         // ---------------- E(t): 4 waves x 4 lanes per env (one more barrier inside, where the sweep parts meet)
         const bool last = t + 1 == T;
         if constexpr (FAST) {
@@ -2324,11 +2476,14 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 const bool done = rden_lds   // (uniform)
                     ? env_step_fast<RPL, true, 2, PARTS>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0)
                     : env_step_fast<RPL, false, 2, PARTS>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0);
-                if (part == 0) {   // (uniform) the row-writing wave: reset observation of finished envs, per-env scalars
-                    if (__builtin_amdgcn_ballot_w64(done) != 0) {
-                        if (done)
+                if (__builtin_amdgcn_ballot_w64(done) != 0) {
+                    if (done) {
+                        if (part == 0)   // (uniform) the row-writing wave: reset observation of finished envs
                             for (int f = g; f < D; f += 4) lrow[f] = ft.reset[f];
+                        env_reset_fast(h0, st, k72);
                     }
+                }
+                if (part == 0) {   // (uniform) the row-writing wave: per-env scalars
                     if (g == 0 && e_valid) {
                         rew_buf[(int64_t)t * N + e_env] = rw;
                         float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;
@@ -2338,20 +2493,22 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                     }
                 }
             }
+            PC_STAMP(6)
             lds_barrier();
+            PC_STAMP(7)
             // rows -> rollout buffer: the workgroup's 32 rows are contiguous there (32 * D floats): waves 0 .. 2 (.. 4) store 64 float4 each
             {
                 float* dstg = (last ? next_obs : obs_buf + (int64_t)(t + 1) * N * D) + e_wg * D;
                 const int64_t left = N - e_wg;
-                const int n_rows = left >= 32 ? 32 : (int)left;
-                if (vec_ok && n_rows == 32) {
+                const int n_rows = left >= EPW ? EPW : (int)left;
+                if (vec_ok && n_rows == EPW) {
                     const int i = lane + 64 * wave;
-                    if (i < 8 * DC) reinterpret_cast<f32x4*>(dstg)[i] = reinterpret_cast<const f32x4*>(sObs)[i];
+                    if (i < EPW / 4 * DC) reinterpret_cast<f32x4*>(dstg)[i] = reinterpret_cast<const f32x4*>(sObs)[i];
                 } else {
                     for (int i = tid; i < n_rows * D; i += 512) dstg[i] = sObs[i];
                 }
             }
-        } else {
+        } else if constexpr (EPW == 32) {
             if (!(dbg & 2)) {
                 float* orow = !e_valid ? nullptr : (last ? next_obs + e_env * D : obs_buf + ((int64_t)(t + 1) * N + e_env) * D);
                 float rw;
@@ -3578,7 +3735,9 @@ int pc_rollout_set_fast(int on) {
 }
 
 int pc_rollout_set_epw(int envs_per_workgroup) {
-    if (envs_per_workgroup != 0 && envs_per_workgroup != 128 && envs_per_workgroup != 256) return PC_ERR_INVALID_ARG;
+    if (envs_per_workgroup != 0 && envs_per_workgroup != 16 && envs_per_workgroup != 32 && envs_per_workgroup != 128 &&
+        envs_per_workgroup != 256)
+        return PC_ERR_INVALID_ARG;
     g_rollout_epw_override = envs_per_workgroup;
     return PC_OK;
 }
@@ -3745,7 +3904,8 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     const bool fast = !small && !e->track_id && A == 9 && e->D >= 17 && e->D <= 40 && e->hdr_host[0].G <= TAB_MAX_GATES && g_rollout_fast;
     const size_t lds_big = fast ? (size_t)(img + 256 * e->D + 256 + FT_FLOATS) * sizeof(float)
                                 : (size_t)(img + 256 * (4 * KS + 1) + 256 + TAB_FLOATS) * sizeof(float);
-    const bool fast_small = small && !e->track_id && A == 9 && e->D >= 17 && e->D <= 40 && e->hdr_host[0].G <= TAB_MAX_GATES && g_rollout_fast;
+    const bool fast_small = small && !e->track_id && A == 9 && e->D >= 17 && e->D <= 40 && e->hdr_host[0].G <= TAB_MAX_GATES &&
+                            e->hdr_host[0].nV <= FT_VTX_MAX && g_rollout_fast;
     const size_t lds_small = fast_small ? (size_t)(img + 8 * 32 * 17 + 32 * 40 + 32 + FT_FLOATS) * sizeof(float)
                                         : (size_t)(img + 8 * 32 * 17 + 32 * (4 * KS + 1) + 32 + TAB_FLOATS) * sizeof(float);
     size_t lds = small ? lds_small : lds_big;
@@ -3756,9 +3916,13 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     if (g_rollout_rden == 0 || e->track_id || lds + (size_t)rden_lds * sizeof(float) > 160 * 1024) rden_lds = 0;
     lds += (size_t)rden_lds * sizeof(float);
     const int rpl = small ? (e->R + 3) / 4 : (e->R + 1) / 2;  // 4 (x 4 sweep parts) or 2 lanes per env
-    const int epw = g_rollout_epw_override ? g_rollout_epw_override
-                                           : ((!small && e->N <= g_rollout_epw128_max) ? 128 : 256);   // big form: envs per workgroup
-    const int blocks = (int)(small ? (e->N + 31) / 32 : (e->N + epw - 1) / epw);
+    const int epw = g_rollout_epw_override >= 128 ? g_rollout_epw_override
+                                                  : ((!small && e->N <= g_rollout_epw128_max) ? 128 : 256);   // big form: envs per workgroup
+    // small form: 16 envs per workgroup up to 4096 envs (<= 256 workgroups: one per CU), else 32
+    const int epw_small = (g_rollout_epw_override == 16 || g_rollout_epw_override == 32) ? g_rollout_epw_override
+                          : ((fast_small && prec != 0 && e->R <= 17 && e->N <= 4096) ? 16 : 32);
+    if (small && epw_small == 16 && !(fast_small && prec != 0 && e->R <= 17)) return PC_ERR_UNSUPPORTED;
+    const int blocks = (int)(small ? (e->N + epw_small - 1) / epw_small : (e->N + epw - 1) / epw);
     const int vec_ok = ((e->N * e->D) % 4 == 0) ? 1 : 0;      // the waves' 32-row blocks are 16-byte aligned in the buffers
     const int mode = (fast || fast_small) ? (rden_lds ? 2 : 1) : 0;
     hipStream_t st = (hipStream_t)stream;
@@ -3781,21 +3945,24 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
         else if (mode == 1) PC_ROLL_M(KSV, RPLV, PRC, 1);                                                                \
         else PC_ROLL_M(KSV, RPLV, PRC, 0);                                                                               \
     } while (0)
-#define PC_ROLLS_M(KSV, RPLV, PRC, MD)                                                                                   \
+#define PC_ROLLS_M(KSV, RPLV, PRC, MD, EPWV)                                                                             \
     do {                                                                                                                 \
         static bool attr_set[64] = {false};                                                                              \
         if (e->device < 64 && !attr_set[e->device]) {                                                                    \
-            HIPCHK(hipFuncSetAttribute((const void*)rollout_small_kernel<KSV, RPLV, PRC, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HIPCHK(hipFuncSetAttribute((const void*)rollout_small_kernel<KSV, RPLV, PRC, MD, EPWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_set[e->device] = true;                                                                                  \
         }                                                                                                                \
-        hipLaunchKernelGGL((rollout_small_kernel<KSV, RPLV, PRC, MD>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, \
+        hipLaunchKernelGGL((rollout_small_kernel<KSV, RPLV, PRC, MD, EPWV>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, \
                            seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, \
                            next_term, next_trunc, rden_lds, vec_ok);                                                             \
     } while (0)
 #define PC_ROLLS(KSV, RPLV, PRC)                                                                                         \
     do {                                                                                                                 \
-        if (mode) PC_ROLLS_M(KSV, RPLV, PRC, 1);    /* (the small form takes the 1/den table as a run-time branch) */   \
-        else PC_ROLLS_M(KSV, RPLV, PRC, 0);                                                                              \
+        if constexpr (PRC != 0 && RPLV <= 5) {                                                                           \
+            if (mode && epw_small == 16) { PC_ROLLS_M(KSV, RPLV, PRC, 1, 16); break; }                                   \
+        }                                                                                                                \
+        if (mode) PC_ROLLS_M(KSV, RPLV, PRC, 1, 32);    /* (the small form takes the 1/den table as a run-time branch) */   \
+        else PC_ROLLS_M(KSV, RPLV, PRC, 0, 32);                                                                          \
     } while (0)
     if (small) {
         if (KS == 5 && rpl == 3) { if (prec == 2) PC_ROLLS(5, 3, 2); else if (prec) PC_ROLLS(5, 3, 1); else PC_ROLLS(5, 3, 0); }        // 12 rays

@@ -35,7 +35,8 @@ assert n == len(buf), n
 import numpy as np
 st = np.array(buf, dtype=np.uint64).reshape(8, NT, NPH).astype(np.int64)
 t0 = st.min()
-names = ["split", "policy", "draw", "env-pre", "sweep", "post", "copy-out"]
+names = (["split", "policy", "draw", "env-pre", "sweep", "post", "copy-out"] if tr.cfg.n_envs > 16384 else
+         ["tiles", "barrier1", "draw+bar2", "env-pre", "sweep part", "xchg+post", "barrier3"])
 print(f"rollout mode {tr.rollout_mode}; cycles (s_memtime ticks) per phase, mean over {NT} steps")
 print("wave " + " ".join(f"{n:>9s}" for n in names) + "   step total")
 for w in range(8):
