@@ -143,6 +143,39 @@ def test_both_workgroup_sizes_of_the_big_form_at_small_n(n_envs, epw):
     assert float(res["mega"][5].sum()) > 0
 
 
+@pytest.mark.parametrize("epw", [16, 32])
+@pytest.mark.parametrize("n_envs,num_rays", [(1000, 16), (8000, 16), (500, 12)])
+def test_both_workgroup_sizes_of_the_small_form(n_envs, num_rays, epw):
+    """The small form (hidden tiles and sweep parts split over the eight waves of a workgroup) with 16 envs per workgroup --
+    what BASELINE configs[1] (4096 envs) takes: one workgroup on every CU -- and with 32, forced at other batch sizes: bitwise
+    the per-step kernels (split policy form), two rollouts so that auto-resets are inside the window."""
+    res = {}
+    lib.pc_policy_set_split(1)
+    lib.pc_rollout_set_form(1)
+    lib.pc_rollout_set_epw(epw)
+    try:
+        for mode in ("steps", "mega"):
+            tr = Trainer(PPOConfig(n_envs=n_envs, n_steps=96, num_rays=num_rays, track=TRACKS["big_track"], rollout_kernel=mode,
+                                   use_graphs=False, seed=4), device="cuda")
+            for _ in range(2):
+                tr.rollout()
+                tr.buffer.ptr = 0
+            torch.cuda.synchronize()
+            assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
+            res[mode] = _snap(tr)
+            res[mode + "_state"] = tr.envs.get_state()
+            tr.close()
+    finally:
+        lib.pc_policy_set_split(-1)
+        lib.pc_rollout_set_form(-1)
+        lib.pc_rollout_set_epw(0)
+    for i, (a, b) in enumerate(zip(res["steps"], res["mega"])):
+        assert torch.equal(a, b), i
+    for k in res["mega_state"]:
+        assert np.array_equal(res["mega_state"][k], res["steps_state"][k]), k
+    assert float(res["mega"][5].sum()) > 0
+
+
 # ------------------------------------------------------------------------------------------------
 # the reference's ray / segment unit cases through the HIP kernels
 # ------------------------------------------------------------------------------------------------
