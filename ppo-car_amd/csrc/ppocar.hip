@@ -411,7 +411,7 @@ __device__ __forceinline__ void wall_sweep_unrolled(const Vtx* vt, const int n_c
         for (int j = 0; j < NP; ++j) {
             f32x2 u;
             if constexpr (TAB) {
-                u = (f32x2){un * rd[2 * j][I], un * rd[2 * j + 1][I]};
+                u = (f32x2){un * rd[2 * j][I], 2 * j + 1 < RPL ? un * rd[2 * j + 1][I] : 0.0f};   // (odd RPL: the last slot is padding)
             } else {
                 const f32x2 den = __builtin_elementwise_fma(ey2, dx2[j], -(ex2 * dy2[j]));
                 const f32x2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
@@ -419,7 +419,7 @@ __device__ __forceinline__ void wall_sweep_unrolled(const Vtx* vt, const int n_c
             }
             const f32x2 t = cp[j] * (-c[j]);
             q[2 * j] = and_or(__float_as_uint(t.x), sgn, __float_as_uint(u.x));
-            q[2 * j + 1] = and_or(__float_as_uint(t.y), sgn, __float_as_uint(u.y));
+            if (2 * j + 1 < RPL) q[2 * j + 1] = and_or(__float_as_uint(t.y), sgn, __float_as_uint(u.y));
         }
     };
     float axA = 0.0f, ayA = 0.0f, axB = 0.0f, ayB = 0.0f;
@@ -440,7 +440,7 @@ __device__ __forceinline__ void wall_sweep_unrolled(const Vtx* vt, const int n_c
         f32x4 rd[2 * NP];
         if constexpr (TAB) {
 #pragma unroll
-            for (int s = 0; s < 2 * NP; ++s) rd[s] = rrow[s][gq];
+            for (int s = 0; s < RPL; ++s) rd[s] = rrow[s][gq];
         }
 #pragma unroll
         for (int I = 0; I < 4; I += 2) {
@@ -452,7 +452,7 @@ __device__ __forceinline__ void wall_sweep_unrolled(const Vtx* vt, const int n_c
             side(v1, axA, ayA, cA);
             cand(v1, axB, ayB, cB, cA, rd, I + 1, q1);
 #pragma unroll
-            for (int s = 0; s < 2 * NP; ++s) bb[s] = min(min(bb[s], q0[s]), q1[s]);   // v_min3_u32
+            for (int s = 0; s < RPL; ++s) bb[s] = min(min(bb[s], q0[s]), q1[s]);   // v_min3_u32
         }
         // one scheduling region per group: left alone, the scheduler hoists every group's table rows and vertex records
         // to the top of the 1300-instruction block and spills
@@ -1786,7 +1786,7 @@ __device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const i
         for (int j = 0; j < NP; ++j) {
             f32x2 u;
             if constexpr (TAB) {
-                u = (f32x2){un * rd[2 * j][I], un * rd[2 * j + 1][I]};
+                u = (f32x2){un * rd[2 * j][I], 2 * j + 1 < RPL ? un * rd[2 * j + 1][I] : 0.0f};   // (odd RPL: the last slot is padding)
             } else {
                 const f32x2 den = __builtin_elementwise_fma(ey2, dx2[j], -(ex2 * dy2[j]));
                 const f32x2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
@@ -1794,7 +1794,7 @@ __device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const i
             }
             const f32x2 t = cp[j] * (-c[j]);
             q[2 * j] = and_or(__float_as_uint(t.x), sgn, __float_as_uint(u.x));
-            q[2 * j + 1] = and_or(__float_as_uint(t.y), sgn, __float_as_uint(u.y));
+            if (2 * j + 1 < RPL) q[2 * j + 1] = and_or(__float_as_uint(t.y), sgn, __float_as_uint(u.y));
         }
     };
     const int ngrp = nV >> 2;
@@ -1817,7 +1817,7 @@ __device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const i
         f32x4 rd[2 * NP];
         if constexpr (TAB) {
 #pragma unroll
-            for (int s = 0; s < 2 * NP; ++s) rd[s] = rrow[s][gq];
+            for (int s = 0; s < RPL; ++s) rd[s] = rrow[s][gq];
         }
         f64x2 xy[4];
         f32x4 ee[4];
@@ -1834,7 +1834,7 @@ __device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const i
             side(xy[I + 1], axA, ayA, cA);
             cand(ee[I + 1].x, ee[I + 1].y, axB, ayB, cB, cA, rd, I + 1, q1);
 #pragma unroll
-            for (int s = 0; s < 2 * NP; ++s) bb[s] = min(min(bb[s], q0[s]), q1[s]);   // v_min3_u32
+            for (int s = 0; s < RPL; ++s) bb[s] = min(min(bb[s], q0[s]), q1[s]);   // v_min3_u32
         }
     }
 }
