@@ -1625,8 +1625,11 @@ __device__ unsigned long long g_stamps[8 * STAMP_NT * STAMP_NPH];
 #define PC_STAMP(ph)                                                                                                      \
     if (blockIdx.x == 0 && t >= STAMP_T0 && t < STAMP_T0 + STAMP_NT && lane == 0)                                        \
         g_stamps[((wave * STAMP_NT) + (t - STAMP_T0)) * STAMP_NPH + (ph)] = __builtin_amdgcn_s_memtime();
+__device__ unsigned long long g_stamps_u[16];    // the minibatch kernel (K10), workgroup 0, thread 0, of the last launch
+#define PC_STAMP_U(ph) if (wg == 0 && threadIdx.x == 0) g_stamps_u[ph] = __builtin_amdgcn_s_memtime();
 #else
 #define PC_STAMP(ph)
+#define PC_STAMP_U(ph)
 #endif
 // ------------------------------------------------------------------------------------------
 // The env step of the persistent big-form rollout (K9), single track, every gather table in LDS.
@@ -2773,10 +2776,12 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
     __shared__ float sMet[S][3];
     __shared__ float sSmp[S][4];                                          // act, old_lp, adv, ret of my samples
     __shared__ __attribute__((aligned(16))) float sT[H * LDT > 2 * S * LDH + 16 * LDH + 2 * S * 16 ? H * LDT : 2 * S * LDH + 16 * LDH + 2 * S * 16];
+    static_assert(H * LDT >= H * DMAX + 8, "the tile holds one [H][D] block in natural order plus an alignment shift");
     float* sHid = sT;                    // [2][S][LDH]  hidden activations (actor, critic)         } alias the transposition
     float* sW2 = sT + 2 * S * LDH;       // [16][LDH]    output-layer weights, row A = the critic's  } tile: used between
     float* sP2 = sW2 + 16 * LDH;         // [2][S][16]   the two k-halves of layer 2                 } the load and store phases
     const int u = threadIdx.x;
+    PC_STAMP_U(0)
     __syncthreads();  // a previous pass's readers of the shared arrays are done (persistent epoch kernel)
     // flat parameter offsets
     const int o_aW1 = 0, o_ab1 = H * D, o_aW2 = o_ab1 + H, o_ab2 = o_aW2 + A * H, o_cW1 = o_ab2 + A, o_cb1 = o_cW1 + H * D,
@@ -2799,16 +2804,22 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
     const float w2c = param[o_cW2 + u], b1a = param[o_ab1 + u], b1c = param[o_cb1 + u];
     const int ob = u & 15;                                                // my output index in the layer-2 epilogue
     const float b2 = ob < A ? param[o_ab2 + ob] : (ob == A ? param[o_cb2] : 0.0f);
-    // W1 of both nets: element e = u + 256 j of the [H][D] block sits at (row, col) = (e / D, e % D), tracked incrementally
-    const int qD = 256 / D, rD = 256 - qD * D;
-    float w1raw[2][DMAX];
-    {
-        int e = u;
+    // W1 of both nets with 16-byte loads: the [H][D] block at parameter offset `off` is fetched as the aligned float4 window
+    // [off & ~3, off + H D) -- NV4 loads per thread and net instead of D dword loads (the kernel's memory instructions were a
+    // third of its time: profiles/, K10 phase stamps) -- and goes through the LDS tile in that same natural order.
+    constexpr int NV4 = (H * DMAX + 3 + 1023) / 1024 + 1;
+    f32x4 w1raw4[2][NV4];
+    int w1_shift[2], w1_n4[2];
 #pragma unroll
-        for (int j = 0; j < DMAX; ++j) {
-            w1raw[0][j] = j < D ? param[o_aW1 + e] : 0.0f;
-            w1raw[1][j] = j < D ? param[o_cW1 + e] : 0.0f;
-            e += 256;
+    for (int net = 0; net < 2; ++net) {
+        const int off = net == 0 ? o_aW1 : o_cW1, b4 = off & ~3;
+        w1_shift[net] = off - b4;
+        w1_n4[net] = (off + H * D - b4 + 3) >> 2;
+        const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(param + b4);
+#pragma unroll
+        for (int j = 0; j < NV4; ++j) {
+            const int i4 = u + 256 * j;
+            w1raw4[net][j] = i4 < w1_n4[net] ? src[i4] : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         }
     }
     // ---- second-level loads (addresses came from idx)
@@ -2847,26 +2858,22 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
             sX[sidx][f] = (b < B && f < D) ? obs[idx[b] * D + f] : 0.0f;
         }
     }
-    // ---- W1 rows into registers through the LDS tile (one net at a time: the tile holds [H][D] once)
+    PC_STAMP_U(1)
+    // ---- W1 rows into registers through the LDS tile (one net at a time: the tile holds [H][D] once, natural order)
     float w1a[DMAX], w1c[DMAX];
 #pragma unroll
     for (int net = 0; net < 2; ++net) {
         lds_barrier();  // LDS-only: __syncthreads() would also wait for every outstanding global access
-        int row = u / D, col = u - row * D;
 #pragma unroll
-        for (int j = 0; j < DMAX; ++j) {
-            if (j < D) sT[row * LDT + col] = w1raw[net][j];
-            row += qD;
-            col += rD;
-            if (col >= D) {
-                col -= D;
-                ++row;
-            }
+        for (int j = 0; j < NV4; ++j) {
+            const int i4 = u + 256 * j;
+            if (i4 < w1_n4[net]) reinterpret_cast<f32x4*>(sT)[i4] = w1raw4[net][j];
         }
         lds_barrier();  // LDS-only: __syncthreads() would also wait for every outstanding global access
+        const float* row = sT + w1_shift[net] + u * D;       // (row stride D floats: conflict-free for odd D)
 #pragma unroll
         for (int f = 0; f < DMAX; ++f) {
-            const float w = f < D ? sT[u * LDT + f] : 0.0f;
+            const float w = f < D ? row[f] : 0.0f;
             if (net == 0) w1a[f] = w;
             else w1c[f] = w;
         }
@@ -2877,6 +2884,7 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
     if (!prep) adv_stats(a_loc, a_sum, B, sh, mean, sd);   // (uniform branch)
     __syncthreads();   // (also: every thread has read its W1 row out of the tile, which sHid / sW2 alias)
 
+    PC_STAMP_U(2)
     // ---- forward, layer 1 (Linear + ReLU), both nets
     // (DMAX = 40: the sample loops stay rolled and the activations are re-read from LDS in the backward pass -- fully
     // unrolled, the compiler keeps all S x D sample values live at once and spills a hundred registers)
@@ -2911,6 +2919,7 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
 #pragma unroll
     for (int o = 0; o < 16; ++o) sW2[o * LDH + u] = o < A ? w2a[o] : (o == A ? w2c : 0.0f);
     __syncthreads();
+    PC_STAMP_U(3)
     // ---- forward, layer 2: out[s][o] = sum_u W2[o][u] h[s][u], one thread per (sample, output, half of the hidden units),
     // sequential in u (fixed order: deterministic); LDH = 257 keeps the 16 rows a wave touches in distinct banks
     {
@@ -2930,6 +2939,7 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
         if (o <= A) sOut[sidx][o] = b2 + sP2[sidx * 16 + o] + sP2[(S + sidx) * 16 + o];
     }
     __syncthreads();
+    PC_STAMP_U(4)
     // ---- loss and its gradient w.r.t. the outputs, one thread per sample (train.py:235-255; as ppo_loss_kernel)
     if (u < S) {
         const int b = s0 + u;
@@ -2981,6 +2991,7 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
         sMet[u][2] = ent;
     }
     __syncthreads();
+    PC_STAMP_U(5)
     // ---- backward: every thread for its hidden unit; gradient accumulators in registers
     float g1a[DMAX], g1c[DMAX], g2a[16], g2c = 0.0f, gb1a = 0.0f, gb1c = 0.0f;
 #pragma unroll
@@ -3019,19 +3030,24 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
 #pragma unroll
         for (int sidx = 0; sidx < S; ++sidx) backward_sample(sidx, ha[sidx], hc[sidx]);
     }
-    // ---- this workgroup's gradient partial, in flat parameter order; the [H][D] blocks through the tile again
-    float* __restrict__ P = partial + (size_t)wg * n_param;
-    P[o_ab1 + u] = gb1a;
+    PC_STAMP_U(6)
+    // ---- this workgroup's gradient partial.  Layout of a partial (pc_internal: ppo_partial_index): [aW1 (H D)][cW1 (H D)]
+    // [ab1, aW2, ab2][cb1, cW2, cb2], rows of n_pad = n_param rounded up to 4 floats -- both [H][D] blocks 16-byte aligned, so
+    // they leave through the LDS tile (natural order) as float4 stores: D / 4 instead of D stores per thread and net.
+    const int HD = H * D, n_pad = (n_param + 3) & ~3;
+    float* __restrict__ P = partial + (size_t)wg * n_pad;
+    float* __restrict__ Pm = P + HD;                  // natural index i of the middle / tail blocks -> Pm[i] (see ppo_partial_index)
+    Pm[o_ab1 + u] = gb1a;
     P[o_cb1 + u] = gb1c;
 #pragma unroll
     for (int o = 0; o < 16; ++o)
-        if (o < A) P[o_aW2 + o * H + u] = g2a[o];
+        if (o < A) Pm[o_aW2 + o * H + u] = g2a[o];
     P[o_cW2 + u] = g2c;
     if (u <= A) {  // output-layer biases: sum of dout over my samples
         float t = 0.0f;
 #pragma unroll
         for (int sidx = 0; sidx < S; ++sidx) t += sDout[sidx][u];
-        if (u < A) P[o_ab2 + u] = t;
+        if (u < A) Pm[o_ab2 + u] = t;
         else P[o_cb2] = t;
     }
     if (u < 3) {
@@ -3045,22 +3061,16 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
         lds_barrier();  // (not __syncthreads(): that waits for the stores already in flight, ~2 us each time)
 #pragma unroll
         for (int f = 0; f < DMAX; ++f)
-            if (f < D) sT[u * LDT + f] = net == 0 ? g1a[f] : g1c[f];
+            if (f < D) sT[u * D + f] = net == 0 ? g1a[f] : g1c[f];
         lds_barrier();  // (not __syncthreads(): that waits for the stores already in flight, ~2 us each time)
-        float* __restrict__ dst = P + (net == 0 ? o_aW1 : o_cW1);
-        int row = u / D, col = u - row * D, e = u;
+        f32x4* __restrict__ dst = reinterpret_cast<f32x4*>(P + net * HD);
 #pragma unroll
-        for (int j = 0; j < DMAX; ++j) {
-            if (j < D) dst[e] = sT[row * LDT + col];
-            e += 256;
-            row += qD;
-            col += rD;
-            if (col >= D) {
-                col -= D;
-                ++row;
-            }
+        for (int j = 0; j < NV4; ++j) {
+            const int i4 = u + 256 * j;
+            if (i4 < (HD >> 2)) dst[i4] = reinterpret_cast<const f32x4*>(sT)[i4];
         }
     }
+    PC_STAMP_U(7)
 }
 
 template <int DMAX>
@@ -3077,6 +3087,7 @@ __global__ __launch_bounds__(256) void ppo_fwdbwd_kernel(const int64_t* __restri
 // K11: flat_grad[i] = sum_p partial[p][i] (fixed order: deterministic); block-wise squared-norm partials for the clip;
 // block 0 folds the metric partials into the running sums (train.py:263-266) and advances the Adam step counter.
 __device__ __forceinline__ void grad_reduce_body(const int blk, const float* __restrict__ partial, const int n_part, const int n,
+                                                          const int HD, const int mid_end, const int n_pad,
                                                           float* __restrict__ grad, float* __restrict__ norm_partial,
                                                           const float* __restrict__ metric_partial, const int B, const float vf,
                                                           const float ec, float* __restrict__ metrics, float* __restrict__ step_count) {
@@ -3085,22 +3096,25 @@ __device__ __forceinline__ void grad_reduce_body(const int blk, const float* __r
     const int i = blk * blockDim.x + threadIdx.x;
     float g = 0.0f;
     if (i < n) {
+        // natural flat index i -> index inside a partial (ppo_fwdbwd_body's layout: both [H][D] blocks first, 16-byte aligned)
+        const int pm = i < HD ? i : (i < mid_end ? i + HD : (i < mid_end + HD ? i - (mid_end - HD) : i));
+        const float* __restrict__ pp = partial + pm;
         int pidx = 0;
         for (; pidx + 32 <= n_part; pidx += 32) {  // 32 independent loads in flight (the partials were written by other
             float t[32];                              // workgroups: every load is a cold miss); summed in index order
 #pragma unroll
-            for (int j = 0; j < 32; ++j) t[j] = partial[(size_t)(pidx + j) * n + i];
+            for (int j = 0; j < 32; ++j) t[j] = pp[(size_t)(pidx + j) * n_pad];
 #pragma unroll
             for (int j = 0; j < 32; ++j) g += t[j];
         }
         for (; pidx + 8 <= n_part; pidx += 8) {
             float t[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = partial[(size_t)(pidx + j) * n + i];
+            for (int j = 0; j < 8; ++j) t[j] = pp[(size_t)(pidx + j) * n_pad];
 #pragma unroll
             for (int j = 0; j < 8; ++j) g += t[j];
         }
-        for (; pidx < n_part; ++pidx) g += partial[(size_t)pidx * n + i];
+        for (; pidx < n_part; ++pidx) g += pp[(size_t)pidx * n_pad];
     }
     if (i < n) grad[i] = g;
     const float ss = block_sum(g * g, sh);
@@ -3127,11 +3141,14 @@ __device__ __forceinline__ void grad_reduce_body(const int blk, const float* __r
     }
 }
 
+// HD = H * D (the size of one first-layer weight block), mid_end = the natural offset of the critic's (actor.0.weight, actor.0.bias,
+// actor.2.weight, actor.2.bias | critic.0.weight ...), n_pad = the partials' row stride
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restrict__ partial, const int n_part, const int n,
+                                                          const int HD, const int mid_end, const int n_pad,
                                                           float* __restrict__ grad, float* __restrict__ norm_partial,
                                                           const float* __restrict__ metric_partial, const int B, const float vf,
                                                           const float ec, float* __restrict__ metrics, float* __restrict__ step_count) {
-    grad_reduce_body(blockIdx.x, partial, n_part, n, grad, norm_partial, metric_partial, B, vf, ec, metrics, step_count);
+    grad_reduce_body(blockIdx.x, partial, n_part, n, HD, mid_end, n_pad, grad, norm_partial, metric_partial, B, vf, ec, metrics, step_count);
 }
 
 // K12: clip_grad_norm_ + Adam, one element per thread; the squared norm arrives as per-block partials of K11 and
@@ -3611,6 +3628,11 @@ int pc_debug_read_stamps(unsigned long long* out, int n) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), total * sizeof(unsigned long long)) != hipSuccess) return -3;
     return total;
 }
+int pc_debug_read_stamps_u(unsigned long long* out) {
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_u), 16 * sizeof(unsigned long long)) != hipSuccess) return -3;
+    return 16;
+}
 #endif
 
 int pc_env_get_state(pc_env* e, double* px, double* py, double* vx, double* vy, double* rot, int64_t* time_step,
@@ -3985,7 +4007,7 @@ int64_t pc_ppo_workspace_floats(int B, int D, int H, int A) {
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40 || B < 2 || B > 1024) return PC_ERR_UNSUPPORTED;
     const int64_t n_param = 2 * ((int64_t)H * D + H) + (int64_t)A * H + A + H + 1;
     const int64_t n_part = (B + FB_S - 1) / FB_S;
-    return n_part * n_param + n_part * 4 + (n_param + 255) / 256;
+    return n_part * ((n_param + 3) & ~(int64_t)3) + n_part * 4 + (n_param + 255) / 256;
 }
 
 static int ppo_minibatch_impl(int device, const int64_t* idx, const float* prep, int B, int D, int H, int A, const float* obs,
@@ -4002,8 +4024,10 @@ static int ppo_minibatch_impl(int device, const int64_t* idx, const float* prep,
     const int n_param = 2 * (H * D + H) + A * H + A + H + 1;
     const int n_part = (B + FB_S - 1) / FB_S;
     const int n_blk = (n_param + 255) / 256;
+    const int n_pad = (n_param + 3) & ~3;          // a partial's row stride: 16-byte aligned rows
+    const int HD = H * D, mid_end = HD + H + A * H + A;   // natural offset of critic.0.weight (ppo_fwdbwd_body's o_cW1)
     float* partial = workspace;
-    float* metric_partial = partial + (size_t)n_part * n_param;
+    float* metric_partial = partial + (size_t)n_part * n_pad;
     float* norm_partial = metric_partial + n_part * 4;
     hipStream_t st = (hipStream_t)stream;
     if (D <= 24)
@@ -4012,7 +4036,7 @@ static int ppo_minibatch_impl(int device, const int64_t* idx, const float* prep,
     else
         hipLaunchKernelGGL(ppo_fwdbwd_kernel<40>, dim3(n_part), dim3(256), 0, st, idx, B, D, A, obs, act, old_logprob, adv, ret, param,
                            (float)clip_ratio, (float)vf_coef, (float)ent_coef, partial, metric_partial, prep);
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3(n_blk), dim3(256), 0, st, partial, n_part, n_param, grad, norm_partial, metric_partial, B,
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3(n_blk), dim3(256), 0, st, partial, n_part, n_param, HD, mid_end, n_pad, grad, norm_partial, metric_partial, B,
                        (float)vf_coef, (float)ent_coef, metrics, apply ? step_count : nullptr);
     if (apply)
         hipLaunchKernelGGL(adam_kernel, dim3(n_blk), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, step_count, lr_dev, norm_partial,
