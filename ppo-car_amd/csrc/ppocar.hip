@@ -2775,11 +2775,11 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
     __shared__ float sDout[S][16];
     __shared__ float sMet[S][3];
     __shared__ float sSmp[S][4];                                          // act, old_lp, adv, ret of my samples
-    __shared__ __attribute__((aligned(16))) float sT[H * LDT > 2 * S * LDH + 16 * LDH + 2 * S * 16 ? H * LDT : 2 * S * LDH + 16 * LDH + 2 * S * 16];
+    __shared__ __attribute__((aligned(16))) float sT[H * LDT > 2 * S * LDH + 16 * LDH + 4 * S * 16 ? H * LDT : 2 * S * LDH + 16 * LDH + 4 * S * 16];
     static_assert(H * LDT >= H * DMAX + 8, "the tile holds one [H][D] block in natural order plus an alignment shift");
     float* sHid = sT;                    // [2][S][LDH]  hidden activations (actor, critic)         } alias the transposition
     float* sW2 = sT + 2 * S * LDH;       // [16][LDH]    output-layer weights, row A = the critic's  } tile: used between
-    float* sP2 = sW2 + 16 * LDH;         // [2][S][16]   the two k-halves of layer 2                 } the load and store phases
+    float* sP2 = sW2 + 16 * LDH;         // [<= 4][S][16] the k-parts of layer 2                     } the load and store phases
     const int u = threadIdx.x;
     PC_STAMP_U(0)
     __syncthreads();  // a previous pass's readers of the shared arrays are done (persistent epoch kernel)
@@ -2920,75 +2920,82 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
     for (int o = 0; o < 16; ++o) sW2[o * LDH + u] = o < A ? w2a[o] : (o == A ? w2c : 0.0f);
     __syncthreads();
     PC_STAMP_U(3)
-    // ---- forward, layer 2: out[s][o] = sum_u W2[o][u] h[s][u], one thread per (sample, output, half of the hidden units),
-    // sequential in u (fixed order: deterministic); LDH = 257 keeps the 16 rows a wave touches in distinct banks
+    // ---- forward, layer 2: out[s][o] = sum_u W2[o][u] h[s][u]: the S (A + 1) dot products, each cut into as many k-parts as
+    // 256 threads allow (3 at A = 9: 86 hidden units per thread instead of the 128 of a fixed split in halves), sequential in u
+    // within a part and parts summed in order (deterministic); LDH = 257 keeps the rows a wave touches in distinct banks
+    const int n_out = A + 1, n_pair = S * n_out, n_kp = 256 / n_pair < 4 ? 256 / n_pair : 4;
     {
-        const int sidx = u >> 5, o = (u >> 1) & 15, kh = u & 1;
-        float acc = 0.0f;
-        if (o <= A) {
-            const float* hrow = sHid + ((o < A ? 0 : S) + sidx) * LDH + kh * (H / 2);
-            const float* wrow = sW2 + o * LDH + kh * (H / 2);
-#pragma unroll 16
-            for (int k = 0; k < H / 2; ++k) acc = __builtin_fmaf(wrow[k], hrow[k], acc);
+        const int kp = u / n_pair, pr = u - kp * n_pair, sidx = pr / n_out, o = pr - sidx * n_out;
+        if (kp < n_kp) {
+            const int k0 = H * kp / n_kp, k1 = H * (kp + 1) / n_kp;
+            const float* hrow = sHid + ((o < A ? 0 : S) + sidx) * LDH;
+            const float* wrow = sW2 + o * LDH;
+            float acc = 0.0f;
+#pragma unroll 8
+            for (int k = k0; k < k1; ++k) acc = __builtin_fmaf(wrow[k], hrow[k], acc);
+            sP2[(kp * S + sidx) * 16 + o] = acc;
         }
-        sP2[(kh * S + sidx) * 16 + o] = acc;
     }
     __syncthreads();
     if (u < S * 16) {
         const int sidx = u >> 4, o = u & 15;
-        if (o <= A) sOut[sidx][o] = b2 + sP2[sidx * 16 + o] + sP2[(S + sidx) * 16 + o];
+        if (o <= A) {
+            float t = b2;
+            for (int kp = 0; kp < n_kp; ++kp) t += sP2[(kp * S + sidx) * 16 + o];
+            sOut[sidx][o] = t;
+        }
     }
     __syncthreads();
     PC_STAMP_U(4)
-    // ---- loss and its gradient w.r.t. the outputs, one thread per sample (train.py:235-255; as ppo_loss_kernel)
-    if (u < S) {
-        const int b = s0 + u;
-        float pl = 0.0f, vl = 0.0f, ent = 0.0f;
-        if (b < B) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (k < A) mx = fmaxf(mx, sOut[u][k]);
-            float ex[16], sum = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (k >= A) break;
-                ex[k] = expf(sOut[u][k] - mx);
-                sum += ex[k];
-            }
-            const float lse = mx + logf(sum), inv = 1.0f / sum;
-            const int a = (int)sSmp[u][0];
-            float new_lp = 0.0f, pk[16], lpk[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (k >= A) break;
-                lpk[k] = sOut[u][k] - lse;
-                pk[k] = ex[k] * inv;                                          // softmax, one expf per action
-                ent -= pk[k] * lpk[k];
-                if (k == a) new_lp = lpk[k];
-            }
-            const float r = expf(new_lp - sSmp[u][1]);                        // :235
-            const float An = (sSmp[u][2] - mean) / sd;                        // :238-240
-            const float rc = fminf(fmaxf(r, 1.0f - clip), 1.0f + clip);
-            const float pl1 = -An * r, pl2 = -An * rc;                        // :243-244
-            pl = fmaxf(pl1, pl2);                                             // :245
-            const float dv = sOut[u][A] - sSmp[u][3];
-            vl = 0.5f * dv * dv;                                              // :249
-            const float g_lp = (pl1 >= pl2 ? -An : 0.0f) * r * invB;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                float dk = 0.0f;
-                if (k < A) dk = g_lp * ((k == a ? 1.0f : 0.0f) - pk[k]) + ec * invB * pk[k] * (lpk[k] + ent);
-                else if (k == A) dk = vf * dv * invB;
-                sDout[u][k] = dk;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) sDout[u][k] = 0.0f;
+    // ---- loss and its gradient w.r.t. the outputs (train.py:235-255; as ppo_loss_kernel), 16 lanes per sample: lane k of a
+    // 16-lane row holds output k (logits 0..A-1, the value at A); row-wide max / sums by DPP rotations (tree order), everything
+    // after the reductions is computed redundantly by the row's lanes.  (One THREAD per sample walked the ten exponentials, the
+    // logarithm and the division as one dependent chain: 6 k cycles, an eighth of the kernel.)
+    if (u < S * 16) {
+#define PC_ROW_ROR(v, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n), 0xf, 0xf, false))
+        const int sidx = u >> 4, k = u & 15, b = s0 + sidx;
+        const bool live = b < B;
+        const float o = sOut[sidx][k < 16 ? k : 0];
+        const float l = k < A ? o : -INFINITY;
+        float mx = l;
+        mx = fmaxf(mx, PC_ROW_ROR(mx, 8));
+        mx = fmaxf(mx, PC_ROW_ROR(mx, 4));
+        mx = fmaxf(mx, PC_ROW_ROR(mx, 2));
+        mx = fmaxf(mx, PC_ROW_ROR(mx, 1));
+        const float ex = k < A ? expf(l - mx) : 0.0f;
+        float sum = ex;
+        sum += PC_ROW_ROR(sum, 8);
+        sum += PC_ROW_ROR(sum, 4);
+        sum += PC_ROW_ROR(sum, 2);
+        sum += PC_ROW_ROR(sum, 1);
+        const float lse = mx + logf(sum), inv = 1.0f / sum;
+        const float lpk = k < A ? l - lse : 0.0f;
+        const float pk = ex * inv;                                            // softmax, one expf per action
+        float ent = -(pk * lpk);
+        ent += PC_ROW_ROR(ent, 8);
+        ent += PC_ROW_ROR(ent, 4);
+        ent += PC_ROW_ROR(ent, 2);
+        ent += PC_ROW_ROR(ent, 1);
+        const int a = (int)sSmp[sidx][0];
+        const float new_lp = __shfl(lpk, (u & 48) + (a & 15), 64);            // the row's lane a
+        const float r = expf(new_lp - sSmp[sidx][1]);                         // :235
+        const float An = (sSmp[sidx][2] - mean) / sd;                         // :238-240
+        const float rc = fminf(fmaxf(r, 1.0f - clip), 1.0f + clip);
+        const float pl1 = -An * r, pl2 = -An * rc;                            // :243-244
+        const float pl = fmaxf(pl1, pl2);                                     // :245
+        const float dv = __shfl(o, (u & 48) + A, 64) - sSmp[sidx][3];
+        const float vl = 0.5f * dv * dv;                                      // :249
+        const float g_lp = (pl1 >= pl2 ? -An : 0.0f) * r * invB;
+        float dk = 0.0f;
+        if (k < A) dk = g_lp * ((k == a ? 1.0f : 0.0f) - pk) + ec * invB * pk * (lpk + ent);
+        else if (k == A) dk = vf * dv * invB;
+        sDout[sidx][k] = live ? dk : 0.0f;
+        if (k == 0) {
+            sMet[sidx][0] = live ? pl : 0.0f;
+            sMet[sidx][1] = live ? vl : 0.0f;
+            sMet[sidx][2] = live ? ent : 0.0f;
         }
-        sMet[u][0] = pl;
-        sMet[u][1] = vl;
-        sMet[u][2] = ent;
+#undef PC_ROW_ROR
     }
     __syncthreads();
     PC_STAMP_U(5)
