@@ -170,6 +170,12 @@ def main():
     if world_env is None and args.gpus > 1:
         sys.exit(spawn_ranks(args))
 
+    # Only the JSON line may reach stdout: RCCL prints a version banner there when a communicator is created.  Everything else
+    # this process (and the libraries it loads) writes to fd 1 goes to stderr; the line itself is written to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
 
@@ -402,7 +408,8 @@ def main():
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, torch)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

@@ -211,6 +211,12 @@ int pc_ppo_loss(int device, const float* logits, const float* values, const floa
                 float* dlogits, float* dvalues, float* metrics, void* stream);
 int pc_clip_adam(int device, float* param, float* grad, float* exp_avg, float* exp_avg_sq, float* step_count, const float* lr_dev,
                  int64_t n, double max_norm, double grad_scale, double beta1, double beta2, double eps, void* stream);
+/* The same step for the multi-rank form of pc_ppo_minibatch (apply = 2: the gradient kernels have already advanced the step
+ * counter): n / 256 workgroups, each summing the bucket's squares itself in one fixed order (replicas stay bit-identical).
+ * `grad` = the all-reduced SUM over ranks, left untouched; grad_scale = 1 / world_size.  (train.py:260-261) */
+int pc_clip_adam_advanced(int device, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count,
+                          const float* lr_dev, int64_t n, double max_norm, double grad_scale, double beta1, double beta2, double eps,
+                          void* stream);
 
 /* ---- one whole PPO minibatch step (train.py:230-261) with no library GEMM: gather, both MLPs forward, the clipped-PPO
  * loss, both MLPs backward, and (apply != 0) clip_grad_norm_ + Adam, as three launches.  `param` / `grad` / `exp_avg` /
@@ -218,7 +224,8 @@ int pc_clip_adam(int device, float* param, float* grad, float* exp_avg, float* e
  * actor.2.weight [A][H], actor.2.bias, critic.0.weight, critic.0.bias, critic.2.weight [1][H], critic.2.bias); idx [B]
  * indexes the flattened trajectories obs [M][D], act / old_logprob / adv / ret [M].  grad receives the (clipped, when
  * applied) gradient; metrics[4] += (policy_loss, value_loss, entropy, total); step_count [1] float and lr_dev [1] live on
- * the device.  apply == 0 stops after the gradient (multi-rank: all-reduce it, then pc_clip_adam).  workspace: device
+ * the device.  apply == 0 stops after the gradient; apply == 2 stops after the gradient but advances the step counter
+ * (multi-rank: all-reduce the gradient, then pc_clip_adam_advanced).  workspace: device
  * buffer of pc_ppo_workspace_floats(B, D, H, A) floats.  Deterministic (fixed summation order, no atomics).
  * PC_ERR_UNSUPPORTED unless H == 256, A <= 15, D <= 40, 2 <= B <= 1024. */
 int64_t pc_ppo_workspace_floats(int B, int D, int H, int A);

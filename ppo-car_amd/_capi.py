@@ -85,6 +85,7 @@ _sig = {
     "pc_ppo_gather": (_i, [_i, _vp, _i, _i] + [_vp] * 10 + [_vp]),
     "pc_ppo_loss": (_i, [_i] + [_vp] * 6 + [_i, _i, _d, _d, _d, _vp, _vp, _vp, _vp]),
     "pc_clip_adam": (_i, [_i] + [_vp] * 6 + [_i64, _d, _d, _d, _d, _d, _vp]),
+    "pc_clip_adam_advanced": (_i, [_i] + [_vp] * 6 + [_i64, _d, _d, _d, _d, _d, _vp]),
     "pc_ppo_workspace_floats": (_i64, [_i, _i, _i, _i]),
     "pc_ppo_prepared_floats": (_i64, [_i, _i]),
     "pc_ppo_prepare": (_i, [_i, _vp, _i64, _i, _i, _i] + [_vp] * 5 + [_vp, _vp]),

@@ -3203,6 +3203,53 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, fl
 }
 
 
+// K12m: clip_grad_norm_ + Adam for the MULTI-RANK step, after the gradient all-reduce: the bucket holds the SUM over ranks
+// (grad_scale = 1 / world_size averages it), so the squared norm cannot come from K11's per-block partials.  One element per
+// thread as in K12; every workgroup first sums the squares of the whole bucket itself (59 KB out of L2, the same fixed order in
+// every workgroup and on every rank: replicas stay bit-identical) instead of one 1024-thread workgroup walking the bucket twice
+// (pc_clip_adam).  The step counter has already been advanced by K11 (pc_ppo_minibatch with apply = 2).
+__global__ __launch_bounds__(256) void clip_adam_mb_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ exp_avg,
+                                                           float* __restrict__ exp_avg_sq, const float* __restrict__ step_count,
+                                                           const float* __restrict__ lr_dev, const int n, const float max_norm,
+                                                           const float grad_scale, const float beta1, const float beta2, const float eps) {
+    __shared__ float sh[16];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    const float g_own = live ? grad[i] * grad_scale : 0.0f, m0 = live ? exp_avg[i] : 0.0f, v0 = live ? exp_avg_sq[i] : 0.0f;
+    const float p0 = live ? param[i] : 0.0f;
+    const float step = step_count[0], lr = lr_dev[0];
+    // the bucket was written by another kernel (other XCDs' L2s): every load pays the fabric's latency, so all of a thread's
+    // loads are issued before the first is used -- 16 x 16 bytes in flight cover 16 k floats per pass
+    float ss = 0.0f;
+    const bool vec = (reinterpret_cast<uintptr_t>(grad) & 15) == 0;
+    const int n4 = vec ? n >> 2 : 0;
+    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(grad);
+    for (int j0 = threadIdx.x; j0 < n4; j0 += 16 * 256) {
+        float4 t[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t[q] = j0 + 256 * q < n4 ? g4[j0 + 256 * q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float a = t[q].x * grad_scale, b = t[q].y * grad_scale, c = t[q].z * grad_scale, d = t[q].w * grad_scale;
+            ss += a * a; ss += b * b; ss += c * c; ss += d * d;
+        }
+    }
+    for (int j = 4 * n4 + threadIdx.x; j < n; j += 256) { const float a = grad[j] * grad_scale; ss += a * a; }
+    const float total_norm = sqrtf(block_sum(ss, sh));
+    const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);   // clip_coef_clamped
+    const float bc1 = 1.0f - powf(beta1, step), bc2_sqrt = sqrtf(1.0f - powf(beta2, step));
+    const float step_size = lr / bc1;
+    if (!live) return;
+    // (the bucket itself is left as the all-reduce delivered it: other workgroups may still be reading it for their norm)
+    const float g = g_own * coef;
+    const float m = m0 + (1.0f - beta1) * (g - m0);
+    const float v = beta2 * v0 + (1.0f - beta2) * g * g;
+    exp_avg[i] = m;
+    exp_avg_sq[i] = v;
+    param[i] = p0 - step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
+}
+
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -3911,6 +3958,18 @@ int pc_clip_adam(int device, float* param, float* grad, float* exp_avg, float* e
     return PC_OK;
 }
 
+int pc_clip_adam_advanced(int device, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count,
+                          const float* lr_dev, int64_t n, double max_norm, double grad_scale, double beta1, double beta2, double eps,
+                          void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step_count || !lr_dev || n < 1 || n > (1 << 26)) return PC_ERR_INVALID_ARG;
+    DeviceGuard guard(device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    hipLaunchKernelGGL(clip_adam_mb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, const_cast<float*>(grad),
+                       exp_avg, exp_avg_sq, step_count, lr_dev, (int)n, (float)max_norm, (float)grad_scale, (float)beta1, (float)beta2, (float)eps);
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
+
 int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
                const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
                float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, void* stream) {
@@ -4024,7 +4083,9 @@ static int ppo_minibatch_impl(int device, const int64_t* idx, const float* prep,
                               float* workspace, int apply, void* stream) {
     if (!param || !grad || !metrics || !workspace) return PC_ERR_INVALID_ARG;
     if (!prep && (!idx || !obs || !act || !old_logprob || !adv || !ret)) return PC_ERR_INVALID_ARG;
-    if (apply && (!exp_avg || !exp_avg_sq || !step_count || !lr_dev)) return PC_ERR_INVALID_ARG;
+    if (apply == 1 && (!exp_avg || !exp_avg_sq || !step_count || !lr_dev)) return PC_ERR_INVALID_ARG;
+    if (apply == 2 && !step_count) return PC_ERR_INVALID_ARG;
+    if (apply < 0 || apply > 2) return PC_ERR_INVALID_ARG;
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40 || B < 2 || B > 1024) return PC_ERR_UNSUPPORTED;
     DeviceGuard guard(device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
@@ -4045,7 +4106,7 @@ static int ppo_minibatch_impl(int device, const int64_t* idx, const float* prep,
                            (float)clip_ratio, (float)vf_coef, (float)ent_coef, partial, metric_partial, prep);
     hipLaunchKernelGGL(grad_reduce_kernel, dim3(n_blk), dim3(256), 0, st, partial, n_part, n_param, HD, mid_end, n_pad, grad, norm_partial, metric_partial, B,
                        (float)vf_coef, (float)ent_coef, metrics, apply ? step_count : nullptr);
-    if (apply)
+    if (apply == 1)
         hipLaunchKernelGGL(adam_kernel, dim3(n_blk), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, step_count, lr_dev, norm_partial,
                            n_blk, n_param, (float)max_norm, (float)beta1, (float)beta2, (float)eps);
     HIPCHK(hipGetLastError());

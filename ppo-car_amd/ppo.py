@@ -209,6 +209,15 @@ class PPOLearner:
                                self.flat_param.numel(), cfg.max_grad_norm, 1.0 / self.world_size, 0.9, 0.999, 1e-5,
                                self._stream()), "pc_clip_adam")
 
+    def _custom_apply(self):
+        """clip + Adam after the gradient exchange of the custom (hand-written kernel) minibatch step: the step counter was
+        advanced by the gradient kernels (apply = 2), the bucket holds the sum over ranks."""
+        cfg = self.cfg
+        check(lib.pc_clip_adam_advanced(self._dev_index(), self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                        self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(), self.lr_dev.data_ptr(),
+                                        self.flat_param.numel(), cfg.max_grad_norm, 1.0 / self.world_size, 0.9, 0.999, 1e-5,
+                                        self._stream()), "pc_clip_adam_advanced")
+
     def custom_minibatch_step(self, idx, obs, act, logprob, adv, ret):
         """pc_ppo_minibatch: gather + forward + loss + backward (+ clip + Adam when single-rank) with no library GEMM."""
         cfg, a1, a2 = self.cfg, self.agent.actor[0], self.agent.actor[2]
@@ -218,11 +227,11 @@ class PPOLearner:
                                    self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
                                    self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(), self.lr_dev.data_ptr(), cfg.clip_ratio,
                                    cfg.vf_coef, cfg.ent_coef, cfg.max_grad_norm, 0.9, 0.999, 1e-5, self.metrics.data_ptr(),
-                                   self._ws.data_ptr(), 1 if single else 0, self._stream()), "pc_ppo_minibatch")
+                                   self._ws.data_ptr(), 1 if single else 2, self._stream()), "pc_ppo_minibatch")
         if not single:
             import torch.distributed as dist
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)     # the 1/W is folded into pc_clip_adam
-            self._fused_apply()
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)     # the 1/W is folded into the clip + Adam kernel
+            self._custom_apply()
 
     def prepare_minibatches(self, idx_all, n_mb, obs, act, logprob, adv, ret):
         """pc_ppo_prepare: gather all train_iters x n_mb minibatches of the epoch in one launch (sample rows, per-sample
@@ -254,12 +263,12 @@ class PPOLearner:
                                             a1.out_features, a2.out_features, self.flat_param.data_ptr(), self.flat_grad.data_ptr(),
                                             self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(),
                                             self.lr_dev.data_ptr(), cfg.clip_ratio, cfg.vf_coef, cfg.ent_coef, cfg.max_grad_norm, 0.9,
-                                            0.999, 1e-5, self.metrics.data_ptr(), self._ws.data_ptr(), 1 if single else 0,
+                                            0.999, 1e-5, self.metrics.data_ptr(), self._ws.data_ptr(), 1 if single else 2,
                                             self._stream()), "pc_ppo_minibatch_prepared")
         if not single:
             import torch.distributed as dist
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)     # the 1/W is folded into pc_clip_adam
-            self._fused_apply()
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)     # the 1/W is folded into the clip + Adam kernel
+            self._custom_apply()
 
     def fused_minibatch_step(self, idx, obs, act, logprob, adv, ret):
         self._fused_fwd_bwd(idx, obs, act, logprob, adv, ret)

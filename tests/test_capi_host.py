@@ -169,6 +169,7 @@ def test_shape_menus_are_reported_without_a_gpu():
     assert lib.pc_policy_set_split(2) == _capi.PC_ERR_INVALID_ARG and lib.pc_policy_set_split(-1) == 0
     n = lib.pc_ppo_workspace_floats(512, 23, 256, 9)
     n_param = 2 * (256 * 23 + 256) + 9 * 256 + 9 + 256 + 1
-    assert n_param == 14858 and n == 64 * n_param + 64 * 4 + (n_param + 255) // 256
+    n_pad = (n_param + 3) // 4 * 4                      # a partial's row stride: 16-byte aligned rows
+    assert n_param == 14858 and n == 64 * n_pad + 64 * 4 + (n_param + 255) // 256
     assert lib.pc_ppo_workspace_floats(2048, 23, 256, 9) == _capi.PC_ERR_UNSUPPORTED    # batch above 1024
     assert lib.pc_ppo_workspace_floats(512, 23, 64, 9) == _capi.PC_ERR_UNSUPPORTED

@@ -416,6 +416,35 @@ def test_custom_minibatch_kernels_match_torch_autograd(B, D):
     assert float((p0 - p1).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("n,world", [(14858, 4), (300, 1), (70001, 8)])
+def test_multi_rank_clip_adam_kernel_matches_torch(n, world):
+    """pc_clip_adam_advanced (the multi-rank step after the all-reduce: bucket = sum over ranks, step counter already advanced)
+    against clip_grad_norm_ + torch.optim.Adam on the averaged gradient (train.py:260-261), several steps, big and small norms."""
+    from ppo_car_amd._capi import check, lib
+    g = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=g)
+    ref_p = torch.nn.Parameter(p0.clone().cuda())
+    opt = torch.optim.Adam([ref_p], lr=2.5e-4, eps=1e-5)
+    param, m, v = p0.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    step, lr = torch.zeros(1).cuda(), torch.full((1,), 2.5e-4).cuda()
+    for it in range(6):
+        bucket = (torch.randn(n, generator=g) * (0.001 if it % 2 else 1.0) * world).cuda()       # the sum over `world` ranks
+        before = bucket.clone()
+        ref_p.grad = bucket / world
+        torch.nn.utils.clip_grad_norm_([ref_p], 0.5)
+        opt.step()
+        step += 1                                                                               # what K11 does under apply = 2
+        check(lib.pc_clip_adam_advanced(0, param.data_ptr(), bucket.data_ptr(), m.data_ptr(), v.data_ptr(), step.data_ptr(),
+                                        lr.data_ptr(), n, 0.5, 1.0 / world, 0.9, 0.999, 1e-5,
+                                        torch.cuda.current_stream().cuda_stream), "pc_clip_adam_advanced")
+        assert torch.equal(bucket, before)                                                      # the bucket is left as delivered
+    torch.cuda.synchronize()
+    assert float((param - ref_p.detach()).abs().max()) < 2e-6
+    st = opt.state[ref_p]
+    assert torch.allclose(m, st["exp_avg"], atol=1e-7, rtol=1e-5) and torch.allclose(v, st["exp_avg_sq"], atol=1e-9, rtol=1e-5)
+    assert lib.pc_clip_adam_advanced(0, None, None, None, None, None, None, n, 0.5, 1.0, 0.9, 0.999, 1e-5, None) != 0
+
+
 def test_checkpoint_resume_continues_bit_for_bit(tmp_path):
     """3 epochs in one go == 2 epochs, save, fresh trainer, load, 1 more epoch (policy, optimizer state, env state,
     device Philox counters and the host index generator all restored)."""
