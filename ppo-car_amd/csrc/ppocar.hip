@@ -1181,11 +1181,13 @@ __device__ __forceinline__ unsigned pk_f16(float a, float b) {  // low half = fp
     const f32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2v));
 }
+// l = fp16(v - h): v_fma_mixlo/mixhi_f16 read h straight out of the packed pair (as fp16), form fma(h, -1, v) -- exact -- and
+// round it once to fp16 into the low / high half: three instructions per pair of values, where converting h back, subtracting
+// and converting again takes five (tools/split_mix_check.hip: the same bits on 4 M pairs, fp16-denormal residuals included).
 __device__ __forceinline__ void split_pair_h(float a, float b, unsigned& p0, unsigned& p1) {
     p0 = pk_f16(a, b);
-    const f16x2v h = __builtin_bit_cast(f16x2v, p0);
-    const f32x2 r = (f32x2){a, b} - (f32x2){(float)h.x, (float)h.y};
-    p1 = pk_f16(r.x, r.y);
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(p1) : "v"(p0), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(p1) : "v"(p0), "v"(b));
 }
 
 template <int PREC> __device__ __forceinline__ Pieces<PREC> split8(const float (&v)[8]) {
