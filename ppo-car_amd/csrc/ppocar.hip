@@ -4003,7 +4003,8 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     // the track's 1/den table rides along in LDS when it fits (big_track: 361 x 28 floats = 40 KB); else the sweep forms
     // den and its reciprocal itself -- same bits either way
     int rden_lds = 361 * e->hdr_host[0].nV;
-    if (g_rollout_rden == 0 || e->track_id || lds + (size_t)rden_lds * sizeof(float) > 160 * 1024) rden_lds = 0;
+    // (the big form at 33 rays has 4 KB left: no closed track's table fits, so that shape is built without the table mode)
+    if (g_rollout_rden == 0 || e->track_id || lds + (size_t)rden_lds * sizeof(float) > 160 * 1024 || (!small && KS == 10)) rden_lds = 0;
     lds += (size_t)rden_lds * sizeof(float);
     const int rpl = small ? (e->R + 3) / 4 : (e->R + 1) / 2;  // 4 (x 4 sweep parts) or 2 lanes per env
     const int epw = g_rollout_epw_override >= 128 ? g_rollout_epw_override
@@ -4061,7 +4062,10 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
         else return PC_ERR_UNSUPPORTED;
     } else if (KS == 5 && rpl == 6) { if (prec == 2) PC_ROLL(5, 6, 2); else if (prec) PC_ROLL(5, 6, 1); else PC_ROLL(5, 6, 0); }       // 12 rays, D = 18
     else if (KS == 6 && rpl == 9) { if (prec == 2) PC_ROLL(6, 9, 2); else if (prec) PC_ROLL(6, 9, 1); else PC_ROLL(6, 9, 0); }          // 16 -> 17 rays, D = 23
-    else if (KS == 10 && rpl == 17 && prec) { if (prec == 2) PC_ROLL(10, 17, 2); else PC_ROLL(10, 17, 1); }                               // 32 -> 33 rays, D = 39
+    else if (KS == 10 && rpl == 17 && prec) {                                                                                             // 32 -> 33 rays, D = 39
+        if (prec == 2) { if (mode) PC_ROLL_M(10, 17, 2, 1); else PC_ROLL_M(10, 17, 2, 0); }
+        else { if (mode) PC_ROLL_M(10, 17, 1, 1); else PC_ROLL_M(10, 17, 1, 0); }
+    }
     else return PC_ERR_UNSUPPORTED;
 #undef PC_ROLL_M
 #undef PC_ROLLS_M

@@ -86,8 +86,8 @@ def _oracle_replay_check(cfg, snaps, first_obs, what):
     return worst, ties, float(alive.mean())
 
 
-@pytest.mark.parametrize("n_envs,num_rays,n_steps", [(65536, 16, 128), (65536, 32, 128), (4096, 16, 1024)],
-                         ids=["target_65536x17rays", "cfg2_65536x33rays", "cfg1_4096x1024steps"])
+@pytest.mark.parametrize("n_envs,num_rays,n_steps", [(65536, 16, 1024), (65536, 32, 128), (4096, 16, 1024)],
+                         ids=["target_65536x1024x17rays", "cfg2_65536x128x33rays", "cfg1_4096x1024x17rays"])
 def test_default_dispatch_rollout_vs_step_kernels_and_oracle(n_envs, num_rays, n_steps):
     res, first = {}, None
     assert lib.pc_build_ablate() == 0
