@@ -133,34 +133,44 @@ def cpu_baseline(cfg, torch, budget_s=12.0):
 
 
 def parity_check(tr, cfg, torch, np, envs=256, steps=64):
-    """One more pc_rollout launch of this trainer (same shape, same kernel, after the timed region): its first `envs` envs x
-    `steps` steps replayed through the CPU oracle from the env state the launch started from."""
+    """One more pc_rollout launch of this trainer (same shape, same kernel, after the timed region): `envs` envs x `steps` steps
+    of it replayed through the CPU oracle from the env state the launch started from.  A mixed-track batch (track list, in
+    blocks: ppo.Trainer's layout) is checked on one slice per track."""
     import oracle
     st = tr.envs.get_state()
-    P = min(envs, cfg.n_envs)
+    tracks = list(cfg.track) if isinstance(cfg.track, (list, tuple)) else [cfg.track]
+    nt = len(tracks)
     T = min(steps, cfg.n_steps - 1)            # rows 1..T of the buffer hold the observations after steps 0..T-1
-    first = tr.next_obs[:P].clone()
+    first_all = tr.next_obs.clone()
     tr.rollout()
     torch.cuda.synchronize()
     b = tr.buffer
-    acts = b.act_buf[:T, :P].cpu().numpy().astype(np.int64)
-    ora = oracle.OracleVecEnv(oracle.Track(cfg.track), P, num_rays=cfg.num_rays, reward_scaling=cfg.reward_scaling, threads=4)
-    ora.reset()
-    ora.set_state(**{k: st[k][:P] for k in ("px", "py", "vx", "vy", "rot", "time_step", "next_gate", "passed")})
-    OB, RW = b.obs_buf[:T + 1, :P].cpu().numpy(), b.rew_buf[:T, :P].cpu().numpy()
-    TE, TR = b.term_buf[:T + 1, :P].cpu().numpy() != 0, b.trunc_buf[:T + 1, :P].cpu().numpy() != 0
-    alive = np.ones(P, bool)
-    worst, flips = float(np.abs(OB[0] - first.cpu().numpy()).max()), 0
-    for t in range(T):
-        o, r, te, trn = ora.step(acts[t])
-        bad = (TE[t + 1] != te) | (TR[t + 1] != trn) | (RW[t] != r.astype(np.float32))
-        flips += int((bad & alive).sum())
-        alive &= ~bad
-        if alive.any():
-            worst = max(worst, float(np.abs(OB[t + 1][alive] - o[alive]).max()))
-    return {"kernel": tr.rollout_mode, "envs": P, "steps": T, "obs_max_abs_err": worst, "obs_tolerance": 1e-5,
+    i = np.arange(cfg.n_envs)
+    tid = np.minimum((i // 32 * 32) * nt // cfg.n_envs, nt - 1)
+    worst, flips, checked = 0.0, 0, 0
+    for k, path in enumerate(tracks):
+        lo = int(np.argmax(tid == k))
+        P = min(max(envs // nt, 32), int((tid == k).sum()))
+        sl = slice(lo, lo + P)
+        acts = b.act_buf[:T, sl].cpu().numpy().astype(np.int64)
+        ora = oracle.OracleVecEnv(oracle.Track(path), P, num_rays=cfg.num_rays, reward_scaling=cfg.reward_scaling, threads=4)
+        ora.reset()
+        ora.set_state(**{f: st[f][sl] for f in ("px", "py", "vx", "vy", "rot", "time_step", "next_gate", "passed")})
+        OB, RW = b.obs_buf[:T + 1, sl].cpu().numpy(), b.rew_buf[:T, sl].cpu().numpy()
+        TE, TR = b.term_buf[:T + 1, sl].cpu().numpy() != 0, b.trunc_buf[:T + 1, sl].cpu().numpy() != 0
+        alive = np.ones(P, bool)
+        worst = max(worst, float(np.abs(OB[0] - first_all[sl].cpu().numpy()).max()))
+        for t in range(T):
+            o, r, te, trn = ora.step(acts[t])
+            bad = (TE[t + 1] != te) | (TR[t + 1] != trn) | (RW[t] != r.astype(np.float32))
+            flips += int((bad & alive).sum())
+            alive &= ~bad
+            if alive.any():
+                worst = max(worst, float(np.abs(OB[t + 1][alive] - o[alive]).max()))
+        checked += P
+    return {"kernel": tr.rollout_mode, "envs": checked, "tracks": nt, "steps": T, "obs_max_abs_err": worst, "obs_tolerance": 1e-5,
             "envs_left_oracle_trajectory_at_a_near_tie": flips, "rewards_and_flags": "exact on every env still on the oracle's trajectory",
-            "ok": bool(worst <= 1e-5 and flips <= max(2, P // 50)),
+            "ok": bool(worst <= 1e-5 and flips <= max(2, checked // 50)),
             "checker": "oracle/carenv_oracle.c (float64 restatement of car_env.py:693-760), teacher-forced by the stored actions"}
 
 
@@ -303,7 +313,7 @@ def main():
     tr.phase_events = None
 
     extras = {}
-    if rank == 0 and world == 1 and not args.no_extras and args.env_dtype == "f32" and not mixed:
+    if rank == 0 and world == 1 and not args.no_extras and args.env_dtype == "f32":
         try:
             extras["parity_check"] = parity_check(tr, cfg, torch, np)
         except Exception as ex:                      # the check must never take the benchmark line down with it

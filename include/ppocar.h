@@ -164,7 +164,9 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
  *   (action, logprob, value) = Agent.get_action_and_value(obs_t)      [pc_policy_act's arithmetic and RNG, offset + t]
  *   obs_{t+1}, reward, terminated, truncated = envs.step(action)      [pc_env_step's arithmetic]
  *   Buffer.store(...)                                                 [rows written in place]
- * Inputs: the env handle (F32; single track, or mixed tracks with every aligned block of 32 envs on one track), the
+ * Inputs: the env handle (F32; single track, or mixed tracks with every aligned block of 32 envs on one track -- when the
+ * blocks are as large as the launch's workgroups, 128 / 256 envs in the large form and 16 / 32 in the small one, each
+ * workgroup stages its track's tables in LDS as for a single track, else every wave reads them from global memory), the
  * policy weight image of pc_policy_pack, and next_obs /
  * next_term / next_trunc [N] = observation and flags the rollout starts from (the caller has copied them into row 0 of
  * obs_buf / term_buf / trunc_buf, as Trainer does).  Outputs: obs_buf [T][N][D] rows 1..T-1, act_buf (float32, buffer.py:13),

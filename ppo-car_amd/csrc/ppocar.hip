@@ -1682,8 +1682,8 @@ constexpr int FT_HEAD = 0, FT_WRAP = FT_HEAD + 72 * 4, FT_ACT = FT_WRAP + 76, FT
               FT_VTX_MAX = 64, FT_FLOATS = FT_VTX + FT_VTX_MAX * 8;
 static_assert(FT_ACT % 4 == 0 && FT_GATES % 4 == 0 && FT_DIR % 4 == 0 && FT_VTX % 4 == 0, "16-byte aligned records");
 
-__device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p, const TrackHdr& h0, float* sTab, const int tid,
-                                                      const int nthreads) {
+__device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p, const TrackHdr& h0, const int trk, float* sTab,
+                                                      const int tid, const int nthreads) {
     int* dst = reinterpret_cast<int*>(sTab);
     const int* head = reinterpret_cast<const int*>(p.headtab + h0.head_off);
     for (int i = tid; i < 72 * 4; i += nthreads) dst[FT_HEAD + i] = head[i];
@@ -1711,7 +1711,7 @@ __device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p,
         const float2 cs = dir[j];
         *reinterpret_cast<f32x4*>(sTab + FT_DIR + 4 * i) = (f32x4){cs.x, cs.y, __uint_as_float(rden_base + (unsigned)(j * h0.nV) * 4u), 0.0f};
     }
-    const int* ro = reinterpret_cast<const int*>(p.reset_obs);
+    const int* ro = reinterpret_cast<const int*>(p.reset_obs + (size_t)trk * p.D);
     for (int i = tid; i < p.D; i += nthreads) dst[FT_RESET + i] = ro[i];
     if (h0.nV <= FT_VTX_MAX) {
         const int* vs = reinterpret_cast<const int*>(p.vtx + h0.vtx_off);
@@ -2108,16 +2108,20 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, lk = lane >> 4;
     policy_stage_image<IMG>(image, lds, tid);
-    const TrackHdr h0 = cload(p.hdr);
+    // FAST with a mixed-track batch: the host checked that every workgroup's envs lie on ONE track, whose tables it stages
+    const int trk_wg = (FAST && p.track_id)
+                           ? __builtin_amdgcn_readfirstlane((int)p.track_id[min((int64_t)blockIdx.x * epw, p.N - 1)]) : 0;
+    const TrackHdr h0 = cload(p.hdr + trk_wg);
     EnvParams<float> q = p;
     FastTabs ft = {};
-    if constexpr (FAST) ft = stage_fast_tables(p, h0, sTab, tid, 512);
+    if constexpr (FAST) ft = stage_fast_tables(p, h0, trk_wg, sTab, tid, 512);
     else q = stage_tables(p, sTab, tid, 512);
-    // the track's 1/den table, when the host found room for it: rden_lds = its size in floats (else 0)
+    // the track's 1/den table, when the host found room for it (rden_lds != 0; sized for the batch's largest track)
     float* sRden = sTab + (FAST ? FT_FLOATS : TAB_FLOATS);
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(p.rden + h0.rden_off);
-        for (int i = tid; i < rden_lds / 4; i += 512) reinterpret_cast<f32x4*>(sRden)[i] = src[i];
+        const int n4 = rden_lds ? 361 * h0.nV / 4 : 0;     // nV is a multiple of 4
+        for (int i = tid; i < n4; i += 512) reinterpret_cast<f32x4*>(sRden)[i] = src[i];
     }
     const lds_cfp rdl = (lds_cfp)sRden;
 
@@ -2354,16 +2358,20 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, lk = lane >> 4;
     policy_stage_image<IMG>(image, lds, tid);
-    const TrackHdr h0 = cload(p.hdr);
+    // FAST with a mixed-track batch: the workgroup's envs lie on ONE track (every aligned block of 32 does), whose tables it stages
+    const int trk_wg = (FAST && p.track_id)
+                           ? __builtin_amdgcn_readfirstlane((int)p.track_id[min((int64_t)blockIdx.x * EPW, p.N - 1)]) : 0;
+    const TrackHdr h0 = cload(p.hdr + trk_wg);
     EnvParams<float> q = p;
     FastTabs ft = {};
-    if constexpr (FAST) ft = stage_fast_tables(p, h0, sTab, tid, 512);
+    if constexpr (FAST) ft = stage_fast_tables(p, h0, trk_wg, sTab, tid, 512);
     else q = stage_tables(p, sTab, tid, 512);
-    // the track's 1/den table, when the host found room for it: rden_lds = its size in floats (else 0)
+    // the track's 1/den table, when the host found room for it (rden_lds != 0; sized for the batch's largest track)
     float* sRden = sTab + (FAST ? FT_FLOATS : TAB_FLOATS);
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(p.rden + h0.rden_off);
-        for (int i = tid; i < rden_lds / 4; i += 512) reinterpret_cast<f32x4*>(sRden)[i] = src[i];
+        const int n4 = rden_lds ? 361 * h0.nV / 4 : 0;     // nV is a multiple of 4
+        for (int i = tid; i < n4; i += 512) reinterpret_cast<f32x4*>(sRden)[i] = src[i];
     }
     const lds_cfp rdl = (lds_cfp)sRden;
 
@@ -3306,6 +3314,7 @@ struct pc_env {
     double* rot = nullptr;
     uint8_t* track_id = nullptr;
     bool track_blocks32 = false;   // mixed tracks: every aligned block of 32 envs holds ONE track (what pc_rollout needs)
+    int track_block = 0;           // ... the largest of 256 / 128 / 64 / 32 for which that holds (0: none)
     TrackHdr* hdr = nullptr;
     Seg* segs = nullptr;
     Vtx* vtx = nullptr;
@@ -3520,12 +3529,12 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
     HIPCHK(hipMalloc((void**)&e->iv, N * sizeof(int4)));
     if (f64) HIPCHK(hipMalloc((void**)&e->rot, N * sizeof(double)));
     if (track_id) {
-        e->track_blocks32 = true;
-        for (size_t i = 0; i < N; ++i)
-            if (track_id[i] != track_id[i & ~(size_t)31]) {
-                e->track_blocks32 = false;
-                break;
-            }
+        for (int blk = 256; blk >= 32 && !e->track_block; blk >>= 1) {
+            bool ok = true;
+            for (size_t i = 0; i < N && ok; ++i) ok = track_id[i] == track_id[i & ~(size_t)(blk - 1)];
+            if (ok) e->track_block = blk;
+        }
+        e->track_blocks32 = e->track_block >= 32;
         HIPCHK(hipMalloc((void**)&e->track_id, N));
         HIPCHK(hipMemcpy(e->track_id, track_id, N, hipMemcpyHostToDevice));
     }
@@ -3988,27 +3997,32 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     // large batches: 256 envs per workgroup, every wave independent; small batches: 32 envs per workgroup, hidden tiles and
     // wall-sweep parts split over the waves
     const bool small = g_rollout_form == 1 || (g_rollout_form < 0 && e->N <= PC_SPLIT_MAX_ENVS);
-    // big form, fast mode: single track, Discrete(9), every gather table in LDS behind LDS pointers, dense observation rows
-    // (each wave's output tile aliases its own 32 observation rows -- dead between the policy pass's operand load and the env
-    // step's store of the next observation: needs D >= 17)
-    const bool fast = !small && !e->track_id && A == 9 && e->D >= 17 && e->D <= 40 && e->hdr_host[0].G <= TAB_MAX_GATES && g_rollout_fast;
+    const int epw = g_rollout_epw_override >= 128 ? g_rollout_epw_override
+                                                  : ((!small && e->N <= g_rollout_epw128_max) ? 128 : 256);   // big form: envs per workgroup
+    int max_G = 0, max_nV = 0;
+    for (const TrackHdr& h : e->hdr_host) { max_G = std::max(max_G, h.G); max_nV = std::max(max_nV, h.nV); }
+    // fast mode: Discrete(9), every gather table in LDS behind LDS pointers, dense observation rows (big form: each wave's output
+    // tile aliases its own 32 observation rows -- dead between the policy pass's operand load and the env step's store of the
+    // next observation: needs D >= 17).  A workgroup stages ONE track's tables: single-track batches, or mixed ones in which
+    // every workgroup's block of envs lies on one track.
+    const bool fast_shape = A == 9 && e->D >= 17 && e->D <= 40 && max_G <= TAB_MAX_GATES && g_rollout_fast;
+    const bool fast = !small && fast_shape && (!e->track_id || e->track_block >= epw);
     const size_t lds_big = fast ? (size_t)(img + 256 * e->D + 256 + FT_FLOATS) * sizeof(float)
                                 : (size_t)(img + 256 * (4 * KS + 1) + 256 + TAB_FLOATS) * sizeof(float);
-    const bool fast_small = small && !e->track_id && A == 9 && e->D >= 17 && e->D <= 40 && e->hdr_host[0].G <= TAB_MAX_GATES &&
-                            e->hdr_host[0].nV <= FT_VTX_MAX && g_rollout_fast;
+    const bool fast_small = small && fast_shape && max_nV <= FT_VTX_MAX;     // (a small-form workgroup is 16 or 32 envs)
     const size_t lds_small = fast_small ? (size_t)(img + 8 * 32 * 17 + 32 * 40 + 32 + FT_FLOATS) * sizeof(float)
                                         : (size_t)(img + 8 * 32 * 17 + 32 * (4 * KS + 1) + 32 + TAB_FLOATS) * sizeof(float);
     size_t lds = small ? lds_small : lds_big;
     if (lds > 160 * 1024) return PC_ERR_UNSUPPORTED;
     // the track's 1/den table rides along in LDS when it fits (big_track: 361 x 28 floats = 40 KB); else the sweep forms
-    // den and its reciprocal itself -- same bits either way
-    int rden_lds = 361 * e->hdr_host[0].nV;
+    // den and its reciprocal itself -- same bits either way.  Mixed batches: in the fast modes only (room for the largest track).
     // (the big form at 33 rays has 4 KB left: no closed track's table fits, so that shape is built without the table mode)
-    if (g_rollout_rden == 0 || e->track_id || lds + (size_t)rden_lds * sizeof(float) > 160 * 1024 || (!small && KS == 10)) rden_lds = 0;
+    int rden_lds = 361 * max_nV;
+    if (g_rollout_rden == 0 || (e->track_id && !(small ? fast_small : fast)) || lds + (size_t)rden_lds * sizeof(float) > 160 * 1024 ||
+        (!small && KS == 10))
+        rden_lds = 0;
     lds += (size_t)rden_lds * sizeof(float);
     const int rpl = small ? (e->R + 3) / 4 : (e->R + 1) / 2;  // 4 (x 4 sweep parts) or 2 lanes per env
-    const int epw = g_rollout_epw_override >= 128 ? g_rollout_epw_override
-                                                  : ((!small && e->N <= g_rollout_epw128_max) ? 128 : 256);   // big form: envs per workgroup
     // small form: 16 envs per workgroup up to 4096 envs (<= 256 workgroups: one per CU), else 32
     const int epw_small = (g_rollout_epw_override == 16 || g_rollout_epw_override == 32) ? g_rollout_epw_override
                           : ((fast_small && prec != 0 && e->R <= 17 && e->N <= 4096) ? 16 : 32);

@@ -248,11 +248,13 @@ def test_rollout_forms_agree_with_default_dispatch():
         assert torch.equal(a, b), i
 
 
-@pytest.mark.parametrize("n_envs,form", [(4096, -1), (1000, 0), (65536, -1)])
+@pytest.mark.parametrize("n_envs,form", [(4096, -1), (1000, 0), (8192, 0), (1000, 1), (65536, -1)])
 def test_mixed_track_batches_through_the_persistent_rollout_kernel(n_envs, form):
     """BASELINE configs[4] (track.json and big_track.json in one batch): with every aligned block of 32 envs on one track
-    pc_rollout steps the batch (each wave / workgroup reads its own track's tables) bit-identically to the per-step
-    kernels; with the tracks interleaved env by env it reports PC_ERR_UNSUPPORTED and the trainer takes the per-step path."""
+    pc_rollout steps the batch bit-identically to the per-step kernels -- in the fast modes when every WORKGROUP's envs lie on
+    one track (it stages that track's tables in LDS: 4096 / 65536 default dispatch, 8192 big form, 1000 small form), else
+    with every wave reading its own track's tables from global memory (1000 envs, big form: the halves meet at env 480);
+    with the tracks interleaved env by env it reports PC_ERR_UNSUPPORTED and the trainer takes the per-step path."""
     from ppo_car_amd._capi import lib
     tracks = [TRACKS["track"], TRACKS["big_track"]]
     res = {}
