@@ -364,15 +364,19 @@ def main():
         n_prod = {"fp16x2": 3, "bf16x3": 6, "fp32": 1}[args.policy_arith]
         track_name = "track.json + big_track.json (halves)" if mixed else "big_track.json"
         roof = {"kernel": dom_name, "bound": "valu" if not mixed else "valu (mixed tracks: flops priced with big_track's 24 walls)",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "achieved": per_step_flops * units / sec / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": per_step_flops * units / sec / 1e12 / VALU_PEAK_TFLOPS, "traffic": None,
                 "launch_us": dom_us, "launch_us_method": dom_method, "algorithmic_bytes_per_launch": algo_bytes,
                 "env_steps_per_launch": units,
-                "note": "achieved / peak / frac = SURVEY 8(d)'s algorithmic bytes against the HBM peak (the figure the task prices); the "
-                        "launch is bound by the SIMDs' vector pipes (fp32 ray geometry: 66 flop/B against a ridge of 20), see `valu`",
-                "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS},
+                "note": "the launch is bound by the SIMDs' vector issue port (fp32 ray geometry: 66 flop/B against a ridge of 20; PMC: "
+                        "vector issue 85-89 % busy, DESIGN.md section 4.2): achieved / peak / frac price SURVEY 8(d)'s env-step flops "
+                        "(" + f"{per_step_flops}" + " per env step) against the fp32 vector peak -- most of the kernel's vector instructions are not "
+                        "FMAs, so the flop fraction understates the port's occupancy; `hbm` = SURVEY 8(d)'s algorithmic bytes against the "
+                        "HBM peak (the figure the task prices), `traffic` = the PMC bytes per launch; `mfma` = the policy GEMMs",
+                "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None},
                 "valu": {"achieved": per_step_flops * units / sec / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": per_step_flops * units / sec / 1e12 / VALU_PEAK_TFLOPS,
-                         "counts": "SURVEY 8(d) env-step flops only (11.6 kflop per env step at 16 rays)"},
+                         "counts": "SURVEY 8(d) env-step flops only"},
                 "k1_standalone": k1,
                 "gae": {"kernel": "gae_kernel (K3)", "bound": "hbm", "launch_us": gae_us,
                         "achieved": GAE_BYTES * cfg.n_envs * cfg.n_steps / (gae_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -411,7 +415,7 @@ def main():
                 key = (f"rollout_{args.env_dtype}_n{nr}_N{cfg.n_envs}_T{cfg.n_steps}" if mega_us is not None
                        else f"{args.env_dtype}_n{nr}_N{cfg.n_envs}")
                 if key in tf and not mixed:
-                    out["roofline"]["traffic"] = tf[key]["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic"] = out["roofline"]["hbm"]["traffic"] = tf[key]["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = tf[key].get("source", "profiles/k1_traffic.json")
             except Exception:
                 pass

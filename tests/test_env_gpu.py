@@ -105,6 +105,15 @@ def test_teacher_forced_f32(track, n, grp):
     env.set_state(**{k: g[f"{grp}_pre_{k}"].reshape(-1) for k in STATE})
     obs, rew, term, trunc, fin, gp = _step(env, g[f"{grp}_action"].reshape(-1))
     assert np.abs(fin - g[f"{grp}_step_obs"].reshape(M, -1)).max() <= OBS_TOL_F32
+    # the six header entries (car_env.py:578-584: position, velocity, heading cos / sin) come from the float64 state.  The F32
+    # mode forms them as `v * (1 / d)` in float64 and reads the heading from a table of start_rot + 5 k (the reference's rot is
+    # a running float64 sum): the float64 values differ in the last place at most, so the float32 entries are the reference's
+    # bits except where that last place straddles a float32 rounding boundary -- never more than one float32 ulp, and rare
+    hdr, ref_hdr = fin[:, :6], g[f"{grp}_step_obs"].reshape(M, -1)[:, :6]
+    # (an entry that is zero up to rounding, e.g. the cosine of a quarter turn at 6e-17, is compared on the scale of 1e-6)
+    diff = np.abs(hdr - ref_hdr)
+    assert (diff <= np.spacing(np.maximum(np.abs(ref_hdr), np.float32(1e-6)))).all() and (diff != 0).mean() < 1e-3, \
+        (diff.max(), (diff != 0).mean())
     wall_ok = g[f"{grp}_wall_margin"].reshape(-1) > MARGIN_PX
     gate_ok = g[f"{grp}_gate_margin"].reshape(-1) > MARGIN_PX
     term_ref, trunc_ref = g[f"{grp}_terminated"].reshape(-1), g[f"{grp}_truncated"].reshape(-1)
