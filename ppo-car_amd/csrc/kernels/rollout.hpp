@@ -1,0 +1,934 @@
+// rollout.hpp -- part of the single translation unit ppocar.hip (included there, in order; not a stand-alone header).
+// K9 rollout_kernel / K9s rollout_small_kernel: the whole rollout as one persistent launch; the table-driven fast env step; developer stamps.
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// Developer-only phase timeline of the big-form rollout kernel (make stamps -> libppocar_stamps.so, -DPC_STAMPS): workgroup 0's
+// eight waves write s_memtime at every phase boundary of steps 64..71 into a device array that tools/k9_timeline.py reads back.
+// The product build contains none of this.
+#ifdef PC_STAMPS
+constexpr int STAMP_T0 = 64, STAMP_NT = 8, STAMP_NPH = 8;
+__device__ unsigned long long g_stamps[8 * STAMP_NT * STAMP_NPH];
+#define PC_STAMP(ph)                                                                                                      \
+    if (blockIdx.x == 0 && t >= STAMP_T0 && t < STAMP_T0 + STAMP_NT && lane == 0)                                        \
+        g_stamps[((wave * STAMP_NT) + (t - STAMP_T0)) * STAMP_NPH + (ph)] = __builtin_amdgcn_s_memtime();
+__device__ unsigned long long g_stamps_u[16];    // the minibatch kernel (K10), workgroup 0, thread 0, of the last launch
+#define PC_STAMP_U(ph) if (wg == 0 && threadIdx.x == 0) g_stamps_u[ph] = __builtin_amdgcn_s_memtime();
+#else
+#define PC_STAMP(ph)
+#define PC_STAMP_U(ph)
+#endif
+// ------------------------------------------------------------------------------------------
+// The env step of the persistent big-form rollout (K9), single track, every gather table in LDS.
+// Same arithmetic as env_step_core<float> -- its buffers are compared bit for bit with the per-step kernels' -- but laid out
+// for a wave that owns its 32 envs outright (2 lanes per env) and whose cost is VALU issue slots, not latency:
+//   * no branches: the action is decoded through a 16-entry table (thrust factor, friction factor, turn, forward bonus),
+//     rewards / counters / the reset are selects;
+//   * every table access is an explicit LDS read (ds_read), never a generic (flat) load -- those count on vmcnt AND lgkmcnt,
+//     so each one used to wait for every global store the wave had in flight;
+//   * the heading index is kept reduced mod 72 through a 74-entry wrap table instead of an integer division per step;
+//   * an unused ray slot (17 rays on 2 lanes: 9 + 8) repeats the lane's last ray instead of being predicated off;
+//   * the observation row goes to LDS only; the wave then copies its 32 rows -- contiguous in the rollout buffer -- to
+//     global memory with 16-byte stores (three per lane instead of 23 scattered dword stores), and an env that finished its
+//     episode gets its reset observation in a rarely taken, wave-uniformly skipped fix-up.
+// ------------------------------------------------------------------------------------------
+constexpr int TAB_MAX_GATES = 128;  // reward gates of a track staged in LDS (32 bytes each)
+struct ActLut {          // one per action 0..15 (9..15: no-op, car_env.py:721), 32 bytes
+    double thrust;       // acc = heading * thrust: +0.8 forward, -0.8 backward, 0 none (car_env.py:423-438)
+    double fric;         // velocity factor after the thrust: 1 - 0.2 without thrust, 1 with (car_env.py:454-455)
+    int dk;              // turn in 5-degree steps: -1 left, +1 right (car_env.py:440-442)
+    int fwd;             // 1: the +0.01 forward bonus (car_env.py:700,710,714)
+    int pad0, pad1;
+};
+// (plain ext_vector element types: a struct cannot be copied out of an address-space-qualified pointer in C++)
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) f64x2* lds_cd2;
+typedef const __attribute__((address_space(3))) f64x4* lds_cd4;
+typedef const __attribute__((address_space(3))) f32x2* lds_cf2;
+typedef const __attribute__((address_space(3))) i32x2* lds_ci2;
+typedef const __attribute__((address_space(3))) int* lds_ci;
+typedef const __attribute__((address_space(3))) f32x4* lds_f4c;
+typedef __attribute__((address_space(3))) float* lds_fp;
+
+struct FastTabs {        // LDS addresses of the staged tables (wave-uniform)
+    lds_cd2 head;        // [72] (cos, sin) of radians(start_rot + 5 j), float64
+    lds_ci wrap;         // [74] j - 1 reduced mod 72, j = 0..73
+    lds_cd2 act;         // [16] ActLut records, 32 bytes each: (thrust, fric) then (dk, fwd)
+    lds_cd4 gates;       // [G] (x1, y1, x2, y2)
+    lds_f4c dir;         // [720] direction lattice, twice around: (cos, sin, LDS byte address of the direction's 1/den row, -)
+    lds_cfp reset;       // [D] the track's reset observation
+    lds_cd2 vtx;         // [nV] the wall vertex chain, 32 bytes each: (x, y) float64 then (ex, ey, brk, -) -- small form only (nV <= 64)
+    lds_cfp rden;        // [361][nV] or unused
+};
+constexpr int FT_HEAD = 0, FT_WRAP = FT_HEAD + 72 * 4, FT_ACT = FT_WRAP + 76, FT_GATES = FT_ACT + 16 * 8,
+              FT_DIR = FT_GATES + TAB_MAX_GATES * 8, FT_RESET = FT_DIR + 720 * 4, FT_VTX = FT_RESET + 40,
+              FT_VTX_MAX = 64, FT_FLOATS = FT_VTX + FT_VTX_MAX * 8;
+static_assert(FT_ACT % 4 == 0 && FT_GATES % 4 == 0 && FT_DIR % 4 == 0 && FT_VTX % 4 == 0, "16-byte aligned records");
+
+__device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p, const TrackHdr& h0, const int trk, float* sTab,
+                                                      const int tid, const int nthreads) {
+    int* dst = reinterpret_cast<int*>(sTab);
+    const int* head = reinterpret_cast<const int*>(p.headtab + h0.head_off);
+    for (int i = tid; i < 72 * 4; i += nthreads) dst[FT_HEAD + i] = head[i];
+    for (int i = tid; i < 74; i += nthreads) dst[FT_WRAP + i] = i == 0 ? 71 : (i == 73 ? 0 : i - 1);
+    if (tid < 16) {
+        const int a = tid;
+        const bool fwd = (a == 0) | (a == 4) | (a == 5), bwd = (a == 1) | (a == 6) | (a == 7);     // car_env.py:698-722
+        const bool left = (a == 2) | (a == 4) | (a == 6), right = (a == 3) | (a == 5) | (a == 7);
+        ActLut L;
+        L.thrust = fwd ? 0.8 : (bwd ? -0.8 : 0.0);
+        L.fric = (fwd | bwd) ? 1.0 : 1 - 0.2;
+        L.dk = (left ? -1 : 0) + (right ? 1 : 0);
+        L.fwd = fwd ? 1 : 0;
+        L.pad0 = L.pad1 = 0;
+        *reinterpret_cast<ActLut*>(sTab + FT_ACT + 8 * a) = L;
+    }
+    const int* gates = reinterpret_cast<const int*>(p.segs + h0.gate_off);
+    for (int i = tid; i < h0.G * 8; i += nthreads) dst[FT_GATES + i] = gates[i];
+    // The direction lattice twice around (a ray's index 5 k + step_deg * ray < 720 needs no reduction mod 360), each entry
+    // with the LDS byte address of its row of the 1/den table: one 16-byte read per ray slot replaces the index arithmetic.
+    const float2* dir = p.dirtab + h0.dir_off;
+    const unsigned rden_base = (unsigned)(size_t)(lds_cfp)(sTab + FT_FLOATS);
+    for (int i = tid; i < 720; i += nthreads) {
+        const int j = i < 360 ? i : i - 360;
+        const float2 cs = dir[j];
+        *reinterpret_cast<f32x4*>(sTab + FT_DIR + 4 * i) = (f32x4){cs.x, cs.y, __uint_as_float(rden_base + (unsigned)(j * h0.nV) * 4u), 0.0f};
+    }
+    const int* ro = reinterpret_cast<const int*>(p.reset_obs + (size_t)trk * p.D);
+    for (int i = tid; i < p.D; i += nthreads) dst[FT_RESET + i] = ro[i];
+    if (h0.nV <= FT_VTX_MAX) {
+        const int* vs = reinterpret_cast<const int*>(p.vtx + h0.vtx_off);
+        for (int i = tid; i < h0.nV * 8; i += nthreads) dst[FT_VTX + i] = vs[i];
+    }
+    FastTabs ft;
+    ft.head = (lds_cd2)(sTab + FT_HEAD);
+    ft.wrap = (lds_ci)(sTab + FT_WRAP);
+    ft.act = (lds_cd2)(sTab + FT_ACT);
+    ft.gates = (lds_cd4)(sTab + FT_GATES);
+    ft.dir = (lds_f4c)(sTab + FT_DIR);
+    ft.reset = (lds_cfp)(sTab + FT_RESET);
+    ft.vtx = (lds_cd2)(sTab + FT_VTX);
+    ft.rden = (lds_cfp)(sTab + FT_FLOATS);
+    return ft;
+}
+
+struct FastLane {        // per-lane invariants of the env step (a handful of registers instead of three per ray slot)
+    int rs0, rstep, rs_last;  // ray slot s of lane g (of G per env) is ray min(g + G s, R - 1): angle offsets step_deg * ray, x 16 (bytes
+                              // of the direction table), the table's LDS address folded into rs0 / rs_last
+    int colmask;              // bit s: slot s is one of Car.check_collision's rays
+    lds_fp lray, llast;       // this lane's first ray column of its observation row (slot s: + G s floats), and the last slot's
+};
+template <int RPL, int G>
+__device__ __forceinline__ FastLane fast_lane(const EnvParams<float>& p, const FastTabs& ft, const int g, float* row) {
+    FastLane fl;
+    const int dir_base = (int)(size_t)ft.dir;
+    fl.rs0 = dir_base + 16 * g * p.step_deg;
+    fl.rstep = 16 * G * p.step_deg;
+    fl.rs_last = dir_base + 16 * (p.R - 1) * p.step_deg;
+    fl.colmask = 0;
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) {
+        const int ray = min(g + G * s, p.R - 1);
+        // Car.check_collision's rays: r in range(0, n, n // 4) (:389) -- nominal n, not R
+        const bool is_col = ray < 64 ? (bool)((p.colbits >> ray) & 1) : ((ray < p.n_nominal) & (ray % p.q == 0));
+        fl.colmask |= (is_col ? 1 : 0) << s;
+    }
+    fl.lray = (lds_fp)(row + 6 + g);
+    fl.llast = (lds_fp)(row + 6 + min(g + G * (RPL - 1), p.R - 1));
+    return fl;
+}
+// exchange with the neighbouring lane (the other lane of the env): DPP quad_perm [1, 0, 3, 2], one VALU instruction
+__device__ __forceinline__ int swap_pair(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false); }
+
+// The float32 wall sweep of the SMALL persistent form: part `part` of PARTS of the vertex chain, read from its LDS copy
+// (ft.vtx) instead of through scalar loads.  A part is only one or two groups of four vertices, so what counts is latency, not
+// issue slots: a group's vertex records and 1/den rows are all requested at its top, the four vertices' side values are
+// independent instruction chains, chain-break vertices are computed rather than branched around (their candidates are NaN: see
+// wall_sweep_unrolled), and two vertices share a v_min3_u32.  Same bits as wall_sweep_f32<RPL, PARTS, TAB>.
+template <int RPL, int PARTS, bool TAB, bool ADDR = false>
+__device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const int part, const double npx, const double npy,
+                                               const float (&dx)[RPL], const float (&dy)[RPL], const int (&didx)[RPL], lds_cfp rdl,
+                                               unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
+    constexpr int NP = (RPL + 1) / 2;
+    typedef const __attribute__((address_space(3))) f32x4* lds_f4;
+    f32x2 dx2[NP], dy2[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        dx2[j] = (f32x2){dx[2 * j], 2 * j + 1 < RPL ? dx[2 * j + 1] : 0.0f};
+        dy2[j] = (f32x2){dy[2 * j], 2 * j + 1 < RPL ? dy[2 * j + 1] : 0.0f};
+        bb[2 * j] = bb[2 * j + 1] = 0x447a0000u;  // 1000.0f, Ray.get_distance :198
+    }
+    const unsigned sgn = sign_mask();
+    auto side = [&](const f64x2 xy, float& ax, float& ay, f32x2 (&c)[NP]) {
+        ax = (float)(xy.x - npx);
+        ay = (float)(xy.y - npy);
+        const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay};
+#pragma unroll
+        for (int j = 0; j < NP; ++j) c[j] = __builtin_elementwise_fma(ay2, dx2[j], -(ax2 * dy2[j]));
+    };
+    auto cand = [&](const float ex, const float ey, const float axp, const float ayp, const f32x2 (&cp)[NP], const f32x2 (&c)[NP],
+                    const f32x4 (&rd)[2 * NP], const int I, unsigned (&q)[2 * NP]) {
+        const float un = __builtin_fmaf(ey, axp, -(ex * ayp));
+        const f32x2 un2 = {un, un}, ex2 = {ex, ex}, ey2 = {ey, ey};
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            f32x2 u;
+            if constexpr (TAB) {
+                u = (f32x2){un * rd[2 * j][I], 2 * j + 1 < RPL ? un * rd[2 * j + 1][I] : 0.0f};   // (odd RPL: the last slot is padding)
+            } else {
+                const f32x2 den = __builtin_elementwise_fma(ey2, dx2[j], -(ex2 * dy2[j]));
+                const f32x2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                u = un2 * rc;
+            }
+            const f32x2 t = cp[j] * (-c[j]);
+            q[2 * j] = and_or(__float_as_uint(t.x), sgn, __float_as_uint(u.x));
+            if (2 * j + 1 < RPL) q[2 * j + 1] = and_or(__float_as_uint(t.y), sgn, __float_as_uint(u.y));
+        }
+    };
+    const int ngrp = nV >> 2;
+    const int gbeg = PARTS > 1 ? ngrp * part / PARTS : 0;
+    const int gend = PARTS > 1 ? ngrp * (part + 1) / PARTS : ngrp;
+    float axA = 0.0f, ayA = 0.0f, axB = 0.0f, ayB = 0.0f;
+    f32x2 cA[NP], cB[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) cA[j] = cB[j] = (f32x2){0.0f, 0.0f};
+    if (PARTS > 1 && gbeg > 0) side(vt[2 * (4 * gbeg - 1)], axA, ayA, cA);   // the vertex before the range: the chain's previous side values
+    lds_f4 rrow[2 * NP];
+    if constexpr (TAB) {
+#pragma unroll
+        for (int s = 0; s < 2 * NP; ++s) {
+            if constexpr (ADDR) rrow[s] = (lds_f4)(size_t)(s < RPL ? (unsigned)didx[s] : (unsigned)(size_t)rdl + 1440u * (unsigned)nV);
+            else rrow[s] = (lds_f4)(rdl + __umul24(s < RPL ? didx[s] : 360, nV));
+        }
+    }
+    for (int gq = gbeg; gq < gend; ++gq) {
+        f32x4 rd[2 * NP];
+        if constexpr (TAB) {
+#pragma unroll
+            for (int s = 0; s < RPL; ++s) rd[s] = rrow[s][gq];
+        }
+        f64x2 xy[4];
+        f32x4 ee[4];
+#pragma unroll
+        for (int I = 0; I < 4; ++I) {
+            xy[I] = vt[2 * (4 * gq + I)];
+            ee[I] = *(lds_f4)(vt + 2 * (4 * gq + I) + 1);
+        }
+#pragma unroll
+        for (int I = 0; I < 4; I += 2) {
+            unsigned q0[2 * NP], q1[2 * NP];
+            side(xy[I], axB, ayB, cB);
+            cand(ee[I].x, ee[I].y, axA, ayA, cA, cB, rd, I, q0);
+            side(xy[I + 1], axA, ayA, cA);
+            cand(ee[I + 1].x, ee[I + 1].y, axB, ayB, cB, cA, rd, I + 1, q1);
+#pragma unroll
+            for (int s = 0; s < RPL; ++s) bb[s] = min(min(bb[s], q0[s]), q1[s]);   // v_min3_u32
+        }
+    }
+}
+
+// LG = log2 of the lanes per env (1: K9, a wave owns 32 envs; 2: K9s, 16 envs per wave).  PARTS > 1 (K9s): the wall sweep is split
+// over PARTS waves of the workgroup -- this wave sweeps vertex part `part`, the per-ray minima meet in LDS (`exch`: the env's
+// [rays][PARTS] floats) across ONE workgroup barrier (every thread of the workgroup must make the call), and all waves finish
+// the step on identical values; only `write_row` waves store the observation row.
+template <int RPL, bool TAB, int LG = 1, int PARTS = 1>
+__device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const TrackHdr& h, const FastTabs& ft, const FastLane& fl,
+                                              const int (&gq)[2], const int g,
+                                              EnvRegs& st, int& k72, const int a, const double reward_scale, lds_fp lrow,
+                                              float& reward_f, float& term_f, float& trunc_f, const int t = 0, const int lane = 0,
+                                              const int wave = 0, const int part = 0, float* exch = nullptr, const bool write_row = true) {
+    constexpr int G = 1 << LG;
+    // ---- action, heading before and after the turn (car_env.py:698-722, :440-442)
+    const f64x2 Lf = ft.act[2 * a];                                     // (thrust, fric)
+    const i32x2 Li = *(lds_ci2)(ft.act + 2 * a + 1);                    // (dk, fwd)
+    struct { double thrust, fric; int dk, fwd; } L = {Lf.x, Lf.y, Li.x, Li.y};
+    const f64x2 cs0 = ft.head[k72];
+    const int k72n = ft.wrap[k72 + L.dk + 1];
+    const f64x2 cs1 = ft.head[k72n];
+    // ---- Car.update physics (car_env.py:452-461), float64: thrust with the PRE-turn heading, friction without thrust, clip
+    double nvx = (st.vx + cs0.x * L.thrust) * L.fric, nvy = (st.vy + cs0.y * L.thrust) * L.fric;
+    nvx = fmin(fmax(nvx, -10.0), 10.0);      // np.clip per component (:457); the velocity is never NaN
+    nvy = fmin(fmax(nvy, -10.0), 10.0);
+    const double opx = st.px, opy = st.py;
+    const double npx = opx + nvx, npy = opy + nvy;
+
+    // ---- ray directions at the new heading: lattice entry 5 k + step_deg * ray (< 720: the table goes twice around), read as
+    // (cos, sin, LDS address of the direction's 1/den row) through a byte address that costs one add per slot
+    float dx[RPL], dy[RPL];
+    int didx[RPL];    // TAB: the LDS byte address of the slot's 1/den row
+    const int k80n = 80 * k72n;                                         // 16 bytes x 5 entries per turn step
+    const int m0 = k80n + fl.rs0, m_last = k80n + fl.rs_last;
+    {
+        int m = m0;
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            // ray(s) = min(g + G s, R - 1): only the last slot can exceed the ray count
+            const f32x4 cs = *(lds_f4c)(size_t)(unsigned)(s + 1 < RPL ? m : min(m, m_last));
+            dx[s] = cs.x;
+            dy[s] = cs.y;
+            didx[s] = (int)__float_as_uint(cs.z);
+            m += fl.rstep;
+        }
+    }
+    // ---- Car.get_passed_gate (:394-408): the four collision rays at the PREVIOUS pose against gate[next], dealt over the lanes
+    const f64x4 gv = ft.gates[st.next];
+    const Seg gate = {gv.x, gv.y, gv.z, gv.w};
+    const int k80o = 80 * k72;
+    bool gate_hit = false;
+#pragma unroll
+    for (int jj = 0; jj < 4 / G; ++jj) {
+        const f32x4 cs = *(lds_f4c)(size_t)(unsigned)(k80o + gq[jj]);
+        gate_hit |= Math<float>::cast(gate, opx, opy, cs.x, cs.y) < 10.0f;  // :387,:390
+    }
+    // ---- wall sweep.  More than 12 ray slots per lane (33 rays: 17) are swept in TWO passes over the vertex chain, 9 + 8
+    // slots: one pass would need ~40 more registers than the 256 a wave has at two waves per SIMD (it spilled 67 of them
+    // to scratch); the second pass repeats only the per-vertex position arithmetic (4 of ~50 instructions per vertex and pass).
+    constexpr int R1 = RPL > 12 ? (RPL + 1) / 2 : RPL, R2 = RPL - R1;
+    unsigned bb[RPL + 2];
+    PC_STAMP(4)
+    {
+        const float(&dxa)[R1] = *reinterpret_cast<const float(*)[R1]>(&dx[0]);
+        const float(&dya)[R1] = *reinterpret_cast<const float(*)[R1]>(&dy[0]);
+        const int(&dia)[R1] = *reinterpret_cast<const int(*)[R1]>(&didx[0]);
+        unsigned ba[2 * ((R1 + 1) / 2)];
+        if (PARTS > 1)                  // small form: latency-oriented sweep over the LDS copy of the chain
+            wall_sweep_lds<R1, PARTS, TAB, true>(ft.vtx, h.nV, part, npx, npy, dxa, dya, dia, ft.rden, ba);
+        else if (h.nV == 28)            // (wave-uniform) big_track's chain: the unrolled sweep
+            wall_sweep_unrolled<R1, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxa, dya, dia, ft.rden, ba);
+        else
+            wall_sweep_f32<R1, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dxa, dya, dia, ft.rden, ba);
+#pragma unroll
+        for (int s = 0; s < R1; ++s) bb[s] = ba[s];
+    }
+    if constexpr (R2 > 0) {
+        __builtin_amdgcn_sched_barrier(0);   // the passes one after the other
+        const float(&dxb)[R2] = *reinterpret_cast<const float(*)[R2]>(&dx[R1]);
+        const float(&dyb)[R2] = *reinterpret_cast<const float(*)[R2]>(&dy[R1]);
+        const int(&dib)[R2] = *reinterpret_cast<const int(*)[R2]>(&didx[R1]);
+        unsigned bc[2 * ((R2 + 1) / 2)];
+        if (PARTS > 1)
+            wall_sweep_lds<R2, PARTS, TAB, true>(ft.vtx, h.nV, part, npx, npy, dxb, dyb, dib, ft.rden, bc);
+        else if (h.nV == 28)
+            wall_sweep_unrolled<R2, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxb, dyb, dib, ft.rden, bc);
+        else
+            wall_sweep_f32<R2, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dxb, dyb, dib, ft.rden, bc);
+#pragma unroll
+        for (int s = 0; s < R2; ++s) bb[R1 + s] = bc[s];
+    }
+    if constexpr (PARTS > 1) {   // the parts' minima meet in LDS (min is exact: the same bits as one wave sweeping everything)
+        unsigned* ex = reinterpret_cast<unsigned*>(exch);
+        int ray = g;
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const int r = s + 1 < RPL ? ray : min(ray, p.R - 1);
+            ex[r * PARTS + part] = bb[s];
+            ray += G;
+        }
+        lds_barrier();
+        ray = g;
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const int r = s + 1 < RPL ? ray : min(ray, p.R - 1);
+            unsigned m = ex[r * PARTS];
+#pragma unroll
+            for (int q = 1; q < PARTS; ++q) m = min(m, ex[r * PARTS + q]);
+            bb[s] = m;
+            ray += G;
+        }
+    }
+    PC_STAMP(5)
+    // Car.check_collision (:376-392): any collision ray closer than 10 px.  Distances are non-negative floats, so the
+    // smallest one is the unsigned minimum of the bit patterns; a slot that is not a collision ray is masked to +inf.
+    unsigned hm = 0x7f800000u;
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) {
+        // bit s of colmask: slot s is one of Car.check_collision's rays; (bit ? 0 : 0x7f800000) without a register per slot
+        const unsigned nc = ((unsigned)__builtin_amdgcn_sbfe(fl.colmask, s, 1) & 0x7f800000u) ^ 0x7f800000u;
+        hm = min(hm, bb[s] | nc);
+    }
+    int flags = (gate_hit ? 1 : 0) | (hm < 0x41200000u ? 2 : 0);       // 0x41200000 = 10.0f
+    flags |= swap_pair(flags);                                          // any() over the env's G lanes
+    if constexpr (G == 4) flags |= __builtin_amdgcn_update_dpp(0, flags, 0x4e, 0xf, 0xf, false);   // quad_perm [2, 3, 0, 1]
+    static_assert(G == 2 || G == 4, "2 or 4 lanes per env");
+    gate_hit = flags & 1;
+    const bool destroyed = ((flags & 2) != 0) | (h.start_collides != 0);
+    // ---- bookkeeping (car_env.py:694-750): float64 reward in the reference's order of accumulation
+    double rw = L.fwd ? 0.01 : 0.0;                                     // 0.0 + 0.01
+    const bool lap = gate_hit & (st.next == h.G - 1);                   // :730 remaining == 0
+    rw = rw + (gate_hit ? 1.0 : 0.0);                                   // :727
+    rw = rw + (lap ? 10.0 : 0.0);                                       // :732
+    const int passed = st.passed + (gate_hit ? 1 : 0);
+    const int next = gate_hit ? (lap ? 0 : st.next + 1) : st.next;      // :734-741
+    const int time = st.time + 1;                                       // :745
+    rw = rw + (destroyed ? -3.0 : 0.0);                                 // :748
+    const bool trunc = !destroyed & (time >= 1000);                     // :749-750
+    const bool done = destroyed | trunc;
+    reward_f = (float)(rw * reward_scale);
+    term_f = destroyed ? 1.0f : 0.0f;
+    trunc_f = trunc ? 1.0f : 0.0f;
+    // ---- observation row -> LDS (the reset observation of a finished env is written by the caller's fix-up)
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) {   // ray slot s -> column 6 + ray(s): G floats apart from the lane's first; the clamped last slot apart
+        const float o = Math<float>::norm_dist(__uint_as_float(bb[s]));     // :593
+        if (write_row) {
+            if (s + 1 < RPL) fl.lray[G * s] = o;
+            else fl.llast[0] = o;
+        }
+    }
+    if (g == 0 && write_row) {
+        lrow[0] = Math<float>::norm(npx, 1280.0);  // :578-581
+        lrow[1] = Math<float>::norm(npy, 720.0);
+        lrow[2] = Math<float>::norm(nvx, 10.0);
+        lrow[3] = Math<float>::norm(nvy, 10.0);
+        lrow[4] = (float)cs1.x;                    // :584-588
+        lrow[5] = (float)cs1.y;
+    }
+    // ---- new state (CarEnv.reset for a finished env, :677-686, is the caller's rarely taken fix-up: env_reset_fast)
+    st.px = npx;
+    st.py = npy;
+    st.vx = nvx;
+    st.vy = nvy;
+    st.k += L.dk;
+    k72 = k72n;
+    st.time = time;
+    st.next = next;
+    st.passed = passed;
+    return done;
+}
+
+// CarEnv.reset (car_env.py:677-686) of a finished env's registers
+__device__ __forceinline__ void env_reset_fast(const TrackHdr& h, EnvRegs& st, int& k72) {
+    st.px = h.start_x; st.py = h.start_y; st.vx = 0.0; st.vy = 0.0;
+    st.k = 0; st.time = 0; st.next = 0; st.passed = 0;
+    k72 = 0;
+}
+
+// Developer-only timing ablation of the persistent rollout kernels: a SEPARATE build (make ABLATE=n -> libppocar_ablate.so,
+// never loaded by the product or the tests) compiled with -DPC_ABLATE=n skips the policy MFMAs (1), the env step (2) or
+// the draw (4).  The shipped library is built with PC_ABLATE = 0: there is no run-time switch that makes a kernel do less.
+#ifndef PC_ABLATE
+#define PC_ABLATE 0
+#endif
+// K9: the whole rollout (train.py:173-195) as ONE persistent launch.
+// A workgroup (8 waves) owns 256 envs for all T steps: the policy weights stay in LDS, the env state in
+// registers, the observation of step t passes from the env step to the policy step through LDS; per step an
+// env costs 116 B of HBM writes (its buffer rows) and no reads.  Envs never interact and the weights are fixed
+// during a rollout, so there is no inter-workgroup communication at all -- and no intra-workgroup one either:
+// every WAVE owns 32 envs outright (policy step as one 32-column MFMA problem, then the env step of the same 32
+// envs with 2 lanes per env), so after the weight image is staged there is not a single barrier.  The two waves
+// that share a SIMD are started half a step apart, so one is in its matrix-core phase while the other is in its
+// VALU phase (with PREC = 1 the policy GEMMs run on the bf16 matrix pipe and leave the fp32 ALUs to the env step).
+//   P(t): X^T from LDS -> policy pass -> draw -> action to LDS, (act, logprob, value) rows t to HBM
+//   E(t): action from LDS -> env_step_core -> obs row t+1 to HBM and LDS, (rew, term, trunc)
+// Same arithmetic, same Philox counters as the policy_kernel / env_step_kernel pair: bit-identical buffers.
+// ------------------------------------------------------------------------------------------
+// Persistent rollout kernels: the small per-track tables every env step GATHERS from (heading table, reward gates, ray
+// table, reset observation) are copied into LDS once and the EnvParams pointers redirected, so that a gather on the
+// step's critical path costs an LDS access instead of a global-memory round trip.  Single-track batches only (the
+// kernels' precondition).  The caller synchronises the workgroup before the first use.
+constexpr int TAB_DIR = 72 * 4 + TAB_MAX_GATES * 8, TAB_RESET = TAB_DIR + 361 * 2 + 2, TAB_FLOATS = TAB_RESET + 40;
+__device__ __forceinline__ EnvParams<float> stage_tables(const EnvParams<float>& p, float* sTab, const int tid, const int nthreads) {
+    if (p.track_id) return p;  // mixed-track batch: the tables are read where they lie (global memory, L2-resident)
+    const TrackHdr h0 = cload(p.hdr);
+    int* dst = reinterpret_cast<int*>(sTab);
+    EnvParams<float> q = p;
+    const int* head = reinterpret_cast<const int*>(p.headtab + h0.head_off);
+    for (int i = tid; i < 72 * 4; i += nthreads) dst[i] = head[i];
+    q.headtab = reinterpret_cast<const double2*>(sTab) - h0.head_off;
+    if (h0.G <= TAB_MAX_GATES) {
+        const int* gates = reinterpret_cast<const int*>(p.segs + h0.gate_off);
+        for (int i = tid; i < h0.G * 8; i += nthreads) dst[72 * 4 + i] = gates[i];
+        q.segs = reinterpret_cast<const Seg*>(sTab + 72 * 4) - h0.gate_off;   // the F32 step reads only gates from segs
+    }
+    {
+        const int* dir = reinterpret_cast<const int*>(p.dirtab + h0.dir_off);
+        for (int i = tid; i < 361 * 2; i += nthreads) dst[TAB_DIR + i] = dir[i];
+        q.dirtab = reinterpret_cast<const float2*>(sTab + TAB_DIR) - h0.dir_off;
+    }
+    if (p.D <= 40) {
+        const int* ro = reinterpret_cast<const int*>(p.reset_obs);
+        for (int i = tid; i < p.D; i += nthreads) dst[TAB_RESET + i] = ro[i];
+        q.reset_obs = sTab + TAB_RESET;
+    }
+    return q;
+}
+
+// MODE 0: the gather tables where stage_tables puts them (generic pointers; mixed-track batches read them from global
+//         memory), env step = env_step_core.  MODE 1 / 2: single track, A = 9, every table in LDS behind explicit LDS
+//         pointers, env step = env_step_fast (2: with the 1/den table), observation rows copied out by the wave.
+template <int KS, int RPL, int PREC, int MODE>
+__global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, const float* __restrict__ image, const int A,
+                                                      const int T, const double reward_scale, const uint64_t seed,
+                                                      const uint64_t offset, const uint64_t* __restrict__ offset_dev,
+                                                      float* __restrict__ obs_buf, float* __restrict__ act_buf,
+                                                      float* __restrict__ rew_buf, float* __restrict__ val_buf,
+                                                      float* __restrict__ term_buf, float* __restrict__ trunc_buf,
+                                                      float* __restrict__ logprob_buf, float* __restrict__ next_obs,
+                                                      float* __restrict__ next_term, float* __restrict__ next_trunc,
+                                                      const int rden_lds, const int epw, const int vec_ok) {
+    constexpr int dbg = PC_ABLATE;  // 0 in the product build (see PC_ABLATE)
+    constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, ET = 2;
+    constexpr int NG = pol_ng(KS), KB = pol_kb(KS);
+    constexpr int IMG = PREC ? polx_image_dwords(PREC, NG) : pol_image_padded(KS);
+    constexpr bool FAST = MODE != 0;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sW1 = lds;
+    float* sB1 = PREC ? lds + polx_w1_dwords(PREC, NG) + polx_w2_dwords(PREC) : sW1 + 2 * HID * LD1;
+    float* sW2 = sB1 + 2 * HID;
+    float* sB2 = PREC ? sB1 + 512 : sW2 + NT * 4 * 64;
+    const unsigned* sW1p = reinterpret_cast<const unsigned*>(lds);
+    const unsigned* sW2p = sW1p + polx_w1_dwords(PREC ? PREC : 1, NG);
+    const float* sW2c = sB2 + 16;                  // PREC 1: critic output weights [256]
+    const int64_t N = p.N;
+    constexpr int DC = RPL == 6 ? 18 : (RPL == 9 ? 23 : 39);   // FAST: 6 + the ray count the 2-lanes-per-env menu implies (12 / 17 / 33)
+    const int D = FAST ? DC : p.D;
+    // observation of the step in flight, [256 envs][LDX]: FAST keeps the rows dense (LDX = D, exactly the rollout buffer's
+    // layout: a wave's 32 rows are one contiguous block there and here)
+    const int LDX = FAST ? D : 4 * KS + 1;
+    float* sObs = lds + IMG;
+    int* sAct = reinterpret_cast<int*>(sObs + 256 * LDX);
+    float* sTab = reinterpret_cast<float*>(sAct + 256);    // staged per-track tables
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lc = lane & 15, lk = lane >> 4;
+    policy_stage_image<IMG>(image, lds, tid);
+    // FAST with a mixed-track batch: the host checked that every workgroup's envs lie on ONE track, whose tables it stages
+    const int trk_wg = (FAST && p.track_id)
+                           ? __builtin_amdgcn_readfirstlane((int)p.track_id[min((int64_t)blockIdx.x * epw, p.N - 1)]) : 0;
+    const TrackHdr h0 = cload(p.hdr + trk_wg);
+    EnvParams<float> q = p;
+    FastTabs ft = {};
+    if constexpr (FAST) ft = stage_fast_tables(p, h0, trk_wg, sTab, tid, 512);
+    else q = stage_tables(p, sTab, tid, 512);
+    // the track's 1/den table, when the host found room for it (rden_lds != 0; sized for the batch's largest track)
+    float* sRden = sTab + (FAST ? FT_FLOATS : TAB_FLOATS);
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.rden + h0.rden_off);
+        const int n4 = rden_lds ? 361 * h0.nV / 4 : 0;     // nV is a multiple of 4
+        for (int i = tid; i < n4; i += 512) reinterpret_cast<f32x4*>(sRden)[i] = src[i];
+    }
+    const lds_cfp rdl = (lds_cfp)sRden;
+
+    // this wave's 32 envs: local rows [pbase, pbase + 32); env-step identity: 2 lanes per env
+    const int pbase = wave * 32;
+    const int el = pbase + (lane >> 1), g = lane & 1;
+    // epw = envs per workgroup: 256 (all 8 waves) or 128 (waves 4..7 only help to stage LDS and leave: at <= 32768 envs
+    // that doubles the workgroups, one wave per SIMD on all 256 CUs instead of two on half of them)
+    const int64_t e_wave = (int64_t)blockIdx.x * epw + pbase;      // first env of this wave
+    const int64_t e_env = e_wave + (lane >> 1);
+    const bool e_valid = e_env < N;
+    EnvRegs st = {};
+    if (e_valid) st = env_load<float>(p, e_env);
+    // mixed-track batch: this wave's envs share one track (the host checked every aligned block of 32 envs)
+    const int trk = p.track_id ? (int)p.track_id[e_valid ? e_env : N - 1] : 0;
+    for (int f = g; f < (FAST ? D : 4 * KS); f += 2) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
+    // this wave's output tile [32 envs][LDO] lives in its own observation rows: they are dead from the policy pass's
+    // operand load until the env step stores the next observation (32 * LDX >= 32 * LDO floats: D >= 17 on the host's menu)
+    static_assert(4 * KS + 1 >= 17, "the output tile must fit the wave's observation rows");
+    float* myOut = sObs + wave * 32 * LDX;
+    const uint64_t off0 = offset + (offset_dev ? *offset_dev : 0);
+    PhiloxBlock rnd = {};  // the sampling lanes' current Philox block (4 steps' draws)
+    // FAST: per-lane invariants of the env step.  Ray slot s of lane g is ray min(g + 2 s, R - 1): the odd slot that 17 or
+    // 33 rays leave over on lane 1 repeats that lane pair's last ray (same value, same address) instead of being masked.
+    int gq[2] = {0, 0}, k72 = 0;
+    FastLane fl = {};
+    if constexpr (FAST) {
+        fl = fast_lane<RPL, 2>(p, ft, g, sObs + el * LDX);
+        gq[0] = (int)(size_t)ft.dir + 16 * g * p.q * p.step_deg;            // Car.get_passed_gate's rays j * (n // 4), j = g and g + 2,
+        gq[1] = (int)(size_t)ft.dir + 16 * (g + 2) * p.q * p.step_deg;      // as byte addresses into the direction table
+        k72 = Math<float>::mod72(st.k);
+    }
+    const lds_fp lrow = (lds_fp)(sObs + el * LDX);
+    __syncthreads();  // the weight image is in place; from here on the waves never synchronise again
+    if (pbase >= epw) return;
+    // (no deliberate phase offset between the two waves of a SIMD: with the priorities below they fall into opposite
+    // phases by themselves; a start-up stagger measured 1 % slower)
+    // The loop-carried env state came from global loads.  Passed through an empty asm it is, for the compiler's s_waitcnt
+    // insertion, a fresh register value: waited for HERE, once -- otherwise the first use inside the loop carries a
+    // conservative `s_waitcnt vmcnt(1)` on every iteration, i.e. a wait for the wave's own global stores of the step before.
+    asm volatile("" : "+v"(st.px), "+v"(st.py), "+v"(st.vx), "+v"(st.vy), "+v"(st.k), "+v"(st.time), "+v"(st.next), "+v"(st.passed), "+v"(k72));
+
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        PC_STAMP(0)
+        {
+            // ---------------- P(t)
+            f32x4 out[ET];
+#pragma unroll
+            for (int et = 0; et < ET; ++et) out[et] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (PREC == 0) {
+                float x[ET][KS];
+#pragma unroll
+                for (int et = 0; et < ET; ++et)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const int f = 4 * ks + lk;
+                        x[et][ks] = (!FAST || f < D) ? sObs[(pbase + 16 * et + lc) * LDX + f] : 0.0f;
+                    }
+                // Wave priority: the policy pass (MFMA chains, whose results it waits for anyway) runs at the lowest priority (0),
+                // the env step -- dense dependent VALU work -- above it (2), the short serial draw in between highest (3).  The two waves of a
+                // SIMD are in opposite phases most of the time; with equal priorities the issue arbiter interleaves them
+                // instruction by instruction and both crawl, with the env-step wave preferred the matrix pipe still gets
+                // its instructions in the gaps.  Measured inside the benchmark's epochs: 20.5 -> 18.7 ms per rollout.
+                __builtin_amdgcn_s_setprio(0);
+                if (!(dbg & 1)) policy_pass<KS>(sW1, sB1, sW2, 0, NT, x, out, lc, lk, lane);  // dbg: timing ablations only
+                __builtin_amdgcn_s_setprio(3);
+            } else {
+                Pieces<PREC> x[ET][KB];
+#pragma unroll
+                for (int et = 0; et < ET; ++et) {
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) {
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int f = 8 * (4 * kb + lk) + j;
+                            v[j] = f < D ? sObs[(pbase + 16 * et + lc) * LDX + f] : 0.0f;
+                            if constexpr (PREC == 2) v[j] = clamp_h(v[j] * PolScale<PREC>::sx);   // the observations' scaled domain
+                        }
+                        x[et][kb] = split8<PREC>(v);
+                    }
+                }
+                float val[ET] = {0.0f, 0.0f};
+                __builtin_amdgcn_s_setprio(0);
+                PC_STAMP(1)
+                if (!(dbg & 1)) policy_pass16<PREC, KB>(sW1p, sW2p, sB1, sW2c, 0, NT / 2, x, out, val, lc, lk);
+                PC_STAMP(2)
+                __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+                for (int et = 0; et < ET; ++et) {
+                    float tv = val[et];
+                    tv += __shfl_xor(tv, 16, 64);
+                    tv += __shfl_xor(tv, 32, 64);
+                    if (A >> 2 == lk) out[et][A & 3] += tv;
+                }
+            }
+#pragma unroll
+            for (int et = 0; et < ET; ++et)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) myOut[(16 * et + lc) * LDO + 4 * lk + reg] = out[et][reg];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the tile is written and read by this wave only
+            __builtin_amdgcn_wave_barrier();
+            const int64_t e = e_wave + lane;
+            if (lane < 32 && e < N) {
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = __builtin_fmaf(myOut[lane * LDO + i], PolScale<PREC>::so_inv, sB2[i]);   // outputs back from their scaled domain
+                int act;
+                float lp, val;
+                const uint64_t o = off0 + (uint64_t)t;
+                if (t == 0 || (o & 3) == 0) rnd = philox_block(seed, o >> 2, (uint64_t)e);  // uniform: ten rounds per 4 steps
+                if constexpr (FAST) policy_tail<9>(v, 9, philox_word_uniform(rnd, (unsigned)(o & 3)), act, lp, val, nullptr);
+                else policy_tail(v, A, philox_word_uniform(rnd, (unsigned)(o & 3)), act, lp, val, nullptr);
+                sAct[pbase + lane] = act;
+                const int64_t row = (int64_t)t * N + e;
+                act_buf[row] = (float)act;     // stored as float32 like the reference (buffer.py:13)
+                logprob_buf[row] = lp;
+                val_buf[row] = val;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        const bool last = t + 1 == T;
+        PC_STAMP(3)
+        if constexpr (FAST) {
+            if (!(dbg & 2)) {
+                __builtin_amdgcn_s_setprio(2);
+                // ---------------- E(t)
+                float rw, tf, cf;
+                const int a = e_valid ? sAct[el] : 8;
+                const bool done = env_step_fast<RPL, MODE == 2>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave);
+                PC_STAMP(6)
+                // gymnasium 0.29.1 same-step auto-reset: a finished env returns its reset observation
+                if (__builtin_amdgcn_ballot_w64(done) != 0) {   // wave-uniform: ~1.5 % of env steps end an episode
+                    if (done) {
+                        for (int f = g; f < D; f += 2) lrow[f] = ft.reset[f];
+                        env_reset_fast(h0, st, k72);
+                    }
+                }
+                if (g == 0 && e_valid) {
+                    rew_buf[(int64_t)t * N + e_env] = rw;
+                    float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;    // flags that precede obs t+1
+                    float* tc = last ? next_trunc : trunc_buf + (int64_t)(t + 1) * N;  // (train.py:176-177,195)
+                    tr[e_env] = tf;
+                    tc[e_env] = cf;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the rows are complete (this wave wrote them all)
+                __builtin_amdgcn_wave_barrier();
+                // rows -> rollout buffer: the wave's 32 rows are contiguous there (32 * D floats), 16-byte stores when aligned
+                float* dstg = (last ? next_obs : obs_buf + (int64_t)(t + 1) * N * D) + e_wave * D;
+                const int64_t left = N - e_wave;                       // valid envs from this wave's first on
+                const int n_rows = left >= 32 ? 32 : (int)left;
+                const float* srcl = sObs + pbase * LDX;
+                if (vec_ok && n_rows == 32) {
+#pragma unroll
+                    for (int j = 0; j < (8 * DC + 63) / 64; ++j) {      // 8 * D float4s: 3 (D = 18, 23) or 5 (D = 39) stores per lane
+                        const int i = lane + 64 * j;
+                        if (64 * j + 63 < 8 * DC || i < 8 * DC) reinterpret_cast<f32x4*>(dstg)[i] = reinterpret_cast<const f32x4*>(srcl)[i];
+                    }
+                } else {
+                    for (int i = lane; i < n_rows * D; i += 64) dstg[i] = srcl[i];
+                }
+                PC_STAMP(7)
+            }
+        } else if (e_valid && !(dbg & 2)) {
+            __builtin_amdgcn_s_setprio(2);
+            // ---------------- E(t)
+            float* orow = last ? next_obs + e_env * D : obs_buf + ((int64_t)(t + 1) * N + e_env) * D;
+            float rw;
+            bool term, trunc;
+            int passed;
+            if (rden_lds)  // uniform
+                env_step_core<float, RPL, 1, true>(q, trk, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw,
+                                                   term, trunc, passed, 0, nullptr, rdl);
+            else
+                env_step_core<float, RPL>(q, trk, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw, term,
+                                          trunc, passed);
+            if (g == 0) {
+                rew_buf[(int64_t)t * N + e_env] = rw;
+                float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;    // flags that precede obs t+1
+                float* tc = last ? next_trunc : trunc_buf + (int64_t)(t + 1) * N;  // (train.py:176-177,195)
+                tr[e_env] = term ? 1.0f : 0.0f;
+                tc[e_env] = trunc ? 1.0f : 0.0f;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // obs rows in LDS are this wave's own
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (e_valid && g == 0) env_store<float>(p, e_env, st);
+}
+
+// K9s: the same persistent rollout for SMALL batches (n_envs < ~32 k): a workgroup owns only 32 envs, so that
+// n_envs / 32 workgroups fill the chip.  Per step: the 8 waves split the policy's hidden tiles exactly as
+// policy_kernel<SPLIT> does (partial output tiles summed through LDS, same order: bit-identical), wave 0 draws the
+// 32 actions, then all 512 lanes run the env step with 16 lanes per env.  Three workgroup barriers per step.
+// MODE as in rollout_kernel: 0 = generic tables, env_step_core; 1 / 2 = single track, A = 9, every table in LDS behind LDS
+// pointers, env_step_fast (2: with the 1/den table), dense observation rows copied out by three waves in 16-byte stores.
+template <int KS, int RPL, int PREC, int MODE, int EPW>
+__global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<float> p, const float* __restrict__ image, const int A,
+                                                            const int T, const double reward_scale, const uint64_t seed,
+                                                            const uint64_t offset, const uint64_t* __restrict__ offset_dev,
+                                                            float* __restrict__ obs_buf, float* __restrict__ act_buf,
+                                                            float* __restrict__ rew_buf, float* __restrict__ val_buf,
+                                                            float* __restrict__ term_buf, float* __restrict__ trunc_buf,
+                                                            float* __restrict__ logprob_buf, float* __restrict__ next_obs,
+                                                            float* __restrict__ next_term, float* __restrict__ next_trunc,
+                                                            const int rden_lds, const int vec_ok) {
+    constexpr int dbg = PC_ABLATE;  // 0 in the product build (see PC_ABLATE)
+    // EPW = envs per workgroup: 32 (two groups of 4 waves = 4 sweep parts for 16 envs each; each wave 2 env tiles of the policy
+    // pass) or 16 (up to 4096 envs: twice the workgroups -- all 256 CUs at BASELINE configs[1] -- and every phase of the step
+    // half as long: all 8 waves = 8 sweep parts of the same 16 envs, one env tile per wave).
+    constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, ET = EPW / 16;
+    constexpr int NG = pol_ng(KS), KB = pol_kb(KS);
+    constexpr int IMG = PREC ? polx_image_dwords(PREC, NG) : pol_image_padded(KS);
+    constexpr bool FAST = MODE != 0;
+    constexpr int DC = RPL == 3 ? 18 : (RPL == 5 ? 23 : 39);   // FAST: 6 + the ray count the 4-lanes-per-env menu implies (12 / 17 / 33)
+    static_assert(EPW == 32 || (EPW == 16 && FAST && PREC != 0 && DC <= 23), "16 envs per workgroup: fast mode, split operand forms, <= 17 rays");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sW1 = lds;
+    float* sB1 = PREC ? lds + polx_w1_dwords(PREC, NG) + polx_w2_dwords(PREC) : sW1 + 2 * HID * LD1;
+    float* sW2 = sB1 + 2 * HID;
+    float* sB2 = PREC ? sB1 + 512 : sW2 + NT * 4 * 64;
+    const unsigned* sW1p = reinterpret_cast<const unsigned*>(lds);
+    const unsigned* sW2p = sW1p + polx_w1_dwords(PREC ? PREC : 1, NG);
+    const float* sW2c = sB2 + 16;
+    const int64_t N = p.N;
+    const int D = FAST ? DC : p.D;
+    const int LDX = FAST ? D : 4 * KS + 1;
+    float* sOut = lds + IMG;                       // [8 waves][EPW envs][LDO] partial output tiles
+    float* sObs = sOut + 8 * EPW * LDO;            // [EPW envs][LDX]
+    int* sAct = reinterpret_cast<int*>(sObs + EPW * (FAST ? 40 : LDX));   // (FAST: room for the widest row, so the tables stay 16-byte aligned)
+    float* sTab = reinterpret_cast<float*>(sAct + 32);     // staged per-track tables
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lc = lane & 15, lk = lane >> 4;
+    policy_stage_image<IMG>(image, lds, tid);
+    // FAST with a mixed-track batch: the workgroup's envs lie on ONE track (every aligned block of 32 does), whose tables it stages
+    const int trk_wg = (FAST && p.track_id)
+                           ? __builtin_amdgcn_readfirstlane((int)p.track_id[min((int64_t)blockIdx.x * EPW, p.N - 1)]) : 0;
+    const TrackHdr h0 = cload(p.hdr + trk_wg);
+    EnvParams<float> q = p;
+    FastTabs ft = {};
+    if constexpr (FAST) ft = stage_fast_tables(p, h0, trk_wg, sTab, tid, 512);
+    else q = stage_tables(p, sTab, tid, 512);
+    // the track's 1/den table, when the host found room for it (rden_lds != 0; sized for the batch's largest track)
+    float* sRden = sTab + (FAST ? FT_FLOATS : TAB_FLOATS);
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.rden + h0.rden_off);
+        const int n4 = rden_lds ? 361 * h0.nV / 4 : 0;     // nV is a multiple of 4
+        for (int i = tid; i < n4; i += 512) reinterpret_cast<f32x4*>(sRden)[i] = src[i];
+    }
+    const lds_cfp rdl = (lds_cfp)sRden;
+
+    // env step: wave w sweeps part (w % PARTS) of the wall vertices for 16 envs, 4 lanes (ray groups) per env
+    constexpr int PARTS = 128 / EPW;
+    const int part = __builtin_amdgcn_readfirstlane(wave % PARTS);
+    const int el = (wave / PARTS) * 16 + (lane >> 2), g = lane & 3;
+    constexpr int EXS = EPW == 16 ? PARTS * (DC - 6) : PARTS * 34;   // floats per env: [rays][PARTS]
+    static_assert(EPW * EXS <= 8 * EPW * LDO, "the exchange area aliases the partial output tiles");
+    float* exch = sOut + el * EXS;                 // [rays][PARTS] of this env; aliases the partial output tiles (idle now)
+    const int64_t e_wg = (int64_t)blockIdx.x * EPW;
+    const int64_t e_env = e_wg + el;
+    const bool e_valid = e_env < N;
+    EnvRegs st = {};
+    if (e_valid) st = env_load<float>(p, e_env);
+    // mixed-track batch: this wave's envs share one track (the host checked every aligned block of 32 envs)
+    const int trk = p.track_id ? (int)p.track_id[e_valid ? e_env : N - 1] : 0;
+    for (int f = g + 4 * part; f < (FAST ? D : 4 * KS); f += 4 * PARTS) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
+    float* myOut = sOut + wave * EPW * LDO;
+    const int ht0 = wave * (NT / 8), ht1 = ht0 + NT / 8;
+    const uint64_t off0 = offset + (offset_dev ? *offset_dev : 0);
+    PhiloxBlock rnd = {};  // the sampling lanes' current Philox block (4 steps' draws)
+    int gq[2] = {0, 0}, k72 = 0;
+    FastLane fl = {};
+    if constexpr (FAST) {
+        fl = fast_lane<RPL, 4>(p, ft, g, sObs + el * LDX);
+        gq[0] = (int)(size_t)ft.dir + 16 * g * p.q * p.step_deg;            // Car.get_passed_gate's ray j * (n // 4), j = g (byte address)
+        k72 = Math<float>::mod72(st.k);
+    }
+    const lds_fp lrow = (lds_fp)(sObs + el * LDX);
+    __syncthreads();
+    asm volatile("" : "+v"(st.px), "+v"(st.py), "+v"(st.vx), "+v"(st.vy), "+v"(st.k), "+v"(st.time), "+v"(st.next), "+v"(st.passed), "+v"(k72));
+
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        PC_STAMP(0)
+        // ---------------- P(t), hidden tiles [ht0, ht1) of this wave, all 32 envs
+        f32x4 out[ET];
+#pragma unroll
+        for (int et = 0; et < ET; ++et) out[et] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (PREC == 0) {
+            float x[ET][KS];
+#pragma unroll
+            for (int et = 0; et < ET; ++et)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int f = 4 * ks + lk;
+                    x[et][ks] = (!FAST || f < D) ? sObs[(16 * et + lc) * LDX + f] : 0.0f;
+                }
+            if constexpr (ET == 2) {
+                if (!(dbg & 1)) policy_pass<KS>(sW1, sB1, sW2, ht0, ht1, x, out, lc, lk, lane);  // dbg: timing ablations only
+            }
+        } else {
+            Pieces<PREC> x[ET][KB];
+#pragma unroll
+            for (int et = 0; et < ET; ++et) {
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int f = 8 * (4 * kb + lk) + j;
+                        v[j] = f < D ? sObs[(16 * et + lc) * LDX + f] : 0.0f;
+                        if constexpr (PREC == 2) v[j] = clamp_h(v[j] * PolScale<PREC>::sx);   // the observations' scaled domain
+                    }
+                    x[et][kb] = split8<PREC>(v);
+                }
+            }
+            float val[ET] = {};
+            if (!(dbg & 1)) policy_pass16<PREC, KB, ET>(sW1p, sW2p, sB1, sW2c, wave, -1, x, out, val, lc, lk);
+#pragma unroll
+            for (int et = 0; et < ET; ++et) {
+                float tv = val[et];
+                tv += __shfl_xor(tv, 16, 64);
+                tv += __shfl_xor(tv, 32, 64);
+                if (A >> 2 == lk) out[et][A & 3] += tv;
+            }
+        }
+#pragma unroll
+        for (int et = 0; et < ET; ++et)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) myOut[(16 * et + lc) * LDO + 4 * lk + reg] = out[et][reg];
+        PC_STAMP(1)
+        lds_barrier();
+        PC_STAMP(2)
+        if (lk < EPW / 8) {   // every wave draws for EPW / 8 of the envs, 16 lanes (= outputs) per env, exactly as policy_kernel<SPLIT>
+            const int dl = wave * (EPW / 8) + lk, oi = lc;
+            const int64_t e = e_wg + dl;
+            float ps = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) ps += sOut[(w * EPW + dl) * LDO + oi];  // fixed order
+            const float tsum = __builtin_fmaf(ps, PolScale<PREC>::so_inv, sB2[oi]);   // outputs back from their scaled domain
+            const uint64_t o = off0 + (uint64_t)t;
+            if (t == 0 || (o & 3) == 0) rnd = philox_block(seed, o >> 2, (uint64_t)e);  // uniform: ten rounds per 4 steps
+            int act;
+            float lp, val;
+            if (!(dbg & 4)) policy_tail_row(tsum, oi, A, philox_word_uniform(rnd, (unsigned)(o & 3)), lane, act, lp, val);
+            else { act = 0; lp = tsum; val = tsum; }
+            if (oi == 0 && e < N) {
+                sAct[dl] = act;
+                const int64_t row = (int64_t)t * N + e;
+                act_buf[row] = (float)act;
+                logprob_buf[row] = lp;
+                val_buf[row] = val;
+            }
+        }
+        lds_barrier();
+        PC_STAMP(3)
+        // ---------------- E(t): 4 waves x 4 lanes per env (one more barrier inside, where the sweep parts meet)
+        const bool last = t + 1 == T;
+        if constexpr (FAST) {
+            if (!(dbg & 2)) {
+                float rw, tf, cf;
+                const int a = e_valid ? sAct[el] : 8;
+                const bool done = rden_lds   // (uniform)
+                    ? env_step_fast<RPL, true, 2, PARTS>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0)
+                    : env_step_fast<RPL, false, 2, PARTS>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0);
+                if (__builtin_amdgcn_ballot_w64(done) != 0) {
+                    if (done) {
+                        if (part == 0)   // (uniform) the row-writing wave: reset observation of finished envs
+                            for (int f = g; f < D; f += 4) lrow[f] = ft.reset[f];
+                        env_reset_fast(h0, st, k72);
+                    }
+                }
+                if (part == 0) {   // (uniform) the row-writing wave: per-env scalars
+                    if (g == 0 && e_valid) {
+                        rew_buf[(int64_t)t * N + e_env] = rw;
+                        float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;
+                        float* tc = last ? next_trunc : trunc_buf + (int64_t)(t + 1) * N;
+                        tr[e_env] = tf;
+                        tc[e_env] = cf;
+                    }
+                }
+            }
+            PC_STAMP(6)
+            lds_barrier();
+            PC_STAMP(7)
+            // rows -> rollout buffer: the workgroup's 32 rows are contiguous there (32 * D floats): waves 0 .. 2 (.. 4) store 64 float4 each
+            {
+                float* dstg = (last ? next_obs : obs_buf + (int64_t)(t + 1) * N * D) + e_wg * D;
+                const int64_t left = N - e_wg;
+                const int n_rows = left >= EPW ? EPW : (int)left;
+                if (vec_ok && n_rows == EPW) {
+                    const int i = lane + 64 * wave;
+                    if (i < EPW / 4 * DC) reinterpret_cast<f32x4*>(dstg)[i] = reinterpret_cast<const f32x4*>(sObs)[i];
+                } else {
+                    for (int i = tid; i < n_rows * D; i += 512) dstg[i] = sObs[i];
+                }
+            }
+        } else if constexpr (EPW == 32) {
+            if (!(dbg & 2)) {
+                float* orow = !e_valid ? nullptr : (last ? next_obs + e_env * D : obs_buf + ((int64_t)(t + 1) * N + e_env) * D);
+                float rw;
+                bool term, trunc;
+                int passed;
+                if (rden_lds)  // uniform
+                    env_step_core<float, RPL, PARTS, true>(q, trk, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
+                                                           e_valid && part == 0 ? sObs + el * LDX : nullptr, rw, term, trunc, passed, part,
+                                                           exch, rdl);
+                else
+                    env_step_core<float, RPL, PARTS>(q, trk, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
+                                                     e_valid && part == 0 ? sObs + el * LDX : nullptr, rw, term, trunc, passed, part, exch);
+                if (e_valid && g == 0 && part == 0) {
+                    rew_buf[(int64_t)t * N + e_env] = rw;
+                    float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;
+                    float* tc = last ? next_trunc : trunc_buf + (int64_t)(t + 1) * N;
+                    tr[e_env] = term ? 1.0f : 0.0f;
+                    tc[e_env] = trunc ? 1.0f : 0.0f;
+                }
+            }
+            lds_barrier();
+        }
+    }
+    if (e_valid && g == 0 && part == 0) env_store<float>(p, e_env, st);
+}
