@@ -564,7 +564,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         const int f = 4 * ks + lk;
-                        x[et][ks] = (!FAST || f < D) ? sObs[(pbase + 16 * et + lc) * LDX + f] : 0.0f;
+                        const float raw = sObs[(pbase + 16 * et + lc) * LDX + f];
+                        x[et][ks] = (!FAST || f < D) ? raw : 0.0f;
                     }
                 // Wave priority: the policy pass (MFMA chains, whose results it waits for anyway) runs at the lowest priority (0),
                 // the env step -- dense dependent VALU work -- above it (2), the short serial draw in between highest (3).  The two waves of a
@@ -584,7 +585,12 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const int f = 8 * (4 * kb + lk) + j;
-                            v[j] = f < D ? sObs[(pbase + 16 * et + lc) * LDX + f] : 0.0f;
+                            // K padding (f >= D): the load is unconditional -- it stays inside the workgroup's LDS (a few floats
+                            // into the next row / the action slots) -- and its value discarded by a select: a conditional
+                            // load compiles into one exec-masked branch per feature, each with its own s_waitcnt lgkmcnt(0),
+                            // i.e. 16 LDS round trips in series per step
+                            const float raw = sObs[(pbase + 16 * et + lc) * LDX + f];
+                            v[j] = f < D ? raw : 0.0f;
                             if constexpr (PREC == 2) v[j] = clamp_h(v[j] * PolScale<PREC>::sx);   // the observations' scaled domain
                         }
                         x[et][kb] = split8<PREC>(v);
@@ -804,7 +810,8 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const int f = 4 * ks + lk;
-                    x[et][ks] = (!FAST || f < D) ? sObs[(16 * et + lc) * LDX + f] : 0.0f;
+                    const float raw = sObs[(16 * et + lc) * LDX + f];
+                    x[et][ks] = (!FAST || f < D) ? raw : 0.0f;
                 }
             if constexpr (ET == 2) {
                 if (!(dbg & 1)) policy_pass<KS>(sW1, sB1, sW2, ht0, ht1, x, out, lc, lk, lane);  // dbg: timing ablations only
@@ -819,7 +826,8 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int f = 8 * (4 * kb + lk) + j;
-                        v[j] = f < D ? sObs[(16 * et + lc) * LDX + f] : 0.0f;
+                        const float raw = sObs[(16 * et + lc) * LDX + f];   // unconditional (inside the workgroup's LDS), see K9
+                        v[j] = f < D ? raw : 0.0f;
                         if constexpr (PREC == 2) v[j] = clamp_h(v[j] * PolScale<PREC>::sx);   // the observations' scaled domain
                     }
                     x[et][kb] = split8<PREC>(v);
