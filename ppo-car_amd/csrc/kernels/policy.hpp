@@ -311,27 +311,36 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
     auto layer1 = [&](const int tp, f32x4 (&acc)[2][ET]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int ht = 2 * tp + j;
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(sB1 + 16 * ht + 4 * g);
-            f32x4 hi[ET];
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(sB1 + 16 * (2 * tp + j) + 4 * g);
 #pragma unroll
-            for (int et = 0; et < ET; ++et) hi[et] = bias;
+            for (int et = 0; et < ET; ++et) acc[j][et] = bias;
+        }
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                // feature group 4 kb + g; groups >= NG are K padding (their B operand is all zeros): any finite A will do
-                const int gi = 4 * kb + g, gA = gi < NG ? gi : NG - 1;
-                u32x4 a[NP];
+        for (int kb = 0; kb < KB; ++kb) {
+            // feature group 4 kb + g; groups >= NG are K padding (their B operand is all zeros): any finite A will do
+            const int gi = 4 * kb + g, gA = gi < NG ? gi : NG - 1;
+            u32x4 a[2][NP];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int pc = 0; pc < NP; ++pc)
-                    a[pc] = *reinterpret_cast<const u32x4*>(sW1p + (((ht * NP + pc) * NG + gA) * 16 + lc) * 4);
-#pragma unroll
-                for (int et = 0; et < ET; ++et) {
-                    if constexpr (PREC == 2) hi[et] = mfma3(a, x[et][kb], hi[et]);
-                    else hi[et] = mfma6(a, x[et][kb], hi[et]);
-                }
+                    a[j][pc] = *reinterpret_cast<const u32x4*>(sW1p + ((((2 * tp + j) * NP + pc) * NG + gA) * 16 + lc) * 4);
+            // The 2 x ET accumulator chains advance TOGETHER, product by product: a chain's next MFMA then stands 2 ET
+            // instructions behind the one it depends on (with the chains one after the other it stood ET behind, closer than
+            // the instruction's latency).  Per accumulator the order of the products is unchanged: same bits.
+            if constexpr (PREC == 2) {
+#define PC_L1(ia, ib)                                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int et = 0; et < ET; ++et)                            \
+        acc[j][et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[j][ia]), __builtin_bit_cast(f16x8, x[et][kb].p[ib]), acc[j][et], 0, 0, 0)
+                PC_L1(0, 1); PC_L1(1, 0); PC_L1(0, 0);
+#undef PC_L1
+            } else {
+#define PC_L1(ia, ib)                                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int et = 0; et < ET; ++et)                            \
+        acc[j][et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[j][ia]), __builtin_bit_cast(bf16x8, x[et][kb].p[ib]), acc[j][et], 0, 0, 0)
+                PC_L1(0, 2); PC_L1(1, 1); PC_L1(2, 0); PC_L1(0, 1); PC_L1(1, 0); PC_L1(0, 0);
+#undef PC_L1
             }
-#pragma unroll
-            for (int et = 0; et < ET; ++et) acc[j][et] = hi[et];
         }
     };
     // what follows layer 1 for an ACTOR tile pair (tp < 8): ReLU, operand split, layer 2 on the matrix cores
@@ -339,6 +348,7 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
         u32x4 w2[NP];
 #pragma unroll
         for (int pc = 0; pc < NP; ++pc) w2[pc] = *reinterpret_cast<const u32x4*>(sW2p + (((tp * NP + pc) * 4 + g) * 10 + oA) * 4);
+        Pieces<PREC> h3[ET];
 #pragma unroll
         for (int et = 0; et < ET; ++et) {
             float hv[8];
@@ -352,9 +362,21 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
                     hv[4 + r] = relu_f(acc[1][et][r]);
                 }
             }
-            const Pieces<PREC> h3 = split8<PREC>(hv);
-            if constexpr (PREC == 2) out[et] = mfma3(w2, h3, out[et]);
-            else out[et] = mfma6(w2, h3, out[et]);
+            h3[et] = split8<PREC>(hv);
+        }
+        // the ET output chains advance together, product by product (see layer1); per accumulator the order is unchanged
+        if constexpr (PREC == 2) {
+#define PC_L2(ia, ib)                                                                                                          \
+    _Pragma("unroll") for (int et = 0; et < ET; ++et)                                                                          \
+        out[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w2[ia]), __builtin_bit_cast(f16x8, h3[et].p[ib]), out[et], 0, 0, 0)
+            PC_L2(0, 1); PC_L2(1, 0); PC_L2(0, 0);
+#undef PC_L2
+        } else {
+#define PC_L2(ia, ib)                                                                                                          \
+    _Pragma("unroll") for (int et = 0; et < ET; ++et)                                                                          \
+        out[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2[ia]), __builtin_bit_cast(bf16x8, h3[et].p[ib]), out[et], 0, 0, 0)
+            PC_L2(0, 2); PC_L2(1, 1); PC_L2(2, 0); PC_L2(0, 1); PC_L2(1, 0); PC_L2(0, 0);
+#undef PC_L2
         }
     };
     // ... and for a CRITIC tile pair (tp >= 8): the output layer's dot product on the VALU

@@ -1,0 +1,40 @@
+#!/bin/bash
+# Developer tool: A/B timing of the persistent rollout kernel between builds of the working tree.
+#   tools/ab_run.sh build <name>            (here, hipcc)  -> build/ab_<name>_pkg: the package around a library built from the tree as it is now
+#   tools/ab_run.sh run [n_envs] [n_steps] [rays]  (on the GPU box) -> every build/ab_*_pkg in turn, three rounds, inside a short training
+#                                           run so that the policy is not the random initial one; the product library is not used.
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+cd $ROOT
+if [ "$1" = "build" ]; then
+  d=build/ab_${2}_pkg
+  mkdir -p $d/ppo-car_amd $d/ppo_car_amd
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -Wno-unused-function -Iinclude -Ippo-car_amd/csrc -shared \
+      -o $d/ppo-car_amd/libppocar.so ppo-car_amd/csrc/ppocar.hip ppo-car_amd/csrc/track_json.cpp || exit 1
+  cp ppo-car_amd/*.py $d/ppo-car_amd/ && cp ppo_car_amd/__init__.py $d/ppo_car_amd/
+  exit 0
+fi
+N=${2:-65536}; T=${3:-1024}; R=${4:-16}
+for round in 1 2 3; do
+  for P in $ROOT/build/ab_*_pkg; do
+    python3 - $P $N $T $R <<'PY'
+import sys, os
+pkg, N, T, R = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+sys.path.insert(0, pkg)
+import torch
+from ppo_car_amd.ppo import PPOConfig, Trainer
+root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
+tr = Trainer(PPOConfig(n_envs=N, n_steps=T, num_rays=R, track=f"{root}/tracks/big_track.json", rollout_kernel="mega", seed=3), device="cuda")
+for _ in range(4):
+    tr.run_epoch(sync=False)
+torch.cuda.synchronize()
+ts = []
+for _ in range(6):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); tr.rollout(); e1.record(); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1) * 1e3 / T)
+    tr.update()
+ts.sort()
+print(f"{os.path.basename(pkg):24s} {ts[0]:.3f} (min) {ts[len(ts)//2]:.3f} (median) us per vector step of {N} envs, {R} rays", flush=True)
+PY
+  done
+done
