@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer tool: A/B timing of the persistent rollout kernel between builds of the working tree.
-#   tools/ab_run.sh build <name>            (here, hipcc)  -> build/ab_<name>_pkg: the package around a library built from the tree as it is now
+#   tools/ab_run.sh build <name> [flags]    (here, hipcc)  -> build/ab_<name>_pkg: the package around a library built from the tree as it is now
 #   tools/ab_run.sh run [n_envs] [n_steps] [rays]  (on the GPU box) -> every build/ab_*_pkg in turn, three rounds, inside a short training
 #                                           run so that the policy is not the random initial one; the product library is not used.
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -8,7 +8,7 @@ cd $ROOT
 if [ "$1" = "build" ]; then
   d=build/ab_${2}_pkg
   mkdir -p $d/ppo-car_amd $d/ppo_car_amd
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -Wno-unused-function -Iinclude -Ippo-car_amd/csrc -shared \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -Wno-unused-function -Iinclude -Ippo-car_amd/csrc $3 -shared \
       -o $d/ppo-car_amd/libppocar.so ppo-car_amd/csrc/ppocar.hip ppo-car_amd/csrc/track_json.cpp || exit 1
   cp ppo-car_amd/*.py $d/ppo-car_amd/ && cp ppo_car_amd/__init__.py $d/ppo_car_amd/
   exit 0
