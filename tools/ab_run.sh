@@ -1,7 +1,7 @@
 #!/bin/bash
 # Developer tool: A/B timing of the persistent rollout kernel between builds of the working tree.
 #   tools/ab_run.sh build <name> [flags]    (here, hipcc)  -> build/ab_<name>_pkg: the package around a library built from the tree as it is now
-#   tools/ab_run.sh run [n_envs] [n_steps] [rays]  (on the GPU box) -> every build/ab_*_pkg in turn, three rounds, inside a short training
+#   [AB_MIXED=1] tools/ab_run.sh run [n_envs] [n_steps] [rays]  (on the GPU box; AB_MIXED: track.json + big_track.json in halves) -> every build/ab_*_pkg in turn, three rounds, inside a short training
 #                                           run so that the policy is not the random initial one; the product library is not used.
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd $ROOT
@@ -23,7 +23,8 @@ sys.path.insert(0, pkg)
 import torch
 from ppo_car_amd.ppo import PPOConfig, Trainer
 root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
-tr = Trainer(PPOConfig(n_envs=N, n_steps=T, num_rays=R, track=f"{root}/tracks/big_track.json", rollout_kernel="mega", seed=3), device="cuda")
+track = [f"{root}/tracks/track.json", f"{root}/tracks/big_track.json"] if os.environ.get("AB_MIXED") else f"{root}/tracks/big_track.json"
+tr = Trainer(PPOConfig(n_envs=N, n_steps=T, num_rays=R, track=track, rollout_kernel="mega", seed=3), device="cuda")
 for _ in range(4):
     tr.run_epoch(sync=False)
 torch.cuda.synchronize()
