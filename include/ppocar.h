@@ -189,9 +189,11 @@ int pc_rollout_set_form(int form);
  * form: 16 up to 4096 envs, else 32); 128 / 256 force the big form's choice, 16 / 32 the small form's -- so that the variant a
  * benchmark size takes can be checked at other batch sizes. */
 int pc_rollout_set_epw(int envs_per_workgroup);
-/* A/B / test knob of pc_rollout's big form: 1 (default) = single-track batches take the mode whose gather tables sit in LDS
- * behind LDS pointers, with a branch-free env step and the wave copying its observation rows out in 16-byte stores;
- * 0 = always the generic mode (what mixed-track batches take).  Bit-identical buffers either way. */
+/* A/B / test knob of pc_rollout: 1 (default) = batches whose workgroups each lie on one track take the mode whose gather
+ * tables sit in LDS behind LDS pointers, with a branch-free env step and the wave copying its observation rows out in 16-byte
+ * stores -- at 16 (17) rays in the kernels compiled for a padded wall chain of 28 vertices (big_track.json) when every track of
+ * the batch has one; 2 = the same mode but never those specialised kernels; 0 = always the generic mode (what mixed-track batches whose
+ * workgroups straddle tracks take).  Bit-identical buffers in every case. */
 int pc_rollout_set_fast(int on);
 
 /* ---- the non-GEMM work of one PPO minibatch step (train.py:230-261), three launches:

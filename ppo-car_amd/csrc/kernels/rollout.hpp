@@ -233,7 +233,7 @@ __device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const i
 // over PARTS waves of the workgroup -- this wave sweeps vertex part `part`, the per-ray minima meet in LDS (`exch`: the env's
 // [rays][PARTS] floats) across ONE workgroup barrier (every thread of the workgroup must make the call), and all waves finish
 // the step on identical values; only `write_row` waves store the observation row.
-template <int RPL, bool TAB, int LG = 1, int PARTS = 1>
+template <int RPL, bool TAB, int LG = 1, int PARTS = 1, int SWP = 0>
 __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const TrackHdr& h, const FastTabs& ft, const FastLane& fl,
                                               const int (&gq)[2], const int g,
                                               EnvRegs& st, int& k72, const int a, const double reward_scale, lds_fp lrow,
@@ -295,9 +295,9 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         unsigned ba[2 * ((R1 + 1) / 2)];
         if (PARTS > 1)                  // small form: latency-oriented sweep over the LDS copy of the chain
             wall_sweep_lds<R1, PARTS, TAB, true>(ft.vtx, h.nV, part, npx, npy, dxa, dya, dia, ft.rden, ba);
-        else if (h.nV == 28)            // (wave-uniform) big_track's chain: the unrolled sweep
-            wall_sweep_unrolled<R1, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxa, dya, dia, ft.rden, ba);
-        else
+        else if (SWP == 7 || h.nV == 28)   // (wave-uniform) big_track's chain: the unrolled sweep.  SWP == 7: the host guarantees that
+            wall_sweep_unrolled<R1, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxa, dya, dia, ft.rden, ba);   // chain length
+        else if constexpr (SWP == 0)       // and the generic loop is not even compiled in (1 % from the shorter kernel alone)
             wall_sweep_f32<R1, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dxa, dya, dia, ft.rden, ba);
 #pragma unroll
         for (int s = 0; s < R1; ++s) bb[s] = ba[s];
@@ -310,9 +310,9 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         unsigned bc[2 * ((R2 + 1) / 2)];
         if (PARTS > 1)
             wall_sweep_lds<R2, PARTS, TAB, true>(ft.vtx, h.nV, part, npx, npy, dxb, dyb, dib, ft.rden, bc);
-        else if (h.nV == 28)
+        else if (SWP == 7 || h.nV == 28)
             wall_sweep_unrolled<R2, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxb, dyb, dib, ft.rden, bc);
-        else
+        else if constexpr (SWP == 0)
             wall_sweep_f32<R2, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dxb, dyb, dib, ft.rden, bc);
 #pragma unroll
         for (int s = 0; s < R2; ++s) bb[R1 + s] = bc[s];
@@ -456,8 +456,11 @@ __device__ __forceinline__ EnvParams<float> stage_tables(const EnvParams<float>&
 }
 
 // MODE 0: the gather tables where stage_tables puts them (generic pointers; mixed-track batches read them from global
-//         memory), env step = env_step_core.  MODE 1 / 2: single track, A = 9, every table in LDS behind explicit LDS
+//         memory), env step = env_step_core.  MODE 1 / 2: one track per workgroup, A = 9, every table in LDS behind explicit LDS
 //         pointers, env step = env_step_fast (2: with the 1/den table), observation rows copied out by the wave.
+//         MODE 4 / 3 = 1 / 2 for batches whose tracks all have a padded wall chain of 28 vertices (big_track.json): only the
+//         unrolled sweep is compiled in (built for 17 rays and the default arithmetic: ~1 % from the shorter kernel; the 33-ray
+//         kernel schedules worse without the generic branch -- it spills -- and keeps it).
 template <int KS, int RPL, int PREC, int MODE>
 __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, const float* __restrict__ image, const int A,
                                                       const int T, const double reward_scale, const uint64_t seed,
@@ -644,7 +647,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 // ---------------- E(t)
                 float rw, tf, cf;
                 const int a = e_valid ? sAct[el] : 8;
-                const bool done = env_step_fast<RPL, MODE == 2>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave);
+                const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3, 1, 1, (MODE >= 3 ? 7 : 0)>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave);
                 PC_STAMP(6)
                 // gymnasium 0.29.1 same-step auto-reset: a finished env returns its reset observation
                 if (__builtin_amdgcn_ballot_w64(done) != 0) {   // wave-uniform: ~1.5 % of env steps end an episode

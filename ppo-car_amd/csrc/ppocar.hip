@@ -609,6 +609,7 @@ static int g_rollout_form = -1;       // pc_rollout: -1 auto, 0 = 256 envs per w
 #define PC_SPLIT_MAX_ENVS 16384
 static int64_t g_rollout_epw128_max = 32768;  // big form at or below this many envs: 128 envs (4 waves) per workgroup
 static int g_rollout_epw_override = 0;  // pc_rollout_set_epw: 0 = automatic, 128 / 256 = force (test knob)
+static int g_rollout_nv28 = 1;        // pc_rollout: kernels compiled for a padded wall chain of 28 vertices (big_track.json) when every track of the batch has one
 static int g_rollout_fast = 1;        // pc_rollout: the big form's fast mode (LDS tables behind LDS pointers) when the shape allows it (0: never; A/B knob)
 static int g_rollout_rden = 1;        // pc_rollout: stage the 1/den table in LDS when it fits (0: never; test / tuning knob)
 static int g_policy_precision = 2;    // 0 = fp32-input MFMA; split forms on the 16-bit matrix cores (need D <= 24, A <= 9): 1 = bf16 x 3, 2 = fp16 x 2
@@ -621,8 +622,9 @@ int pc_rollout_set_form(int form) {
 }
 
 int pc_rollout_set_fast(int on) {
-    if (on != 0 && on != 1) return PC_ERR_INVALID_ARG;
-    g_rollout_fast = on;
+    if (on < 0 || on > 2) return PC_ERR_INVALID_ARG;
+    g_rollout_fast = on != 0;
+    g_rollout_nv28 = on == 1;      // 2: fast mode, but never the kernels specialised for a wall chain of 28 vertices
     return PC_OK;
 }
 
@@ -835,6 +837,8 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     const int blocks = (int)(small ? (e->N + epw_small - 1) / epw_small : (e->N + epw - 1) / epw);
     const int vec_ok = ((e->N * e->D) % 4 == 0) ? 1 : 0;      // the waves' 32-row blocks are 16-byte aligned in the buffers
     const int mode = (fast || fast_small) ? (rden_lds ? 2 : 1) : 0;
+    bool all_nv28 = g_rollout_nv28 != 0;
+    for (const TrackHdr& h : e->hdr_host) all_nv28 = all_nv28 && h.nV == 28;
     hipStream_t st = (hipStream_t)stream;
     EnvParams<float> prm = e->params<float>();
     prm.lg = small ? 2 : 1;
@@ -851,6 +855,10 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     } while (0)
 #define PC_ROLL(KSV, RPLV, PRC)                                                                                          \
     do {                                                                                                                 \
+        if constexpr (PRC == 2 && KSV == 6) {   /* (17 rays, default arithmetic only: the chain-of-28 kernels) */        \
+            if (mode == 2 && all_nv28) { PC_ROLL_M(KSV, RPLV, PRC, 3); break; }                                          \
+            if (mode == 1 && all_nv28) { PC_ROLL_M(KSV, RPLV, PRC, 4); break; }                                          \
+        }                                                                                                                \
         if (mode == 2) PC_ROLL_M(KSV, RPLV, PRC, 2);                                                                     \
         else if (mode == 1) PC_ROLL_M(KSV, RPLV, PRC, 1);                                                                \
         else PC_ROLL_M(KSV, RPLV, PRC, 0);                                                                               \
@@ -882,7 +890,7 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
     } else if (KS == 5 && rpl == 6) { if (prec == 2) PC_ROLL(5, 6, 2); else if (prec) PC_ROLL(5, 6, 1); else PC_ROLL(5, 6, 0); }       // 12 rays, D = 18
     else if (KS == 6 && rpl == 9) { if (prec == 2) PC_ROLL(6, 9, 2); else if (prec) PC_ROLL(6, 9, 1); else PC_ROLL(6, 9, 0); }          // 16 -> 17 rays, D = 23
     else if (KS == 10 && rpl == 17 && prec) {                                                                                             // 32 -> 33 rays, D = 39
-        if (prec == 2) { if (mode) PC_ROLL_M(10, 17, 2, 1); else PC_ROLL_M(10, 17, 2, 0); }
+        if (prec == 2) { if (mode) PC_ROLL_M(10, 17, 2, 1); else PC_ROLL_M(10, 17, 2, 0); }   // (its chain-of-28 variant spills: not built)
         else { if (mode) PC_ROLL_M(10, 17, 1, 1); else PC_ROLL_M(10, 17, 1, 0); }
     }
     else return PC_ERR_UNSUPPORTED;

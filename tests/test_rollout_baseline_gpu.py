@@ -114,15 +114,18 @@ def test_default_dispatch_rollout_vs_step_kernels_and_oracle(n_envs, num_rays, n
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("fast", [1, 2, 0], ids=["chain28_kernels", "fast_generic_sweep", "generic_mode"])
 @pytest.mark.parametrize("epw", [128, 256])
 @pytest.mark.parametrize("n_envs", [1000, 512])
-def test_both_workgroup_sizes_of_the_big_form_at_small_n(n_envs, epw):
+def test_both_workgroup_sizes_of_the_big_form_at_small_n(n_envs, epw, fast):
     """The 256-env-per-workgroup variant (what 65536 envs take) and the 128-env one, forced at a small batch: bitwise the
-    per-step kernels, with the 1/den table in LDS (form 0) -- the configuration the benchmark runs."""
+    per-step kernels, with the 1/den table in LDS (form 0) -- the configuration the benchmark runs -- in the kernels compiled
+    for big_track's chain length (the default), in the fast mode's generic-sweep kernels and in the generic mode."""
     res = {}
     lib.pc_policy_set_split(0)
     lib.pc_rollout_set_form(0)
     lib.pc_rollout_set_epw(epw)
+    assert lib.pc_rollout_set_fast(fast) == 0 and lib.pc_rollout_set_fast(3) != 0
     try:
         for mode in ("steps", "mega"):
             tr = Trainer(PPOConfig(n_envs=n_envs, n_steps=96, num_rays=16, track=TRACKS["big_track"], rollout_kernel=mode,
@@ -138,6 +141,7 @@ def test_both_workgroup_sizes_of_the_big_form_at_small_n(n_envs, epw):
         lib.pc_policy_set_split(-1)
         lib.pc_rollout_set_form(-1)
         lib.pc_rollout_set_epw(0)
+        lib.pc_rollout_set_fast(1)
     for i, (a, b) in enumerate(zip(res["steps"], res["mega"])):
         assert torch.equal(a, b), i
     assert float(res["mega"][5].sum()) > 0
