@@ -221,8 +221,12 @@ __global__ __launch_bounds__(256) void ppo_prepare_kernel(const int64_t* __restr
     }
 }
 
-template <int DMAX>
-__device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __restrict__ idx, const int B, const int D, const int A,
+// AC > 0: the action count as a compile-time constant (CarEnv: Discrete(9)) -- with the run-time count every `o < A` inside the
+// unrolled 16-slot loops is a v_cndmask per slot and sample and the FMAs of the unused slots are executed (backward: 219
+// selects + 112 FMAs per thread); the same operations in the same order either way.
+// DC > 0: likewise the observation width (6 + 12 / 17 / 33 rays).
+template <int DMAX, int AC = 0, int DC = 0>
+__device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __restrict__ idx, const int B, const int D_rt, const int A_rt,
                                                 const float* __restrict__ obs, const float* __restrict__ act,
                                                 const float* __restrict__ old_lp, const float* __restrict__ adv,
                                                 const float* __restrict__ ret, const float* __restrict__ param,
@@ -230,6 +234,8 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
                                                 float* __restrict__ partial, float* __restrict__ metric_partial,
                                                 const float* __restrict__ prep) {
     constexpr int H = 256, S = FB_S, LDT = DMAX + 1, LDH = H + 1;
+    const int A = AC > 0 ? AC : A_rt, D = DC > 0 ? DC : D_rt;
+    static_assert(DC <= DMAX, "observation width");
     // Everything in this kernel is latency: a minibatch is 44 MFLOP.  So: every global access coalesced (the [H][D]
     // weight matrices and their gradients go through an LDS tile, transposed there), all loads of a phase in flight
     // together, and no cross-lane reduction chains (layer 2 is a small GEMV out of LDS).
@@ -527,24 +533,28 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
         for (int sidx = 0; sidx < S; ++sidx) t += sMet[sidx][u];
         metric_partial[wg * 4 + u] = t;
     }
+    PC_STAMP_U(8)
 #pragma unroll
     for (int net = 0; net < 2; ++net) {
         lds_barrier();  // (not __syncthreads(): that waits for the stores already in flight, ~2 us each time)
+        if (net == 0) { PC_STAMP_U(9) } else { PC_STAMP_U(12) }
 #pragma unroll
         for (int f = 0; f < DMAX; ++f)
             if (f < D) sT[u * D + f] = net == 0 ? g1a[f] : g1c[f];
         lds_barrier();  // (not __syncthreads(): that waits for the stores already in flight, ~2 us each time)
+        if (net == 0) { PC_STAMP_U(10) } else { PC_STAMP_U(13) }
         f32x4* __restrict__ dst = reinterpret_cast<f32x4*>(P + net * HD);
 #pragma unroll
         for (int j = 0; j < NV4; ++j) {
             const int i4 = u + 256 * j;
             if (i4 < (HD >> 2)) dst[i4] = reinterpret_cast<const f32x4*>(sT)[i4];
         }
+        if (net == 0) { PC_STAMP_U(11) }
     }
     PC_STAMP_U(7)
 }
 
-template <int DMAX>
+template <int DMAX, int AC = 0, int DC = 0>
 __global__ __launch_bounds__(256) void ppo_fwdbwd_kernel(const int64_t* __restrict__ idx, const int B, const int D, const int A,
                                                          const float* __restrict__ obs, const float* __restrict__ act,
                                                          const float* __restrict__ old_lp, const float* __restrict__ adv,
@@ -552,7 +562,7 @@ __global__ __launch_bounds__(256) void ppo_fwdbwd_kernel(const int64_t* __restri
                                                          const float clip, const float vf, const float ec,
                                                          float* __restrict__ partial, float* __restrict__ metric_partial,
                                                          const float* __restrict__ prep) {
-    ppo_fwdbwd_body<DMAX>(blockIdx.x, idx, B, D, A, obs, act, old_lp, adv, ret, param, clip, vf, ec, partial, metric_partial, prep);
+    ppo_fwdbwd_body<DMAX, AC, DC>(blockIdx.x, idx, B, D, A, obs, act, old_lp, adv, ret, param, clip, vf, ec, partial, metric_partial, prep);
 }
 
 // K11: flat_grad[i] = sum_p partial[p][i] (fixed order: deterministic); block-wise squared-norm partials for the clip;

@@ -931,12 +931,16 @@ static int ppo_minibatch_impl(int device, const int64_t* idx, const float* prep,
     float* metric_partial = partial + (size_t)n_part * n_pad;
     float* norm_partial = metric_partial + n_part * 4;
     hipStream_t st = (hipStream_t)stream;
-    if (D <= 24)
-        hipLaunchKernelGGL(ppo_fwdbwd_kernel<24>, dim3(n_part), dim3(256), 0, st, idx, B, D, A, obs, act, old_logprob, adv, ret, param,
-                           (float)clip_ratio, (float)vf_coef, (float)ent_coef, partial, metric_partial, prep);
-    else
-        hipLaunchKernelGGL(ppo_fwdbwd_kernel<40>, dim3(n_part), dim3(256), 0, st, idx, B, D, A, obs, act, old_logprob, adv, ret, param,
-                           (float)clip_ratio, (float)vf_coef, (float)ent_coef, partial, metric_partial, prep);
+#define PC_FB(DM, ACV, DCV)                                                                                              \
+    hipLaunchKernelGGL((ppo_fwdbwd_kernel<DM, ACV, DCV>), dim3(n_part), dim3(256), 0, st, idx, B, D, A, obs, act, old_logprob, adv, ret, param, \
+                       (float)clip_ratio, (float)vf_coef, (float)ent_coef, partial, metric_partial, prep)
+    // CarEnv's shapes (Discrete(9); 6 + 12 / 17 / 33 rays) have their action count and observation width compiled in
+    if (A == 9 && D == 23) PC_FB(24, 9, 23);
+    else if (A == 9 && D == 18) PC_FB(24, 9, 18);
+    else if (A == 9 && D == 39) PC_FB(40, 9, 39);
+    else if (D <= 24) PC_FB(24, 0, 0);
+    else PC_FB(40, 0, 0);
+#undef PC_FB
     hipLaunchKernelGGL(grad_reduce_kernel, dim3(n_blk), dim3(256), 0, st, partial, n_part, n_param, HD, mid_end, n_pad, grad, norm_partial, metric_partial, B,
                        (float)vf_coef, (float)ent_coef, metrics, apply ? step_count : nullptr);
     if (apply == 1)

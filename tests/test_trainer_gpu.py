@@ -366,15 +366,16 @@ def test_two_ranks_on_one_gpu_keep_replicas_identical(tmp_path, use_graphs):
     assert r0["scalars"]["charts/avg_reward"] == pytest.approx(r1["scalars"]["charts/avg_reward"])   # all-reduced scalars
 
 
-@pytest.mark.parametrize("B,D", [(512, 23), (100, 18), (1024, 39)])
-def test_custom_minibatch_kernels_match_torch_autograd(B, D):
+@pytest.mark.parametrize("B,D,A", [(512, 23, 9), (100, 18, 9), (1024, 39, 9), (256, 23, 6), (64, 39, 13)])
+def test_custom_minibatch_kernels_match_torch_autograd(B, D, A):
     """pc_ppo_minibatch (gather + both MLPs forward + loss + backward, no library GEMM, then clip + Adam) against torch:
-    the raw gradient against autograd's, then parameters and metric sums over several optimizer steps."""
+    the raw gradient against autograd's, then parameters and metric sums over several optimizer steps.  A = 9 runs the kernels
+    with CarEnv's action count compiled in, the other counts the generic ones."""
     from ppo_car_amd.ppo import ppo_loss
     M = 5000
     g = torch.Generator().manual_seed(B + D)
     obs = (torch.rand(M, D, generator=g) * 2 - 0.3).cuda()
-    act = torch.randint(0, 9, (M,), generator=g).float().cuda()
+    act = torch.randint(0, A, (M,), generator=g).float().cuda()
     lp = (-torch.rand(M, generator=g) * 2.5).cuda()
     adv = (torch.randn(M, generator=g) * 3 + 0.5).cuda()
     ret = torch.randn(M, generator=g).cuda()
@@ -382,7 +383,7 @@ def test_custom_minibatch_kernels_match_torch_autograd(B, D):
     res = {}
     for custom in (False, True):
         torch.manual_seed(3)
-        agent = pc.Agent(D, 9).cuda()
+        agent = pc.Agent(D, A).cuda()
         with torch.no_grad():
             for p_ in agent.parameters():
                 p_.add_(torch.randn_like(p_) * 0.05)
@@ -393,7 +394,7 @@ def test_custom_minibatch_kernels_match_torch_autograd(B, D):
         if custom:   # raw (unclipped) gradient of the first minibatch: apply = 0
             from ppo_car_amd._capi import check, lib
             i = idxs[0]
-            check(lib.pc_ppo_minibatch(0, i.data_ptr(), B, D, 256, 9, obs.data_ptr(), act.data_ptr(), lp.data_ptr(), adv.data_ptr(),
+            check(lib.pc_ppo_minibatch(0, i.data_ptr(), B, D, 256, A, obs.data_ptr(), act.data_ptr(), lp.data_ptr(), adv.data_ptr(),
                                        ret.data_ptr(), L.flat_param.data_ptr(), L.flat_grad.data_ptr(), None, None, None, None, 0.2,
                                        0.5, 0.001, 0.5, 0.9, 0.999, 1e-5, L.metrics.data_ptr(), L._ws.data_ptr(), 0,
                                        torch.cuda.current_stream().cuda_stream), "pc_ppo_minibatch")

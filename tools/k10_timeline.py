@@ -28,4 +28,8 @@ names = ["loads issued", "W1 in registers", "layer 1", "layer-2 GEMV", "loss", "
 print("K10 workgroup 0 (s_memtime ticks):")
 for i, n in enumerate(names):
     print(f"  {n:18s} {t[i + 1] - t[i]:7d}")
+u = [int(buf[i]) for i in range(16)]
+print("  inside 'stores issued': small stores %d | barrier %d | tile write + barrier (actor) %d | float4 stores %d | barrier %d | "
+      "tile write + barrier (critic) %d | float4 stores %d" % (u[8] - u[6], u[9] - u[8], u[10] - u[9], u[11] - u[10], u[12] - u[11],
+                                                              u[13] - u[12], u[7] - u[13]))
 print(f"  entry -> stores issued {t[7] - t[0]} ticks; eager update of one epoch (GAE + 80 minibatch steps): {e0.elapsed_time(e1):.2f} ms")
