@@ -581,6 +581,13 @@ __device__ __forceinline__ void grad_reduce_body(const int blk, const float* __r
         const int pm = i < HD ? i : (i < mid_end ? i + HD : (i < mid_end + HD ? i - (mid_end - HD) : i));
         const float* __restrict__ pp = partial + pm;
         int pidx = 0;
+        for (; pidx + 64 <= n_part; pidx += 64) {  // 64 independent loads in flight: a minibatch of 512 samples has exactly 64
+            float t[64];                              // partials -- one round trip (same summation order as the narrower stages)
+#pragma unroll
+            for (int j = 0; j < 64; ++j) t[j] = pp[(size_t)(pidx + j) * n_pad];
+#pragma unroll
+            for (int j = 0; j < 64; ++j) g += t[j];
+        }
         for (; pidx + 32 <= n_part; pidx += 32) {  // 32 independent loads in flight (the partials were written by other
             float t[32];                              // workgroups: every load is a cold miss); summed in index order
 #pragma unroll
