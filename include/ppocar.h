@@ -178,6 +178,17 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
 int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
                const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
                float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, void* stream);
+/* pc_rollout with two more per-env outputs (each may be NULL), both [N] float32, so that an epoch needs nothing else between
+ * the rollout and Buffer.calculate_advantages:
+ *   last_value : the critic's value of the FINAL observation -- agent.get_value(next_obs), train.py:200 -- from one more policy
+ *                pass inside the launch (the fused policy step's arithmetic, i.e. what val_buf's rows hold for the other steps);
+ *   reward_sum : the sum over the T steps of the env's (scaled) rewards, accumulated in float32 in step order -- the numerator
+ *                of train.py:272's average reward without re-reading rew_buf.
+ * Everything else exactly as pc_rollout (same buffers bit for bit). */
+int pc_rollout_ex(pc_env* e, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
+                  const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
+                  float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, float* last_value,
+                  float* reward_sum, void* stream);
 
 /* Work decomposition of pc_rollout: -1 = automatic (above 16384 envs: independent waves of 32 envs, 256 envs per workgroup
  * -- 128 up to 32768 envs; else 32 envs per workgroup with the policy's hidden tiles and the wall sweep split over the

@@ -79,6 +79,7 @@ _sig = {
     "pc_policy_pack": (_i, [_i, _i, _i, _i] + [_vp] * 8 + [_vp, _vp]),
     "pc_policy_act": (_i, [_i, _vp, _i64, _i, _i, _i, _vp, C.c_uint64, C.c_uint64, _vp] + [_vp] * 5 + [_vp]),
     "pc_rollout": (_i, [_vp, _vp, _i, _i64, _d, C.c_uint64, C.c_uint64, _vp] + [_vp] * 10 + [_vp]),
+    "pc_rollout_ex": (_i, [_vp, _vp, _i, _i64, _d, C.c_uint64, C.c_uint64, _vp] + [_vp] * 12 + [_vp]),
     "pc_rollout_set_form": (_i, [_i]),
     "pc_rollout_set_epw": (_i, [_i]),
     "pc_rollout_set_fast": (_i, [_i]),

@@ -470,7 +470,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                                                       float* __restrict__ term_buf, float* __restrict__ trunc_buf,
                                                       float* __restrict__ logprob_buf, float* __restrict__ next_obs,
                                                       float* __restrict__ next_term, float* __restrict__ next_trunc,
-                                                      const int rden_lds, const int epw, const int vec_ok) {
+                                                      const int rden_lds, const int epw, const int vec_ok,
+                                                      float* __restrict__ last_val, float* __restrict__ rew_sum) {
     constexpr int dbg = PC_ABLATE;  // 0 in the product build (see PC_ABLATE)
     constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, ET = 2;
     constexpr int NG = pol_ng(KS), KB = pol_kb(KS);
@@ -552,8 +553,14 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     // conservative `s_waitcnt vmcnt(1)` on every iteration, i.e. a wait for the wave's own global stores of the step before.
     asm volatile("" : "+v"(st.px), "+v"(st.py), "+v"(st.vx), "+v"(st.vy), "+v"(st.k), "+v"(st.time), "+v"(st.next), "+v"(st.passed), "+v"(k72));
 
+    // pc_rollout_ex: one more policy pass after the last env step gives the critic's value of the FINAL observation (the
+    // bootstrap value of Buffer.calculate_advantages, train.py:200) -- tail iteration t == T: no draw stored, no env step --,
+    // and every env's reward total rides along in a register (train.py:272's average reward without re-reading rew_buf).
+    const int TT = last_val ? T + 1 : T;
+    float rsum = 0.0f;
 #pragma unroll 1
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < TT; ++t) {
+        const bool tail = t == T;      // (uniform)
         PC_STAMP(0)
         {
             // ---------------- P(t)
@@ -631,14 +638,19 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 if constexpr (FAST) policy_tail<9>(v, 9, philox_word_uniform(rnd, (unsigned)(o & 3)), act, lp, val, nullptr);
                 else policy_tail(v, A, philox_word_uniform(rnd, (unsigned)(o & 3)), act, lp, val, nullptr);
                 sAct[pbase + lane] = act;
-                const int64_t row = (int64_t)t * N + e;
-                act_buf[row] = (float)act;     // stored as float32 like the reference (buffer.py:13)
-                logprob_buf[row] = lp;
-                val_buf[row] = val;
+                if (tail) {
+                    last_val[e] = val;
+                } else {
+                    const int64_t row = (int64_t)t * N + e;
+                    act_buf[row] = (float)act;     // stored as float32 like the reference (buffer.py:13)
+                    logprob_buf[row] = lp;
+                    val_buf[row] = val;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        if (tail) break;
         const bool last = t + 1 == T;
         PC_STAMP(3)
         if constexpr (FAST) {
@@ -648,6 +660,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 float rw, tf, cf;
                 const int a = e_valid ? sAct[el] : 8;
                 const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3, 1, 1, (MODE >= 3 ? 7 : 0)>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave);
+                rsum += rw;
                 PC_STAMP(6)
                 // gymnasium 0.29.1 same-step auto-reset: a finished env returns its reset observation
                 if (__builtin_amdgcn_ballot_w64(done) != 0) {   // wave-uniform: ~1.5 % of env steps end an episode
@@ -694,6 +707,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
             else
                 env_step_core<float, RPL>(q, trk, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw, term,
                                           trunc, passed);
+            rsum += rw;
             if (g == 0) {
                 rew_buf[(int64_t)t * N + e_env] = rw;
                 float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;    // flags that precede obs t+1
@@ -705,7 +719,10 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // obs rows in LDS are this wave's own
         __builtin_amdgcn_wave_barrier();
     }
-    if (e_valid && g == 0) env_store<float>(p, e_env, st);
+    if (e_valid && g == 0) {
+        env_store<float>(p, e_env, st);
+        if (rew_sum) rew_sum[e_env] = rsum;
+    }
 }
 
 // K9s: the same persistent rollout for SMALL batches (n_envs < ~32 k): a workgroup owns only 32 envs, so that
@@ -723,7 +740,8 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                                                             float* __restrict__ term_buf, float* __restrict__ trunc_buf,
                                                             float* __restrict__ logprob_buf, float* __restrict__ next_obs,
                                                             float* __restrict__ next_term, float* __restrict__ next_trunc,
-                                                            const int rden_lds, const int vec_ok) {
+                                                            const int rden_lds, const int vec_ok,
+                                                            float* __restrict__ last_val, float* __restrict__ rew_sum) {
     constexpr int dbg = PC_ABLATE;  // 0 in the product build (see PC_ABLATE)
     // EPW = envs per workgroup: 32 (two groups of 4 waves = 4 sweep parts for 16 envs each; each wave 2 env tiles of the policy
     // pass) or 16 (up to 4096 envs: twice the workgroups -- all 256 CUs at BASELINE configs[1] -- and every phase of the step
@@ -799,8 +817,11 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     __syncthreads();
     asm volatile("" : "+v"(st.px), "+v"(st.py), "+v"(st.vx), "+v"(st.vy), "+v"(st.k), "+v"(st.time), "+v"(st.next), "+v"(st.passed), "+v"(k72));
 
+    const int TT = last_val ? T + 1 : T;   // pc_rollout_ex: tail iteration t == T = the final observation's value only (see rollout_kernel)
+    float rsum = 0.0f;
 #pragma unroll 1
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < TT; ++t) {
+        const bool tail = t == T;          // (uniform)
         PC_STAMP(0)
         // ---------------- P(t), hidden tiles [ht0, ht1) of this wave, all 32 envs
         f32x4 out[ET];
@@ -868,14 +889,19 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
             else { act = 0; lp = tsum; val = tsum; }
             if (oi == 0 && e < N) {
                 sAct[dl] = act;
-                const int64_t row = (int64_t)t * N + e;
-                act_buf[row] = (float)act;
-                logprob_buf[row] = lp;
-                val_buf[row] = val;
+                if (tail) {
+                    last_val[e] = val;
+                } else {
+                    const int64_t row = (int64_t)t * N + e;
+                    act_buf[row] = (float)act;
+                    logprob_buf[row] = lp;
+                    val_buf[row] = val;
+                }
             }
         }
         lds_barrier();
         PC_STAMP(3)
+        if (tail) break;
         // ---------------- E(t): 4 waves x 4 lanes per env (one more barrier inside, where the sweep parts meet)
         const bool last = t + 1 == T;
         if constexpr (FAST) {
@@ -885,6 +911,7 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 const bool done = rden_lds   // (uniform)
                     ? env_step_fast<RPL, true, 2, PARTS>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0)
                     : env_step_fast<RPL, false, 2, PARTS>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0);
+                rsum += rw;
                 if (__builtin_amdgcn_ballot_w64(done) != 0) {
                     if (done) {
                         if (part == 0)   // (uniform) the row-writing wave: reset observation of finished envs
@@ -930,6 +957,7 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 else
                     env_step_core<float, RPL, PARTS>(q, trk, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
                                                      e_valid && part == 0 ? sObs + el * LDX : nullptr, rw, term, trunc, passed, part, exch);
+                rsum += rw;
                 if (e_valid && g == 0 && part == 0) {
                     rew_buf[(int64_t)t * N + e_env] = rw;
                     float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;
@@ -941,5 +969,8 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
             lds_barrier();
         }
     }
-    if (e_valid && g == 0 && part == 0) env_store<float>(p, e_env, st);
+    if (e_valid && g == 0 && part == 0) {
+        env_store<float>(p, e_env, st);
+        if (rew_sum) rew_sum[e_env] = rsum;
+    }
 }

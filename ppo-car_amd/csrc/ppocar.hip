@@ -788,9 +788,10 @@ int pc_clip_adam_advanced(int device, float* param, const float* grad, float* ex
     return PC_OK;
 }
 
-int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
-               const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
-               float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, void* stream) {
+static int rollout_impl(pc_env* e, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
+                        const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
+                        float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, float* last_value,
+                        float* reward_sum, void* stream) {
     if (!e || !image || !obs_buf || !act_buf || !rew_buf || !val_buf || !term_buf || !trunc_buf || !logprob_buf || !next_obs ||
         !next_term || !next_trunc || T < 1 || T > (1 << 24))
         return PC_ERR_INVALID_ARG;
@@ -851,7 +852,7 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
         }                                                                                                                \
         hipLaunchKernelGGL((rollout_kernel<KSV, RPLV, PRC, MD>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, seed, \
                            offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs,  \
-                           next_term, next_trunc, rden_lds, epw, vec_ok);                                                \
+                           next_term, next_trunc, rden_lds, epw, vec_ok, last_value, reward_sum);                        \
     } while (0)
 #define PC_ROLL(KSV, RPLV, PRC)                                                                                          \
     do {                                                                                                                 \
@@ -872,7 +873,7 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
         }                                                                                                                \
         hipLaunchKernelGGL((rollout_small_kernel<KSV, RPLV, PRC, MD, EPWV>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, \
                            seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, \
-                           next_term, next_trunc, rden_lds, vec_ok);                                                             \
+                           next_term, next_trunc, rden_lds, vec_ok, last_value, reward_sum);                                     \
     } while (0)
 #define PC_ROLLS(KSV, RPLV, PRC)                                                                                         \
     do {                                                                                                                 \
@@ -900,6 +901,21 @@ int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_sc
 #undef PC_ROLL
     HIPCHK(hipGetLastError());
     return PC_OK;
+}
+
+int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
+               const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
+               float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, void* stream) {
+    return rollout_impl(e, image, A, T, reward_scale, seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf,
+                        logprob_buf, next_obs, next_term, next_trunc, nullptr, nullptr, stream);
+}
+
+int pc_rollout_ex(pc_env* e, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
+                  const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
+                  float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, float* last_value,
+                  float* reward_sum, void* stream) {
+    return rollout_impl(e, image, A, T, reward_scale, seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf,
+                        logprob_buf, next_obs, next_term, next_trunc, last_value, reward_sum, stream);
 }
 
 int64_t pc_ppo_workspace_floats(int B, int D, int H, int A) {

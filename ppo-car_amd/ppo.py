@@ -535,6 +535,8 @@ class Trainer:
         self.k1_events = []
         self.phase_events = None     # bench.py: list of (start, rollout_end, update_end) events per epoch
         self.rng_base = torch.zeros(1, dtype=torch.int64, device=self.device)   # device-side Philox offset base
+        self._boot_val = self._rew_sum = None
+        self._aux_valid = False
         self._rollout_graph = None
         self._eager_rollouts = 0
         self.rollout_mode = None
@@ -588,14 +590,19 @@ class Trainer:
         if self.mega_events is not None:    # bench.py: HIP events on the launch stream around the one launch
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        rc = lib.pc_rollout(self.envs._h, agent._image.data_ptr(), self.act_dim, cfg.n_steps, float(cfg.reward_scaling),
-                            int(agent.rng_seed), 0, self.rng_base.data_ptr(), buf.obs_buf.data_ptr(), buf.act_buf.data_ptr(),
-                            buf.rew_buf.data_ptr(), buf.val_buf.data_ptr(), buf.term_buf.data_ptr(), buf.trunc_buf.data_ptr(),
-                            buf.logprob_buf.data_ptr(), self.next_obs.data_ptr(), self.next_term.data_ptr(),
-                            self.next_trunc.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
+        if self._boot_val is None:
+            self._boot_val = torch.empty(cfg.n_envs, device=self.device)       # the final observation's value (train.py:200)
+            self._rew_sum = torch.empty(cfg.n_envs, device=self.device)        # per-env reward totals (train.py:272)
+        rc = lib.pc_rollout_ex(self.envs._h, agent._image.data_ptr(), self.act_dim, cfg.n_steps, float(cfg.reward_scaling),
+                               int(agent.rng_seed), 0, self.rng_base.data_ptr(), buf.obs_buf.data_ptr(), buf.act_buf.data_ptr(),
+                               buf.rew_buf.data_ptr(), buf.val_buf.data_ptr(), buf.term_buf.data_ptr(), buf.trunc_buf.data_ptr(),
+                               buf.logprob_buf.data_ptr(), self.next_obs.data_ptr(), self.next_term.data_ptr(),
+                               self.next_trunc.data_ptr(), self._boot_val.data_ptr(), self._rew_sum.data_ptr(),
+                               torch.cuda.current_stream(self.device).cuda_stream)
         if rc == -5:       # PC_ERR_UNSUPPORTED: shape outside the persistent kernel's menu
             return False
-        check(rc, "pc_rollout")
+        check(rc, "pc_rollout_ex")
+        self._aux_valid = True   # the launch also delivered the bootstrap values and the reward totals of THIS rollout
         if ev is not None:
             ev[1].record()
             self.mega_events.append(ev)
@@ -614,6 +621,7 @@ class Trainer:
         if mode == "auto":
             mode = "mega" if cfg.n_envs >= 256 else "steps"
         done = False
+        self._aux_valid = False
         if mode == "mega" and cfg.policy == "fused" and self.device.type == "cuda" and not self.profile_stride:
             done = self._rollout_mega()
             self.rollout_mode = "mega" if done else "steps"
@@ -638,7 +646,8 @@ class Trainer:
     def update(self):
         buf, agent = self.buffer, self.agent
         with torch.no_grad():
-            next_values = agent.get_value(self.next_obs).reshape(1, -1)                          # train.py:200
+            # train.py:200 -- the persistent rollout kernel has already evaluated the critic on the final observation
+            next_values = (self._boot_val if self._aux_valid else agent.get_value(self.next_obs)).reshape(1, -1)
             adv, ret = buf.calculate_advantages(next_values, self.next_term.reshape(1, -1),
                                                 self.next_trunc.reshape(1, -1))                   # :203
         obs, act, _val, logprob = buf.get()                                                      # :206
@@ -652,8 +661,8 @@ class Trainer:
         self.rollout()
         if ev:
             ev[1].record()
-        with torch.no_grad():
-            rew_mean = self.buffer.rew_buf.mean()
+        with torch.no_grad():   # train.py:272; the persistent rollout kernel delivers per-env totals (no second pass over rew_buf)
+            rew_mean = (self._rew_sum.sum() / float(self.cfg.n_steps * self.cfg.n_envs)) if self._aux_valid else self.buffer.rew_buf.mean()
         self.update()
         if ev:
             ev[2].record()

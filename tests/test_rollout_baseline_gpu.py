@@ -180,6 +180,45 @@ def test_both_workgroup_sizes_of_the_small_form(n_envs, num_rays, epw):
     assert float(res["mega"][5].sum()) > 0
 
 
+@pytest.mark.parametrize("n_envs,num_rays,n_steps", [(65536, 16, 64), (4096, 16, 200), (1000, 32, 50), (3000, 12, 33)])
+def test_rollout_ex_delivers_bootstrap_values_and_reward_totals(n_envs, num_rays, n_steps):
+    """pc_rollout_ex = pc_rollout (same buffers, bit for bit) + the critic's value of the final observation (train.py:200) and
+    every env's reward total (train.py:272's numerator), from inside the same launch -- big and small form."""
+    outs = {}
+    for ex in (True, False):
+        cfg = PPOConfig(n_envs=n_envs, n_steps=n_steps, num_rays=num_rays, track=TRACKS["big_track"], rollout_kernel="mega",
+                        use_graphs=False, seed=21)
+        tr = Trainer(cfg, device="cuda")
+        if ex:
+            tr.rollout()
+            assert tr.rollout_mode == "mega" and tr._aux_valid
+            boot, rsum = tr._boot_val.clone(), tr._rew_sum.clone()
+            with torch.no_grad():
+                ref_v = tr.agent.get_value(tr.next_obs).reshape(-1)
+            assert float((boot - ref_v).abs().max()) <= 1e-5                     # the fused policy step's arithmetic vs torch fp32
+            ref_sum = tr.buffer.rew_buf.double().sum(0)
+            assert float((rsum.double() - ref_sum).abs().max()) <= 1e-4 * max(1.0, float(ref_sum.abs().max()))
+            mean_k = float(rsum.sum() / (n_steps * n_envs))
+            assert mean_k == pytest.approx(float(tr.buffer.rew_buf.mean()), rel=1e-4, abs=1e-7)
+        else:               # the plain entry point, called directly
+            agent, buf = tr.agent, tr.buffer
+            assert agent.pack_policy()
+            buf.obs_buf[0].copy_(tr.next_obs)
+            buf.term_buf[0].copy_(tr.next_term)
+            buf.trunc_buf[0].copy_(tr.next_trunc)
+            rc = lib.pc_rollout(tr.envs._h, agent._image.data_ptr(), tr.act_dim, cfg.n_steps, float(cfg.reward_scaling), int(agent.rng_seed),
+                                0, tr.rng_base.data_ptr(), buf.obs_buf.data_ptr(), buf.act_buf.data_ptr(), buf.rew_buf.data_ptr(),
+                                buf.val_buf.data_ptr(), buf.term_buf.data_ptr(), buf.trunc_buf.data_ptr(), buf.logprob_buf.data_ptr(),
+                                tr.next_obs.data_ptr(), tr.next_term.data_ptr(), tr.next_trunc.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+        torch.cuda.synchronize()
+        outs[ex] = _snap(tr)
+        tr.close()
+    for i, (a, b) in enumerate(zip(outs[True], outs[False])):
+        assert torch.equal(a, b), i
+
+
 # ------------------------------------------------------------------------------------------------
 # the reference's ray / segment unit cases through the HIP kernels
 # ------------------------------------------------------------------------------------------------
