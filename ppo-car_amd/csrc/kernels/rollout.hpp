@@ -665,7 +665,15 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 // gymnasium 0.29.1 same-step auto-reset: a finished env returns its reset observation
                 if (__builtin_amdgcn_ballot_w64(done) != 0) {   // wave-uniform: ~1.5 % of env steps end an episode
                     if (done) {
-                        for (int f = g; f < D; f += 2) lrow[f] = ft.reset[f];
+                        // the reset observation's entries f = g, g + 2, ...: all reads issued, then the writes (rolled, every
+                        // entry is an LDS round trip in series -- and some env of a wave finishes in a third of the steps of a
+                        // young policy)
+                        float ro[(DC + 1) / 2];
+#pragma unroll
+                        for (int j = 0; j < (DC + 1) / 2; ++j) ro[j] = ft.reset[g + 2 * j];     // (the table has 40 slots: in bounds)
+#pragma unroll
+                        for (int j = 0; j < (DC + 1) / 2; ++j)
+                            if (g + 2 * j < DC) lrow[g + 2 * j] = ro[j];
                         env_reset_fast(h0, st, k72);
                     }
                 }
@@ -915,7 +923,14 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 if (__builtin_amdgcn_ballot_w64(done) != 0) {
                     if (done) {
                         if (part == 0)   // (uniform) the row-writing wave: reset observation of finished envs
-                            for (int f = g; f < D; f += 4) lrow[f] = ft.reset[f];
+                        {   // all reads, then the writes (see rollout_kernel)
+                            float ro[(DC + 3) / 4];
+#pragma unroll
+                            for (int j = 0; j < (DC + 3) / 4; ++j) ro[j] = ft.reset[g + 4 * j];
+#pragma unroll
+                            for (int j = 0; j < (DC + 3) / 4; ++j)
+                                if (g + 4 * j < DC) lrow[g + 4 * j] = ro[j];
+                        }
                         env_reset_fast(h0, st, k72);
                     }
                 }
