@@ -575,6 +575,8 @@ __device__ __forceinline__ void grad_reduce_body(const int blk, const float* __r
     __shared__ float sh[16];
     __syncthreads();  // (shared scratch reuse when called in a loop)
     const int i = blk * blockDim.x + threadIdx.x;
+    // workgroup 0 also folds the metric partials: their first 256 words are requested now, under the gradient loads
+    const float mp_first = (blk == 0 && (int)threadIdx.x < n_part * 4) ? metric_partial[threadIdx.x] : 0.0f;
     float g = 0.0f;
     if (i < n) {
         // natural flat index i -> index inside a partial (ppo_fwdbwd_body's layout: both [H][D] blocks first, 16-byte aligned)
@@ -612,10 +614,15 @@ __device__ __forceinline__ void grad_reduce_body(const int blk, const float* __r
         float mt[3] = {0.0f, 0.0f, 0.0f};
         for (int p0 = 0; p0 < n_part; p0 += 64) {  // 64 workgroups' (pl, vl, ent, -) at a time, one coalesced load
             __syncthreads();
-            sMp[threadIdx.x] = p0 * 4 + (int)threadIdx.x < n_part * 4 ? metric_partial[p0 * 4 + threadIdx.x] : 0.0f;
+            sMp[threadIdx.x] = p0 == 0 ? mp_first : (p0 * 4 + (int)threadIdx.x < n_part * 4 ? metric_partial[p0 * 4 + threadIdx.x] : 0.0f);
             __syncthreads();
-            if (threadIdx.x < 3)
-                for (int pidx = 0; pidx < 64 && p0 + pidx < n_part; ++pidx) mt[threadIdx.x] += sMp[pidx * 4 + threadIdx.x];
+            if (threadIdx.x < 3) {   // all 64 reads first, then the sum in index order (rolled, every read is an LDS round trip in
+                float mv[64];        // series: 64 x ~70 cycles on the one workgroup the whole launch then waits for)
+#pragma unroll
+                for (int pidx = 0; pidx < 64; ++pidx) mv[pidx] = sMp[pidx * 4 + threadIdx.x];   // (slots past n_part hold 0)
+#pragma unroll
+                for (int pidx = 0; pidx < 64; ++pidx) mt[threadIdx.x] += mv[pidx];
+            }
         }
         if (threadIdx.x < 3) sh[threadIdx.x] = mt[threadIdx.x] / (float)B;
         __syncthreads();
