@@ -407,7 +407,76 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
     }
     const int ta1 = tp1 < 8 ? tp1 : 8;
     int tp = tp0;
-    layer1(tp, accA);
+    if constexpr (KB == 1) {
+        // One K block (D <= 24): a pair's weight operands and biases are read from LDS ONE PAIR AHEAD, before the epilogue that
+        // precedes their MFMAs -- read where they are used, every layer-1 block opens with an exposed LDS round trip.
+        struct L1Ops { u32x4 a[2][NP]; f32x4 bias[2]; };
+        auto load1 = [&](const int tpl, L1Ops& o) {
+            const int gA = g < NG ? g : NG - 1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                o.bias[j] = *reinterpret_cast<const f32x4*>(sB1 + 16 * (2 * tpl + j) + 4 * g);
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc)
+                    o.a[j][pc] = *reinterpret_cast<const u32x4*>(sW1p + ((((2 * tpl + j) * NP + pc) * NG + gA) * 16 + lc) * 4);
+            }
+        };
+        auto mfma1 = [&](const L1Ops& o, f32x4 (&acc)[2][ET]) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int et = 0; et < ET; ++et) acc[j][et] = o.bias[j];
+            if constexpr (PREC == 2) {
+#define PC_L1(ia, ib)                                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int et = 0; et < ET; ++et)                            \
+        acc[j][et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, o.a[j][ia]), __builtin_bit_cast(f16x8, x[et][0].p[ib]), acc[j][et], 0, 0, 0)
+                PC_L1(0, 1); PC_L1(1, 0); PC_L1(0, 0);
+#undef PC_L1
+            } else {
+#define PC_L1(ia, ib)                                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int et = 0; et < ET; ++et)                            \
+        acc[j][et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, o.a[j][ia]), __builtin_bit_cast(bf16x8, x[et][0].p[ib]), acc[j][et], 0, 0, 0)
+                PC_L1(0, 2); PC_L1(1, 1); PC_L1(2, 0); PC_L1(0, 1); PC_L1(1, 0); PC_L1(0, 0);
+#undef PC_L1
+            }
+        };
+        L1Ops oa, ob;
+        load1(tp, oa);
+        load1(tp + 1, ob);
+        mfma1(oa, accA);
+#pragma unroll 1
+        for (; tp < ta1 && tp + 2 < tp1; tp += 2) {
+            mfma1(ob, accB);
+            load1(tp + 2, oa);
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue_actor(tp, accA);
+            mfma1(oa, accA);
+            load1(tp + 3 < 16 ? tp + 3 : 15, ob);
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue_actor(tp + 1, accB);
+        }
+#pragma unroll 1
+        for (; tp + 2 < tp1; tp += 2) {
+            mfma1(ob, accB);
+            load1(tp + 2, oa);
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue_critic(tp, accA);
+            mfma1(oa, accA);
+            load1(tp + 3 < 16 ? tp + 3 : 15, ob);
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue_critic(tp + 1, accB);
+        }
+        mfma1(ob, accB);       // the last two pairs
+        if (tp < 8) {              // (uniform)
+            epilogue_actor(tp, accA);
+            epilogue_actor(tp + 1, accB);
+        } else {
+            epilogue_critic(tp, accA);
+            epilogue_critic(tp + 1, accB);
+        }
+        return;
+    }
+    layer1(tp, accA);   // two K blocks (D = 39): operands read where they are used (the prefetch's 24 registers are not there)
 #pragma unroll 1
     for (; tp < ta1 && tp + 2 < tp1; tp += 2) {
         layer1(tp + 1, accB);
