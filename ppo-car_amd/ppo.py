@@ -700,6 +700,7 @@ class Trainer:
         L = self.learner
         if sd["fused"] != L.fused:
             raise ValueError("checkpoint was written with a different update path (fused_update)")
+        self._aux_valid = False     # bootstrap values / reward totals of an earlier rollout do not belong to the loaded state
         with torch.no_grad():
             self.agent.load_state_dict(sd["agent"])        # parameters are views into the flat buffer: copied in place
             if L.fused:
