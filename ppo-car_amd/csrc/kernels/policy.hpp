@@ -523,7 +523,7 @@ __device__ __forceinline__ void policy_tail(const float (&v)[16], const int A_rt
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         if (i >= A) break;
-        ex[i] = expf(v[i] - mx);
+        ex[i] = softmax_exp(v[i] - mx);
         sum += ex[i];
     }
     const float lse = mx + logf(sum);  // Categorical(logits=...) normalises: logits - logsumexp
@@ -558,7 +558,7 @@ __device__ __forceinline__ void policy_tail_row(const float v, const int i, cons
     mx = fmaxf(mx, PC_ROW_ROR(mx, 4));
     mx = fmaxf(mx, PC_ROW_ROR(mx, 2));
     mx = fmaxf(mx, PC_ROW_ROR(mx, 1));
-    const float ex = i < A ? expf(l - mx) : 0.0f;
+    const float ex = i < A ? softmax_exp(l - mx) : 0.0f;
     float sum = ex;
     sum += PC_ROW_ROR(sum, 8);
     sum += PC_ROW_ROR(sum, 4);
