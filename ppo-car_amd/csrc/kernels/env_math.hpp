@@ -11,28 +11,46 @@ struct TrackHdr {        // one per track, read with scalar loads
     int head_off;        // F32: heading table [72] (cos, sin) of radians(start_rot + 5 j)
     int start_collides;  // Car.update at reset already hits a wall (car_env.py:686,468-469)
     int vtx_off, nV;     // F32: the walls again as vertex chains, vtx[vtx_off .. vtx_off+nV); nV is padded to a multiple of 4
-    int dir_off;         // F32: ray direction table [361] of this track in dirtab (entry 360 = (0, 0): no ray)
+    int dir_off;         // F32: ray direction table [361] of this track in dirtab / dirtab64 (entry 360 = (0, 0): no ray)
     int rden_off;        // F32: 1/den table [361][nV] of this track in rden (row 360 = +inf: never hits)
-    int n_chain, pad_;   // F32: chain vertices before the padding to a multiple of 4 (vtx[n_chain .. nV) are sentinels)
+    int n_chain;         // F32: chain vertices before the padding to a multiple of 4 (vtx[n_chain .. nV) are sentinels)
+    unsigned idx_mask;   // F32: (1 << b) - 1, b = max(5, ceil(log2(nV))): the low bits of a sweep candidate carry its vertex index
     double start_x, start_y, start_rot;
+    float bx0, bx1, by0, by1;   // F32: bounding box of the wall vertices (the sweep's acceptance window is priced from it)
 };
 
 // One wall / gate segment as the reference holds it (Boundary.get_points, car_env.py:74): 32 bytes.
 struct Seg { double x1, y1, x2, y2; };
 
 // F32 wall sweep: the walls as chains of vertices.  Vertex k closes the segment (k-1, k) unless it
-// starts a new chain (brk).  (ex, ey) = p[k-1] - p[k] rounded from float64.  32 bytes = one s_load_dwordx8.
+// starts a new chain: then its edge (ex, ey) is (0, 0) (a real wall has length).  (ex, ey) = the UNIT vector along p[k-1] - p[k]
+// rounded from float64 -- the selector's u = cross(e, a) / cross(e, dir) does not depend on the edge's length, and with a unit
+// edge cross(e, a) is the car's distance from the wall line in pixels, which makes its rounding threshold one number per car --,
+// (exs, eys) the same scaled by 2^-40 (exact): the sweep's selector values live in that scaled domain (see wall_sweep_f32).
+// 32 bytes = one s_load_dwordx8.
 // Why chains: the reference's hit test 0 < t < 1 (car_env.py:178) is "the two endpoints lie strictly on
 // opposite sides of the ray line".  Evaluated per VERTEX -- one cross product c_k = cross(p_k - pos, dir)
 // shared by the two segments that meet there -- a float32 ray cannot slip between two adjacent walls
 // through the rounding-wide crack that two independently rounded t's leave at their common corner.
-struct Vtx { double x, y; float ex, ey; int brk, pad; };
+struct Vtx { double x, y; float ex, ey, exs, eys; };
+__device__ __forceinline__ bool vtx_brk(const Vtx& v) {   // chain start / padding sentinel: a zero edge (integer test: stays on the SALU)
+    return ((__float_as_uint(v.ex) | __float_as_uint(v.ey)) << 1) == 0u;
+}
+// The float64 refinement's view of the same chain: vertex k closes the segment (x1, y1) -> (x1 - ex, y1 - ey), with
+// (ex, ey) = p[k-1] - p[k] formed in float64 as the reference forms (x1 - x2), (y1 - y2) (car_env.py:171).  Chain starts and
+// padding have a zero edge.  32 bytes.
+struct SegD { double x1, y1, ex, ey; };
+// ... and per vertex k: the chain neighbours of segment k -- prev = the segment that shares its first endpoint, next = the one
+// that shares its second (0: none; a closed loop wraps) -- and h = 0.5 - (0.05 px) / |e_k|: a refined hit whose parameter t
+// satisfies |t - 0.5| < h lies at least 0.05 px inside the segment's ends.
+struct NbrH { double h; int prev_next, pad; };   // prev in the low 16 bits, next in the high 16; 16 bytes
 
 template <typename T> struct EnvParams {
     int64_t N;
     int lg;              // log2(lanes per env)
     int n_nominal;       // Car num_rays (car_env.py:227)
     int q;               // n // 4: stride of the collision rays (car_env.py:389)
+    int nc;              // how many there are: len(range(0, n, n // 4)) -- 4 when 4 divides n, up to 7 otherwise
     int step_deg;        // 360 // n (car_env.py:269)
     int R, D;            // actual ray count, obs dim 6 + R
     uint64_t colbits;    // bit r set <=> ray r < 64 is one of Car.check_collision's rays (r < n and r % (n // 4) == 0)
@@ -48,6 +66,9 @@ template <typename T> struct EnvParams {
     // offset from start_rot, so all directions live on a 360-entry lattice per track.
     const float2* __restrict__ dirtab;      // [n_tracks][361] (cos, sin) of radians(start_rot + j), float64 libm, rounded
     const float* __restrict__ rden;         // [n_tracks][361][nV] 1 / (ey*dx - ex*dy) exactly as the sweep computes it (device-built)
+    const double2* __restrict__ dirtab64;   // [n_tracks][361] the same lattice in float64 (libm): the refinement's ray directions
+    const SegD* __restrict__ seg64;         // F32 only: the wall chains for the refinement, indexed like vtx
+    const NbrH* __restrict__ nbrh;          // F32 only: chain neighbours / end margins, indexed like vtx
     const float* __restrict__ reset_obs;    // [n_tracks][D]
 };
 
@@ -76,26 +97,98 @@ __device__ __forceinline__ double cast_ref(double x1, double y1, double x2, doub
     return 1000.0;
 }
 
-// ---- float32: relative-coordinate cast -----------------------------------------------------------
-// a_k = p_k - pos (formed in float64, then rounded: small near a wall, so nearly exact where it matters),
-// c_k = cross(a_k, dir) = ay_k*dx - ax_k*dy, e = p1 - p2.  With the reference's t, u (car_env.py:171-176):
+// ---- F32 mode = float32 SELECTOR + float64 REFINEMENT ---------------------------------------------------------
+// a_k = p_k - pos (formed in float64, then rounded), c_k = cross(a_k, dir) = ay_k*dx - ax_k*dy, e = p1 - p2.  With the
+// reference's t, u (car_env.py:171-176; x3 - x4 = -dx, y3 - y4 = -dy):
 //   den = ey*dx - ex*dy = c1 - c2,   t = c1/den,   u = (ey*ax1 - ex*ay1)/den = un/den
-//   0 < t < 1  <=>  c1 and c2 have strictly opposite signs  <=>  c1*c2 < 0
-// and the distance |pos - pt| equals u because |dir| = 1.  den is formed from e directly (not as
-// c1 - c2, which cancels badly for short far segments).  Parallel (den == 0, :172): c1 == c2, no hit.
-// Returns min(best, hit distance): Ray.get_distance's running minimum (:203-207).
+//   0 < t < 1  <=>  c1 and c2 have strictly opposite signs,   and the distance |pos - pt| equals u because |dir| = 1.
+// The float32 wall sweep (env_step.hpp) only SELECTS, per ray, the wall segment with the smallest float32 u among the
+// segments it cannot exclude; the distance that is reported -- observation, `< 10.0` tests (car_env.py:387-390) -- is then
+// recomputed for that one segment in float64 from the float64 car position, the float64 direction lattice and the
+// float64 wall coordinates, under the reference's strict test `0 < t < 1 and u > 0` (car_env.py:178).
 __device__ __forceinline__ float cross_f(float ax, float ay, float dx, float dy) {
     return __builtin_fmaf(ay, dx, -(ax * dy));
 }
-__device__ __forceinline__ float cast_fast(float best, float c1, float c2, float un, float ex, float ey, float dx,
-                                           float dy) {
-    const float den = __builtin_fmaf(ey, dx, -(ex * dy));
-    const float u = un * __builtin_amdgcn_rcpf(den);
-    // u > 0 and u < best in ONE compare: for non-negative floats the unsigned bit patterns order like the values,
-    // and a negative (or NaN) u has the sign (or all exponent) bits set, i.e. compares above any finite best.
-    // (u == +0 passes where the reference's u > 0 rejects: the ray origin exactly on a wall line.)
-    const bool better = (c1 * c2 < 0.0f) & (__float_as_uint(u) < __float_as_uint(best));
-    return better ? u : best;
+
+// float64 numerators / denominator of Ray.cast (car_env.py:171-176) for the segment sg and the ray (px, py) + s (dx, dy)
+struct CastD { double den, tn, un; };
+__device__ __forceinline__ CastD cast_terms(const SegD& sg, const double px, const double py, const double dx, const double dy) {
+    const double ax = sg.x1 - px, ay = sg.y1 - py;                 // (x1 - x3), (y1 - y3)
+    CastD r;
+    r.den = __builtin_fma(sg.ey, dx, -(sg.ex * dy));               // :171
+    r.tn = __builtin_fma(ay, dx, -(ax * dy));                      // :175 numerator
+    r.un = __builtin_fma(sg.ey, ax, -(sg.ex * ay));                // :176 numerator
+    return r;
+}
+// 1 / den to ~2^-46 relative (v_rcp_f64 is good to ~2^-23; one Newton step squares that): the refined distance un * (1/den)
+// is then within 2e-14 relative -- 2e-11 px at the 1000 px ray limit -- of the exactly rounded quotient.
+__device__ __forceinline__ double rcp_d(const double den) {
+    const double r0 = __builtin_amdgcn_rcp(den);
+    return __builtin_fma(r0, __builtin_fma(-den, r0, 1.0), r0);
+}
+// the reference's `0 < t < 1 and u > 0` (car_env.py:178) on the numerators: no rounding of a quotient is involved
+__device__ __forceinline__ bool strict_hit(const CastD& c) {
+    return (c.tn * c.den > 0.0) & (__builtin_fabs(c.tn) < __builtin_fabs(c.den)) & (c.un * c.den > 0.0);
+}
+// Ray.get_distance (car_env.py:186-213) of ONE ray against a whole wall chain in float64: the refinement's exhaustive form,
+// taken only by the rare lanes whose float32 selection could not be certified (see refine_careful).  segs(1 .. n - 1).
+template <typename LoadSeg>
+__device__ __forceinline__ double scan_chain_d(const LoadSeg& segs, const int n, const double px, const double py, const double dx,
+                                               const double dy) {
+    double best = 1000.0;                                          // :198
+    for (int k = 1; k < n; ++k) {
+        const SegD sg = segs(k);
+        const CastD c = cast_terms(sg, px, py, dx, dy);
+        if (strict_hit(c)) best = __builtin_fmin(best, c.un * rcp_d(c.den));   // :203-207
+    }
+    return best;
+}
+// ---- the float64 distance of one ray, given the float32 sweep's selection `sel` (candidate bits: vertex index in the low bits;
+// index 0 = "nothing certified": the sweep found no segment within 1000.5 px, or it flagged the ray as too close to a vertex
+// or the car as too close to a wall line for float32 side tests to be trusted).
+//   refine_fast     the selected segment's hit in float64; `ok` iff it lies at least 0.05 px inside both ends of the segment
+//                   (|t - 0.5| < h) and in front of the car (u > 0) -- then it is the answer (for an unflagged ray the sweep's side
+//                   tests are certain, every wall the reference hits was a candidate, and two candidates can be ordered wrongly
+//                   by float32 only where two walls meet);
+//   refine_careful  everything else (a few 1e-4 of the rays): a hit within 0.05 px of a corner is compared with the two chain
+//                   neighbours under the strict test; with nothing certified the whole chain is scanned in float64.
+// Every decision is per lane and depends on that lane's ray only: the result does not depend on the launch geometry.
+// (segs(k) / nbrh(k): accessors of the chain tables -- global memory in the per-step kernel, LDS in the persistent ones)
+template <typename LoadSeg, typename LoadH>
+__device__ __forceinline__ double refine_fast(const int k, const LoadSeg& segs, const LoadH& hmargin, const double px, const double py,
+                                              const double dx, const double dy, bool& ok) {
+    const SegD sg = segs(k);                                       // (k == 0: a chain start, zero edge: den == 0, t is NaN -> !ok)
+    const CastD c = cast_terms(sg, px, py, dx, dy);
+    const double r = rcp_d(c.den);
+    const double u = c.un * r, t = c.tn * r;
+    ok = (__builtin_fabs(t - 0.5) < hmargin(k)) & (u > 0.0);
+    return __builtin_fmin(u, 1000.0);                              // :198,:210-211
+}
+template <typename LoadSeg, typename LoadNbr>
+__device__ __forceinline__ double refine_careful(const int k, const LoadSeg& segs, const LoadNbr& nbrh, const int nV, const double px,
+                                                 const double py, const double dx, const double dy) {
+    double d = 1000.0;
+    bool any = false;
+    if (k != 0) {
+        const CastD c = cast_terms(segs(k), px, py, dx, dy);
+        if (strict_hit(c)) {   // the selection is a hit: is a chain neighbour's hit (around the corner it lies next to) nearer?
+            d = c.un * rcp_d(c.den);
+            any = true;
+            const NbrH nh = nbrh(k);
+            const CastD cp = cast_terms(segs(nh.prev_next & 0xffff), px, py, dx, dy);   // (index 0 = no neighbour: zero edge, never a hit)
+            if (strict_hit(cp)) d = __builtin_fmin(d, cp.un * rcp_d(cp.den));
+            const CastD cn = cast_terms(segs((int)((unsigned)nh.prev_next >> 16)), px, py, dx, dy);
+            if (strict_hit(cn)) d = __builtin_fmin(d, cn.un * rcp_d(cn.den));
+        }
+    }
+    if (!any) d = scan_chain_d(segs, nV, px, py, dx, dy);
+    return __builtin_fmin(d, 1000.0);
+}
+// one ray against one segment (the reward gates: Car.check_collision(gate), car_env.py:387-390), float64, strict
+__device__ __forceinline__ double cast_d(const Seg& s, const double px, const double py, const double dx, const double dy) {
+    const SegD sg = {s.x1, s.y1, s.x1 - s.x2, s.y1 - s.y2};
+    const CastD c = cast_terms(sg, px, py, dx, dy);
+    return strict_hit(c) ? __builtin_fmin(c.un * rcp_d(c.den), 1000.0) : 1000.0;
 }
 
 template <typename T> struct Math;
@@ -145,14 +238,8 @@ template <> struct Math<float> {
         dx = cs.x;
         dy = cs.y;
     }
-    static __device__ __forceinline__ float cast(const Seg& sg, double px, double py, float dx, float dy) {
-        const float ax1 = (float)(sg.x1 - px), ay1 = (float)(sg.y1 - py);
-        const float ax2 = (float)(sg.x2 - px), ay2 = (float)(sg.y2 - py);
-        const float ex = (float)(sg.x1 - sg.x2), ey = (float)(sg.y1 - sg.y2);
-        const float un = __builtin_fmaf(ey, ax1, -(ex * ay1));
-        return cast_fast(1000.0f, cross_f(ax1, ay1, dx, dy), cross_f(ax2, ay2, dx, dy), un, ex, ey, dx, dy);
-    }
-    static __device__ __forceinline__ float norm_dist(float d) { return d * 0.001f; }
+    // observation entry of a refined distance: d / 1000 (car_env.py:593) as a float64 multiply, then the float32 cast (:595)
+    static __device__ __forceinline__ float norm_dist(double d) { return (float)(d * 0.001); }
     // float64 multiply by the reciprocal, then the float32 cast: equals (float)(v / d) unless v/d sits
     // within 1e-16 (relative) of a float32 rounding boundary
     static __device__ __forceinline__ float norm(double v, double d) { return (float)(v * (1.0 / d)); }

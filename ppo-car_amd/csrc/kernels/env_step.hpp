@@ -63,71 +63,168 @@ __device__ __forceinline__ unsigned and_or(unsigned a, unsigned m, unsigned c) {
 // global stores (__syncthreads() waits vmcnt(0) too: ~1 us of store latency per barrier in the rollout loop).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// ---- the float32 wall sweep: Car.get_distances (car_env.py:360-374) for the RPL ray slots of one lane against the vertex
-// chain `vt` (nV vertices, a multiple of 4), part `part` of PARTS.  dx / dy = the slots' directions, didx = their lattice
-// indices (TAB: rows of the 1/den table `rdl` in LDS).  bb = the slots' minimum distances as float bit patterns.
-// ADDR: didx holds the LDS BYTE ADDRESSES of the slots' 1/den rows (env_step_fast's direction table delivers them) instead of
-// lattice indices.
+// ------------------------------------------------------------------------------------------
+// The float32 wall sweep = the SELECTOR of Car.get_distances (car_env.py:360-374): for the RPL ray slots of one lane, which
+// wall segment is hit first.  The distances themselves are recomputed in float64 afterwards (refine_fast / refine_careful,
+// env_math.hpp).
+//
+// Per ray slot and chain vertex k (segment (k-1, k)) the sweep forms a CANDIDATE and keeps the unsigned minimum of the
+// candidates' bit patterns (for non-negative floats unsigned order is value order):
+//   c_k   = cross(a_k, dir), a_k = p_k - pos formed in float64 then rounded: one per VERTEX, shared by the two segments that meet
+//           there, so that a float32 ray cannot slip between two adjacent walls through their common corner;
+//   P     = clamp01(c_{k-1} * c_k): exactly 0 iff the endpoints do not lie strictly on the same side of the ray line -- the
+//           reference's 0 < t < 1 (car_env.py:178) up to the sign of a zero; one v_pk_mul_f32 with the clamp modifier per two slots;
+//   cand  = fma(un', 1/den, P), un' = 2^-40 * cross(e, a_{k-1}) with e the wall's unit vector (the reference's u numerator, :176,
+//           over the wall's length): u * 2^-40 for a crossed segment, >= 2^-40 ... 1 otherwise (any real distance is <=
+//           1000 * 2^-40 ~ 1e-9, and two same-side values whose product is below 1e-9 have raised a flag, below), negative (sign
+//           bit: above every non-negative pattern) for a hit behind the car (u < 0), NaN for a chain start (0 * inf); ONE v_fma_f32;
+//   bits  = (bits(cand) & ~idx_mask) | k: the vertex index rides in the low mantissa bits (5 for <= 32 vertices: the selector
+//           compares distances to 2^-19 relative; equal within that, the lower index wins); v_and_or_b32.
+// Beside the minimum the sweep keeps, per PAIR of ray slots, the smallest |c_k| it saw and, per lane, the smallest |un'|: a ray
+// that passes a vertex closer than the float32 rounding of c (tau_c), or a car closer to a wall's line than the rounding of un
+// (tau_u), is FLAGGED -- its side tests / the sign of u cannot be trusted -- and gets selection 0.
+// What comes out per slot: the index of the nearest crossed segment, or 0 = nothing certified (flagged, or nothing within
+// 1000.5 px).  For an unflagged ray every side test and every sign of u is the exact one, so every wall the reference hits was
+// a candidate and the selected one is a real hit; float32 can still ORDER two hits wrongly, but only if they lie within its
+// rounding of each other, i.e. where two walls meet: the refinement re-examines the chain neighbours whenever the refined hit
+// lies within 0.05 px of a segment end.  Selection 0 is resolved by a float64 scan of the whole chain under the reference's
+// strict test.  What is assumed of a track: two walls come within ~0.01 px of each other only at a shared vertex, and the
+// track fits 2000 px (the flag thresholds are priced from the car's distance to the track's bounding box).
+// ------------------------------------------------------------------------------------------
+constexpr unsigned SEL_INIT = 0x307a2000u;       // bits(1000.5f * 2^-40): "nothing selected" (vertex index 0 is a chain start)
+constexpr float SEL_SCALE = 0x1p-40f;
+
+__device__ __forceinline__ unsigned sgpr_const(const unsigned v) {   // a constant in an SGPR that the optimiser cannot fold into a literal
+    unsigned m;
+    asm("s_mov_b32 %0, %1" : "=s"(m) : "i"(v));
+    return m;
+}
+// (a & m) | k with the vertex index as an inline constant (unrolled sweeps) or in a VGPR (loops)
+template <int K> __device__ __forceinline__ unsigned and_or_k(unsigned a, unsigned m) {
+    static_assert(K >= 0 && K <= 64, "inline constant");
+    unsigned d;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(m), "n"(K));
+    return d;
+}
+// v_pk_mul_f32 with the clamp modifier: clamp01(a * b) on two ray slots at once
+__device__ __forceinline__ f32x2 pk_mul_clamp(const f32x2 a, const f32x2 b) {
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// The flag thresholds for a car at (npx, npy).  With u = 2^-24: a_k, dir and the unit edge are rounded to float32 (relative u
+// each), a cross product is a multiply and an fma, so |c~_k - c_k| and |un~ - un| stay below 8 u M_k, M_k = |a_k|_inf <= R = the
+// largest |coordinate difference| between the car and the track's bounding box.  tau = 16 u R = 2^-20 R.
+__device__ __forceinline__ float flag_threshold(const TrackHdr& h, const double npx, const double npy) {
+    const float px = (float)npx, py = (float)npy;
+    const float rx = fmaxf(fabsf(h.bx0 - px), fabsf(h.bx1 - px)), ry = fmaxf(fabsf(h.by0 - py), fabsf(h.by1 - py));
+    return fmaxf(rx, ry) * 0x1p-20f;
+}
+
+// The per-lane sweep state shared by the three forms of the sweep (scalar-load loop, unrolled, LDS copy of the chain)
+template <int RPL, bool TAB> struct Sweep {
+    static constexpr int NP = (RPL + 1) / 2;
+    f32x2 dx2[NP], dy2[NP];
+    float cm[NP];     // per pair of ray slots: the smallest |c_k| over the vertices seen
+    float um;         // the smallest |un'| over the segments seen
+    unsigned keep;
+    __device__ __forceinline__ void init(const float (&dx)[RPL], const float (&dy)[RPL], const unsigned idx_mask, unsigned (&bb)[2 * NP]) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {   // ray slots in PAIRS (packed fp32); an odd last slot is padded with a direction-0 ray
+            dx2[j] = (f32x2){dx[2 * j], 2 * j + 1 < RPL ? dx[2 * j + 1] : 0.0f};
+            dy2[j] = (f32x2){dy[2 * j], 2 * j + 1 < RPL ? dy[2 * j + 1] : 0.0f};
+            bb[2 * j] = bb[2 * j + 1] = SEL_INIT;
+            cm[j] = 1e30f;
+        }
+        um = 1e30f;
+        keep = ~idx_mask;
+    }
+    // side values of a vertex at (vx, vy): a = p - pos (float64, then rounded), c = cross(a, dir) per ray slot
+    __device__ __forceinline__ void side(const double vx, const double vy, const double npx, const double npy, float& ax, float& ay,
+                                         f32x2 (&c)[NP]) {
+        ax = (float)(vx - npx);
+        ay = (float)(vy - npy);
+        const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay};
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            c[j] = __builtin_elementwise_fma(ay2, dx2[j], -(ax2 * dy2[j]));
+            if (2 * j + 1 < RPL) cm[j] = __builtin_fminf(__builtin_fminf(cm[j], __builtin_fabsf(c[j].x)), __builtin_fabsf(c[j].y));   // v_min3_f32 |.|
+            else cm[j] = __builtin_fminf(cm[j], __builtin_fabsf(c[j].x));
+        }
+    }
+    // candidate values (before the index is merged in) of the segment closed by a vertex with unit edge (ex, ey) / scaled unit edge
+    // (exs, eys): (axp, ayp, cp) belong to the segment's first endpoint, c to the closing vertex; rd[s][I] = the slots' 1/den (TAB)
+    __device__ __forceinline__ void cand(const float ex, const float ey, const float exs, const float eys, const float axp,
+                                         const float ayp, const f32x2 (&cp)[NP], const f32x2 (&c)[NP], const f32x4 (&rd)[2 * NP],
+                                         const int I, float (&u)[2 * NP]) {
+        const float un = __builtin_fmaf(eys, axp, -(exs * ayp));
+        // (a chain start's record carries (exs, eys) = (1, 0) beside its zero edge: |un'| = |ayp| there -- never small -- and its
+        // candidate is still +-inf or NaN, (un' or 0) * (1 / 0))
+        um = __builtin_fminf(um, __builtin_fabsf(un));
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const f32x2 P = pk_mul_clamp(cp[j], c[j]);
+            float r0, r1 = 0.0f;
+            if constexpr (TAB) {
+                r0 = rd[2 * j][I];
+                if (2 * j + 1 < RPL) r1 = rd[2 * j + 1][I];
+            } else {
+                const f32x2 ex2 = {ex, ex}, ey2 = {ey, ey};
+                const f32x2 den = __builtin_elementwise_fma(ey2, dx2[j], -(ex2 * dy2[j]));  // = rden_build_kernel's
+                r0 = __builtin_amdgcn_rcpf(den.x);
+                r1 = __builtin_amdgcn_rcpf(den.y);
+            }
+            u[2 * j] = __builtin_fmaf(un, r0, P.x);
+            if (2 * j + 1 < RPL) u[2 * j + 1] = __builtin_fmaf(un, r1, P.y);   // (odd RPL: the last slot is padding)
+        }
+    }
+    // after the sweep: selection 0 ("nothing certified") for the slots of a flagged pair / of a flagged lane
+    __device__ __forceinline__ void apply_flags(const float tau, unsigned (&bb)[2 * NP]) const {
+        const bool lane_bad = um < tau * SEL_SCALE;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const bool bad = lane_bad | (cm[j] < tau);
+            bb[2 * j] = bad ? 0u : bb[2 * j];
+            if (2 * j + 1 < RPL) bb[2 * j + 1] = bad ? 0u : bb[2 * j + 1];
+        }
+    }
+};
+
+// Scalar-load loop form: vertex chain `vt` (nV vertices, a multiple of 4) read through wave-uniform scalar loads, part `part` of
+// PARTS.  dx / dy = the slots' directions, didx = their lattice indices (TAB: rows of the 1/den table `rdl` in LDS; ADDR: didx
+// holds the LDS BYTE ADDRESSES of those rows instead).  bb = the slots' selections (candidate bit patterns).
 template <int RPL, int PARTS, bool TAB, bool ADDR = false>
 __device__ __forceinline__ void wall_sweep_f32(const Vtx* vt, const int nV, const int part, const double npx, const double npy,
                                                const float (&dx)[RPL], const float (&dy)[RPL], const int (&didx)[RPL], lds_cfp rdl,
-                                               unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
-    // Ray slots in PAIRS (packed fp32: one v_pk_* per two rays); an odd last slot is padded with a direction-0 ray that
-    // never hits.  The running minimum is kept as the float's bit pattern: for non-negative floats unsigned order is
-    // value order, so   best = min_u32(best, u_bits | sign(-(c1*c2)))   accepts u exactly when the endpoints lie
-    // on strictly opposite sides of the ray line (c1*c2 < 0) AND 0 <= u < best -- a rejected candidate (same side,
-    // u negative, u NaN) has its sign or all exponent bits set and compares above any finite best.  Two VALU
-    // instructions per ray after the products instead of two compares and a select.
-    // (u == +0 passes where the reference's u > 0 rejects: the ray origin exactly on a wall line.)
+                                               const float tau, const unsigned idx_mask, unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
     constexpr int NP = (RPL + 1) / 2;
-    f32x2 dx2[NP], dy2[NP];
+    Sweep<RPL, TAB> sw;
+    sw.init(dx, dy, idx_mask, bb);
+    // vertex k closes the segment (k-1, k): (axp, ayp, cp) belong to k-1, c to k; rd = the slots' 1/den rows (TAB)
+    auto close = [&](const Vtx& v, const int k, const float axp, const float ayp, const f32x2 (&cp)[NP], const f32x2 (&c)[NP],
+                     const f32x4 (&rd)[2 * NP], const int I) {
+        float u[2 * NP];
+        sw.cand(v.ex, v.ey, v.exs, v.eys, axp, ayp, cp, c, rd, I, u);
+        unsigned kv;
+        asm("v_mov_b32 %0, %1" : "=v"(kv) : "s"(k));
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        dx2[j] = (f32x2){dx[2 * j], 2 * j + 1 < RPL ? dx[2 * j + 1] : 0.0f};
-        dy2[j] = (f32x2){dy[2 * j], 2 * j + 1 < RPL ? dy[2 * j + 1] : 0.0f};
-        bb[2 * j] = bb[2 * j + 1] = 0x447a0000u;  // 1000.0f, Ray.get_distance :198
-    }
-    const unsigned sgn = sign_mask();
-    // side values of vertex k: a_k = p_k - pos (float64, then rounded), c_k = cross(a_k, dir) per ray
-    auto side = [&](const Vtx& v, float& ax, float& ay, f32x2 (&c)[NP]) {
-        ax = (float)(v.x - npx);
-        ay = (float)(v.y - npy);
-        const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay};
-#pragma unroll
-        for (int j = 0; j < NP; ++j) c[j] = __builtin_elementwise_fma(ay2, dx2[j], -(ax2 * dy2[j]));
+        for (int s = 0; s < RPL; ++s) bb[s] = min(bb[s], and_or(__float_as_uint(u[s]), sw.keep, kv));
     };
-    // vertex k closes the segment (k-1, k): (axp, ayp, cp) belong to k-1, c to k; rdv = the slots' 1/den (TAB)
-    auto close = [&](const Vtx& v, const float axp, const float ayp, const f32x2 (&cp)[NP], const f32x2 (&c)[NP],
-                     const float (&rdv)[2 * NP]) {
-        const float un = __builtin_fmaf(v.ey, axp, -(v.ex * ayp));
-        const f32x2 un2 = {un, un}, ex2 = {v.ex, v.ex}, ey2 = {v.ey, v.ey};
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            f32x2 u;
-            if constexpr (TAB) {
-                u = (f32x2){un * rdv[2 * j], un * rdv[2 * j + 1]};
-            } else {
-                const f32x2 den = __builtin_elementwise_fma(ey2, dx2[j], -(ex2 * dy2[j]));  // = rden_build_kernel's
-                const f32x2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                u = un2 * rc;
-            }
-            const f32x2 t = cp[j] * (-c[j]);  // sign clear <=> strictly opposite sides
-            bb[2 * j] = min(bb[2 * j], and_or(__float_as_uint(t.x), sgn, __float_as_uint(u.x)));
-            bb[2 * j + 1] = min(bb[2 * j + 1], and_or(__float_as_uint(t.y), sgn, __float_as_uint(u.y)));
-        }
-    };
-    // Vertex GROUPS of four (the host pads every track's chain to a multiple of 4 with chain-break sentinels);
+    // Vertex GROUPS of four (the host pads every track's chain to a multiple of 4 with chain-start sentinels);
     // this part's groups [gbeg, gend).  The vertex before the range supplies the chain's previous side values.
     const int ngrp = nV >> 2;
     const int gbeg = PARTS > 1 ? ngrp * part / PARTS : 0;
     const int gend = PARTS > 1 ? ngrp * (part + 1) / PARTS : ngrp;
     // The "previous vertex" registers alternate between sets A and B (no copies); wave-uniform vertex records ->
     // s_load_dwordx8, prefetched one vertex ahead under the VALU work.
-    float axA = 0.0f, ayA = 0.0f, axB = 0.0f, ayB = 0.0f;
+    float axA = 1.0f, ayA = 1.0f, axB = 1.0f, ayB = 1.0f;   // (nonzero: the first chain start's |un'| must not look like a car on a wall line)
     f32x2 cA[NP], cB[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) cA[j] = cB[j] = (f32x2){0.0f, 0.0f};
-    if (PARTS > 1 && gbeg > 0) side(cload(vt + 4 * gbeg - 1), axA, ayA, cA);
+    if (PARTS > 1 && gbeg > 0) {
+        const Vtx v = cload(vt + 4 * gbeg - 1);
+        sw.side(v.x, v.y, npx, npy, axA, ayA, cA);
+    }
     // TAB: one 16-byte LDS read per ray slot and group = the slot's 1/den for the group's four vertices
     typedef const __attribute__((address_space(3))) f32x4* lds_row;
     lds_row rrow[2 * NP];
@@ -139,22 +236,19 @@ __device__ __forceinline__ void wall_sweep_f32(const Vtx* vt, const int nV, cons
         }
     }
     Vtx nxt = cload(vt + (gbeg < gend ? 4 * gbeg : 0));
-    // (A one-group-ahead prefetch of the table rows into a second register set was measured and dropped: inside the
-    // benchmark, with the wave priorities, it is 1.5 % slower than loading each group's rows at its top.)
 #define PC_VERTEX(RD, I, PAX, PAY, PC, NAX, NAY, NC)                                                                     \
     {                                                                                                                \
         const Vtx v = nxt;                                                                                           \
         nxt = cload(vt + (k + I + 1 < 4 * gend ? k + I + 1 : k + I));                                                \
-        side(v, NAX, NAY, NC);                                                                                       \
-        float rdv[2 * NP];                                                                                           \
-        _Pragma("unroll") for (int s = 0; s < 2 * NP; ++s) rdv[s] = TAB ? RD[s][I] : 0.0f;                          \
-        if (!v.brk) close(v, PAX, PAY, PC, NC, rdv);                                                                 \
+        sw.side(v.x, v.y, npx, npy, NAX, NAY, NC);                                                                   \
+        if (!vtx_brk(v)) close(v, k + I, PAX, PAY, PC, NC, RD, I);                                                   \
     }
     for (int gq = gbeg; gq < gend; ++gq) {
         f32x4 rd[2 * NP];
-        if constexpr (TAB) {
 #pragma unroll
-            for (int s = 0; s < 2 * NP; ++s) rd[s] = rrow[s][gq - gbeg];
+        for (int s = 0; s < 2 * NP; ++s) {
+            rd[s] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (TAB) rd[s] = rrow[s][gq - gbeg];
         }
         const int k = 4 * gq;
         PC_VERTEX(rd, 0, axA, ayA, cA, axB, ayB, cB)
@@ -163,58 +257,27 @@ __device__ __forceinline__ void wall_sweep_f32(const Vtx* vt, const int nV, cons
         PC_VERTEX(rd, 3, axB, ayB, cB, axA, ayA, cA)
     }
 #undef PC_VERTEX
+    sw.apply_flags(tau, bb);
 }
 
 // The same sweep for a track whose chain has exactly NGRP groups of four vertices, fully unrolled and WITHOUT a branch per
 // vertex (persistent big-form kernel: big_track has 24 walls in 2 loops = 26 chain vertices, padded to 28):
-//   * the 1/den rows are read with immediate offsets (no address arithmetic per group);
+//   * the 1/den rows are read with immediate offsets (no address arithmetic per group), the vertex index is an inline constant;
 //   * two consecutive vertices share one v_min3_u32 per ray slot instead of two v_min_u32;
-//   * a chain-break vertex is not skipped but computed: its edge (ex, ey) is (0, 0), so un = 0 and 1/den = +-inf (what
-//     rden_build_kernel's v_rcp_f32 of 0 stores, too), u = 0 * inf = NaN, whose bit pattern lies above every finite distance:
+//   * a chain-start vertex is not skipped but computed: its edge is (0, 0), so un' = 0 and 1/den = +-inf (what
+//     rden_build_kernel's v_rcp_f32 of 0 stores, too), 0 * inf + P = NaN, whose bit pattern lies above every finite distance:
 //     the candidate can never win the unsigned minimum.  Only the trailing padding pair(s) are skipped (n_chain).
 // The minimum is exact, so the result is the very same bits as wall_sweep_f32's.
 template <int RPL, bool TAB, int NGRP, bool ADDR = false>
 __device__ __forceinline__ void wall_sweep_unrolled(const Vtx* vt, const int n_chain, const double npx, const double npy,
                                                     const float (&dx)[RPL], const float (&dy)[RPL], const int (&didx)[RPL], lds_cfp rdl,
-                                                    unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
+                                                    const float tau, unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
     constexpr int NP = (RPL + 1) / 2, nV = 4 * NGRP;
-    f32x2 dx2[NP], dy2[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        dx2[j] = (f32x2){dx[2 * j], 2 * j + 1 < RPL ? dx[2 * j + 1] : 0.0f};
-        dy2[j] = (f32x2){dy[2 * j], 2 * j + 1 < RPL ? dy[2 * j + 1] : 0.0f};
-        bb[2 * j] = bb[2 * j + 1] = 0x447a0000u;  // 1000.0f, Ray.get_distance :198
-    }
-    const unsigned sgn = sign_mask();
-    auto side = [&](const Vtx& v, float& ax, float& ay, f32x2 (&c)[NP]) {
-        ax = (float)(v.x - npx);
-        ay = (float)(v.y - npy);
-        const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay};
-#pragma unroll
-        for (int j = 0; j < NP; ++j) c[j] = __builtin_elementwise_fma(ay2, dx2[j], -(ax2 * dy2[j]));
-    };
-    // candidates of the segment that vertex v closes: the hit distance's bits, with the sign bit set unless the segment's
-    // endpoints lie on strictly opposite sides of the ray line (as wall_sweep_f32's `close`)
-    auto cand = [&](const Vtx& v, const float axp, const float ayp, const f32x2 (&cp)[NP], const f32x2 (&c)[NP], const f32x4 (&rd)[2 * NP],
-                    const int I, unsigned (&q)[2 * NP]) {
-        const float un = __builtin_fmaf(v.ey, axp, -(v.ex * ayp));
-        const f32x2 un2 = {un, un}, ex2 = {v.ex, v.ex}, ey2 = {v.ey, v.ey};
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            f32x2 u;
-            if constexpr (TAB) {
-                u = (f32x2){un * rd[2 * j][I], 2 * j + 1 < RPL ? un * rd[2 * j + 1][I] : 0.0f};   // (odd RPL: the last slot is padding)
-            } else {
-                const f32x2 den = __builtin_elementwise_fma(ey2, dx2[j], -(ex2 * dy2[j]));
-                const f32x2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                u = un2 * rc;
-            }
-            const f32x2 t = cp[j] * (-c[j]);
-            q[2 * j] = and_or(__float_as_uint(t.x), sgn, __float_as_uint(u.x));
-            if (2 * j + 1 < RPL) q[2 * j + 1] = and_or(__float_as_uint(t.y), sgn, __float_as_uint(u.y));
-        }
-    };
-    float axA = 0.0f, ayA = 0.0f, axB = 0.0f, ayB = 0.0f;
+    static_assert(nV <= 32, "five index bits");
+    Sweep<RPL, TAB> sw;
+    sw.init(dx, dy, 31u, bb);
+    const unsigned keep = sgpr_const(0xffffffe0u);
+    float axA = 1.0f, ayA = 1.0f, axB = 1.0f, ayB = 1.0f;   // (nonzero: the first chain start's |un'| must not look like a car on a wall line)
     f32x2 cA[NP], cB[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) cA[j] = cB[j] = (f32x2){0.0f, 0.0f};
@@ -227,29 +290,35 @@ __device__ __forceinline__ void wall_sweep_unrolled(const Vtx* vt, const int n_c
             else rrow[s] = (lds_row)(rdl + __umul24(s < RPL ? didx[s] : 360, nV));
         }
     }
+    auto pair = [&](auto KC, const f32x4 (&rd)[2 * NP]) {   // vertices K, K + 1 (K even): sets A -> B -> A
+        constexpr int K = decltype(KC)::value, I = K & 3;
+        const Vtx v0 = cload(vt + K), v1 = cload(vt + K + 1);
+        float u0[2 * NP], u1[2 * NP];
+        sw.side(v0.x, v0.y, npx, npy, axB, ayB, cB);
+        sw.cand(v0.ex, v0.ey, v0.exs, v0.eys, axA, ayA, cA, cB, rd, I, u0);
+        sw.side(v1.x, v1.y, npx, npy, axA, ayA, cA);
+        sw.cand(v1.ex, v1.ey, v1.exs, v1.eys, axB, ayB, cB, cA, rd, I + 1, u1);
 #pragma unroll
-    for (int gq = 0; gq < NGRP; ++gq) {
+        for (int s = 0; s < RPL; ++s)
+            bb[s] = min(min(bb[s], and_or_k<K>(__float_as_uint(u0[s]), keep)), and_or_k<K + 1>(__float_as_uint(u1[s]), keep));   // v_min3_u32
+    };
+    auto group = [&](auto GC) {
+        constexpr int gq = decltype(GC)::value;
         f32x4 rd[2 * NP];
-        if constexpr (TAB) {
 #pragma unroll
-            for (int s = 0; s < RPL; ++s) rd[s] = rrow[s][gq];
+        for (int s = 0; s < 2 * NP; ++s) {
+            rd[s] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (TAB) { if (s < RPL) rd[s] = rrow[s][gq]; }
         }
-#pragma unroll
-        for (int I = 0; I < 4; I += 2) {
-            if (gq == NGRP - 1 && 4 * gq + I >= n_chain) break;   // (wave-uniform; only the last group can hold a padding pair)
-            const Vtx v0 = cload(vt + 4 * gq + I), v1 = cload(vt + 4 * gq + I + 1);
-            unsigned q0[2 * NP], q1[2 * NP];
-            side(v0, axB, ayB, cB);
-            cand(v0, axA, ayA, cA, cB, rd, I, q0);
-            side(v1, axA, ayA, cA);
-            cand(v1, axB, ayB, cB, cA, rd, I + 1, q1);
-#pragma unroll
-            for (int s = 0; s < RPL; ++s) bb[s] = min(min(bb[s], q0[s]), q1[s]);   // v_min3_u32
-        }
+        pair(std::integral_constant<int, 4 * gq>{}, rd);
+        if (gq < NGRP - 1 || 4 * gq + 2 < n_chain)   // (wave-uniform; only the last group can hold a padding pair)
+            pair(std::integral_constant<int, 4 * gq + 2>{}, rd);
         // one scheduling region per group: left alone, the scheduler hoists every group's table rows and vertex records
         // to the top of the 1300-instruction block and spills
         __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, NGRP>{});
+    sw.apply_flags(tau, bb);
 }
 
 // One CarEnv.step (car_env.py:693-760) + TransformReward + same-step auto-reset for the env whose state the
@@ -312,8 +381,9 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
     const double npx = opx + nvx, npy = opy + nvy;  // :459
 
     // ---- my rays: directions at the new pose; gate test at the OLD pose for the collision rays
-    T dx[RPL], dy[RPL], best[RPL];
-    int didx[RPL];  // F32: the slots' direction-lattice indices
+    T dx[RPL], dy[RPL];
+    double best[RPL];   // min(1000, distance) per ray slot (F32: the float64 refinement of the float32 sweep's selection)
+    int didx[RPL];      // F32: the slots' direction-lattice indices
     bool gate_hit = false;
     uint64_t colmask = 0;  // which of my ray slots are collision rays
     const Seg gate = p.segs[h.gate_off + st.next];  // only gate[next] can fire (the oracle does the full scan)
@@ -342,7 +412,7 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
                 dy[s] = 0;
             }
         }
-        best[s] = (T)1000;  // Ray.get_distance :198
+        best[s] = 1000.0;  // Ray.get_distance :198
         // Car.check_collision's rays: r in range(0, n, n // 4) (:389) -- nominal n, not R
         // (host-built bitmask for rays < 64: a runtime modulo per ray slot costs ~20 VALU instructions)
         const bool is_col = valid & (ray < 64 ? (bool)((p.colbits >> ray) & 1) : ((ray < p.n_nominal) & (ray % p.q == 0)));
@@ -356,18 +426,19 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
         }
     }
     if constexpr (sizeof(T) == 4) {
-        // Car.get_passed_gate (:394-408): the four collision rays j * (n // 4) at the PREVIOUS pose against gate[next].  Any
-        // lane can cast any ray (directions come from the lattice table), so the four casts are dealt round-robin to the
-        // env's lanes instead of falling on whichever lane owns those rays (with rays strided over the lanes: all on lane 0).
+        // Car.get_passed_gate (:394-408): the collision rays j * (n // 4), j < nc (four when 4 divides n; range(0, n, n // 4) has up
+        // to seven otherwise) at the PREVIOUS pose against gate[next], cast in float64 (cast_d: one segment, strict test).  Any
+        // lane can cast any ray (directions come from the lattice table), so the casts are dealt round-robin to the env's lanes
+        // instead of falling on whichever lane owns those rays (with rays strided over the lanes: all on lane 0).
         const int k5o = 5 * Math<float>::mod72(st.k);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < 7; ++jj) {
             const int j = g + jj * G;
-            if (jj * G < 4) {  // uniform
-                const unsigned m = (unsigned)(k5o + (j < 4 ? j : 0) * p.q * p.step_deg);
-                const float2 cs = p.dirtab[h.dir_off + (int)min(m, m - 360u)];
-                const bool hit = Math<float>::cast(gate, opx, opy, cs.x, cs.y) < 10.0f;  // :387,:390
-                gate_hit |= hit & (j < 4);
+            if (jj * G < p.nc) {  // uniform
+                const unsigned m = (unsigned)(k5o + (j < p.nc ? j : 0) * p.q * p.step_deg);
+                const double2 cs = p.dirtab64[h.dir_off + (int)min(m, m - 360u)];
+                const bool hit = cast_d(gate, opx, opy, cs.x, cs.y) < 10.0;  // :387,:390
+                gate_hit |= hit & (j < p.nc);
             }
         }
     }
@@ -375,9 +446,62 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
     // ---- wall sweep: Car.get_distances (:360-374) -- also serves Car.check_collision (E2)
     if constexpr (sizeof(T) == 4) {
         unsigned bb[2 * ((RPL + 1) / 2)];
-        wall_sweep_f32<RPL, PARTS, TAB>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dx, dy, didx, rdl, bb);
+        wall_sweep_f32<RPL, PARTS, TAB>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dx, dy, didx, rdl, flag_threshold(h, npx, npy),
+                                        h.idx_mask, bb);
+        if constexpr (PARTS > 1) {   // the parts' selections meet in LDS (the minimum is exact: the same bits as one wave sweeping everything)
+            unsigned* ex = reinterpret_cast<unsigned*>(exch);
 #pragma unroll
-        for (int s = 0; s < RPL; ++s) best[s] = __uint_as_float(bb[s]);
+            for (int s = 0; s < RPL; ++s) {
+                const int ray = g + s * G;
+                if (ray < p.R) ex[ray * PARTS + part] = bb[s];
+            }
+            lds_barrier();
+#pragma unroll
+            for (int s = 0; s < RPL; ++s) {
+                const int ray = g + s * G;
+                if (ray < p.R) {
+                    unsigned m = ex[ray * PARTS];
+#pragma unroll
+                    for (int q = 1; q < PARTS; ++q) m = min(m, ex[ray * PARTS + q]);
+                    bb[s] = m;
+                }
+            }
+        }
+        // the float64 refinement of every slot's selection (refine_fast / refine_careful, env_math.hpp)
+        const SegD* sg64 = p.seg64 + h.vtx_off;
+        const NbrH* nb = p.nbrh + h.vtx_off;
+        const auto segs = [sg64](const int k) { return sg64[k]; };
+        const auto nbrs = [nb](const int k) { return nb[k]; };
+        const auto hmar = [nb](const int k) { return nb[k].h; };
+        uint64_t todo = 0;   // bit s: slot s needs the careful path (RPL <= 33)
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            if (g + s * G < p.R) {
+                const double2 d64 = p.dirtab64[h.dir_off + didx[s]];
+                bool ok;
+                best[s] = refine_fast((int)(bb[s] & h.idx_mask), segs, hmar, npx, npy, d64.x, d64.y, ok);
+                todo |= ok ? 0ull : 1ull << s;
+            }
+        }
+        // the rare rest, one slot of one lane at a time through ONE copy of the careful code (select chains instead of
+        // dynamically indexed registers)
+        while (__builtin_amdgcn_ballot_w64(todo != 0) != 0) {
+            const int s0 = todo ? __builtin_ctzll(todo) : -1;
+            unsigned sel = 0;
+            int di = 360;
+#pragma unroll
+            for (int s = 0; s < RPL; ++s) {
+                sel = s == s0 ? bb[s] : sel;
+                di = s == s0 ? didx[s] : di;
+            }
+            if (s0 >= 0) {
+                const double2 d64 = p.dirtab64[h.dir_off + di];
+                const double d = refine_careful((int)(sel & h.idx_mask), segs, nbrs, h.nV, npx, npy, d64.x, d64.y);
+#pragma unroll
+                for (int s = 0; s < RPL; ++s) best[s] = s == s0 ? d : best[s];
+                todo &= todo - 1;
+            }
+        }
     } else {
         const Seg* walls = p.segs + h.wall_off;
         Seg nxt = cload(walls);
@@ -391,28 +515,10 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
             }
         }
     }
-    if constexpr (PARTS > 1) {
-#pragma unroll
-        for (int s = 0; s < RPL; ++s) {
-            const int ray = g + s * G;
-            if (ray < p.R) exch[ray * PARTS + part] = (float)best[s];
-        }
-        lds_barrier();
-#pragma unroll
-        for (int s = 0; s < RPL; ++s) {
-            const int ray = g + s * G;
-            if (ray < p.R) {
-                float m = exch[ray * PARTS];
-#pragma unroll
-                for (int q = 1; q < PARTS; ++q) m = fminf(m, exch[ray * PARTS + q]);
-                best[s] = (T)m;
-            }
-        }
-    }
     const bool store = PARTS == 1 || part == 0;
     bool wall_hit = false;
 #pragma unroll
-    for (int s = 0; s < RPL; ++s) wall_hit |= ((colmask >> s) & 1) & (best[s] < (T)10);  // :390
+    for (int s = 0; s < RPL; ++s) wall_hit |= ((colmask >> s) & 1) & (best[s] < 10.0);  // :390
 
     // ---- any() over the env's lanes: xor butterfly inside the 2^lg-lane group
     int flags = (gate_hit ? 1 : 0) | (wall_hit ? 2 : 0);
@@ -584,15 +690,21 @@ __global__ void reset_obs_kernel(const EnvParams<T> p, int n_tracks, float* __re
     o[5] = (float)sh;
     bool hit = false;
     for (int ray = 0; ray < p.R; ++ray) {
-        T dx, dy;
-        Math<T>::ray_dir(p, h, ray, 0, h.start_rot, dx, dy);
-        T best = (T)1000;
-        for (int w = 0; w < h.S; ++w) {
-            const T d = Math<T>::cast(p.segs[h.wall_off + w], npx, npy, dx, dy);
-            if (d < best) best = d;
+        double best = 1000.0;
+        if constexpr (sizeof(T) == 4) {   // F32: the float64 chain scan the step's refinement falls back to (same arithmetic per segment)
+            const double2 d64 = p.dirtab64[h.dir_off + Math<float>::dir_index(p, 0, ray)];
+            const SegD* sg64 = p.seg64 + h.vtx_off;
+            best = scan_chain_d([sg64](const int k) { return sg64[k]; }, h.nV, npx, npy, d64.x, d64.y);
+        } else {
+            T dx, dy;
+            Math<T>::ray_dir(p, h, ray, 0, h.start_rot, dx, dy);
+            for (int w = 0; w < h.S; ++w) {
+                const T d = Math<T>::cast(p.segs[h.wall_off + w], npx, npy, dx, dy);
+                if (d < best) best = d;
+            }
         }
         o[6 + ray] = Math<T>::norm_dist(best);
-        if (ray < p.n_nominal && ray % p.q == 0 && best < (T)10) hit = true;
+        if (ray < p.n_nominal && ray % p.q == 0 && best < 10.0) hit = true;
     }
     start_collides[trk] = hit ? 1 : 0;
 }

@@ -57,16 +57,26 @@ struct FastTabs {        // LDS addresses of the staged tables (wave-uniform)
     lds_ci wrap;         // [74] j - 1 reduced mod 72, j = 0..73
     lds_cd2 act;         // [16] ActLut records, 32 bytes each: (thrust, fric) then (dk, fwd)
     lds_cd4 gates;       // [G] (x1, y1, x2, y2)
-    lds_f4c dir;         // [720] direction lattice, twice around: (cos, sin, LDS byte address of the direction's 1/den row, -)
+    lds_f4c dir;         // [720] direction lattice, twice around: (cos, sin, LDS byte address of the direction's 1/den row,
+                         //       LDS byte address of the direction's float64 (cos, sin) in dir64)
     lds_cfp reset;       // [D] the track's reset observation
-    lds_cd2 vtx;         // [nV] the wall vertex chain, 32 bytes each: (x, y) float64 then (ex, ey, brk, -) -- small form only (nV <= 64)
+    lds_cd2 vtx;         // [nV] the wall vertex chain, 32 bytes each: (x, y) float64 then (ex, ey, exs, eys) -- small form only (nV <= 64)
+    lds_cd4 seg;         // [nV] the chain for the float64 refinement: (x1, y1, ex, ey) float64 per closing vertex (nV <= 64)
+    lds_cd2 nbr;         // [nV] NbrH records, 16 bytes each: (h float64, then prev | next << 16, -)
+    lds_cd2 dir64;       // [360] (cos, sin) float64 of the direction lattice
     lds_cfp rden;        // [361][nV] or unused
 };
+// Region offsets in floats.  The big form sweeps its chain through scalar loads and never reads `vtx`: its `seg` table takes that
+// region (the 33-ray shape has no 2 KB to spare); the small form keeps both.
 constexpr int FT_HEAD = 0, FT_WRAP = FT_HEAD + 72 * 4, FT_ACT = FT_WRAP + 76, FT_GATES = FT_ACT + 16 * 8,
               FT_DIR = FT_GATES + TAB_MAX_GATES * 8, FT_RESET = FT_DIR + 720 * 4, FT_VTX = FT_RESET + 40,
-              FT_VTX_MAX = 64, FT_FLOATS = FT_VTX + FT_VTX_MAX * 8;
-static_assert(FT_ACT % 4 == 0 && FT_GATES % 4 == 0 && FT_DIR % 4 == 0 && FT_VTX % 4 == 0, "16-byte aligned records");
+              FT_VTX_MAX = 64, FT_NBR = FT_VTX + FT_VTX_MAX * 8, FT_DIR64 = FT_NBR + FT_VTX_MAX * 4, FT_SEG_SMALL = FT_DIR64 + 360 * 4,
+              FT_FLOATS_BIG = FT_SEG_SMALL, FT_FLOATS_SMALL = FT_SEG_SMALL + FT_VTX_MAX * 8;
+__host__ __device__ constexpr int ft_floats(bool small) { return small ? FT_FLOATS_SMALL : FT_FLOATS_BIG; }
+static_assert(FT_ACT % 4 == 0 && FT_GATES % 4 == 0 && FT_DIR % 4 == 0 && FT_VTX % 4 == 0 && FT_NBR % 4 == 0 && FT_DIR64 % 4 == 0 &&
+              FT_SEG_SMALL % 4 == 0, "16-byte aligned records");
 
+template <bool SMALL>
 __device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p, const TrackHdr& h0, const int trk, float* sTab,
                                                       const int tid, const int nthreads) {
     int* dst = reinterpret_cast<int*>(sTab);
@@ -88,19 +98,31 @@ __device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p,
     const int* gates = reinterpret_cast<const int*>(p.segs + h0.gate_off);
     for (int i = tid; i < h0.G * 8; i += nthreads) dst[FT_GATES + i] = gates[i];
     // The direction lattice twice around (a ray's index 5 k + step_deg * ray < 720 needs no reduction mod 360), each entry
-    // with the LDS byte address of its row of the 1/den table: one 16-byte read per ray slot replaces the index arithmetic.
+    // with the LDS byte addresses of its row of the 1/den table and of its float64 twin: one 16-byte read per ray slot
+    // replaces the index arithmetic.
+    constexpr int FT_SEG = SMALL ? FT_SEG_SMALL : FT_VTX;
     const float2* dir = p.dirtab + h0.dir_off;
-    const unsigned rden_base = (unsigned)(size_t)(lds_cfp)(sTab + FT_FLOATS);
+    const unsigned rden_base = (unsigned)(size_t)(lds_cfp)(sTab + ft_floats(SMALL));
+    const unsigned d64_base = (unsigned)(size_t)(lds_cfp)(sTab + FT_DIR64);
     for (int i = tid; i < 720; i += nthreads) {
         const int j = i < 360 ? i : i - 360;
         const float2 cs = dir[j];
-        *reinterpret_cast<f32x4*>(sTab + FT_DIR + 4 * i) = (f32x4){cs.x, cs.y, __uint_as_float(rden_base + (unsigned)(j * h0.nV) * 4u), 0.0f};
+        *reinterpret_cast<f32x4*>(sTab + FT_DIR + 4 * i) =
+            (f32x4){cs.x, cs.y, __uint_as_float(rden_base + (unsigned)(j * h0.nV) * 4u), __uint_as_float(d64_base + 16u * (unsigned)j)};
     }
+    const int* d64 = reinterpret_cast<const int*>(p.dirtab64 + h0.dir_off);
+    for (int i = tid; i < 360 * 4; i += nthreads) dst[FT_DIR64 + i] = d64[i];
     const int* ro = reinterpret_cast<const int*>(p.reset_obs + (size_t)trk * p.D);
     for (int i = tid; i < p.D; i += nthreads) dst[FT_RESET + i] = ro[i];
     if (h0.nV <= FT_VTX_MAX) {
-        const int* vs = reinterpret_cast<const int*>(p.vtx + h0.vtx_off);
-        for (int i = tid; i < h0.nV * 8; i += nthreads) dst[FT_VTX + i] = vs[i];
+        if constexpr (SMALL) {
+            const int* vs = reinterpret_cast<const int*>(p.vtx + h0.vtx_off);
+            for (int i = tid; i < h0.nV * 8; i += nthreads) dst[FT_VTX + i] = vs[i];
+        }
+        const int* sg = reinterpret_cast<const int*>(p.seg64 + h0.vtx_off);
+        for (int i = tid; i < h0.nV * 8; i += nthreads) dst[FT_SEG + i] = sg[i];
+        const int* nb = reinterpret_cast<const int*>(p.nbrh + h0.vtx_off);
+        for (int i = tid; i < h0.nV * 4; i += nthreads) dst[FT_NBR + i] = nb[i];
     }
     FastTabs ft;
     ft.head = (lds_cd2)(sTab + FT_HEAD);
@@ -110,7 +132,10 @@ __device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p,
     ft.dir = (lds_f4c)(sTab + FT_DIR);
     ft.reset = (lds_cfp)(sTab + FT_RESET);
     ft.vtx = (lds_cd2)(sTab + FT_VTX);
-    ft.rden = (lds_cfp)(sTab + FT_FLOATS);
+    ft.seg = (lds_cd4)(sTab + FT_SEG);
+    ft.nbr = (lds_cd2)(sTab + FT_NBR);
+    ft.dir64 = (lds_cd2)(sTab + FT_DIR64);
+    ft.rden = (lds_cfp)(sTab + ft_floats(SMALL));
     return ft;
 }
 
@@ -142,59 +167,30 @@ __device__ __forceinline__ FastLane fast_lane(const EnvParams<float>& p, const F
 // exchange with the neighbouring lane (the other lane of the env): DPP quad_perm [1, 0, 3, 2], one VALU instruction
 __device__ __forceinline__ int swap_pair(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false); }
 
-// The float32 wall sweep of the SMALL persistent form: part `part` of PARTS of the vertex chain, read from its LDS copy
-// (ft.vtx) instead of through scalar loads.  A part is only one or two groups of four vertices, so what counts is latency, not
-// issue slots: a group's vertex records and 1/den rows are all requested at its top, the four vertices' side values are
-// independent instruction chains, chain-break vertices are computed rather than branched around (their candidates are NaN: see
-// wall_sweep_unrolled), and two vertices share a v_min3_u32.  Same bits as wall_sweep_f32<RPL, PARTS, TAB>.
+// The float32 wall sweep (selector: see env_step.hpp) of the SMALL persistent form: part `part` of PARTS of the vertex chain, read
+// from its LDS copy (ft.vtx) instead of through scalar loads.  A part is only one or two groups of four vertices, so what counts
+// is latency, not issue slots: a group's vertex records and 1/den rows are all requested at its top, the four vertices' side
+// values are independent instruction chains, chain-start vertices are computed rather than branched around (their candidates
+// are NaN: see wall_sweep_unrolled), and two vertices share a v_min3_u32.  Same bits as wall_sweep_f32<RPL, PARTS, TAB>.
 template <int RPL, int PARTS, bool TAB, bool ADDR = false>
 __device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const int part, const double npx, const double npy,
                                                const float (&dx)[RPL], const float (&dy)[RPL], const int (&didx)[RPL], lds_cfp rdl,
-                                               unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
+                                               const float tau, const unsigned idx_mask, unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
     constexpr int NP = (RPL + 1) / 2;
     typedef const __attribute__((address_space(3))) f32x4* lds_f4;
-    f32x2 dx2[NP], dy2[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        dx2[j] = (f32x2){dx[2 * j], 2 * j + 1 < RPL ? dx[2 * j + 1] : 0.0f};
-        dy2[j] = (f32x2){dy[2 * j], 2 * j + 1 < RPL ? dy[2 * j + 1] : 0.0f};
-        bb[2 * j] = bb[2 * j + 1] = 0x447a0000u;  // 1000.0f, Ray.get_distance :198
-    }
-    const unsigned sgn = sign_mask();
-    auto side = [&](const f64x2 xy, float& ax, float& ay, f32x2 (&c)[NP]) {
-        ax = (float)(xy.x - npx);
-        ay = (float)(xy.y - npy);
-        const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay};
-#pragma unroll
-        for (int j = 0; j < NP; ++j) c[j] = __builtin_elementwise_fma(ay2, dx2[j], -(ax2 * dy2[j]));
-    };
-    auto cand = [&](const float ex, const float ey, const float axp, const float ayp, const f32x2 (&cp)[NP], const f32x2 (&c)[NP],
-                    const f32x4 (&rd)[2 * NP], const int I, unsigned (&q)[2 * NP]) {
-        const float un = __builtin_fmaf(ey, axp, -(ex * ayp));
-        const f32x2 un2 = {un, un}, ex2 = {ex, ex}, ey2 = {ey, ey};
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            f32x2 u;
-            if constexpr (TAB) {
-                u = (f32x2){un * rd[2 * j][I], 2 * j + 1 < RPL ? un * rd[2 * j + 1][I] : 0.0f};   // (odd RPL: the last slot is padding)
-            } else {
-                const f32x2 den = __builtin_elementwise_fma(ey2, dx2[j], -(ex2 * dy2[j]));
-                const f32x2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                u = un2 * rc;
-            }
-            const f32x2 t = cp[j] * (-c[j]);
-            q[2 * j] = and_or(__float_as_uint(t.x), sgn, __float_as_uint(u.x));
-            if (2 * j + 1 < RPL) q[2 * j + 1] = and_or(__float_as_uint(t.y), sgn, __float_as_uint(u.y));
-        }
-    };
+    Sweep<RPL, TAB> sw;
+    sw.init(dx, dy, idx_mask, bb);
     const int ngrp = nV >> 2;
     const int gbeg = PARTS > 1 ? ngrp * part / PARTS : 0;
     const int gend = PARTS > 1 ? ngrp * (part + 1) / PARTS : ngrp;
-    float axA = 0.0f, ayA = 0.0f, axB = 0.0f, ayB = 0.0f;
+    float axA = 1.0f, ayA = 1.0f, axB = 1.0f, ayB = 1.0f;   // (nonzero: see wall_sweep_unrolled)
     f32x2 cA[NP], cB[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) cA[j] = cB[j] = (f32x2){0.0f, 0.0f};
-    if (PARTS > 1 && gbeg > 0) side(vt[2 * (4 * gbeg - 1)], axA, ayA, cA);   // the vertex before the range: the chain's previous side values
+    if (PARTS > 1 && gbeg > 0) {   // the vertex before the range: the chain's previous side values
+        const f64x2 xy = vt[2 * (4 * gbeg - 1)];
+        sw.side(xy.x, xy.y, npx, npy, axA, ayA, cA);
+    }
     lds_f4 rrow[2 * NP];
     if constexpr (TAB) {
 #pragma unroll
@@ -205,28 +201,33 @@ __device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const i
     }
     for (int gq = gbeg; gq < gend; ++gq) {
         f32x4 rd[2 * NP];
-        if constexpr (TAB) {
 #pragma unroll
-            for (int s = 0; s < RPL; ++s) rd[s] = rrow[s][gq];
+        for (int s = 0; s < 2 * NP; ++s) {
+            rd[s] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (TAB) { if (s < RPL) rd[s] = rrow[s][gq]; }
         }
         f64x2 xy[4];
         f32x4 ee[4];
 #pragma unroll
         for (int I = 0; I < 4; ++I) {
             xy[I] = vt[2 * (4 * gq + I)];
-            ee[I] = *(lds_f4)(vt + 2 * (4 * gq + I) + 1);
+            ee[I] = *(lds_f4)(vt + 2 * (4 * gq + I) + 1);      // (ex, ey, exs, eys)
         }
+        unsigned kv;
+        asm("v_mov_b32 %0, %1" : "=v"(kv) : "s"(4 * gq));
 #pragma unroll
         for (int I = 0; I < 4; I += 2) {
-            unsigned q0[2 * NP], q1[2 * NP];
-            side(xy[I], axB, ayB, cB);
-            cand(ee[I].x, ee[I].y, axA, ayA, cA, cB, rd, I, q0);
-            side(xy[I + 1], axA, ayA, cA);
-            cand(ee[I + 1].x, ee[I + 1].y, axB, ayB, cB, cA, rd, I + 1, q1);
+            float u0[2 * NP], u1[2 * NP];
+            sw.side(xy[I].x, xy[I].y, npx, npy, axB, ayB, cB);
+            sw.cand(ee[I].x, ee[I].y, ee[I].z, ee[I].w, axA, ayA, cA, cB, rd, I, u0);
+            sw.side(xy[I + 1].x, xy[I + 1].y, npx, npy, axA, ayA, cA);
+            sw.cand(ee[I + 1].x, ee[I + 1].y, ee[I + 1].z, ee[I + 1].w, axB, ayB, cB, cA, rd, I + 1, u1);
 #pragma unroll
-            for (int s = 0; s < RPL; ++s) bb[s] = min(min(bb[s], q0[s]), q1[s]);   // v_min3_u32
+            for (int s = 0; s < RPL; ++s)   // (index = 4 gq + I: the group's base in a register, I as an inline constant; v_min3_u32)
+                bb[s] = min(min(bb[s], and_or(__float_as_uint(u0[s]), sw.keep, kv + I)), and_or(__float_as_uint(u1[s]), sw.keep, kv + I + 1));
         }
     }
+    sw.apply_flags(tau, bb);
 }
 
 // LG = log2 of the lanes per env (1: K9, a wave owns 32 envs; 2: K9s, 16 envs per wave).  PARTS > 1 (K9s): the wall sweep is split
@@ -272,21 +273,25 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
             m += fl.rstep;
         }
     }
-    // ---- Car.get_passed_gate (:394-408): the four collision rays at the PREVIOUS pose against gate[next], dealt over the lanes
+    // ---- Car.get_passed_gate (:394-408): the four collision rays at the PREVIOUS pose against gate[next], dealt over the lanes,
+    // cast in float64 (the lattice entry names its float64 twin)
     const f64x4 gv = ft.gates[st.next];
     const Seg gate = {gv.x, gv.y, gv.z, gv.w};
     const int k80o = 80 * k72;
     bool gate_hit = false;
 #pragma unroll
     for (int jj = 0; jj < 4 / G; ++jj) {
-        const f32x4 cs = *(lds_f4c)(size_t)(unsigned)(k80o + gq[jj]);
-        gate_hit |= Math<float>::cast(gate, opx, opy, cs.x, cs.y) < 10.0f;  // :387,:390
+        const unsigned a64 = (unsigned)*(lds_ci)(size_t)(unsigned)(k80o + gq[jj] + 12);
+        const f64x2 cs = *(lds_cd2)(size_t)a64;
+        gate_hit |= cast_d(gate, opx, opy, cs.x, cs.y) < 10.0;  // :387,:390
     }
-    // ---- wall sweep.  More than 12 ray slots per lane (33 rays: 17) are swept in TWO passes over the vertex chain, 9 + 8
-    // slots: one pass would need ~40 more registers than the 256 a wave has at two waves per SIMD (it spilled 67 of them
-    // to scratch); the second pass repeats only the per-vertex position arithmetic (4 of ~50 instructions per vertex and pass).
+    // ---- wall sweep (float32 selector, env_step.hpp).  More than 12 ray slots per lane (33 rays: 17) are swept in TWO passes over
+    // the vertex chain, 9 + 8 slots: one pass would need ~40 more registers than the 256 a wave has at two waves per SIMD (it
+    // spilled 67 of them to scratch); the second pass repeats only the per-vertex position arithmetic (4 of ~50 instructions per
+    // vertex and pass).
     constexpr int R1 = RPL > 12 ? (RPL + 1) / 2 : RPL, R2 = RPL - R1;
     unsigned bb[RPL + 2];
+    const float tau = flag_threshold(h, npx, npy);
     PC_STAMP(4)
     {
         const float(&dxa)[R1] = *reinterpret_cast<const float(*)[R1]>(&dx[0]);
@@ -294,11 +299,11 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         const int(&dia)[R1] = *reinterpret_cast<const int(*)[R1]>(&didx[0]);
         unsigned ba[2 * ((R1 + 1) / 2)];
         if (PARTS > 1)                  // small form: latency-oriented sweep over the LDS copy of the chain
-            wall_sweep_lds<R1, PARTS, TAB, true>(ft.vtx, h.nV, part, npx, npy, dxa, dya, dia, ft.rden, ba);
+            wall_sweep_lds<R1, PARTS, TAB, true>(ft.vtx, h.nV, part, npx, npy, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
         else if (SWP == 7 || h.nV == 28)   // (wave-uniform) big_track's chain: the unrolled sweep.  SWP == 7: the host guarantees that
-            wall_sweep_unrolled<R1, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxa, dya, dia, ft.rden, ba);   // chain length
+            wall_sweep_unrolled<R1, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxa, dya, dia, ft.rden, tau, ba);   // chain length
         else if constexpr (SWP == 0)       // and the generic loop is not even compiled in (1 % from the shorter kernel alone)
-            wall_sweep_f32<R1, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dxa, dya, dia, ft.rden, ba);
+            wall_sweep_f32<R1, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
 #pragma unroll
         for (int s = 0; s < R1; ++s) bb[s] = ba[s];
     }
@@ -309,15 +314,15 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         const int(&dib)[R2] = *reinterpret_cast<const int(*)[R2]>(&didx[R1]);
         unsigned bc[2 * ((R2 + 1) / 2)];
         if (PARTS > 1)
-            wall_sweep_lds<R2, PARTS, TAB, true>(ft.vtx, h.nV, part, npx, npy, dxb, dyb, dib, ft.rden, bc);
+            wall_sweep_lds<R2, PARTS, TAB, true>(ft.vtx, h.nV, part, npx, npy, dxb, dyb, dib, ft.rden, tau, h.idx_mask, bc);
         else if (SWP == 7 || h.nV == 28)
-            wall_sweep_unrolled<R2, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxb, dyb, dib, ft.rden, bc);
+            wall_sweep_unrolled<R2, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxb, dyb, dib, ft.rden, tau, bc);
         else if constexpr (SWP == 0)
-            wall_sweep_f32<R2, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dxb, dyb, dib, ft.rden, bc);
+            wall_sweep_f32<R2, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dxb, dyb, dib, ft.rden, tau, h.idx_mask, bc);
 #pragma unroll
         for (int s = 0; s < R2; ++s) bb[R1 + s] = bc[s];
     }
-    if constexpr (PARTS > 1) {   // the parts' minima meet in LDS (min is exact: the same bits as one wave sweeping everything)
+    if constexpr (PARTS > 1) {   // the parts' selections meet in LDS (min is exact: the same bits as one wave sweeping everything)
         unsigned* ex = reinterpret_cast<unsigned*>(exch);
         int ray = g;
 #pragma unroll
@@ -339,16 +344,62 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         }
     }
     PC_STAMP(5)
-    // Car.check_collision (:376-392): any collision ray closer than 10 px.  Distances are non-negative floats, so the
-    // smallest one is the unsigned minimum of the bit patterns; a slot that is not a collision ray is masked to +inf.
-    unsigned hm = 0x7f800000u;
+    // ---- float64 refinement of every slot's selection (refine_fast / refine_careful, env_math.hpp): the distance the observation
+    // reports and Car.check_collision (:376-392) tests against 10 px.  The chain tables are read from LDS; a slot's float64
+    // direction is found through its lattice entry (re-read: nine addresses are cheaper to keep than nine more live registers in
+    // the sweep).
+    const lds_cd4 sgl = ft.seg;
+    const lds_cd2 nbl = ft.nbr;
+    const auto segs = [sgl](const int k) { const f64x4 v = sgl[k]; return SegD{v.x, v.y, v.z, v.w}; };
+    const auto hmar = [nbl](const int k) { return *(const __attribute__((address_space(3))) double*)(nbl + k); };
+    const auto nbrs = [nbl](const int k) {
+        const f64x2 v = nbl[k];
+        NbrH n;
+        n.h = v.x;
+        n.prev_next = (int)(unsigned)__double_as_longlong(v.y);
+        n.pad = 0;
+        return n;
+    };
+    bool wall_hit = false;
+    unsigned todo = 0;   // bit s: slot s needs the careful path
+    {
+        int m = m0;
 #pragma unroll
-    for (int s = 0; s < RPL; ++s) {
-        // bit s of colmask: slot s is one of Car.check_collision's rays; (bit ? 0 : 0x7f800000) without a register per slot
-        const unsigned nc = ((unsigned)__builtin_amdgcn_sbfe(fl.colmask, s, 1) & 0x7f800000u) ^ 0x7f800000u;
-        hm = min(hm, bb[s] | nc);
+        for (int s = 0; s < RPL; ++s) {
+            const unsigned a64 = (unsigned)*(lds_ci)(size_t)(unsigned)((s + 1 < RPL ? m : min(m, m_last)) + 12);
+            const f64x2 d64 = *(lds_cd2)(size_t)a64;
+            bool ok;
+            const double d = refine_fast((int)(bb[s] & h.idx_mask), segs, hmar, npx, npy, d64.x, d64.y, ok);
+            todo |= ok ? 0u : 1u << s;
+            wall_hit |= (bool)__builtin_amdgcn_sbfe(fl.colmask, s, 1) & ok & (d < 10.0);    // bit s of colmask: slot s is one of Car.check_collision's rays
+            const float o = Math<float>::norm_dist(d);                                      // :593
+            if (write_row) {   // ray slot s -> column 6 + ray(s): G floats apart from the lane's first; the clamped last slot apart
+                if (s + 1 < RPL) fl.lray[G * s] = o;
+                else fl.llast[0] = o;
+            }
+            m += fl.rstep;
+        }
     }
-    int flags = (gate_hit ? 1 : 0) | (hm < 0x41200000u ? 2 : 0);       // 0x41200000 = 10.0f
+    // the rare rest, one slot of one lane at a time through ONE copy of the careful code (a select chain picks the slot's selection)
+    while (__builtin_amdgcn_ballot_w64(todo != 0) != 0) {
+        const int s0 = todo ? __builtin_ctz(todo) : -1;
+        unsigned sel = 0;
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) sel = s == s0 ? bb[s] : sel;
+        if (s0 >= 0) {
+            const int ms = m0 + s0 * fl.rstep;
+            const unsigned a64 = (unsigned)*(lds_ci)(size_t)(unsigned)((s0 + 1 < RPL ? ms : min(ms, m_last)) + 12);
+            const f64x2 d64 = *(lds_cd2)(size_t)a64;
+            const double d = refine_careful((int)(sel & h.idx_mask), segs, nbrs, h.nV, npx, npy, d64.x, d64.y);
+            wall_hit |= (bool)((fl.colmask >> s0) & 1) & (d < 10.0);
+            if (write_row) {
+                const lds_fp dst = s0 + 1 < RPL ? fl.lray + G * s0 : fl.llast;
+                dst[0] = Math<float>::norm_dist(d);
+            }
+            todo &= todo - 1;
+        }
+    }
+    int flags = (gate_hit ? 1 : 0) | (wall_hit ? 2 : 0);
     flags |= swap_pair(flags);                                          // any() over the env's G lanes
     if constexpr (G == 4) flags |= __builtin_amdgcn_update_dpp(0, flags, 0x4e, 0xf, 0xf, false);   // quad_perm [2, 3, 0, 1]
     static_assert(G == 2 || G == 4, "2 or 4 lanes per env");
@@ -368,15 +419,8 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     reward_f = (float)(rw * reward_scale);
     term_f = destroyed ? 1.0f : 0.0f;
     trunc_f = trunc ? 1.0f : 0.0f;
-    // ---- observation row -> LDS (the reset observation of a finished env is written by the caller's fix-up)
-#pragma unroll
-    for (int s = 0; s < RPL; ++s) {   // ray slot s -> column 6 + ray(s): G floats apart from the lane's first; the clamped last slot apart
-        const float o = Math<float>::norm_dist(__uint_as_float(bb[s]));     // :593
-        if (write_row) {
-            if (s + 1 < RPL) fl.lray[G * s] = o;
-            else fl.llast[0] = o;
-        }
-    }
+    // ---- observation row -> LDS: the ray columns were written by the refinement loop (the reset observation of a finished env is
+    // written by the caller's fix-up)
     if (g == 0 && write_row) {
         lrow[0] = Math<float>::norm(npx, 1280.0);  // :578-581
         lrow[1] = Math<float>::norm(npy, 720.0);
@@ -503,10 +547,10 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const TrackHdr h0 = cload(p.hdr + trk_wg);
     EnvParams<float> q = p;
     FastTabs ft = {};
-    if constexpr (FAST) ft = stage_fast_tables(p, h0, trk_wg, sTab, tid, 512);
+    if constexpr (FAST) ft = stage_fast_tables<false>(p, h0, trk_wg, sTab, tid, 512);
     else q = stage_tables(p, sTab, tid, 512);
     // the track's 1/den table, when the host found room for it (rden_lds != 0; sized for the batch's largest track)
-    float* sRden = sTab + (FAST ? FT_FLOATS : TAB_FLOATS);
+    float* sRden = sTab + (FAST ? ft_floats(false) : TAB_FLOATS);
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(p.rden + h0.rden_off);
         const int n4 = rden_lds ? 361 * h0.nV / 4 : 0;     // nV is a multiple of 4
@@ -784,10 +828,10 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     const TrackHdr h0 = cload(p.hdr + trk_wg);
     EnvParams<float> q = p;
     FastTabs ft = {};
-    if constexpr (FAST) ft = stage_fast_tables(p, h0, trk_wg, sTab, tid, 512);
+    if constexpr (FAST) ft = stage_fast_tables<true>(p, h0, trk_wg, sTab, tid, 512);
     else q = stage_tables(p, sTab, tid, 512);
     // the track's 1/den table, when the host found room for it (rden_lds != 0; sized for the batch's largest track)
-    float* sRden = sTab + (FAST ? FT_FLOATS : TAB_FLOATS);
+    float* sRden = sTab + (FAST ? ft_floats(true) : TAB_FLOATS);
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(p.rden + h0.rden_off);
         const int n4 = rden_lds ? 361 * h0.nV / 4 : 0;     // nV is a multiple of 4

@@ -46,6 +46,7 @@
 //               Rewards are bit-exact with the reference's float32(r * reward_scaling).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -53,6 +54,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "ppocar_internal.h"
@@ -126,6 +128,9 @@ struct pc_env {
     double2* headtab = nullptr;
     float2* dirtab = nullptr;
     float* rden = nullptr;
+    double2* dirtab64 = nullptr;
+    SegD* seg64 = nullptr;
+    NbrH* nbrh = nullptr;
     float* reset_obs = nullptr;
 
     template <typename T> EnvParams<T> params() const {
@@ -134,6 +139,7 @@ struct pc_env {
         p.lg = lg;
         p.n_nominal = n_nominal;
         p.q = n_nominal / 4;
+        p.nc = (n_nominal + p.q - 1) / p.q;
         p.step_deg = 360 / n_nominal;
         p.R = R;
         p.D = D;
@@ -149,6 +155,9 @@ struct pc_env {
         p.headtab = headtab;
         p.dirtab = dirtab;
         p.rden = rden;
+        p.dirtab64 = dirtab64;
+        p.seg64 = seg64;
+        p.nbrh = nbrh;
         p.reset_obs = reset_obs;
         return p;
     }
@@ -275,6 +284,9 @@ void pc_env_destroy(pc_env* e) {
     (void)hipFree(e->headtab);
     (void)hipFree(e->dirtab);
     (void)hipFree(e->rden);
+    (void)hipFree(e->dirtab64);
+    (void)hipFree(e->seg64);
+    (void)hipFree(e->nbrh);
     (void)hipFree(e->reset_obs);
     delete e;
 }
@@ -286,6 +298,9 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
     std::vector<Vtx> vtx;
     std::vector<double2> headtab;
     std::vector<float2> dirtab;
+    std::vector<double2> dirtab64;
+    std::vector<SegD> seg64;
+    std::vector<NbrH> nbrh;
     size_t rden_floats = 0;
     e->hdr_host.resize(e->n_tracks);
     for (int k = 0; k < e->n_tracks; ++k) {
@@ -299,23 +314,73 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
         for (size_t i = 0; i < t->gates.size(); i += 4) segs.push_back(Seg{t->gates[i], t->gates[i + 1], t->gates[i + 2], t->gates[i + 3]});
         // walls as vertex chains: a segment continues the chain iff it starts exactly where the previous ended
         h.vtx_off = (int)vtx.size();
+        // the sweep's view of a wall: the UNIT vector along (x1 - x2, y1 - y2) (car_env.py:171) in float32, and its copy scaled by 2^-40
+        const auto edge = [](const Seg& sg) {
+            const double ex = sg.x1 - sg.x2, ey = sg.y1 - sg.y2, len = std::hypot(ex, ey);
+            if (len == 0.0) return Vtx{sg.x2, sg.y2, 0.f, 0.f, 1.f, 0.f};     // a wall without length is never hit: a chain start
+            const float fx = (float)(ex / len), fy = (float)(ey / len);
+            return Vtx{sg.x2, sg.y2, fx, fy, fx * 0x1p-40f, fy * 0x1p-40f};
+        };
         for (int w = 0; w < h.S; ++w) {
             const Seg& sg = segs[h.wall_off + w];
             const bool cont = w > 0 && segs[h.wall_off + w - 1].x2 == sg.x1 && segs[h.wall_off + w - 1].y2 == sg.y1;
-            if (!cont) vtx.push_back(Vtx{sg.x1, sg.y1, 0.f, 0.f, 1, 0});
-            vtx.push_back(Vtx{sg.x2, sg.y2, (float)(sg.x1 - sg.x2), (float)(sg.y1 - sg.y2), 0, 0});
+            if (!cont) {
+                vtx.push_back(Vtx{sg.x1, sg.y1, 0.f, 0.f, 1.f, 0.f});            // chain start: zero edge (scaled copy (1, 0): see Sweep::cand)
+                seg64.push_back(SegD{sg.x1, sg.y1, 0.0, 0.0});
+            }
+            vtx.push_back(edge(sg));
+            seg64.push_back(SegD{sg.x1, sg.y1, sg.x1 - sg.x2, sg.y1 - sg.y2});
         }
         h.n_chain = (int)vtx.size() - h.vtx_off;
-        h.pad_ = 0;
-        while ((vtx.size() - h.vtx_off) % 4)  // the sweep walks vertex groups of four: pad with chain-break sentinels
-            vtx.push_back(Vtx{vtx.back().x, vtx.back().y, 0.f, 0.f, 1, 0});
+        while ((vtx.size() - h.vtx_off) % 4) {  // the sweep walks vertex groups of four: pad with chain-start sentinels
+            vtx.push_back(Vtx{vtx.back().x, vtx.back().y, 0.f, 0.f, 1.f, 0.f});
+            seg64.push_back(SegD{vtx.back().x, vtx.back().y, 0.0, 0.0});
+        }
         h.nV = (int)vtx.size() - h.vtx_off;
+        if (h.nV > 65535) return PC_ERR_UNSUPPORTED;
+        {   // low bits of a sweep candidate that carry the vertex index (at least 5: the unrolled 28-vertex sweep's constant)
+            int b = 5;
+            while ((1 << b) < h.nV) ++b;
+            h.idx_mask = (1u << b) - 1u;
+        }
+        // chain neighbours and end margins of every segment (struct NbrH), bounding box of the vertices
+        {
+            const int n = h.nV, o = h.vtx_off;
+            const auto is_start = [&](int k) { return seg64[o + k].ex == 0.0 && seg64[o + k].ey == 0.0; };
+            double bx0 = 1e300, bx1 = -1e300, by0 = 1e300, by1 = -1e300;
+            for (int k = 0; k < n; ++k) {
+                bx0 = std::min(bx0, vtx[o + k].x); bx1 = std::max(bx1, vtx[o + k].x);
+                by0 = std::min(by0, vtx[o + k].y); by1 = std::max(by1, vtx[o + k].y);
+            }
+            h.bx0 = (float)bx0; h.bx1 = (float)bx1; h.by0 = (float)by0; h.by1 = (float)by1;
+            for (int k = 0; k < n; ++k) {
+                NbrH nh;
+                nh.h = -1.0;        // chain starts / padding: no segment (|t - 0.5| < h never holds)
+                nh.prev_next = 0;
+                nh.pad = 0;
+                if (!is_start(k)) {
+                    int c0 = k;     // first vertex of this chain, and its last
+                    while (!is_start(c0)) --c0;
+                    int c1 = k;
+                    while (c1 + 1 < h.n_chain && !is_start(c1 + 1)) ++c1;
+                    const bool closed = c1 > c0 && vtx[o + c0].x == vtx[o + c1].x && vtx[o + c0].y == vtx[o + c1].y;
+                    const int prev = k - 1 > c0 ? k - 1 : (closed && c1 != k ? c1 : 0);       // shares this segment's first endpoint
+                    const int next = k + 1 <= c1 ? k + 1 : (closed && c0 + 1 != k ? c0 + 1 : 0);   // shares its second endpoint
+                    nh.prev_next = prev | (next << 16);
+                    const double len = std::hypot(seg64[o + k].ex, seg64[o + k].ey);
+                    nh.h = 0.5 - 0.05 / len;
+                }
+                nbrh.push_back(nh);
+            }
+        }
         h.dir_off = (int)dirtab.size();
         for (int j = 0; j < 360; ++j) {  // direction lattice: start_rot + j degrees, np.radians then libm cos/sin
             const double a = (t->start_rot + (double)j) * (PC_PI / 180.0);
             dirtab.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
+            dirtab64.push_back(make_double2(std::cos(a), std::sin(a)));
         }
         dirtab.push_back(make_float2(0.f, 0.f));
+        dirtab64.push_back(make_double2(0.0, 0.0));
         h.rden_off = (int)rden_floats;
         rden_floats += (size_t)361 * h.nV;
         h.head_off = (int)headtab.size();
@@ -354,6 +419,13 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
     HIPCHK(hipMemcpy(e->headtab, headtab.data(), headtab.size() * sizeof(double2), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&e->dirtab, dirtab.size() * sizeof(float2)));
     HIPCHK(hipMemcpy(e->dirtab, dirtab.data(), dirtab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    static_assert(sizeof(SegD) == 32 && sizeof(NbrH) == 16, "refinement tables: 32 / 16 bytes per chain vertex");
+    HIPCHK(hipMalloc((void**)&e->dirtab64, dirtab64.size() * sizeof(double2)));
+    HIPCHK(hipMemcpy(e->dirtab64, dirtab64.data(), dirtab64.size() * sizeof(double2), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&e->seg64, seg64.size() * sizeof(SegD)));
+    HIPCHK(hipMemcpy(e->seg64, seg64.data(), seg64.size() * sizeof(SegD), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&e->nbrh, nbrh.size() * sizeof(NbrH)));
+    HIPCHK(hipMemcpy(e->nbrh, nbrh.data(), nbrh.size() * sizeof(NbrH), hipMemcpyHostToDevice));
     if (!f64) {
         HIPCHK(hipMalloc((void**)&e->rden, rden_floats * sizeof(float)));
         hipLaunchKernelGGL(rden_build_kernel, dim3(64), dim3(256), 0, 0, e->params<float>(), e->n_tracks, e->rden);
@@ -710,9 +782,9 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
 #define PC_POL(KSV, SPL, PRC)                                                                                            \
     do {                                                                                                                 \
         static bool attr_set[64] = {false};                                                                              \
-        if (device < 64 && !attr_set[device]) {                                                                          \
+        if (device >= 64 || !attr_set[device]) {                                                                         \
             HIPCHK(hipFuncSetAttribute((const void*)policy_kernel<KSV, SPL, PRC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_set[device] = true;                                                                                     \
+            if (device < 64) attr_set[device] = true;                                                                    \
         }                                                                                                                \
         hipLaunchKernelGGL((policy_kernel<KSV, SPL, PRC>), dim3(blocks), dim3(512), lds, st, obs, N, D, A, image, seed, offset, offset_dev, \
                            action, action_f32, logprob, value, logits_out);                                              \
@@ -813,13 +885,20 @@ static int rollout_impl(pc_env* e, const float* image, int A, int64_t T, double 
     // tile aliases its own 32 observation rows -- dead between the policy pass's operand load and the env step's store of the
     // next observation: needs D >= 17).  A workgroup stages ONE track's tables: single-track batches, or mixed ones in which
     // every workgroup's block of envs lies on one track.
-    const bool fast_shape = A == 9 && e->D >= 17 && e->D <= 40 && max_G <= TAB_MAX_GATES && g_rollout_fast;
-    const bool fast = !small && fast_shape && (!e->track_id || e->track_block >= epw);
-    const size_t lds_big = fast ? (size_t)(img + 256 * e->D + 256 + FT_FLOATS) * sizeof(float)
-                                : (size_t)(img + 256 * (4 * KS + 1) + 256 + TAB_FLOATS) * sizeof(float);
-    const bool fast_small = small && fast_shape && max_nV <= FT_VTX_MAX;     // (a small-form workgroup is 16 or 32 envs)
-    const size_t lds_small = fast_small ? (size_t)(img + 8 * 32 * 17 + 32 * 40 + 32 + FT_FLOATS) * sizeof(float)
-                                        : (size_t)(img + 8 * 32 * 17 + 32 * (4 * KS + 1) + 32 + TAB_FLOATS) * sizeof(float);
+    // The fast kernels carry their observation width as a compile-time constant derived from the ray slots per lane (12 / 17 /
+    // 33 rays) and cast exactly four collision rays at the reward gate: num_rays 12 / 16 / 32 (what BASELINE's configs name).  Any
+    // other count that maps onto the same slots (17 or 18 nominal rays -> 18 actual: the slots of 17; 31 -> 33 with five
+    // collision rays) takes the generic mode, which reads all of that from the handle.
+    const bool fast_rays = e->n_nominal == 12 || e->n_nominal == 16 || e->n_nominal == 32;
+    const bool fast_shape = A == 9 && fast_rays && e->D >= 17 && e->D <= 40 && max_G <= TAB_MAX_GATES && g_rollout_fast;
+    // (the float64 refinement gathers the chain from LDS: at most FT_VTX_MAX vertices; a shape whose fast-mode tables do not fit
+    // beside the weight image -- the fp32 image at 33 rays -- takes the generic mode)
+    const size_t lds_fast_big = (size_t)(img + 256 * e->D + 256 + FT_FLOATS_BIG) * sizeof(float);
+    const bool fast = !small && fast_shape && max_nV <= FT_VTX_MAX && (!e->track_id || e->track_block >= epw) && lds_fast_big <= 160 * 1024;
+    const size_t lds_big = fast ? lds_fast_big : (size_t)(img + 256 * (4 * KS + 1) + 256 + TAB_FLOATS) * sizeof(float);
+    const size_t lds_fast_small = (size_t)(img + 8 * 32 * 17 + 32 * 40 + 32 + FT_FLOATS_SMALL) * sizeof(float);
+    const bool fast_small = small && fast_shape && max_nV <= FT_VTX_MAX && lds_fast_small <= 160 * 1024;     // (a small-form workgroup is 16 or 32 envs)
+    const size_t lds_small = fast_small ? lds_fast_small : (size_t)(img + 8 * 32 * 17 + 32 * (4 * KS + 1) + 32 + TAB_FLOATS) * sizeof(float);
     size_t lds = small ? lds_small : lds_big;
     if (lds > 160 * 1024) return PC_ERR_UNSUPPORTED;
     // the track's 1/den table rides along in LDS when it fits (big_track: 361 x 28 floats = 40 KB); else the sweep forms
@@ -836,7 +915,8 @@ static int rollout_impl(pc_env* e, const float* image, int A, int64_t T, double 
                           : ((fast_small && prec != 0 && e->R <= 17 && e->N <= 4096) ? 16 : 32);
     if (small && epw_small == 16 && !(fast_small && prec != 0 && e->R <= 17)) return PC_ERR_UNSUPPORTED;
     const int blocks = (int)(small ? (e->N + epw_small - 1) / epw_small : (e->N + epw - 1) / epw);
-    const int vec_ok = ((e->N * e->D) % 4 == 0) ? 1 : 0;      // the waves' 32-row blocks are 16-byte aligned in the buffers
+    // 16-byte stores of the waves' 32-row blocks: the rows' offsets inside the buffers AND the buffers themselves are aligned
+    const int vec_ok = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
     const int mode = (fast || fast_small) ? (rden_lds ? 2 : 1) : 0;
     bool all_nv28 = g_rollout_nv28 != 0;
     for (const TrackHdr& h : e->hdr_host) all_nv28 = all_nv28 && h.nV == 28;
@@ -846,9 +926,9 @@ static int rollout_impl(pc_env* e, const float* image, int A, int64_t T, double 
 #define PC_ROLL_M(KSV, RPLV, PRC, MD)                                                                                    \
     do {                                                                                                                 \
         static bool attr_set[64] = {false};                                                                              \
-        if (e->device < 64 && !attr_set[e->device]) {                                                                    \
+        if (e->device >= 64 || !attr_set[e->device]) {                                                                    \
             HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<KSV, RPLV, PRC, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_set[e->device] = true;                                                                                  \
+            if (e->device < 64) attr_set[e->device] = true;                                                                                \
         }                                                                                                                \
         hipLaunchKernelGGL((rollout_kernel<KSV, RPLV, PRC, MD>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, seed, \
                            offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs,  \
@@ -867,9 +947,9 @@ static int rollout_impl(pc_env* e, const float* image, int A, int64_t T, double 
 #define PC_ROLLS_M(KSV, RPLV, PRC, MD, EPWV)                                                                             \
     do {                                                                                                                 \
         static bool attr_set[64] = {false};                                                                              \
-        if (e->device < 64 && !attr_set[e->device]) {                                                                    \
+        if (e->device >= 64 || !attr_set[e->device]) {                                                                    \
             HIPCHK(hipFuncSetAttribute((const void*)rollout_small_kernel<KSV, RPLV, PRC, MD, EPWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_set[e->device] = true;                                                                                  \
+            if (e->device < 64) attr_set[e->device] = true;                                                                                \
         }                                                                                                                \
         hipLaunchKernelGGL((rollout_small_kernel<KSV, RPLV, PRC, MD, EPWV>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, \
                            seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, \

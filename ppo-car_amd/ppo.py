@@ -63,9 +63,10 @@ class PPOConfig:
                                            # kernels per step (HIP-graph replayed); "auto": mega whenever pc_rollout supports the shape
     policy: str = "fused"                  # rollout policy step: "fused" (one MFMA kernel: MLPs + draw),
                                            # "sample" (torch GEMMs + sampling kernel), "torch" (reference ops)
-    capture_collectives: bool = True       # multi-rank + backend nccl (RCCL): the per-minibatch gradient all-reduce is captured INSIDE
-                                           # the epoch's update graph (one replay per epoch, as on a single rank); False / gloo: the
-                                           # minibatch steps are enqueued eagerly around an eager all-reduce
+    capture_collectives: bool = False      # multi-rank + backend nccl (RCCL): True = the per-minibatch gradient all-reduce is captured
+                                           # INSIDE the epoch's update graph (one replay per epoch, as on a single rank).  Off by default:
+                                           # a captured RCCL collective has only ever run on a ONE-rank communicator here (no multi-GPU box);
+                                           # False / gloo: the minibatch steps are enqueued eagerly around an eager all-reduce
     force_collective: bool = False         # test knob: take the multi-rank update path (all-reduce + pc_clip_adam) on ONE rank
 
 
@@ -652,6 +653,7 @@ class Trainer:
                                                 self.next_trunc.reshape(1, -1))                   # :203
         obs, act, _val, logprob = buf.get()                                                      # :206
         self.learner.update(obs.view(-1, *self.obs_dim), act.view(-1), logprob.view(-1), adv.view(-1), ret.view(-1))
+        self._aux_valid = False     # the in-kernel bootstrap values belong to THAT rollout and THOSE parameters only
 
     def run_epoch(self, sync=True):
         """One epoch = rollout + update.  Returns the reference's scalars (train.py:286-292) when sync."""
