@@ -36,14 +36,12 @@ struct Vtx { double x, y; float ex, ey, exs, eys; };
 __device__ __forceinline__ bool vtx_brk(const Vtx& v) {   // chain start / padding sentinel: a zero edge (integer test: stays on the SALU)
     return ((__float_as_uint(v.ex) | __float_as_uint(v.ey)) << 1) == 0u;
 }
-// The float64 refinement's view of the same chain: vertex k closes the segment (x1, y1) -> (x1 - ex, y1 - ey), with
-// (ex, ey) = p[k-1] - p[k] formed in float64 as the reference forms (x1 - x2), (y1 - y2) (car_env.py:171).  Chain starts and
-// padding have a zero edge.  32 bytes.
-struct SegD { double x1, y1, ex, ey; };
-// ... and per vertex k: the chain neighbours of segment k -- prev = the segment that shares its first endpoint, next = the one
-// that shares its second (0: none; a closed loop wraps) -- and h = 0.5 - (0.05 px) / |e_k|: a refined hit whose parameter t
-// satisfies |t - 0.5| < h lies at least 0.05 px inside the segment's ends.
-struct NbrH { double h; int prev_next, pad; };   // prev in the low 16 bits, next in the high 16; 16 bytes
+// The float64 refinement's view of the same chain, one 48-byte record per vertex k = the segment that vertex closes:
+// (x1, y1) -> (x1 - ex, y1 - ey) with (ex, ey) = p[k-1] - p[k] formed in float64 as the reference forms (x1 - x2), (y1 - y2)
+// (car_env.py:171); h = 0.5 - (0.05 px) / |e|: a refined hit whose parameter t satisfies |t - 0.5| < h lies at least 0.05 px
+// inside the segment's ends (-1 for chain starts / padding, which have a zero edge: no segment); prev / next = the chain
+// neighbours of the segment -- prev shares its first endpoint, next its second (0: none; a closed loop wraps).
+struct SegD { double x1, y1, ex, ey, h; int prev_next, pad; };   // prev in the low 16 bits, next in the high 16
 
 template <typename T> struct EnvParams {
     int64_t N;
@@ -68,7 +66,6 @@ template <typename T> struct EnvParams {
     const float* __restrict__ rden;         // [n_tracks][361][nV] 1 / (ey*dx - ex*dy) exactly as the sweep computes it (device-built)
     const double2* __restrict__ dirtab64;   // [n_tracks][361] the same lattice in float64 (libm): the refinement's ray directions
     const SegD* __restrict__ seg64;         // F32 only: the wall chains for the refinement, indexed like vtx
-    const NbrH* __restrict__ nbrh;          // F32 only: chain neighbours / end margins, indexed like vtx
     const float* __restrict__ reset_obs;    // [n_tracks][D]
 };
 
@@ -143,50 +140,48 @@ __device__ __forceinline__ double scan_chain_d(const LoadSeg& segs, const int n,
     }
     return best;
 }
-// ---- the float64 distance of one ray, given the float32 sweep's selection `sel` (candidate bits: vertex index in the low bits;
+// ---- the float64 distance of one ray, given the float32 sweep's selection (candidate bits: vertex index k in the low bits;
 // index 0 = "nothing certified": the sweep found no segment within 1000.5 px, or it flagged the ray as too close to a vertex
 // or the car as too close to a wall line for float32 side tests to be trusted).
 //   refine_fast     the selected segment's hit in float64; `ok` iff it lies at least 0.05 px inside both ends of the segment
-//                   (|t - 0.5| < h) and in front of the car (u > 0) -- then it is the answer (for an unflagged ray the sweep's side
-//                   tests are certain, every wall the reference hits was a candidate, and two candidates can be ordered wrongly
-//                   by float32 only where two walls meet);
+//                   (|t - 0.5| < h; false for k == 0, whose zero edge makes t NaN) -- then u is the answer: for an unflagged ray the
+//                   sweep's side tests and signs of u are the exact ones, so every wall the reference hits was a candidate and the
+//                   selected one is a real hit in front of the car; float32 can order two hits wrongly only where two walls meet;
 //   refine_careful  everything else (a few 1e-4 of the rays): a hit within 0.05 px of a corner is compared with the two chain
 //                   neighbours under the strict test; with nothing certified the whole chain is scanned in float64.
 // Every decision is per lane and depends on that lane's ray only: the result does not depend on the launch geometry.
-// (segs(k) / nbrh(k): accessors of the chain tables -- global memory in the per-step kernel, LDS in the persistent ones)
-template <typename LoadSeg, typename LoadH>
-__device__ __forceinline__ double refine_fast(const int k, const LoadSeg& segs, const LoadH& hmargin, const double px, const double py,
-                                              const double dx, const double dy, bool& ok) {
-    const SegD sg = segs(k);                                       // (k == 0: a chain start, zero edge: den == 0, t is NaN -> !ok)
+// (segs(k): accessor of the chain table -- global memory in the per-step kernel, LDS in the persistent ones)
+__device__ __forceinline__ double refine_fast(const SegD& sg, const double px, const double py, const double dx, const double dy, bool& ok) {
     const CastD c = cast_terms(sg, px, py, dx, dy);
     const double r = rcp_d(c.den);
-    const double u = c.un * r, t = c.tn * r;
-    ok = (__builtin_fabs(t - 0.5) < hmargin(k)) & (u > 0.0);
-    return __builtin_fmin(u, 1000.0);                              // :198,:210-211
+    ok = __builtin_fabs(__builtin_fma(c.tn, r, -0.5)) < sg.h;
+    return c.un * r;
 }
-template <typename LoadSeg, typename LoadNbr>
-__device__ __forceinline__ double refine_careful(const int k, const LoadSeg& segs, const LoadNbr& nbrh, const int nV, const double px,
-                                                 const double py, const double dx, const double dy) {
+template <typename LoadSeg>
+__device__ __forceinline__ double refine_careful(const int k, const LoadSeg& segs, const int nV, const double px, const double py,
+                                                 const double dx, const double dy) {
     double d = 1000.0;
     bool any = false;
     if (k != 0) {
-        const CastD c = cast_terms(segs(k), px, py, dx, dy);
+        const SegD sg = segs(k);
+        const CastD c = cast_terms(sg, px, py, dx, dy);
         if (strict_hit(c)) {   // the selection is a hit: is a chain neighbour's hit (around the corner it lies next to) nearer?
             d = c.un * rcp_d(c.den);
             any = true;
-            const NbrH nh = nbrh(k);
-            const CastD cp = cast_terms(segs(nh.prev_next & 0xffff), px, py, dx, dy);   // (index 0 = no neighbour: zero edge, never a hit)
+            const CastD cp = cast_terms(segs(sg.prev_next & 0xffff), px, py, dx, dy);   // (index 0 = no neighbour: zero edge, never a hit)
             if (strict_hit(cp)) d = __builtin_fmin(d, cp.un * rcp_d(cp.den));
-            const CastD cn = cast_terms(segs((int)((unsigned)nh.prev_next >> 16)), px, py, dx, dy);
+            const CastD cn = cast_terms(segs((int)((unsigned)sg.prev_next >> 16)), px, py, dx, dy);
             if (strict_hit(cn)) d = __builtin_fmin(d, cn.un * rcp_d(cn.den));
         }
     }
     if (!any) d = scan_chain_d(segs, nV, px, py, dx, dy);
-    return __builtin_fmin(d, 1000.0);
+    return d;
 }
+// min(1000, d) / 1000 as the observation holds it (Ray.get_distance :198,:210-211; car_env.py:593,:595)
+__device__ __forceinline__ float obs_dist(const double d) { return (float)(__builtin_fmin(d, 1000.0) * 0.001); }
 // one ray against one segment (the reward gates: Car.check_collision(gate), car_env.py:387-390), float64, strict
 __device__ __forceinline__ double cast_d(const Seg& s, const double px, const double py, const double dx, const double dy) {
-    const SegD sg = {s.x1, s.y1, s.x1 - s.x2, s.y1 - s.y2};
+    const SegD sg = {s.x1, s.y1, s.x1 - s.x2, s.y1 - s.y2, 0.0, 0, 0};
     const CastD c = cast_terms(sg, px, py, dx, dy);
     return strict_hit(c) ? __builtin_fmin(c.un * rcp_d(c.den), 1000.0) : 1000.0;
 }
@@ -238,8 +233,8 @@ template <> struct Math<float> {
         dx = cs.x;
         dy = cs.y;
     }
-    // observation entry of a refined distance: d / 1000 (car_env.py:593) as a float64 multiply, then the float32 cast (:595)
-    static __device__ __forceinline__ float norm_dist(double d) { return (float)(d * 0.001); }
+    // observation entry of a refined distance: min(1000, d) / 1000 (car_env.py:198,:593) as a float64 multiply, then the float32 cast (:595)
+    static __device__ __forceinline__ float norm_dist(double d) { return obs_dist(d); }
     // float64 multiply by the reciprocal, then the float32 cast: equals (float)(v / d) unless v/d sits
     // within 1e-16 (relative) of a float32 rounding boundary
     static __device__ __forceinline__ float norm(double v, double d) { return (float)(v * (1.0 / d)); }

@@ -469,17 +469,14 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
         }
         // the float64 refinement of every slot's selection (refine_fast / refine_careful, env_math.hpp)
         const SegD* sg64 = p.seg64 + h.vtx_off;
-        const NbrH* nb = p.nbrh + h.vtx_off;
         const auto segs = [sg64](const int k) { return sg64[k]; };
-        const auto nbrs = [nb](const int k) { return nb[k]; };
-        const auto hmar = [nb](const int k) { return nb[k].h; };
         uint64_t todo = 0;   // bit s: slot s needs the careful path (RPL <= 33)
 #pragma unroll
         for (int s = 0; s < RPL; ++s) {
             if (g + s * G < p.R) {
                 const double2 d64 = p.dirtab64[h.dir_off + didx[s]];
                 bool ok;
-                best[s] = refine_fast((int)(bb[s] & h.idx_mask), segs, hmar, npx, npy, d64.x, d64.y, ok);
+                best[s] = refine_fast(sg64[bb[s] & h.idx_mask], npx, npy, d64.x, d64.y, ok);
                 todo |= ok ? 0ull : 1ull << s;
             }
         }
@@ -496,7 +493,7 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
             }
             if (s0 >= 0) {
                 const double2 d64 = p.dirtab64[h.dir_off + di];
-                const double d = refine_careful((int)(sel & h.idx_mask), segs, nbrs, h.nV, npx, npy, d64.x, d64.y);
+                const double d = refine_careful((int)(sel & h.idx_mask), segs, h.nV, npx, npy, d64.x, d64.y);
 #pragma unroll
                 for (int s = 0; s < RPL; ++s) best[s] = s == s0 ? d : best[s];
                 todo &= todo - 1;

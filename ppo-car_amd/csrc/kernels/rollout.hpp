@@ -61,22 +61,24 @@ struct FastTabs {        // LDS addresses of the staged tables (wave-uniform)
                          //       LDS byte address of the direction's float64 (cos, sin) in dir64)
     lds_cfp reset;       // [D] the track's reset observation
     lds_cd2 vtx;         // [nV] the wall vertex chain, 32 bytes each: (x, y) float64 then (ex, ey, exs, eys) -- small form only (nV <= 64)
-    lds_cd4 seg;         // [nV] the chain for the float64 refinement: (x1, y1, ex, ey) float64 per closing vertex (nV <= 64)
-    lds_cd2 nbr;         // [nV] NbrH records, 16 bytes each: (h float64, then prev | next << 16, -)
+    lds_cd2 seg;         // [nV] the chain for the float64 refinement: SegD records, 48 bytes each (nV <= 64)
     lds_cd2 dir64;       // [360] (cos, sin) float64 of the direction lattice
     lds_cfp rden;        // [361][nV] or unused
 };
 // Region offsets in floats.  The big form sweeps its chain through scalar loads and never reads `vtx`: its `seg` table takes that
-// region (the 33-ray shape has no 2 KB to spare); the small form keeps both.
+// region; the small form keeps both.  The float64 direction lattice sits at a FIXED distance behind the float32 one, entry for
+// entry, twice around like it (TWICE: a slot's float64 direction is one LDS read at its float32 entry's address + FT_D64_BYTES);
+// the 33-ray big form has no 5.6 KB to spare and keeps one turn (the address is reduced mod 360 entries with two integer ops).
 constexpr int FT_HEAD = 0, FT_WRAP = FT_HEAD + 72 * 4, FT_ACT = FT_WRAP + 76, FT_GATES = FT_ACT + 16 * 8,
               FT_DIR = FT_GATES + TAB_MAX_GATES * 8, FT_RESET = FT_DIR + 720 * 4, FT_VTX = FT_RESET + 40,
-              FT_VTX_MAX = 64, FT_NBR = FT_VTX + FT_VTX_MAX * 8, FT_DIR64 = FT_NBR + FT_VTX_MAX * 4, FT_SEG_SMALL = FT_DIR64 + 360 * 4,
-              FT_FLOATS_BIG = FT_SEG_SMALL, FT_FLOATS_SMALL = FT_SEG_SMALL + FT_VTX_MAX * 8;
-__host__ __device__ constexpr int ft_floats(bool small) { return small ? FT_FLOATS_SMALL : FT_FLOATS_BIG; }
-static_assert(FT_ACT % 4 == 0 && FT_GATES % 4 == 0 && FT_DIR % 4 == 0 && FT_VTX % 4 == 0 && FT_NBR % 4 == 0 && FT_DIR64 % 4 == 0 &&
-              FT_SEG_SMALL % 4 == 0, "16-byte aligned records");
+              FT_VTX_MAX = 64, FT_DIR64 = FT_VTX + FT_VTX_MAX * 12;   // (the vtx region holds 32-byte Vtx or 48-byte SegD records)
+constexpr int FT_D64_BYTES = (FT_DIR64 - FT_DIR) * 4;
+__host__ __device__ constexpr int ft_seg_small(bool twice) { return FT_DIR64 + (twice ? 720 : 360) * 4; }
+__host__ __device__ constexpr int ft_floats(bool small, bool twice) { return ft_seg_small(twice) + (small ? FT_VTX_MAX * 12 : 0); }
+static_assert(FT_ACT % 4 == 0 && FT_GATES % 4 == 0 && FT_DIR % 4 == 0 && FT_VTX % 4 == 0 && FT_DIR64 % 4 == 0,
+              "16-byte aligned records");
 
-template <bool SMALL>
+template <bool SMALL, bool TWICE>
 __device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p, const TrackHdr& h0, const int trk, float* sTab,
                                                       const int tid, const int nthreads) {
     int* dst = reinterpret_cast<int*>(sTab);
@@ -98,20 +100,17 @@ __device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p,
     const int* gates = reinterpret_cast<const int*>(p.segs + h0.gate_off);
     for (int i = tid; i < h0.G * 8; i += nthreads) dst[FT_GATES + i] = gates[i];
     // The direction lattice twice around (a ray's index 5 k + step_deg * ray < 720 needs no reduction mod 360), each entry
-    // with the LDS byte addresses of its row of the 1/den table and of its float64 twin: one 16-byte read per ray slot
-    // replaces the index arithmetic.
-    constexpr int FT_SEG = SMALL ? FT_SEG_SMALL : FT_VTX;
+    // with the LDS byte address of its row of the 1/den table: one 16-byte read per ray slot replaces the index arithmetic.
+    constexpr int FT_SEG = SMALL ? ft_seg_small(TWICE) : FT_VTX;
     const float2* dir = p.dirtab + h0.dir_off;
-    const unsigned rden_base = (unsigned)(size_t)(lds_cfp)(sTab + ft_floats(SMALL));
-    const unsigned d64_base = (unsigned)(size_t)(lds_cfp)(sTab + FT_DIR64);
+    const unsigned rden_base = (unsigned)(size_t)(lds_cfp)(sTab + ft_floats(SMALL, TWICE));
     for (int i = tid; i < 720; i += nthreads) {
         const int j = i < 360 ? i : i - 360;
         const float2 cs = dir[j];
-        *reinterpret_cast<f32x4*>(sTab + FT_DIR + 4 * i) =
-            (f32x4){cs.x, cs.y, __uint_as_float(rden_base + (unsigned)(j * h0.nV) * 4u), __uint_as_float(d64_base + 16u * (unsigned)j)};
+        *reinterpret_cast<f32x4*>(sTab + FT_DIR + 4 * i) = (f32x4){cs.x, cs.y, __uint_as_float(rden_base + (unsigned)(j * h0.nV) * 4u), 0.0f};
     }
     const int* d64 = reinterpret_cast<const int*>(p.dirtab64 + h0.dir_off);
-    for (int i = tid; i < 360 * 4; i += nthreads) dst[FT_DIR64 + i] = d64[i];
+    for (int i = tid; i < (TWICE ? 720 : 360) * 4; i += nthreads) dst[FT_DIR64 + i] = d64[i < 360 * 4 ? i : i - 360 * 4];
     const int* ro = reinterpret_cast<const int*>(p.reset_obs + (size_t)trk * p.D);
     for (int i = tid; i < p.D; i += nthreads) dst[FT_RESET + i] = ro[i];
     if (h0.nV <= FT_VTX_MAX) {
@@ -120,9 +119,7 @@ __device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p,
             for (int i = tid; i < h0.nV * 8; i += nthreads) dst[FT_VTX + i] = vs[i];
         }
         const int* sg = reinterpret_cast<const int*>(p.seg64 + h0.vtx_off);
-        for (int i = tid; i < h0.nV * 8; i += nthreads) dst[FT_SEG + i] = sg[i];
-        const int* nb = reinterpret_cast<const int*>(p.nbrh + h0.vtx_off);
-        for (int i = tid; i < h0.nV * 4; i += nthreads) dst[FT_NBR + i] = nb[i];
+        for (int i = tid; i < h0.nV * 12; i += nthreads) dst[FT_SEG + i] = sg[i];
     }
     FastTabs ft;
     ft.head = (lds_cd2)(sTab + FT_HEAD);
@@ -132,10 +129,9 @@ __device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p,
     ft.dir = (lds_f4c)(sTab + FT_DIR);
     ft.reset = (lds_cfp)(sTab + FT_RESET);
     ft.vtx = (lds_cd2)(sTab + FT_VTX);
-    ft.seg = (lds_cd4)(sTab + FT_SEG);
-    ft.nbr = (lds_cd2)(sTab + FT_NBR);
+    ft.seg = (lds_cd2)(sTab + FT_SEG);
     ft.dir64 = (lds_cd2)(sTab + FT_DIR64);
-    ft.rden = (lds_cfp)(sTab + ft_floats(SMALL));
+    ft.rden = (lds_cfp)(sTab + ft_floats(SMALL, TWICE));
     return ft;
 }
 
@@ -234,13 +230,22 @@ __device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const i
 // over PARTS waves of the workgroup -- this wave sweeps vertex part `part`, the per-ray minima meet in LDS (`exch`: the env's
 // [rays][PARTS] floats) across ONE workgroup barrier (every thread of the workgroup must make the call), and all waves finish
 // the step on identical values; only `write_row` waves store the observation row.
-template <int RPL, bool TAB, int LG = 1, int PARTS = 1, int SWP = 0>
+template <int RPL, bool TAB, int LG = 1, int PARTS = 1, int SWP = 0, bool TWICE = true>
 __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const TrackHdr& h, const FastTabs& ft, const FastLane& fl,
                                               const int (&gq)[2], const int g,
                                               EnvRegs& st, int& k72, const int a, const double reward_scale, lds_fp lrow,
                                               float& reward_f, float& term_f, float& trunc_f, const int t = 0, const int lane = 0,
                                               const int wave = 0, const int part = 0, float* exch = nullptr, const bool write_row = true) {
     constexpr int G = 1 << LG;
+    // the float64 twin of the lattice entry at LDS byte address m (see FT_D64_BYTES)
+    const unsigned dir_b = (unsigned)(size_t)ft.dir;
+    const auto dir64_at = [&](const int m) {
+        if constexpr (TWICE) return *(lds_cd2)(size_t)(unsigned)(m + FT_D64_BYTES);
+        else {
+            const unsigned off = (unsigned)m - dir_b;
+            return *(lds_cd2)(size_t)(dir_b + (unsigned)FT_D64_BYTES + min(off, off - 5760u));
+        }
+    };
     // ---- action, heading before and after the turn (car_env.py:698-722, :440-442)
     const f64x2 Lf = ft.act[2 * a];                                     // (thrust, fric)
     const i32x2 Li = *(lds_ci2)(ft.act + 2 * a + 1);                    // (dk, fwd)
@@ -281,8 +286,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     bool gate_hit = false;
 #pragma unroll
     for (int jj = 0; jj < 4 / G; ++jj) {
-        const unsigned a64 = (unsigned)*(lds_ci)(size_t)(unsigned)(k80o + gq[jj] + 12);
-        const f64x2 cs = *(lds_cd2)(size_t)a64;
+        const f64x2 cs = dir64_at(k80o + gq[jj]);
         gate_hit |= cast_d(gate, opx, opy, cs.x, cs.y) < 10.0;  // :387,:390
     }
     // ---- wall sweep (float32 selector, env_step.hpp).  More than 12 ray slots per lane (33 rays: 17) are swept in TWO passes over
@@ -348,38 +352,57 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     // reports and Car.check_collision (:376-392) tests against 10 px.  The chain tables are read from LDS; a slot's float64
     // direction is found through its lattice entry (re-read: nine addresses are cheaper to keep than nine more live registers in
     // the sweep).
-    const lds_cd4 sgl = ft.seg;
-    const lds_cd2 nbl = ft.nbr;
-    const auto segs = [sgl](const int k) { const f64x4 v = sgl[k]; return SegD{v.x, v.y, v.z, v.w}; };
-    const auto hmar = [nbl](const int k) { return *(const __attribute__((address_space(3))) double*)(nbl + k); };
-    const auto nbrs = [nbl](const int k) {
-        const f64x2 v = nbl[k];
-        NbrH n;
-        n.h = v.x;
-        n.prev_next = (int)(unsigned)__double_as_longlong(v.y);
-        n.pad = 0;
-        return n;
+    const lds_cd2 sgl = ft.seg;
+    const auto segs = [sgl](const int k) {     // one 48-byte record = three 16-byte LDS reads
+        const f64x2 a = sgl[3 * k], b = sgl[3 * k + 1], c = sgl[3 * k + 2];
+        return SegD{a.x, a.y, b.x, b.y, c.x, (int)(unsigned)__double_as_longlong(c.y), 0};
     };
     bool wall_hit = false;
     unsigned todo = 0;   // bit s: slot s needs the careful path
-    {
-        int m = m0;
+    // Car.check_collision's slots as WAVE masks built on the scalar unit: the lanes g, g + G, ... of the wave share one colmask
+    // (fast_lane), so slot s is a collision slot on the lane set (bit s of that colmask ? those lanes : none).
+    constexpr uint64_t LANES_G0 = G == 2 ? 0x5555555555555555ull : 0x1111111111111111ull;
+    int colm_g[G];
 #pragma unroll
-        for (int s = 0; s < RPL; ++s) {
-            const unsigned a64 = (unsigned)*(lds_ci)(size_t)(unsigned)((s + 1 < RPL ? m : min(m, m_last)) + 12);
-            const f64x2 d64 = *(lds_cd2)(size_t)a64;
-            bool ok;
-            const double d = refine_fast((int)(bb[s] & h.idx_mask), segs, hmar, npx, npy, d64.x, d64.y, ok);
-            todo |= ok ? 0u : 1u << s;
-            wall_hit |= (bool)__builtin_amdgcn_sbfe(fl.colmask, s, 1) & ok & (d < 10.0);    // bit s of colmask: slot s is one of Car.check_collision's rays
-            const float o = Math<float>::norm_dist(d);                                      // :593
-            if (write_row) {   // ray slot s -> column 6 + ray(s): G floats apart from the lane's first; the clamped last slot apart
-                if (s + 1 < RPL) fl.lray[G * s] = o;
-                else fl.llast[0] = o;
+    for (int gg = 0; gg < G; ++gg) colm_g[gg] = __builtin_amdgcn_readlane(fl.colmask, gg);
+    uint64_t hit_mask = 0;
+    // Slots in batches: every LDS read of a batch -- the selected segments' records, the slots' float64 directions -- is issued
+    // before the first float64 instruction, so that the wave pays the LDS round trip once per batch, not once per slot.
+    constexpr int NB = RPL <= 9 ? RPL : (RPL + 1) / 2;
+#pragma unroll
+    for (int s0 = 0; s0 < RPL; s0 += NB) {
+        SegD sg[NB];
+        f64x2 d64[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int s = s0 + j;
+            if (s < RPL) {
+                const int m = m0 + s * fl.rstep;
+                sg[j] = segs((int)(bb[s] & h.idx_mask));
+                d64[j] = dir64_at(s + 1 < RPL ? m : min(m, m_last));
             }
-            m += fl.rstep;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int s = s0 + j;
+            if (s < RPL) {
+                bool ok;
+                const double d = refine_fast(sg[j], npx, npy, d64[j].x, d64[j].y, ok);
+                todo |= ok ? 0u : 1u << s;
+                uint64_t col_lanes = 0;
+#pragma unroll
+                for (int gg = 0; gg < G; ++gg) col_lanes |= ((colm_g[gg] >> s) & 1) ? LANES_G0 << gg : 0ull;
+                hit_mask |= __builtin_amdgcn_ballot_w64(ok & (d < 10.0)) & col_lanes;           // :387-390 on Car.check_collision's rays
+                const float o = obs_dist(d);                                                    // :593
+                if (write_row) {   // ray slot s -> column 6 + ray(s): G floats apart from the lane's first; the clamped last slot apart
+                    if (s + 1 < RPL) fl.lray[G * s] = o;
+                    else fl.llast[0] = o;
+                }
+            }
         }
     }
+    wall_hit = __builtin_amdgcn_inverse_ballot_w64(hit_mask);
     // the rare rest, one slot of one lane at a time through ONE copy of the careful code (a select chain picks the slot's selection)
     while (__builtin_amdgcn_ballot_w64(todo != 0) != 0) {
         const int s0 = todo ? __builtin_ctz(todo) : -1;
@@ -388,13 +411,12 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         for (int s = 0; s < RPL; ++s) sel = s == s0 ? bb[s] : sel;
         if (s0 >= 0) {
             const int ms = m0 + s0 * fl.rstep;
-            const unsigned a64 = (unsigned)*(lds_ci)(size_t)(unsigned)((s0 + 1 < RPL ? ms : min(ms, m_last)) + 12);
-            const f64x2 d64 = *(lds_cd2)(size_t)a64;
-            const double d = refine_careful((int)(sel & h.idx_mask), segs, nbrs, h.nV, npx, npy, d64.x, d64.y);
+            const f64x2 d64 = dir64_at(s0 + 1 < RPL ? ms : min(ms, m_last));
+            const double d = refine_careful((int)(sel & h.idx_mask), segs, h.nV, npx, npy, d64.x, d64.y);
             wall_hit |= (bool)((fl.colmask >> s0) & 1) & (d < 10.0);
             if (write_row) {
                 const lds_fp dst = s0 + 1 < RPL ? fl.lray + G * s0 : fl.llast;
-                dst[0] = Math<float>::norm_dist(d);
+                dst[0] = obs_dist(d);
             }
             todo &= todo - 1;
         }
@@ -547,10 +569,10 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const TrackHdr h0 = cload(p.hdr + trk_wg);
     EnvParams<float> q = p;
     FastTabs ft = {};
-    if constexpr (FAST) ft = stage_fast_tables<false>(p, h0, trk_wg, sTab, tid, 512);
+    if constexpr (FAST) ft = stage_fast_tables<false, RPL != 17>(p, h0, trk_wg, sTab, tid, 512);
     else q = stage_tables(p, sTab, tid, 512);
     // the track's 1/den table, when the host found room for it (rden_lds != 0; sized for the batch's largest track)
-    float* sRden = sTab + (FAST ? ft_floats(false) : TAB_FLOATS);
+    float* sRden = sTab + (FAST ? ft_floats(false, RPL != 17) : TAB_FLOATS);
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(p.rden + h0.rden_off);
         const int n4 = rden_lds ? 361 * h0.nV / 4 : 0;     // nV is a multiple of 4
@@ -703,7 +725,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 // ---------------- E(t)
                 float rw, tf, cf;
                 const int a = e_valid ? sAct[el] : 8;
-                const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3, 1, 1, (MODE >= 3 ? 7 : 0)>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave);
+                const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3, 1, 1, (MODE >= 3 ? 7 : 0), RPL != 17>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave);
                 rsum += rw;
                 PC_STAMP(6)
                 // gymnasium 0.29.1 same-step auto-reset: a finished env returns its reset observation
@@ -828,10 +850,10 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     const TrackHdr h0 = cload(p.hdr + trk_wg);
     EnvParams<float> q = p;
     FastTabs ft = {};
-    if constexpr (FAST) ft = stage_fast_tables<true>(p, h0, trk_wg, sTab, tid, 512);
+    if constexpr (FAST) ft = stage_fast_tables<true, true>(p, h0, trk_wg, sTab, tid, 512);
     else q = stage_tables(p, sTab, tid, 512);
     // the track's 1/den table, when the host found room for it (rden_lds != 0; sized for the batch's largest track)
-    float* sRden = sTab + (FAST ? ft_floats(true) : TAB_FLOATS);
+    float* sRden = sTab + (FAST ? ft_floats(true, true) : TAB_FLOATS);
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(p.rden + h0.rden_off);
         const int n4 = rden_lds ? 361 * h0.nV / 4 : 0;     // nV is a multiple of 4

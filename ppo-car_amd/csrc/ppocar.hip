@@ -130,7 +130,6 @@ struct pc_env {
     float* rden = nullptr;
     double2* dirtab64 = nullptr;
     SegD* seg64 = nullptr;
-    NbrH* nbrh = nullptr;
     float* reset_obs = nullptr;
 
     template <typename T> EnvParams<T> params() const {
@@ -157,7 +156,6 @@ struct pc_env {
         p.rden = rden;
         p.dirtab64 = dirtab64;
         p.seg64 = seg64;
-        p.nbrh = nbrh;
         p.reset_obs = reset_obs;
         return p;
     }
@@ -286,7 +284,6 @@ void pc_env_destroy(pc_env* e) {
     (void)hipFree(e->rden);
     (void)hipFree(e->dirtab64);
     (void)hipFree(e->seg64);
-    (void)hipFree(e->nbrh);
     (void)hipFree(e->reset_obs);
     delete e;
 }
@@ -300,7 +297,6 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
     std::vector<float2> dirtab;
     std::vector<double2> dirtab64;
     std::vector<SegD> seg64;
-    std::vector<NbrH> nbrh;
     size_t rden_floats = 0;
     e->hdr_host.resize(e->n_tracks);
     for (int k = 0; k < e->n_tracks; ++k) {
@@ -326,15 +322,15 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
             const bool cont = w > 0 && segs[h.wall_off + w - 1].x2 == sg.x1 && segs[h.wall_off + w - 1].y2 == sg.y1;
             if (!cont) {
                 vtx.push_back(Vtx{sg.x1, sg.y1, 0.f, 0.f, 1.f, 0.f});            // chain start: zero edge (scaled copy (1, 0): see Sweep::cand)
-                seg64.push_back(SegD{sg.x1, sg.y1, 0.0, 0.0});
+                seg64.push_back(SegD{sg.x1, sg.y1, 0.0, 0.0, -1.0, 0, 0});
             }
             vtx.push_back(edge(sg));
-            seg64.push_back(SegD{sg.x1, sg.y1, sg.x1 - sg.x2, sg.y1 - sg.y2});
+            seg64.push_back(SegD{sg.x1, sg.y1, sg.x1 - sg.x2, sg.y1 - sg.y2, -1.0, 0, 0});
         }
         h.n_chain = (int)vtx.size() - h.vtx_off;
         while ((vtx.size() - h.vtx_off) % 4) {  // the sweep walks vertex groups of four: pad with chain-start sentinels
             vtx.push_back(Vtx{vtx.back().x, vtx.back().y, 0.f, 0.f, 1.f, 0.f});
-            seg64.push_back(SegD{vtx.back().x, vtx.back().y, 0.0, 0.0});
+            seg64.push_back(SegD{vtx.back().x, vtx.back().y, 0.0, 0.0, -1.0, 0, 0});
         }
         h.nV = (int)vtx.size() - h.vtx_off;
         if (h.nV > 65535) return PC_ERR_UNSUPPORTED;
@@ -343,7 +339,7 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
             while ((1 << b) < h.nV) ++b;
             h.idx_mask = (1u << b) - 1u;
         }
-        // chain neighbours and end margins of every segment (struct NbrH), bounding box of the vertices
+        // chain neighbours and end margins of every segment (SegD::h, SegD::prev_next), bounding box of the vertices
         {
             const int n = h.nV, o = h.vtx_off;
             const auto is_start = [&](int k) { return seg64[o + k].ex == 0.0 && seg64[o + k].ey == 0.0; };
@@ -354,23 +350,16 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
             }
             h.bx0 = (float)bx0; h.bx1 = (float)bx1; h.by0 = (float)by0; h.by1 = (float)by1;
             for (int k = 0; k < n; ++k) {
-                NbrH nh;
-                nh.h = -1.0;        // chain starts / padding: no segment (|t - 0.5| < h never holds)
-                nh.prev_next = 0;
-                nh.pad = 0;
-                if (!is_start(k)) {
-                    int c0 = k;     // first vertex of this chain, and its last
-                    while (!is_start(c0)) --c0;
-                    int c1 = k;
-                    while (c1 + 1 < h.n_chain && !is_start(c1 + 1)) ++c1;
-                    const bool closed = c1 > c0 && vtx[o + c0].x == vtx[o + c1].x && vtx[o + c0].y == vtx[o + c1].y;
-                    const int prev = k - 1 > c0 ? k - 1 : (closed && c1 != k ? c1 : 0);       // shares this segment's first endpoint
-                    const int next = k + 1 <= c1 ? k + 1 : (closed && c0 + 1 != k ? c0 + 1 : 0);   // shares its second endpoint
-                    nh.prev_next = prev | (next << 16);
-                    const double len = std::hypot(seg64[o + k].ex, seg64[o + k].ey);
-                    nh.h = 0.5 - 0.05 / len;
-                }
-                nbrh.push_back(nh);
+                if (is_start(k)) continue;     // chain starts / padding: no segment (h = -1: |t - 0.5| < h never holds)
+                int c0 = k;     // first vertex of this chain, and its last
+                while (!is_start(c0)) --c0;
+                int c1 = k;
+                while (c1 + 1 < h.n_chain && !is_start(c1 + 1)) ++c1;
+                const bool closed = c1 > c0 && vtx[o + c0].x == vtx[o + c1].x && vtx[o + c0].y == vtx[o + c1].y;
+                const int prev = k - 1 > c0 ? k - 1 : (closed && c1 != k ? c1 : 0);       // shares this segment's first endpoint
+                const int next = k + 1 <= c1 ? k + 1 : (closed && c0 + 1 != k ? c0 + 1 : 0);   // shares its second endpoint
+                seg64[o + k].prev_next = prev | (next << 16);
+                seg64[o + k].h = 0.5 - 0.05 / std::hypot(seg64[o + k].ex, seg64[o + k].ey);
             }
         }
         h.dir_off = (int)dirtab.size();
@@ -419,13 +408,11 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
     HIPCHK(hipMemcpy(e->headtab, headtab.data(), headtab.size() * sizeof(double2), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&e->dirtab, dirtab.size() * sizeof(float2)));
     HIPCHK(hipMemcpy(e->dirtab, dirtab.data(), dirtab.size() * sizeof(float2), hipMemcpyHostToDevice));
-    static_assert(sizeof(SegD) == 32 && sizeof(NbrH) == 16, "refinement tables: 32 / 16 bytes per chain vertex");
+    static_assert(sizeof(SegD) == 48, "refinement table: 48 bytes per chain vertex");
     HIPCHK(hipMalloc((void**)&e->dirtab64, dirtab64.size() * sizeof(double2)));
     HIPCHK(hipMemcpy(e->dirtab64, dirtab64.data(), dirtab64.size() * sizeof(double2), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&e->seg64, seg64.size() * sizeof(SegD)));
     HIPCHK(hipMemcpy(e->seg64, seg64.data(), seg64.size() * sizeof(SegD), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void**)&e->nbrh, nbrh.size() * sizeof(NbrH)));
-    HIPCHK(hipMemcpy(e->nbrh, nbrh.data(), nbrh.size() * sizeof(NbrH), hipMemcpyHostToDevice));
     if (!f64) {
         HIPCHK(hipMalloc((void**)&e->rden, rden_floats * sizeof(float)));
         hipLaunchKernelGGL(rden_build_kernel, dim3(64), dim3(256), 0, 0, e->params<float>(), e->n_tracks, e->rden);
@@ -893,10 +880,10 @@ static int rollout_impl(pc_env* e, const float* image, int A, int64_t T, double 
     const bool fast_shape = A == 9 && fast_rays && e->D >= 17 && e->D <= 40 && max_G <= TAB_MAX_GATES && g_rollout_fast;
     // (the float64 refinement gathers the chain from LDS: at most FT_VTX_MAX vertices; a shape whose fast-mode tables do not fit
     // beside the weight image -- the fp32 image at 33 rays -- takes the generic mode)
-    const size_t lds_fast_big = (size_t)(img + 256 * e->D + 256 + FT_FLOATS_BIG) * sizeof(float);
+    const size_t lds_fast_big = (size_t)(img + 256 * e->D + 256 + ft_floats(false, KS != 10)) * sizeof(float);   // (33 rays: one turn of the float64 lattice)
     const bool fast = !small && fast_shape && max_nV <= FT_VTX_MAX && (!e->track_id || e->track_block >= epw) && lds_fast_big <= 160 * 1024;
     const size_t lds_big = fast ? lds_fast_big : (size_t)(img + 256 * (4 * KS + 1) + 256 + TAB_FLOATS) * sizeof(float);
-    const size_t lds_fast_small = (size_t)(img + 8 * 32 * 17 + 32 * 40 + 32 + FT_FLOATS_SMALL) * sizeof(float);
+    const size_t lds_fast_small = (size_t)(img + 8 * 32 * 17 + 32 * 40 + 32 + ft_floats(true, true)) * sizeof(float);
     const bool fast_small = small && fast_shape && max_nV <= FT_VTX_MAX && lds_fast_small <= 160 * 1024;     // (a small-form workgroup is 16 or 32 envs)
     const size_t lds_small = fast_small ? lds_fast_small : (size_t)(img + 8 * 32 * 17 + 32 * (4 * KS + 1) + 32 + TAB_FLOATS) * sizeof(float);
     size_t lds = small ? lds_small : lds_big;

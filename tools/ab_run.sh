@@ -8,7 +8,7 @@ cd $ROOT
 if [ "$1" = "build" ]; then
   d=build/ab_${2}_pkg
   mkdir -p $d/ppo-car_amd $d/ppo_car_amd
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -Wno-unused-function -Iinclude -Ippo-car_amd/csrc $3 -shared \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++20 -ffp-contract=off -Wno-unused-function -Iinclude -Ippo-car_amd/csrc $3 -shared \
       -o $d/ppo-car_amd/libppocar.so ppo-car_amd/csrc/ppocar.hip ppo-car_amd/csrc/track_json.cpp || exit 1
   cp ppo-car_amd/*.py $d/ppo-car_amd/ && cp ppo_car_amd/__init__.py $d/ppo_car_amd/
   exit 0

@@ -131,6 +131,22 @@ template <int TEST> __global__ void k(unsigned long long* out, float* sink, cons
             asm volatile(X4(X4("ds_read_b128 %0, %2\n ds_read_b128 %1, %2 offset:16\n")) "s_waitcnt lgkmcnt(0)\n" : "=v"(acc0), "=v"(acc1) : "v"(u2 & 0x3f0));
         } else if constexpr (TEST == 48) {  // ds_read_b64 (per-lane addr)
             asm volatile(X4(X4("ds_read_b64 %0, %2\n ds_read_b64 %1, %2 offset:8\n")) "s_waitcnt lgkmcnt(0)\n" : "=v"(p0), "=v"(p1) : "v"((threadIdx.x & 63) * 8));
+        } else if constexpr (TEST == 49) {  // v_rcp_f64
+            asm volatile(X4(X4("v_rcp_f64 %0, %2\n v_rcp_f64 %1, %3\n")) : "+v"(d0), "+v"(d1) : "v"(d2), "v"(d3));
+        } else if constexpr (TEST == 50) {  // v_fma_f64
+            asm volatile(X4(X4("v_fma_f64 %0, %0, %2, %3\n v_fma_f64 %1, %1, %3, %2\n")) : "+v"(d0), "+v"(d1) : "v"(d2), "v"(d3));
+        } else if constexpr (TEST == 51) {  // v_cmp_lt_f64
+            asm volatile(X4(X4("v_cmp_lt_f64 vcc, %0, %1\n v_cmp_lt_f64 vcc, %1, %0\n")) : : "v"(d2), "v"(d3) : "vcc");
+        } else if constexpr (TEST == 52) {  // v_min_f64
+            asm volatile(X4(X4("v_min_f64 %0, %0, %2\n v_min_f64 %1, %1, %3\n")) : "+v"(d0), "+v"(d1) : "v"(d2), "v"(d3));
+        } else if constexpr (TEST == 53) {  // v_cvt_f64_f32
+            asm volatile(X4(X4("v_cvt_f64_f32 %0, %2\n v_cvt_f64_f32 %1, %3\n")) : "+v"(d0), "+v"(d1) : "v"(a2), "v"(a3));
+        } else if constexpr (TEST == 54) {  // v_min3_f32 |.|
+            asm volatile(X4(X4("v_min3_f32 %0, %0, |%2|, |%3|\n v_min3_f32 %1, %1, |%3|, |%2|\n")) : "+v"(a0), "+v"(a1) : "v"(a2), "v"(a3));
+        } else if constexpr (TEST == 55) {  // v_pk_mul_f32 clamp
+            asm volatile(X4(X4("v_pk_mul_f32 %0, %0, %2 clamp\n v_pk_mul_f32 %1, %1, %3 clamp\n")) : "+v"(p0), "+v"(p1) : "v"(p2), "v"(p3));
+        } else if constexpr (TEST == 56) {  // v_and_or_b32 sgpr mask, inline constant
+            asm volatile(X4(X4("v_and_or_b32 %0, %0, %2, 7\n v_and_or_b32 %1, %1, %2, 9\n")) : "+v"(u0), "+v"(u1) : "s"(sgpr_dst = 0xffffffe0));
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -173,7 +189,7 @@ __global__ void lat(unsigned long long* out, float* sink, const int* chain_g) {
 static const char* NAMES[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_add_f64", "v_cvt_f32_f64", "v_and_or+v_min_u32", "v_min3_u32",
                               "v_med3_f32", "v_cvt_pk_f16_f32", "v_cvt_f32_f16(+sdwa)", "v_rcp_f32", "v_exp_f32", "v_readlane_b32",
                               "mfma_16x16x32_f16", "1 mfma + 3 fma", "1 mfma + 7 fma", "v_mul_f32 sgpr", "dep v_fma chain", "dep v_pk_fma chain",
-                              "v_cmp+v_cndmask", "v_perm_b32", "v_mul_f64", "v_mov_dpp", "v_mul_f32 vgpr", "v_add_f32 vgpr", "v_fmac_f32", "v_fma_f32 sgpr src", "v_fma_f32 neg mod", "v_max_f32", "v_min_u32", "v_and_b32", "v_and_or_b32", "v_add_u32", "v_lshlrev_b32", "v_mov_b32", "v_cndmask_b32 (vcc fixed)", "v_cmp_lt_f32", "v_fma_mix_f32", "v_cvt_pkrtz_f16_f32", "v_pk_max_f16", "v_mul_u32_u24", "v_sub_f32 + v_mul_f32 mix", "v_fma_f32 + v_pk_fma alternating", "v_fma_f32 + v_and_or alternating", "v_max3_f32", "v_cvt_f32_i32", "v_log_f32", "ds_read_b128 (same addr)", "ds_read_b64 (per-lane addr)"};
+                              "v_cmp+v_cndmask", "v_perm_b32", "v_mul_f64", "v_mov_dpp", "v_mul_f32 vgpr", "v_add_f32 vgpr", "v_fmac_f32", "v_fma_f32 sgpr src", "v_fma_f32 neg mod", "v_max_f32", "v_min_u32", "v_and_b32", "v_and_or_b32", "v_add_u32", "v_lshlrev_b32", "v_mov_b32", "v_cndmask_b32 (vcc fixed)", "v_cmp_lt_f32", "v_fma_mix_f32", "v_cvt_pkrtz_f16_f32", "v_pk_max_f16", "v_mul_u32_u24", "v_sub_f32 + v_mul_f32 mix", "v_fma_f32 + v_pk_fma alternating", "v_fma_f32 + v_and_or alternating", "v_max3_f32", "v_cvt_f32_i32", "v_log_f32", "ds_read_b128 (same addr)", "ds_read_b64 (per-lane addr)", "v_rcp_f64", "v_fma_f64", "v_cmp_lt_f64", "v_min_f64", "v_cvt_f64_f32", "v_min3_f32 abs", "v_pk_mul_f32 clamp", "v_and_or_b32 sgpr+inline"};
 
 template <int TEST> void run(unsigned long long* d_out, float* d_sink, float* d_src) {
     const int per_rep = 32;
@@ -214,6 +230,7 @@ int main() {
     run<16>(d_out, d_sink, d_src); run<17>(d_out, d_sink, d_src); run<18>(d_out, d_sink, d_src); run<19>(d_out, d_sink, d_src);
     run<20>(d_out, d_sink, d_src); run<21>(d_out, d_sink, d_src); run<22>(d_out, d_sink, d_src);
     run<23>(d_out, d_sink, d_src); run<24>(d_out, d_sink, d_src); run<25>(d_out, d_sink, d_src); run<26>(d_out, d_sink, d_src); run<27>(d_out, d_sink, d_src); run<28>(d_out, d_sink, d_src); run<29>(d_out, d_sink, d_src); run<30>(d_out, d_sink, d_src); run<31>(d_out, d_sink, d_src); run<32>(d_out, d_sink, d_src); run<33>(d_out, d_sink, d_src); run<34>(d_out, d_sink, d_src); run<35>(d_out, d_sink, d_src); run<36>(d_out, d_sink, d_src); run<37>(d_out, d_sink, d_src); run<38>(d_out, d_sink, d_src); run<39>(d_out, d_sink, d_src); run<40>(d_out, d_sink, d_src); run<41>(d_out, d_sink, d_src); run<42>(d_out, d_sink, d_src); run<43>(d_out, d_sink, d_src); run<44>(d_out, d_sink, d_src); run<45>(d_out, d_sink, d_src); run<46>(d_out, d_sink, d_src); run<47>(d_out, d_sink, d_src); run<48>(d_out, d_sink, d_src);
+    run<49>(d_out, d_sink, d_src); run<50>(d_out, d_sink, d_src); run<51>(d_out, d_sink, d_src); run<52>(d_out, d_sink, d_src); run<53>(d_out, d_sink, d_src); run<54>(d_out, d_sink, d_src); run<55>(d_out, d_sink, d_src); run<56>(d_out, d_sink, d_src);
     hipLaunchKernelGGL(lat, dim3(1), dim3(64), 0, 0, d_out, d_sink, d_chain);
     hipDeviceSynchronize();
     unsigned long long h[4];
