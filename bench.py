@@ -86,6 +86,8 @@ def parse_args():
     ap.add_argument("--master-port", type=int, default=None, help="rendezvous port when bench.py starts the ranks itself")
     ap.add_argument("--force-collective", action="store_true", help="1 GPU: take the MULTI-RANK update path (K10, K11, RCCL all-reduce on a 1-rank "
                     "communicator, clip+Adam) -- the multi-GPU update's cost minus the xGMI transport")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "p2p"], help="multi-rank gradient exchange per minibatch: torch.distributed all_reduce (RCCL) "
+                    "or the library's one-shot all-reduce over peer-mapped buffers (pc_xchg_*)")
     ap.add_argument("--capture-collectives", action="store_true", help="multi-rank, backend nccl: capture the per-minibatch all-reduce into the epoch's update graph "
                     "(off by default: the minibatch steps are enqueued eagerly around an eager all-reduce)")
     return ap.parse_args()
@@ -247,8 +249,6 @@ def main():
     if _lib.pc_build_ablate() != 0:
         raise SystemExit("bench.py: libppocar.so is a timing-ablation build (PC_ABLATE != 0)")
     PREC = {"fp16x2": 2, "bf16x3": 1, "fp32": 0}
-    _lib.pc_policy_set_precision(PREC[args.policy_arith])
-    _lib.pc_rollout_set_form(args.rollout_form)
     POLICY_ARITH = {"fp16x2": "fp16x2 split (v = h + l), 3 products, fp32 accumulate on the fp16 matrix cores (fp32-class; DESIGN.md section 5)",
                     "bf16x3": "bf16x3 split, 6 products, fp32 accumulate on the bf16 matrix cores (fp32-equivalent; DESIGN.md section 5)",
                     "fp32": "fp32-input MFMA (exact fp32 fmaf chain)"}[args.policy_arith]
@@ -261,11 +261,16 @@ def main():
     track = ([os.path.join(ROOT, "tracks", "track.json"), os.path.join(ROOT, "tracks", "big_track.json")] if mixed
              else os.path.join(ROOT, "tracks", "big_track.json"))
 
-    def make_trainer():
+    def make_trainer(policy_precision=PREC[args.policy_arith]):
+        # every launch option lives in this trainer's handles (pc_policy, pc_env): nothing process-wide is touched
         cfg_ = PPOConfig(track=track, env_dtype=args.env_dtype, seed=0, policy=args.policy, use_graphs=not args.no_graphs,
                          fused_update=not args.torch_update, custom_mlp=not args.torch_mlp, rollout_kernel=args.rollout_kernel,
-                         force_collective=args.force_collective, capture_collectives=bool(args.capture_collectives), **wl)
-        return cfg_, Trainer(cfg_, device=dev, rank=rank, world_size=world)
+                         force_collective=args.force_collective, capture_collectives=bool(args.capture_collectives),
+                         policy_precision=policy_precision, exchange=args.exchange, **wl)
+        t_ = Trainer(cfg_, device=dev, rank=rank, world_size=world)
+        if args.rollout_form >= 0:
+            t_.envs.set_option("rollout_form", args.rollout_form)
+        return cfg_, t_
 
     cfg, tr = make_trainer()
     tr.profile_stride = 0
@@ -350,8 +355,7 @@ def main():
     if world == 1 and not args.no_extras and args.policy_arith != "fp32" and args.policy == "fused" and not args.force_collective:
         # the price of exact-fp32 policy GEMMs (v_mfma_f32_16x16x4_f32) on the same workload: 3 epochs, outside the headline timing
         try:
-            _lib.pc_policy_set_precision(0)
-            cfg2, tr2 = make_trainer()
+            cfg2, tr2 = make_trainer(policy_precision=0)
             for _ in range(2):
                 tr2.run_epoch(sync=False)
             dt2 = timed(tr2, 3)
@@ -362,8 +366,6 @@ def main():
             del tr2
         except Exception as ex:
             extras["strict_fp32_value"] = {"error": repr(ex)}
-        finally:
-            _lib.pc_policy_set_precision(PREC[args.policy_arith])
 
     if rank == 0:
         env_steps = cfg.n_envs * cfg.n_steps * args.steps * world
@@ -428,6 +430,8 @@ def main():
                        "update_path": ("multi-rank (all-reduce + clip/Adam per minibatch), " + ("captured in the epoch graph" if captured else "enqueued eagerly"))
                        if (world > 1 or args.force_collective) else "single-rank epoch graph",
                        "backend": (dist.get_backend() if dist is not None else None),
+                       "gradient_exchange": (("one-shot all-reduce over peer-mapped buffers (pc_xchg)" if args.exchange == "p2p" else "torch.distributed all_reduce")
+                                             if world > 1 else None),
                        "env_kernel": info, "policy_step": args.policy, "rollout": rollout_mode,
                        "policy_gemm_arithmetic": POLICY_ARITH, "hip_graphs": bool(cfg.use_graphs),
                        "fused_update": bool(cfg.fused_update), "custom_mlp_update": custom, "epoch_split": split,

@@ -18,7 +18,10 @@
  *     default stream).  The library never synchronises in reset/step/gae/sample.
  *   - There is NO CPU fallback: every compute entry point needs a gfx950 device and fails
  *     with PC_ERR_NO_DEVICE / PC_ERR_HIP otherwise.
- *   - One handle per device; a handle is not thread-safe; different handles are independent.
+ *   - One handle per device; a handle is not thread-safe; different handles are independent: every launch option lives in a
+ *     handle (pc_policy: arithmetic form and work decomposition of the policy step; pc_env: pc_env_set_option).  The
+ *     pc_*_set_* entry points marked "process default" only change what handles created AFTERWARDS (and the handle-less
+ *     convenience calls) start from.
  */
 #ifndef PPOCAR_H
 #define PPOCAR_H
@@ -36,12 +39,15 @@ extern "C" {
 #define PC_ERR_HIP (-4)         /* a HIP runtime call failed */
 #define PC_ERR_UNSUPPORTED (-5) /* e.g. more rays than the kernel menu covers */
 #define PC_ERR_NO_DEVICE (-6)   /* no usable gfx950 device */
+#define PC_ERR_TIMEOUT (-7)     /* pc_xchg: a peer rank did not arrive at the gradient exchange */
 
 #define PC_DTYPE_F32 0 /* float32 ray geometry over a float64 kinematic state: the throughput path            */
 #define PC_DTYPE_F64 1 /* float64 throughout, in the reference's operation order: the exact-parity path      */
 
 typedef struct pc_track pc_track;
 typedef struct pc_env pc_env;
+typedef struct pc_policy pc_policy;
+typedef struct pc_xchg pc_xchg;
 
 /* ---- track data: CarEnv.load_track (car_env.py:535-567) + the wall / gate lists that
  * CarEnv.reset builds (car_env.py:651-676).  Host-side, no GPU needed. ------------------ */
@@ -100,6 +106,16 @@ int pc_env_step(pc_env* e, const int64_t* actions, double reward_scale, float* o
  * the finished episode's count is pc_env_step's `gates_passed`).  [N] int32 device arrays, either may be NULL. */
 int pc_env_info(pc_env* e, int32_t* gates_passed, int32_t* time_passed, void* stream);
 
+/* Per-handle launch options of pc_rollout (below); a new handle starts from the process defaults (pc_rollout_set_*).
+ *   PC_OPT_ROLLOUT_FORM  -1 automatic, 0..3 as pc_rollout_set_form
+ *   PC_OPT_ROLLOUT_EPW   0 automatic, 16 / 32 / 128 / 256 as pc_rollout_set_epw
+ *   PC_OPT_ROLLOUT_FAST  0 / 1 / 2 as pc_rollout_set_fast */
+#define PC_OPT_ROLLOUT_FORM 1
+#define PC_OPT_ROLLOUT_EPW 2
+#define PC_OPT_ROLLOUT_FAST 3
+int pc_env_set_option(pc_env* e, int option, int value);
+int pc_env_get_option(const pc_env* e, int option, int* value);
+
 /* Teacher forcing for parity tests: copy the env state from / to HOST arrays of length n_envs
  * (any pointer may be NULL).  `rot` is the heading in degrees.  Synchronous.
  * F32 handles store the heading as a count of 5-degree turns from the track's start angle
@@ -139,11 +155,27 @@ int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, 
  * logprob, value [N]; logits_out [N][A] or NULL.  PC_ERR_UNSUPPORTED unless H == 256, A <= 15, D <= 40
  * (the caller then uses its own GEMMs + pc_sample). */
 int64_t pc_policy_image_floats(int D, int H, int A);
+/* A policy step's configuration as a HANDLE: shape (D, H, A as above), arithmetic form of the two GEMMs (`precision`: 0 / 1 / 2
+ * as described at pc_policy_set_precision, -1 = the process default; a shape the split forms do not cover gets form 0) and work
+ * decomposition (`split`: -1 automatic by batch size, 0 never, 1 always, -2 = the process default).  Handles are immutable and
+ * independent: two of them with different forms can pack and run side by side in one process; a weight image belongs to the
+ * handle that packed it.  pc_policy_get reports the form the shape actually got and the image size.
+ *   pc_policy_pack_p / pc_policy_act_p = pc_policy_pack / pc_policy_act with the handle's form instead of the process default;
+ *   pc_rollout_p = pc_rollout_ex (below) with the handle's form and action count.  (model.py:13-41, train.py:173-195) */
+int pc_policy_create(int device, int D, int H, int A, int precision, int split, pc_policy** out);
+void pc_policy_destroy(pc_policy* p);
+int pc_policy_get(const pc_policy* p, int* precision, int* split, int64_t* image_floats);
+int pc_policy_pack_p(const pc_policy* p, const float* aW1, const float* ab1, const float* aW2, const float* ab2, const float* cW1,
+                     const float* cb1, const float* cW2, const float* cb2, float* image, void* stream);
+int pc_policy_act_p(const pc_policy* p, const float* obs, int64_t N, const float* image, uint64_t seed, uint64_t offset,
+                    const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob, float* value, float* logits_out,
+                    void* stream);
 /* Work decomposition of pc_policy_act: -1 = automatic (hidden tiles split across the waves of a workgroup up to 16384
- * envs), 0 = never split, 1 = always.  The two forms differ in fp32 summation order (last-bit differences).  Tuning /
- * test knob, process-wide. */
+ * envs), 0 = never split, 1 = always.  The two forms differ in fp32 summation order (last-bit differences).  PROCESS DEFAULT
+ * (deprecated as a knob): what pc_policy_create(split = -2) and the handle-less pc_policy_act use. */
 int pc_policy_set_split(int mode);
-/* Arithmetic of the policy step's two GEMMs (process-wide; choose before packing).  All three are fp32-class:
+/* Arithmetic of the policy step's two GEMMs -- PROCESS DEFAULT (deprecated as a knob): what pc_policy_create(precision = -1) and
+ * the handle-less pc_policy_pack / pc_policy_act / pc_rollout use; choose before packing.  All three are fp32-class:
  *   2 (default) = fp16x2: every fp32 operand v = h + 2^-11 l with h = fp16(v), l = fp16((v - h) 2^11) (22 significant
  *       bits at any magnitude); a product is a_h b_h plus the two cross terms in a second, scaled fp32 accumulator
  *       (v_mfma_f32_16x16x32_f16, three per K block).  Max error vs float64 on this MLP 1.3e-7 (a plain fp32 GEMM:
@@ -154,6 +186,8 @@ int pc_policy_set_split(int mode);
  * pc_policy_precision reports the form a (D, H, A) shape will actually get (negative: unsupported shape). */
 int pc_policy_set_precision(int mode);
 int pc_policy_precision(int D, int H, int A);
+/* the two process defaults as they stand (either pointer may be NULL) */
+int pc_policy_defaults(int* precision, int* split);
 int pc_policy_pack(int device, int D, int H, int A, const float* aW1, const float* ab1, const float* aW2, const float* ab2,
                    const float* cW1, const float* cb1, const float* cW2, const float* cb2, float* image, void* stream);
 int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, const float* image, uint64_t seed,
@@ -190,7 +224,14 @@ int pc_rollout_ex(pc_env* e, const float* image, int A, int64_t T, double reward
                   float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, float* last_value,
                   float* reward_sum, void* stream);
 
-/* Work decomposition of pc_rollout: -1 = automatic (above 16384 envs: independent waves of 32 envs, 256 envs per workgroup
+int pc_rollout_p(pc_env* e, const pc_policy* p, const float* image, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
+                 const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
+                 float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, float* last_value,
+                 float* reward_sum, void* stream);
+
+/* PROCESS DEFAULTS of pc_env's rollout options (deprecated as knobs: a handle created afterwards starts from them; use
+ * pc_env_set_option on the handle).
+ * Work decomposition of pc_rollout: -1 = automatic (above 16384 envs: independent waves of 32 envs, 256 envs per workgroup
  * -- 128 up to 32768 envs; else 32 envs per workgroup with the policy's hidden tiles and the wall sweep split over the
  * waves), 0 / 1 force the first / second form; 2 / 3 = forms 0 / 1 with the env step forming 1/den arithmetically instead of
  * reading the track's 1/den table from LDS (what happens anyway when the table does not fit).  All are bit-identical
@@ -264,6 +305,31 @@ int pc_ppo_minibatch_prepared(int device, const float* prepared_mb, int B, int D
                               double ent_coef, double max_norm, double beta1, double beta2, double eps, float* metrics,
                               float* workspace, int apply, void* stream);
 
+
+/* ---- the per-minibatch gradient exchange (one all-reduce(SUM) of the flat gradient bucket between
+ * loss.backward() and clip_grad_norm_, train.py:259-260) as a ONE-SHOT all-reduce over peer-mapped buffers -- the
+ * latency-proof alternative to an RCCL all_reduce for a 49 - 92 KB message: every rank writes its bucket straight into a
+ * slot of every peer's staging buffer (hipIpc-mapped device memory: W - 1 independent xGMI writes), raises an arrival flag,
+ * waits for its own W flags and sums the W slots locally in rank order, so the reduced buckets are bit-identical on all
+ * ranks.  One process per rank (ranks of one node; up to 8):
+ *   pc_xchg_create(device, rank, world, n_floats)   allocates this rank's staging buffer (uncached device memory);
+ *   pc_xchg_local_handle(x, out)                    PC_XCHG_HANDLE_BYTES bytes (a hipIpcMemHandle_t) for the other ranks -- the
+ *                                                   caller carries them across (e.g. torch.distributed.all_gather_object);
+ *   pc_xchg_connect(x, all)                         `all` = world x PC_XCHG_HANDLE_BYTES bytes in rank order: maps the peers;
+ *   pc_xchg_allreduce(x, bucket, stream)            in place, asynchronous on `stream`, capturable into a HIP graph: bucket[0..n)
+ *                                                   := sum over ranks (rank order) of their buckets.  Every rank must make the
+ *                                                   same sequence of calls;
+ *   pc_xchg_status(x)                               synchronises the device; PC_ERR_TIMEOUT if a wait inside any call gave up
+ *                                                   (~2 s without a peer's flag: the kernel then finishes with a wrong sum
+ *                                                   rather than hang the GPU);
+ *   pc_xchg_destroy(x)                              after every rank has finished using it (the caller synchronises the ranks). */
+#define PC_XCHG_HANDLE_BYTES 64
+int pc_xchg_create(int device, int rank, int world, int64_t n_floats, pc_xchg** out);
+int pc_xchg_local_handle(pc_xchg* x, void* handle_out);
+int pc_xchg_connect(pc_xchg* x, const void* all_handles);
+int pc_xchg_allreduce(pc_xchg* x, float* bucket, void* stream);
+int pc_xchg_status(pc_xchg* x);
+void pc_xchg_destroy(pc_xchg* x);
 
 const char* pc_strerror(int code);
 /* Last HIP error string seen by this thread (diagnostics for PC_ERR_HIP). */

@@ -13,8 +13,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libppocar.so")
 
 PC_OK = 0
-PC_ERR_INVALID_ARG, PC_ERR_IO, PC_ERR_PARSE, PC_ERR_HIP, PC_ERR_UNSUPPORTED, PC_ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6
+PC_ERR_INVALID_ARG, PC_ERR_IO, PC_ERR_PARSE, PC_ERR_HIP, PC_ERR_UNSUPPORTED, PC_ERR_NO_DEVICE, PC_ERR_TIMEOUT = -1, -2, -3, -4, -5, -6, -7
+PC_XCHG_HANDLE_BYTES = 64
 PC_DTYPE_F32, PC_DTYPE_F64 = 0, 1
+PC_OPT_ROLLOUT_FORM, PC_OPT_ROLLOUT_EPW, PC_OPT_ROLLOUT_FAST = 1, 2, 3
 DTYPES = {"f32": PC_DTYPE_F32, "float32": PC_DTYPE_F32, "f64": PC_DTYPE_F64, "float64": PC_DTYPE_F64}
 
 
@@ -80,6 +82,15 @@ _sig = {
     "pc_policy_act": (_i, [_i, _vp, _i64, _i, _i, _i, _vp, C.c_uint64, C.c_uint64, _vp] + [_vp] * 5 + [_vp]),
     "pc_rollout": (_i, [_vp, _vp, _i, _i64, _d, C.c_uint64, C.c_uint64, _vp] + [_vp] * 10 + [_vp]),
     "pc_rollout_ex": (_i, [_vp, _vp, _i, _i64, _d, C.c_uint64, C.c_uint64, _vp] + [_vp] * 12 + [_vp]),
+    "pc_policy_create": (_i, [_i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "pc_policy_destroy": (None, [_vp]),
+    "pc_policy_defaults": (_i, [C.POINTER(_i), C.POINTER(_i)]),
+    "pc_policy_get": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64)]),
+    "pc_policy_pack_p": (_i, [_vp] + [_vp] * 8 + [_vp, _vp]),
+    "pc_policy_act_p": (_i, [_vp, _vp, _i64, _vp, C.c_uint64, C.c_uint64, _vp] + [_vp] * 5 + [_vp]),
+    "pc_rollout_p": (_i, [_vp, _vp, _vp, _i64, _d, C.c_uint64, C.c_uint64, _vp] + [_vp] * 12 + [_vp]),
+    "pc_env_set_option": (_i, [_vp, _i, _i]),
+    "pc_env_get_option": (_i, [_vp, _i, C.POINTER(_i)]),
     "pc_rollout_set_form": (_i, [_i]),
     "pc_rollout_set_epw": (_i, [_i]),
     "pc_rollout_set_fast": (_i, [_i]),
@@ -92,6 +103,12 @@ _sig = {
     "pc_ppo_prepare": (_i, [_i, _vp, _i64, _i, _i, _i] + [_vp] * 5 + [_vp, _vp]),
     "pc_ppo_minibatch_prepared": (_i, [_i, _vp, _i, _i, _i, _i] + [_vp] * 6 + [_d] * 7 + [_vp, _vp, _i, _vp]),
     "pc_ppo_minibatch": (_i, [_i, _vp, _i, _i, _i, _i] + [_vp] * 5 + [_vp] * 6 + [_d] * 7 + [_vp, _vp, _i, _vp]),
+    "pc_xchg_create": (_i, [_i, _i, _i, _i64, C.POINTER(_vp)]),
+    "pc_xchg_local_handle": (_i, [_vp, _vp]),
+    "pc_xchg_connect": (_i, [_vp, _vp]),
+    "pc_xchg_allreduce": (_i, [_vp, _vp, _vp]),
+    "pc_xchg_status": (_i, [_vp]),
+    "pc_xchg_destroy": (None, [_vp]),
     "pc_strerror": (C.c_char_p, [_i]),
     "pc_last_hip_error": (C.c_char_p, []),
     "pc_env_launch_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),

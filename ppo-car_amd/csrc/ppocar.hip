@@ -16,6 +16,7 @@
 //   K9  rollout_kernel<KS, RPL, PREC, MODE> / K9s rollout_small_kernel<..., EPW>   the whole rollout (train.py:173-195) as one
 //                                       persistent launch (large / small batches)
 //   K10-12 ppo_fwdbwd / grad_reduce / adam (+ clip_adam_mb, the multi-rank step)   one PPO minibatch step without any library GEMM
+//   K13 xchg_allreduce_kernel          the per-minibatch gradient all-reduce as a one-shot exchange over peer-mapped buffers (pc_xchg_*)
 //
 // Work decomposition of K1: an env is owned by G = 2^lg consecutive lanes of one
 // wavefront ("lanes per env", chosen on the host from n_envs so the chip is filled); lane g of the
@@ -66,6 +67,7 @@
 #include "kernels/policy.hpp"
 #include "kernels/rollout.hpp"
 #include "kernels/update.hpp"
+#include "kernels/exchange.hpp"
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -107,8 +109,22 @@ int pick_rpl(int need) {
 
 }  // namespace
 
+// pc_rollout's dispatch options: per env handle (pc_env_set_option); a new handle starts from the process defaults, which the
+// deprecated pc_rollout_set_* entry points change.
+struct RolloutOpts {
+    int form = -1;        // -1 auto, 0 = 256 envs per workgroup, 1 = 32 envs per workgroup
+    int rden = 1;         // stage the 1/den table in LDS when it fits (0: never; test / tuning knob)
+    int epw_override = 0; // 0 = automatic, 16 / 32 / 128 / 256 = force (test knob)
+    int fast = 1;         // the fast modes (LDS tables behind LDS pointers) when the shape allows them (0: never; A/B knob)
+    int nv28 = 1;         // kernels compiled for a padded wall chain of 28 vertices (big_track.json) when every track of the batch has one
+};
+static RolloutOpts g_rollout_defaults;
+static int g_policy_split_mode = -1;  // process default of pc_policy::split: -1 auto (split below 32768 envs), 0 never, 1 always
+static int g_policy_precision = 2;    // process default of pc_policy::precision: 0 = fp32-input MFMA; split forms on the 16-bit matrix cores (need D <= 40, A <= 9): 1 = bf16 x 3, 2 = fp16 x 2
+
 struct pc_env {
     int device = 0;
+    RolloutOpts opt = g_rollout_defaults;
     int dtype = PC_DTYPE_F32;
     int64_t N = 0;
     int n_nominal = 12, R = 12, D = 18, n_tracks = 0;
@@ -212,6 +228,7 @@ const char* pc_strerror(int code) {
         case PC_ERR_HIP: return "HIP runtime error";
         case PC_ERR_UNSUPPORTED: return "unsupported configuration";
         case PC_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case PC_ERR_TIMEOUT: return "a peer did not arrive at the gradient exchange (pc_xchg)";
         default: return "unknown error";
     }
 }
@@ -659,31 +676,64 @@ int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, 
 }
 
 static int policy_ks(int D) { return D <= 20 ? 5 : (D <= 24 ? 6 : 10); }
-static int g_policy_split_mode = -1;  // -1 auto (split below 32768 envs), 0 never, 1 always
-static int g_rollout_form = -1;       // pc_rollout: -1 auto, 0 = 256 envs per workgroup, 1 = 32 envs per workgroup
 // Batches up to this size take the forms that cut the work of 32 envs over a whole workgroup (policy_kernel<SPLIT>,
 // rollout_small_kernel): n_envs / 32 workgroups, so 16384 envs are two rounds of 256 -- about what the 128-env big form
 // needs for anything up to 32768 envs.  The same bound for both kernels keeps the default per-step and persistent paths
 // bit-identical.
 #define PC_SPLIT_MAX_ENVS 16384
-static int64_t g_rollout_epw128_max = 32768;  // big form at or below this many envs: 128 envs (4 waves) per workgroup
-static int g_rollout_epw_override = 0;  // pc_rollout_set_epw: 0 = automatic, 128 / 256 = force (test knob)
-static int g_rollout_nv28 = 1;        // pc_rollout: kernels compiled for a padded wall chain of 28 vertices (big_track.json) when every track of the batch has one
-static int g_rollout_fast = 1;        // pc_rollout: the big form's fast mode (LDS tables behind LDS pointers) when the shape allows it (0: never; A/B knob)
-static int g_rollout_rden = 1;        // pc_rollout: stage the 1/den table in LDS when it fits (0: never; test / tuning knob)
-static int g_policy_precision = 2;    // 0 = fp32-input MFMA; split forms on the 16-bit matrix cores (need D <= 24, A <= 9): 1 = bf16 x 3, 2 = fp16 x 2
+static const int64_t g_rollout_epw128_max = 32768;  // big form at or below this many envs: 128 envs (4 waves) per workgroup
 
+// the arithmetic form a (D, A) shape gets when `requested` is asked for: the split forms cover D <= 40, A <= 9
+static int policy_prec(int requested, int D, int A) { return (requested >= 1 && D <= 40 && A <= 9) ? requested : 0; }
+
+// One policy step's configuration: shape, arithmetic form, work decomposition.  Immutable after creation; any number of
+// handles with different forms can live in one process (each weight image belongs to the handle that packed it).
+struct pc_policy {
+    int device = 0, D = 0, H = 0, A = 0;
+    int precision = 0;   // the form the shape actually gets (policy_prec)
+    int split = -1;      // -1 automatic (by batch size), 0 never, 1 always
+};
+
+extern "C" {
+
+int pc_policy_create(int device, int D, int H, int A, int precision, int split, pc_policy** out) {
+    if (!out || precision < -1 || precision > 2 || split < -2 || split > 1) return PC_ERR_INVALID_ARG;
+    if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;  // the caller falls back to its own GEMMs
+    pc_policy* p = new (std::nothrow) pc_policy;
+    if (!p) return PC_ERR_INVALID_ARG;
+    p->device = device;
+    p->D = D;
+    p->H = H;
+    p->A = A;
+    p->precision = policy_prec(precision < 0 ? g_policy_precision : precision, D, A);
+    p->split = split == -2 ? g_policy_split_mode : split;
+    *out = p;
+    return PC_OK;
+}
+
+void pc_policy_destroy(pc_policy* p) { delete p; }
+
+int pc_policy_get(const pc_policy* p, int* precision, int* split, int64_t* image_floats) {
+    if (!p) return PC_ERR_INVALID_ARG;
+    if (precision) *precision = p->precision;
+    if (split) *split = p->split;
+    if (image_floats) *image_floats = p->precision ? polx_image_dwords(p->precision, pol_ng(policy_ks(p->D))) : pol_image_padded(policy_ks(p->D));
+    return PC_OK;
+}
+
+// ---- deprecated process-wide defaults: what a handle created with precision = -1 / split = -2 and a new pc_env start from,
+// and what the handle-less pc_policy_* / pc_rollout* entry points use
 int pc_rollout_set_form(int form) {
     if (form < -1 || form > 3) return PC_ERR_INVALID_ARG;
-    g_rollout_rden = form >= 2 ? 0 : 1;              // forms 2 / 3 = forms 0 / 1 without the LDS 1/den table
-    g_rollout_form = form >= 2 ? form - 2 : form;
+    g_rollout_defaults.rden = form >= 2 ? 0 : 1;              // forms 2 / 3 = forms 0 / 1 without the LDS 1/den table
+    g_rollout_defaults.form = form >= 2 ? form - 2 : form;
     return PC_OK;
 }
 
 int pc_rollout_set_fast(int on) {
     if (on < 0 || on > 2) return PC_ERR_INVALID_ARG;
-    g_rollout_fast = on != 0;
-    g_rollout_nv28 = on == 1;      // 2: fast mode, but never the kernels specialised for a wall chain of 28 vertices
+    g_rollout_defaults.fast = on != 0;
+    g_rollout_defaults.nv28 = on == 1;      // 2: fast mode, but never the kernels specialised for a wall chain of 28 vertices
     return PC_OK;
 }
 
@@ -691,7 +741,7 @@ int pc_rollout_set_epw(int envs_per_workgroup) {
     if (envs_per_workgroup != 0 && envs_per_workgroup != 16 && envs_per_workgroup != 32 && envs_per_workgroup != 128 &&
         envs_per_workgroup != 256)
         return PC_ERR_INVALID_ARG;
-    g_rollout_epw_override = envs_per_workgroup;
+    g_rollout_defaults.epw_override = envs_per_workgroup;
     return PC_OK;
 }
 
@@ -701,10 +751,9 @@ int pc_policy_set_precision(int mode) {
     return PC_OK;
 }
 
-static int policy_prec(int D, int A) { return (g_policy_precision >= 1 && D <= 40 && A <= 9) ? g_policy_precision : 0; }
 int pc_policy_precision(int D, int H, int A) {
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
-    return policy_prec(D, A);
+    return policy_prec(g_policy_precision, D, A);
 }
 
 int pc_policy_set_split(int mode) {
@@ -713,21 +762,55 @@ int pc_policy_set_split(int mode) {
     return PC_OK;
 }
 
-int64_t pc_policy_image_floats(int D, int H, int A) {
-    if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
-    const int prec = policy_prec(D, A);
-    return prec ? polx_image_dwords(prec, pol_ng(policy_ks(D))) : pol_image_padded(policy_ks(D));
+int pc_policy_defaults(int* precision, int* split) {
+    if (precision) *precision = g_policy_precision;
+    if (split) *split = g_policy_split_mode;
+    return PC_OK;
 }
 
-int pc_policy_pack(int device, int D, int H, int A, const float* aW1, const float* ab1, const float* aW2, const float* ab2,
-                   const float* cW1, const float* cb1, const float* cW2, const float* cb2, float* image, void* stream) {
+int pc_env_set_option(pc_env* e, int option, int value) {
+    if (!e) return PC_ERR_INVALID_ARG;
+    switch (option) {
+        case PC_OPT_ROLLOUT_FORM:
+            if (value < -1 || value > 3) return PC_ERR_INVALID_ARG;
+            e->opt.rden = value >= 2 ? 0 : 1;
+            e->opt.form = value >= 2 ? value - 2 : value;
+            return PC_OK;
+        case PC_OPT_ROLLOUT_EPW:
+            if (value != 0 && value != 16 && value != 32 && value != 128 && value != 256) return PC_ERR_INVALID_ARG;
+            e->opt.epw_override = value;
+            return PC_OK;
+        case PC_OPT_ROLLOUT_FAST:
+            if (value < 0 || value > 2) return PC_ERR_INVALID_ARG;
+            e->opt.fast = value != 0;
+            e->opt.nv28 = value == 1;
+            return PC_OK;
+        default: return PC_ERR_INVALID_ARG;
+    }
+}
+
+int pc_env_get_option(const pc_env* e, int option, int* value) {
+    if (!e || !value) return PC_ERR_INVALID_ARG;
+    switch (option) {
+        case PC_OPT_ROLLOUT_FORM: *value = e->opt.form < 0 ? -1 : e->opt.form + (e->opt.rden ? 0 : 2); return PC_OK;
+        case PC_OPT_ROLLOUT_EPW: *value = e->opt.epw_override; return PC_OK;
+        case PC_OPT_ROLLOUT_FAST: *value = !e->opt.fast ? 0 : (e->opt.nv28 ? 1 : 2); return PC_OK;
+        default: return PC_ERR_INVALID_ARG;
+    }
+}
+
+}  // extern "C"
+
+static int64_t policy_image_floats_impl(int prec, int D) { return prec ? polx_image_dwords(prec, pol_ng(policy_ks(D))) : pol_image_padded(policy_ks(D)); }
+
+static int policy_pack_impl(int device, int prec, int D, int H, int A, const float* aW1, const float* ab1, const float* aW2, const float* ab2,
+                            const float* cW1, const float* cb1, const float* cW2, const float* cb2, float* image, void* stream) {
     if (!aW1 || !ab1 || !aW2 || !ab2 || !cW1 || !cb1 || !cW2 || !cb2 || !image) return PC_ERR_INVALID_ARG;
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1 || device < 0 || device >= count) return PC_ERR_NO_DEVICE;
     DeviceGuard guard(device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
-    const int prec = policy_prec(D, A);
 #define PC_PACK(PRC, NGV)                                                                                                \
     hipLaunchKernelGGL((policy_pack16_kernel<PRC, NGV>), dim3(64), dim3(256), 0, (hipStream_t)stream, D, A, aW1, ab1, aW2, ab2, cW1, \
                        cb1, cW2, cb2, reinterpret_cast<unsigned*>(image))
@@ -742,9 +825,9 @@ int pc_policy_pack(int device, int D, int H, int A, const float* aW1, const floa
     return PC_OK;
 }
 
-int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, const float* image, uint64_t seed,
-                  uint64_t offset, const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob, float* value,
-                  float* logits_out, void* stream) {
+static int policy_act_impl(int device, int prec, int split_mode, const float* obs, int64_t N, int D, int H, int A, const float* image, uint64_t seed,
+                           uint64_t offset, const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob, float* value,
+                           float* logits_out, void* stream) {
     if (!obs || !image || !action || !logprob || !value || N < 1) return PC_ERR_INVALID_ARG;
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;  // the caller falls back to its own GEMMs
     int count = 0;
@@ -752,7 +835,6 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
     DeviceGuard guard(device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
     const int KS = policy_ks(D);
-    const int prec = policy_prec(D, A);
     const size_t lds = (size_t)((prec ? polx_image_dwords(prec, pol_ng(KS)) : pol_image_padded(KS)) + 8 * 32 * 17) * sizeof(float);
     static int n_cu[64] = {0};
     if (device < 64 && n_cu[device] == 0) {
@@ -762,7 +844,7 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
     }
     const int cus = device < 64 ? n_cu[device] : 256;
     // too few 256-env workgroups to fill the chip: split the hidden tiles over the waves instead
-    const bool split = g_policy_split_mode < 0 ? N <= PC_SPLIT_MAX_ENVS : g_policy_split_mode == 1;
+    const bool split = split_mode < 0 ? N <= PC_SPLIT_MAX_ENVS : split_mode == 1;
     const int64_t chunks = split ? (N + 31) / 32 : (N + 255) / 256;
     const int blocks = (int)(chunks < cus ? chunks : cus);  // one ~100-KB-LDS workgroup per CU, persistent over env chunks
     hipStream_t st = (hipStream_t)stream;
@@ -794,6 +876,39 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
 #undef PC_POL
     HIPCHK(hipGetLastError());
     return PC_OK;
+}
+
+int64_t pc_policy_image_floats(int D, int H, int A) {
+    if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
+    return policy_image_floats_impl(policy_prec(g_policy_precision, D, A), D);
+}
+
+int pc_policy_pack(int device, int D, int H, int A, const float* aW1, const float* ab1, const float* aW2, const float* ab2,
+                   const float* cW1, const float* cb1, const float* cW2, const float* cb2, float* image, void* stream) {
+    if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
+    return policy_pack_impl(device, policy_prec(g_policy_precision, D, A), D, H, A, aW1, ab1, aW2, ab2, cW1, cb1, cW2, cb2, image, stream);
+}
+
+int pc_policy_pack_p(const pc_policy* p, const float* aW1, const float* ab1, const float* aW2, const float* ab2, const float* cW1,
+                     const float* cb1, const float* cW2, const float* cb2, float* image, void* stream) {
+    if (!p) return PC_ERR_INVALID_ARG;
+    return policy_pack_impl(p->device, p->precision, p->D, p->H, p->A, aW1, ab1, aW2, ab2, cW1, cb1, cW2, cb2, image, stream);
+}
+
+int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, const float* image, uint64_t seed,
+                  uint64_t offset, const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob, float* value,
+                  float* logits_out, void* stream) {
+    if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
+    return policy_act_impl(device, policy_prec(g_policy_precision, D, A), g_policy_split_mode, obs, N, D, H, A, image, seed, offset, offset_dev,
+                           action, action_f32, logprob, value, logits_out, stream);
+}
+
+int pc_policy_act_p(const pc_policy* p, const float* obs, int64_t N, const float* image, uint64_t seed, uint64_t offset,
+                    const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob, float* value, float* logits_out,
+                    void* stream) {
+    if (!p) return PC_ERR_INVALID_ARG;
+    return policy_act_impl(p->device, p->precision, p->split, obs, N, p->D, p->H, p->A, image, seed, offset, offset_dev, action, action_f32,
+                           logprob, value, logits_out, stream);
 }
 
 int pc_ppo_gather(int device, const int64_t* idx, int B, int D, const float* obs, const float* act, const float* logprob,
@@ -847,7 +962,7 @@ int pc_clip_adam_advanced(int device, float* param, const float* grad, float* ex
     return PC_OK;
 }
 
-static int rollout_impl(pc_env* e, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
+static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
                         const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
                         float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, float* last_value,
                         float* reward_sum, void* stream) {
@@ -859,12 +974,13 @@ static int rollout_impl(pc_env* e, const float* image, int A, int64_t T, double 
     const int KS = policy_ks(e->D);
     DeviceGuard guard(e->device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
-    const int prec = policy_prec(e->D, A);
+    const int prec = policy_prec(prec_request, e->D, A);
+    const RolloutOpts& o = e->opt;
     const int img = prec ? polx_image_dwords(prec, pol_ng(KS)) : pol_image_padded(KS);
     // large batches: 256 envs per workgroup, every wave independent; small batches: 32 envs per workgroup, hidden tiles and
     // wall-sweep parts split over the waves
-    const bool small = g_rollout_form == 1 || (g_rollout_form < 0 && e->N <= PC_SPLIT_MAX_ENVS);
-    const int epw = g_rollout_epw_override >= 128 ? g_rollout_epw_override
+    const bool small = o.form == 1 || (o.form < 0 && e->N <= PC_SPLIT_MAX_ENVS);
+    const int epw = o.epw_override >= 128 ? o.epw_override
                                                   : ((!small && e->N <= g_rollout_epw128_max) ? 128 : 256);   // big form: envs per workgroup
     int max_G = 0, max_nV = 0;
     for (const TrackHdr& h : e->hdr_host) { max_G = std::max(max_G, h.G); max_nV = std::max(max_nV, h.nV); }
@@ -877,7 +993,7 @@ static int rollout_impl(pc_env* e, const float* image, int A, int64_t T, double 
     // other count that maps onto the same slots (17 or 18 nominal rays -> 18 actual: the slots of 17; 31 -> 33 with five
     // collision rays) takes the generic mode, which reads all of that from the handle.
     const bool fast_rays = e->n_nominal == 12 || e->n_nominal == 16 || e->n_nominal == 32;
-    const bool fast_shape = A == 9 && fast_rays && e->D >= 17 && e->D <= 40 && max_G <= TAB_MAX_GATES && g_rollout_fast;
+    const bool fast_shape = A == 9 && fast_rays && e->D >= 17 && e->D <= 40 && max_G <= TAB_MAX_GATES && o.fast;
     // (the float64 refinement gathers the chain from LDS: at most FT_VTX_MAX vertices; a shape whose fast-mode tables do not fit
     // beside the weight image -- the fp32 image at 33 rays -- takes the generic mode)
     const size_t lds_fast_big = (size_t)(img + 256 * e->D + 256 + ft_floats(false, KS != 10)) * sizeof(float);   // (33 rays: one turn of the float64 lattice)
@@ -892,20 +1008,20 @@ static int rollout_impl(pc_env* e, const float* image, int A, int64_t T, double 
     // den and its reciprocal itself -- same bits either way.  Mixed batches: in the fast modes only (room for the largest track).
     // (the big form at 33 rays has 4 KB left: no closed track's table fits, so that shape is built without the table mode)
     int rden_lds = 361 * max_nV;
-    if (g_rollout_rden == 0 || (e->track_id && !(small ? fast_small : fast)) || lds + (size_t)rden_lds * sizeof(float) > 160 * 1024 ||
+    if (o.rden == 0 || (e->track_id && !(small ? fast_small : fast)) || lds + (size_t)rden_lds * sizeof(float) > 160 * 1024 ||
         (!small && KS == 10))
         rden_lds = 0;
     lds += (size_t)rden_lds * sizeof(float);
     const int rpl = small ? (e->R + 3) / 4 : (e->R + 1) / 2;  // 4 (x 4 sweep parts) or 2 lanes per env
     // small form: 16 envs per workgroup up to 4096 envs (<= 256 workgroups: one per CU), else 32
-    const int epw_small = (g_rollout_epw_override == 16 || g_rollout_epw_override == 32) ? g_rollout_epw_override
+    const int epw_small = (o.epw_override == 16 || o.epw_override == 32) ? o.epw_override
                           : ((fast_small && prec != 0 && e->R <= 17 && e->N <= 4096) ? 16 : 32);
     if (small && epw_small == 16 && !(fast_small && prec != 0 && e->R <= 17)) return PC_ERR_UNSUPPORTED;
     const int blocks = (int)(small ? (e->N + epw_small - 1) / epw_small : (e->N + epw - 1) / epw);
     // 16-byte stores of the waves' 32-row blocks: the rows' offsets inside the buffers AND the buffers themselves are aligned
     const int vec_ok = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
     const int mode = (fast || fast_small) ? (rden_lds ? 2 : 1) : 0;
-    bool all_nv28 = g_rollout_nv28 != 0;
+    bool all_nv28 = o.nv28 != 0;
     for (const TrackHdr& h : e->hdr_host) all_nv28 = all_nv28 && h.nV == 28;
     hipStream_t st = (hipStream_t)stream;
     EnvParams<float> prm = e->params<float>();
@@ -973,16 +1089,26 @@ static int rollout_impl(pc_env* e, const float* image, int A, int64_t T, double 
 int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
                const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
                float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, void* stream) {
-    return rollout_impl(e, image, A, T, reward_scale, seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf,
-                        logprob_buf, next_obs, next_term, next_trunc, nullptr, nullptr, stream);
+    return rollout_impl(e, g_policy_precision, image, A, T, reward_scale, seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf,
+                        trunc_buf, logprob_buf, next_obs, next_term, next_trunc, nullptr, nullptr, stream);
 }
 
 int pc_rollout_ex(pc_env* e, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
                   const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
                   float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, float* last_value,
                   float* reward_sum, void* stream) {
-    return rollout_impl(e, image, A, T, reward_scale, seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf,
-                        logprob_buf, next_obs, next_term, next_trunc, last_value, reward_sum, stream);
+    return rollout_impl(e, g_policy_precision, image, A, T, reward_scale, seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf,
+                        trunc_buf, logprob_buf, next_obs, next_term, next_trunc, last_value, reward_sum, stream);
+}
+
+int pc_rollout_p(pc_env* e, const pc_policy* p, const float* image, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
+                 const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
+                 float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, float* last_value,
+                 float* reward_sum, void* stream) {
+    if (!e || !p) return PC_ERR_INVALID_ARG;
+    if (p->D != e->D || p->device != e->device) return PC_ERR_INVALID_ARG;     // the policy was built for another observation width / device
+    return rollout_impl(e, p->precision, image, p->A, T, reward_scale, seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf,
+                        trunc_buf, logprob_buf, next_obs, next_term, next_trunc, last_value, reward_sum, stream);
 }
 
 int64_t pc_ppo_workspace_floats(int B, int D, int H, int A) {
@@ -1068,6 +1194,129 @@ int pc_ppo_minibatch_prepared(int device, const float* prepared_mb, int B, int D
     return ppo_minibatch_impl(device, nullptr, prepared_mb, B, D, H, A, nullptr, nullptr, nullptr, nullptr, nullptr, param, grad, exp_avg,
                               exp_avg_sq, step_count, lr_dev, clip_ratio, vf_coef, ent_coef, max_norm, beta1, beta2, eps, metrics,
                               workspace, apply, stream);
+}
+
+
+// ---- pc_xchg: one-shot all-reduce over peer-mapped staging buffers (kernels/exchange.hpp) --------------------------------
+}  // extern "C"
+
+struct pc_xchg {
+    int device = 0, rank = 0, world = 1;
+    int64_t n = 0;
+    int n_pad = 0, n_chunks = 0;
+    char* local = nullptr;                       // this rank's staging allocation (uncached device memory)
+    char* peer[XCHG_MAX_RANKS] = {nullptr};      // every rank's allocation as mapped here (peer[rank] == local)
+    bool connected = false;
+    size_t data_bytes() const { return (size_t)2 * world * n_pad * sizeof(float); }
+    size_t flag_bytes() const { return (size_t)2 * world * n_chunks * sizeof(unsigned); }
+    size_t total_bytes() const { return data_bytes() + flag_bytes() + (size_t)n_chunks * sizeof(unsigned) + 64; }
+    XchgView view() const {
+        XchgView v;
+        for (int r = 0; r < XCHG_MAX_RANKS; ++r) {
+            char* b = r < world ? peer[r] : nullptr;
+            v.data[r] = reinterpret_cast<float*>(b);
+            v.flags[r] = reinterpret_cast<unsigned*>(b ? b + data_bytes() : nullptr);
+        }
+        v.epoch = reinterpret_cast<unsigned*>(local + data_bytes() + flag_bytes());
+        v.error = reinterpret_cast<int*>(local + data_bytes() + flag_bytes() + (size_t)n_chunks * sizeof(unsigned));
+        v.rank = rank;
+        v.world = world;
+        v.n = (int)n;
+        v.n_pad = n_pad;
+        v.n_chunks = n_chunks;
+        return v;
+    }
+};
+
+extern "C" {
+
+int pc_xchg_create(int device, int rank, int world, int64_t n_floats, pc_xchg** out) {
+    if (!out || world < 1 || world > XCHG_MAX_RANKS || rank < 0 || rank >= world || n_floats < 1 || n_floats > (1 << 24)) return PC_ERR_INVALID_ARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1 || device < 0 || device >= count) return PC_ERR_NO_DEVICE;
+    DeviceGuard guard(device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    pc_xchg* x = new (std::nothrow) pc_xchg;
+    if (!x) return PC_ERR_INVALID_ARG;
+    x->device = device;
+    x->rank = rank;
+    x->world = world;
+    x->n = n_floats;
+    x->n_chunks = (int)((n_floats + XCHG_CHUNK - 1) / XCHG_CHUNK);
+    x->n_pad = x->n_chunks * XCHG_CHUNK;
+    void* p = nullptr;
+    // uncached, fine-grained device memory: a peer's stores must be visible to a kernel that is already running here
+    hipError_t e = hipExtMallocWithFlags(&p, x->total_bytes(), hipDeviceMallocUncached);
+    if (e != hipSuccess) e = hipExtMallocWithFlags(&p, x->total_bytes(), hipDeviceMallocFinegrained);
+    if (e != hipSuccess) {
+        g_hip_err = std::string("hipExtMallocWithFlags: ") + hipGetErrorString(e);
+        delete x;
+        return PC_ERR_HIP;
+    }
+    x->local = static_cast<char*>(p);
+    x->peer[rank] = x->local;
+    if (hipMemset(p, 0, x->total_bytes()) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipFree(p);
+        delete x;
+        return PC_ERR_HIP;
+    }
+    x->connected = world == 1;
+    *out = x;
+    return PC_OK;
+}
+
+int pc_xchg_local_handle(pc_xchg* x, void* handle_out) {
+    if (!x || !handle_out) return PC_ERR_INVALID_ARG;
+    static_assert(sizeof(hipIpcMemHandle_t) == PC_XCHG_HANDLE_BYTES, "handle size");
+    DeviceGuard guard(x->device);
+    hipIpcMemHandle_t h;
+    HIPCHK(hipIpcGetMemHandle(&h, x->local));
+    memcpy(handle_out, &h, sizeof(h));
+    return PC_OK;
+}
+
+int pc_xchg_connect(pc_xchg* x, const void* all_handles) {
+    if (!x || !all_handles) return PC_ERR_INVALID_ARG;
+    DeviceGuard guard(x->device);
+    for (int r = 0; r < x->world; ++r) {
+        if (r == x->rank || x->peer[r]) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, static_cast<const char*>(all_handles) + (size_t)r * sizeof(h), sizeof(h));
+        void* q = nullptr;
+        HIPCHK(hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess));
+        x->peer[r] = static_cast<char*>(q);
+    }
+    x->connected = true;
+    return PC_OK;
+}
+
+int pc_xchg_allreduce(pc_xchg* x, float* bucket, void* stream) {
+    if (!x || !bucket) return PC_ERR_INVALID_ARG;
+    if (!x->connected) return PC_ERR_INVALID_ARG;
+    DeviceGuard guard(x->device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    hipLaunchKernelGGL(xchg_allreduce_kernel, dim3(x->n_chunks), dim3(256), 0, (hipStream_t)stream, x->view(), bucket);
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_xchg_status(pc_xchg* x) {
+    if (!x) return PC_ERR_INVALID_ARG;
+    DeviceGuard guard(x->device);
+    int err = 0;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(&err, x->view().error, sizeof(int), hipMemcpyDeviceToHost));
+    return err ? PC_ERR_TIMEOUT : PC_OK;
+}
+
+void pc_xchg_destroy(pc_xchg* x) {
+    if (!x) return;
+    DeviceGuard guard(x->device);
+    (void)hipDeviceSynchronize();
+    for (int r = 0; r < x->world; ++r)
+        if (r != x->rank && x->peer[r]) (void)hipIpcCloseMemHandle(x->peer[r]);
+    (void)hipFree(x->local);
+    delete x;
 }
 
 }  // extern "C"

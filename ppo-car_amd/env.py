@@ -224,3 +224,14 @@ class VecCarEnv:
 
     def set_lanes_per_env(self, lanes):
         check(lib.pc_env_set_lanes_per_env(self._h, int(lanes)), "pc_env_set_lanes_per_env")
+
+    OPTIONS = {"rollout_form": 1, "rollout_epw": 2, "rollout_fast": 3}     # PC_OPT_* (include/ppocar.h)
+
+    def set_option(self, name, value):
+        """Per-handle launch option of pc_rollout on THIS vector env (other handles keep theirs)."""
+        check(lib.pc_env_set_option(self._h, self.OPTIONS[name], int(value)), f"pc_env_set_option({name})")
+
+    def get_option(self, name):
+        v = C.c_int()
+        check(lib.pc_env_get_option(self._h, self.OPTIONS[name], C.byref(v)), f"pc_env_get_option({name})")
+        return v.value

@@ -51,6 +51,46 @@ class Agent(nn.Module):
         return all(isinstance(m, nn.Sequential) and len(m) == 3 and isinstance(m[0], nn.Linear) and isinstance(m[1], nn.ReLU)
                    and isinstance(m[2], nn.Linear) for m in (self.actor, self.critic))
 
+    # ---- the fused policy step's configuration lives in a pc_policy HANDLE of this agent (include/ppocar.h): arithmetic form
+    # (`policy_precision`: 0 fp32-input MFMA, 1 bf16x3, 2 fp16x2, -1 = the library's process default) and work decomposition
+    # (`policy_split`: -1 automatic by batch size, 0 / 1, -2 = the process default).  Two agents with different forms coexist.
+    policy_precision = -1
+    policy_split = -2
+
+    def _policy_handle(self):
+        """The pc_policy handle for the current (device, shape, policy_precision, policy_split); None outside the kernel's menu.
+        Handles are cached per key and live as long as the agent."""
+        import ctypes as C
+        a1, a2 = self.actor[0], self.actor[2]
+        dev = a1.weight.device
+        di = dev.index if dev.index is not None else torch.cuda.current_device()
+        cache = self.__dict__.setdefault("_policy_handles", {})
+        dp, ds = C.c_int(), C.c_int()
+        lib.pc_policy_defaults(C.byref(dp), C.byref(ds))
+        prec = dp.value if self.policy_precision < 0 else int(self.policy_precision)      # defaults are resolved HERE: the handle is explicit
+        split = ds.value if self.policy_split == -2 else int(self.policy_split)
+        key = (di, a1.in_features, a1.out_features, a2.out_features, prec, split)
+        if key not in cache:
+            h = C.c_void_p()
+            rc = lib.pc_policy_create(*key, C.byref(h))
+            cache[key] = h if rc == 0 else None
+        return cache[key]
+
+    def policy_form(self):
+        """(precision, split, image_floats) the fused policy step of this agent runs with, or None."""
+        import ctypes as C
+        h = self._policy_handle() if self._std_mlp() else None
+        if h is None:
+            return None
+        pr, sp, n = C.c_int(), C.c_int(), C.c_int64()
+        check(lib.pc_policy_get(h, C.byref(pr), C.byref(sp), C.byref(n)), "pc_policy_get")
+        return pr.value, sp.value, n.value
+
+    def __del__(self):
+        for h in self.__dict__.get("_policy_handles", {}).values():
+            if h is not None:
+                lib.pc_policy_destroy(h)
+
     @torch.no_grad()
     def pack_policy(self):
         """Pack the current weights into the fused policy kernel's LDS image (once per rollout: the weights do
@@ -59,19 +99,19 @@ class Agent(nn.Module):
         if not self._std_mlp():
             return False
         a1, a2, c1, c2 = self.actor[0], self.actor[2], self.critic[0], self.critic[2]
-        D, H, A = a1.in_features, a1.out_features, a2.out_features
-        n = lib.pc_policy_image_floats(D, H, A)
-        if n < 0 or c1.out_features != H or c2.out_features != 1:
+        form = self.policy_form()
+        if form is None or c1.out_features != a1.out_features or c2.out_features != 1:
             return False
+        n = form[2]
         dev = a1.weight.device
         if getattr(self, "_image", None) is None or self._image.numel() != n or self._image.device != dev:
             self._image = torch.empty(n, dtype=torch.float32, device=dev)
-        di = dev.index if dev.index is not None else torch.cuda.current_device()
-        check(lib.pc_policy_pack(di, D, H, A, a1.weight.data_ptr(), a1.bias.data_ptr(), a2.weight.data_ptr(), a2.bias.data_ptr(),
-                                 c1.weight.data_ptr(), c1.bias.data_ptr(), c2.weight.data_ptr(), c2.bias.data_ptr(),
-                                 self._image.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "pc_policy_pack")
+        h = self._policy_handle()
+        check(lib.pc_policy_pack_p(h, a1.weight.data_ptr(), a1.bias.data_ptr(), a2.weight.data_ptr(), a2.bias.data_ptr(),
+                                   c1.weight.data_ptr(), c1.bias.data_ptr(), c2.weight.data_ptr(), c2.bias.data_ptr(),
+                                   self._image.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "pc_policy_pack_p")
         self._image_ok = True
-        self._image_prec = lib.pc_policy_precision(D, H, A)
+        self._image_handle = h       # the image belongs to the handle that packed it
         return True
 
     @torch.no_grad()
@@ -95,18 +135,14 @@ class Agent(nn.Module):
         stream = torch.cuda.current_stream(dev).cuda_stream
         ptr = lambda t: t.data_ptr() if t is not None else None
         if fused and x.is_contiguous() and x.dtype == torch.float32:
-            stale = True
-            if self._std_mlp() and getattr(self, "_image_ok", False):
-                a1_, a2_ = self.actor[0], self.actor[2]
-                stale = self._image_prec != lib.pc_policy_precision(a1_.in_features, a1_.out_features, a2_.out_features)
-            ok = self.pack_policy() if (repack or stale) else True
+            h = self._policy_handle() if self._std_mlp() else None
+            stale = not getattr(self, "_image_ok", False) or getattr(self, "_image_handle", None) is not h
+            ok = h is not None and (self.pack_policy() if (repack or stale) else True)
             if ok:
-                a1, a2 = self.actor[0], self.actor[2]
                 value = out_value if out_value is not None else torch.empty(N, dtype=torch.float32, device=dev)
-                check(lib.pc_policy_act(di, x.data_ptr(), N, x.shape[1], a1.out_features, a2.out_features, self._image.data_ptr(),
-                                        int(self.rng_seed), int(offset), ptr(offset_dev), action.data_ptr(),
-                                        ptr(out_action_f32), logprob.data_ptr(), value.data_ptr(), ptr(out_logits), stream),
-                      "pc_policy_act")
+                check(lib.pc_policy_act_p(h, x.data_ptr(), N, self._image.data_ptr(), int(self.rng_seed), int(offset), ptr(offset_dev),
+                                          action.data_ptr(), ptr(out_action_f32), logprob.data_ptr(), value.data_ptr(), ptr(out_logits),
+                                          stream), "pc_policy_act_p")
                 return action, logprob, value
         if offset_dev is not None:
             raise NotImplementedError("a device-side RNG offset needs the fused policy kernel")

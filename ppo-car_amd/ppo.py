@@ -68,6 +68,13 @@ class PPOConfig:
                                            # a captured RCCL collective has only ever run on a ONE-rank communicator here (no multi-GPU box);
                                            # False / gloo: the minibatch steps are enqueued eagerly around an eager all-reduce
     force_collective: bool = False         # test knob: take the multi-rank update path (all-reduce + pc_clip_adam) on ONE rank
+    exchange: str = "rccl"                 # multi-rank gradient exchange per minibatch: "rccl" = torch.distributed all_reduce (RCCL over xGMI with
+                                           # backend nccl; whatever the process group's backend is otherwise); "p2p" = the library's one-shot
+                                           # all-reduce over peer-mapped buffers (pc_xchg_*: every rank writes its bucket into every peer's slot,
+                                           # sums locally in rank order) -- one xGMI hop of latency instead of a ring / tree schedule, a plain
+                                           # kernel, so it is captured into the epoch graph with any backend
+    policy_precision: int = -1             # arithmetic of the fused policy step's GEMMs: 2 fp16x2, 1 bf16x3, 0 fp32-input MFMA;
+                                           # -1 = the library's default (fp16x2).  Per Trainer (a pc_policy handle), not process-wide
 
 
 def flatten_parameters(module):
@@ -103,6 +110,45 @@ class GradExchange:
             self.flat_grad.div_(self.world_size)
 
 
+class P2PExchange:
+    """pc_xchg_*: the flat gradient bucket summed over the ranks of one node by a one-shot exchange over hipIpc-mapped staging
+    buffers (include/ppocar.h).  The IPC handles travel through torch.distributed (any backend); the exchange itself is one
+    kernel launch on the caller's stream, in place, bit-identical on every rank."""
+
+    def __init__(self, flat_grad, rank, world_size, device):
+        import ctypes as C
+        import torch.distributed as dist
+        self.flat_grad, self.rank, self.world = flat_grad, rank, world_size
+        self.device = torch.device(device)
+        di = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        h = C.c_void_p()
+        check(lib.pc_xchg_create(di, rank, world_size, flat_grad.numel(), C.byref(h)), "pc_xchg_create")
+        self._h = h
+        mine = (C.c_char * 64)()
+        check(lib.pc_xchg_local_handle(h, mine), "pc_xchg_local_handle")
+        handles = [None] * world_size
+        dist.all_gather_object(handles, bytes(mine.raw))
+        blob = b"".join(handles)
+        check(lib.pc_xchg_connect(h, C.c_char_p(blob)), "pc_xchg_connect")
+        dist.barrier()              # every rank has mapped every peer before the first exchange
+
+    def __call__(self):
+        check(lib.pc_xchg_allreduce(self._h, self.flat_grad.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream),
+              "pc_xchg_allreduce")
+
+    def status(self):
+        check(lib.pc_xchg_status(self._h), "pc_xchg_status")
+
+    def close(self):
+        if self._h is not None:
+            import torch.distributed as dist
+            torch.cuda.synchronize(self.device)
+            if dist.is_initialized():
+                dist.barrier()      # no rank frees its staging buffer while a peer may still write into it
+            lib.pc_xchg_destroy(self._h)
+            self._h = None
+
+
 def ppo_loss(agent, obs, act, old_logprob, adv, ret, clip_ratio, vf_coef, ent_coef):
     """One minibatch of train.py:233-255.  `adv` is the raw advantage slice; normalisation is here."""
     _, new_logprobs, entropies, new_values = agent.get_action_and_value(obs, act)
@@ -135,6 +181,11 @@ class PPOLearner:
             dist.broadcast(self.flat_param, src=0)       # every rank starts from rank 0's parameters
         self.exchange = GradExchange(self.flat_grad, world_size)
         self.collective = world_size > 1 or bool(cfg.force_collective)     # the update has an exchange step
+        if cfg.exchange not in ("rccl", "p2p"):
+            raise ValueError(f"PPOConfig.exchange must be 'rccl' or 'p2p', not {cfg.exchange!r}")
+        self.p2p = None
+        if cfg.exchange == "p2p" and world_size > 1 and self.device.type == "cuda":
+            self.p2p = P2PExchange(self.flat_grad, rank, world_size, self.device)
         self._capture_failed = False
         self.graphs = bool(cfg.use_graphs) and self.device.type == "cuda"
         self.fused = bool(cfg.fused_update) and self.device.type == "cuda" and 2 <= cfg.batch_size <= 1024
@@ -210,6 +261,14 @@ class PPOLearner:
                                self.flat_param.numel(), cfg.max_grad_norm, 1.0 / self.world_size, 0.9, 0.999, 1e-5,
                                self._stream()), "pc_clip_adam")
 
+    def _sum_gradients(self):
+        """The one exchange step per minibatch: flat_grad := SUM over ranks (the 1/W is folded into the clip + Adam kernels)."""
+        if self.p2p is not None:
+            self.p2p()
+        else:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+
     def _custom_apply(self):
         """clip + Adam after the gradient exchange of the custom (hand-written kernel) minibatch step: the step counter was
         advanced by the gradient kernels (apply = 2), the bucket holds the sum over ranks."""
@@ -230,8 +289,7 @@ class PPOLearner:
                                    cfg.vf_coef, cfg.ent_coef, cfg.max_grad_norm, 0.9, 0.999, 1e-5, self.metrics.data_ptr(),
                                    self._ws.data_ptr(), 1 if single else 2, self._stream()), "pc_ppo_minibatch")
         if not single:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)     # the 1/W is folded into the clip + Adam kernel
+            self._sum_gradients()
             self._custom_apply()
 
     def prepare_minibatches(self, idx_all, n_mb, obs, act, logprob, adv, ret):
@@ -267,15 +325,13 @@ class PPOLearner:
                                             0.999, 1e-5, self.metrics.data_ptr(), self._ws.data_ptr(), 1 if single else 2,
                                             self._stream()), "pc_ppo_minibatch_prepared")
         if not single:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)     # the 1/W is folded into the clip + Adam kernel
+            self._sum_gradients()
             self._custom_apply()
 
     def fused_minibatch_step(self, idx, obs, act, logprob, adv, ret):
         self._fused_fwd_bwd(idx, obs, act, logprob, adv, ret)
         if self.world_size > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)     # the 1/W is folded into pc_clip_adam
+            self._sum_gradients()     # the 1/W is folded into pc_clip_adam
         self._fused_apply()
 
     def _epoch_body(self, idx_all, n_mb, args):
@@ -296,6 +352,8 @@ class PPOLearner:
         itself can be captured -- backend nccl (RCCL records its kernels into the capturing stream), not gloo."""
         if not self.collective:
             return True
+        if self.p2p is not None or (self.world_size == 1 and self.cfg.exchange == "p2p"):
+            return True         # the one-shot exchange is an ordinary kernel launch
         if self._capture_failed or not self.cfg.capture_collectives:
             return False
         import torch.distributed as dist
@@ -311,6 +369,10 @@ class PPOLearner:
                 self._epoch_body(idx_all, n_mb, args)
             return g
         import torch.distributed as dist
+        if self.p2p is not None:      # plain kernels only: captured like the single-rank update
+            with torch.cuda.graph(g):
+                self._epoch_body(idx_all, n_mb, args)
+            return g
         saved = [t.clone() for t in (self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.metrics)]
         try:
             dist.all_reduce(torch.zeros(1, device=self.device))       # the communicator exists before the capture starts
@@ -484,8 +546,7 @@ class PPOLearner:
                     self._graph_a.replay()
                     if self.world_size > 1:
                         if self.fused:
-                            import torch.distributed as dist
-                            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+                            self._sum_gradients()
                         else:
                             self.exchange()
                         self._graph_b.replay()
@@ -519,6 +580,7 @@ class Trainer:
         self.act_dim = self.envs.act_dim             # train.py:142
         self.agent = Agent(self.obs_dim[0], self.act_dim).to(self.device)   # train.py:145
         self.agent.rng_seed = cfg.seed * 1000003 + rank
+        self.agent.policy_precision = int(cfg.policy_precision)
         self.learner = PPOLearner(self.agent, cfg, self.device, rank, world_size)
         self.optimizer, self.scheduler = self.learner.optimizer, self.learner.scheduler
         self.buffer = Buffer(self.obs_dim, cfg.n_steps, cfg.n_envs, self.device, cfg.gamma, cfg.gae_lambda)   # :152
@@ -594,15 +656,15 @@ class Trainer:
         if self._boot_val is None:
             self._boot_val = torch.empty(cfg.n_envs, device=self.device)       # the final observation's value (train.py:200)
             self._rew_sum = torch.empty(cfg.n_envs, device=self.device)        # per-env reward totals (train.py:272)
-        rc = lib.pc_rollout_ex(self.envs._h, agent._image.data_ptr(), self.act_dim, cfg.n_steps, float(cfg.reward_scaling),
-                               int(agent.rng_seed), 0, self.rng_base.data_ptr(), buf.obs_buf.data_ptr(), buf.act_buf.data_ptr(),
-                               buf.rew_buf.data_ptr(), buf.val_buf.data_ptr(), buf.term_buf.data_ptr(), buf.trunc_buf.data_ptr(),
-                               buf.logprob_buf.data_ptr(), self.next_obs.data_ptr(), self.next_term.data_ptr(),
-                               self.next_trunc.data_ptr(), self._boot_val.data_ptr(), self._rew_sum.data_ptr(),
-                               torch.cuda.current_stream(self.device).cuda_stream)
+        rc = lib.pc_rollout_p(self.envs._h, agent._image_handle, agent._image.data_ptr(), cfg.n_steps, float(cfg.reward_scaling),
+                              int(agent.rng_seed), 0, self.rng_base.data_ptr(), buf.obs_buf.data_ptr(), buf.act_buf.data_ptr(),
+                              buf.rew_buf.data_ptr(), buf.val_buf.data_ptr(), buf.term_buf.data_ptr(), buf.trunc_buf.data_ptr(),
+                              buf.logprob_buf.data_ptr(), self.next_obs.data_ptr(), self.next_term.data_ptr(),
+                              self.next_trunc.data_ptr(), self._boot_val.data_ptr(), self._rew_sum.data_ptr(),
+                              torch.cuda.current_stream(self.device).cuda_stream)
         if rc == -5:       # PC_ERR_UNSUPPORTED: shape outside the persistent kernel's menu
             return False
-        check(rc, "pc_rollout_ex")
+        check(rc, "pc_rollout_p")
         self._aux_valid = True   # the launch also delivered the bootstrap values and the reward totals of THIS rollout
         if ev is not None:
             ev[1].record()
@@ -721,4 +783,7 @@ class Trainer:
         self.agent._rng_offset = sd["agent_rng_offset"]
 
     def close(self):
+        if self.learner.p2p is not None:
+            self.learner.p2p.status()       # a peer that never arrived at an exchange surfaces here as PC_ERR_TIMEOUT
+            self.learner.p2p.close()
         self.envs.close()

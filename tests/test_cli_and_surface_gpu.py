@@ -216,5 +216,6 @@ def test_bench_starts_its_own_ranks(tmp_path):
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["n_envs_total"] == 8192
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["config"]["n_envs_total"] == 8192
+    assert d["config"]["backend"] == "gloo" and d["config"]["rccl_ranks"] == 0      # the line names the transport that really ran
     assert d["value"] > 0 and d["scaling"] == "weak"

@@ -6,7 +6,7 @@ import torch
 
 import oracle
 import ppo_car_amd as pc
-from conftest import GOLDEN
+from conftest import GOLDEN, TRACKS
 
 pytestmark = pytest.mark.gpu
 
@@ -192,7 +192,7 @@ def test_fused_policy_kernel_on_trained_weights_and_harvested_observations(polic
     observations of its last rollout -- among them 300 reset rows (velocity exactly 0: operands below fp16's normal range in
     every scaled domain).  Logits and values of every arithmetic form must stay within 4e-6 of float64 (north_star: 1e-5)."""
     import os
-    from conftest import GOLDEN
+    from conftest import GOLDEN, TRACKS
     f = np.load(os.path.join(GOLDEN, "policy_trained.npz"))
     obs = f["obs"]
     n = len(obs)
@@ -216,3 +216,54 @@ def test_fused_policy_kernel_on_trained_weights_and_harvested_observations(polic
     assert err_l < 4e-6 and err_v < 4e-6
     lp_ref = ref_logits - np.log(np.exp(ref_logits - ref_logits.max(1, keepdims=True)).sum(1, keepdims=True)) - ref_logits.max(1, keepdims=True)
     assert np.abs(lp.cpu().numpy() - lp_ref[np.arange(n), a.cpu().numpy()]).max() < 4e-6
+
+
+def test_two_policy_handles_with_different_arithmetic_coexist():
+    """Every launch option lives in a handle (include/ppocar.h): two agents with different arithmetic forms of the fused policy
+    step, used ALTERNATELY in one process, each produce exactly what they produce alone under the matching process default --
+    and the two differ from each other (fp16x2 vs the exact fp32 chain).  Same for pc_rollout's per-env options.
+    (model.py:34-41, train.py:173-195)"""
+    from ppo_car_amd._capi import lib
+    from ppo_car_amd.model import Agent
+    torch.manual_seed(3)
+    N, D = 4096, 23
+    obs = torch.randn(N, D, device="cuda") * 0.5
+    agents = {}
+    for prec in (2, 0):
+        torch.manual_seed(5)
+        a = Agent(D, 9).cuda()
+        a.rng_seed = 77
+        a.policy_precision = prec
+        agents[prec] = a
+    alone = {}
+    for prec in (2, 0):          # each alone, with the process default set to its form (the pre-handle way)
+        assert lib.pc_policy_set_precision(prec) == 0
+        torch.manual_seed(5)
+        b = Agent(D, 9).cuda()
+        b.rng_seed = 77
+        try:
+            logits = torch.empty(N, 9, device="cuda")
+            _, lp, v = b.act(obs, out_logits=logits, offset=0)
+            alone[prec] = (logits.clone(), lp.clone(), v.clone())
+        finally:
+            lib.pc_policy_set_precision(2)
+    for _ in range(2):           # interleaved, process default untouched (fp16x2)
+        for prec in (0, 2):
+            logits = torch.empty(N, 9, device="cuda")
+            _, lp, v = agents[prec].act(obs, out_logits=logits, offset=0)
+            assert agents[prec].policy_form()[0] == prec
+            for got, want in zip((logits, lp, v), alone[prec]):
+                assert torch.equal(got, want), prec
+    assert not torch.equal(alone[0][0], alone[2][0])          # the two forms do differ in the last bits
+    assert float((alone[0][0] - alone[2][0]).abs().max()) < 1e-5
+
+    # pc_rollout's options: per env handle
+    e1 = pc.VecCarEnv(64, TRACKS["big_track"], num_rays=16)
+    e2 = pc.VecCarEnv(64, TRACKS["big_track"], num_rays=16)
+    e1.set_option("rollout_form", 3)
+    e1.set_option("rollout_epw", 32)
+    assert (e1.get_option("rollout_form"), e1.get_option("rollout_epw")) == (3, 32)
+    assert (e2.get_option("rollout_form"), e2.get_option("rollout_epw"), e2.get_option("rollout_fast")) == (-1, 0, 1)
+    with pytest.raises(pc.PpoCarError):
+        e1.set_option("rollout_epw", 48)
+    e1.close(); e2.close()

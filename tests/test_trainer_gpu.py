@@ -330,19 +330,20 @@ def test_reference_style_loop_runs_on_the_drop_in_surface():
 
 
 
-def _two_rank_worker(rank, world, port, out_dir, use_graphs):
+def _two_rank_worker(rank, world, port, out_dir, use_graphs, exchange="rccl"):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)     # both ranks share cuda:0 here; RCCL needs one GPU per rank
     torch.cuda.set_device(0)
-    cfg = _cfg(n_envs=512, n_steps=64, batch_size=32, train_iters=2, use_graphs=use_graphs, seed=11)
+    cfg = _cfg(n_envs=512, n_steps=64, batch_size=32, train_iters=2, use_graphs=use_graphs, seed=11, exchange=exchange)
     tr = Trainer(cfg, device="cuda:0", rank=rank, world_size=world)
     s1 = tr.run_epoch()
     s2 = tr.run_epoch()
     torch.cuda.synchronize()
-    torch.save({"param": tr.learner.flat_param.cpu(), "acts": tr.buffer.act_buf.cpu(), "scalars": s2, "step": tr.global_step_idx},
-               os.path.join(out_dir, f"r{rank}_{int(use_graphs)}.pt"))
+    torch.save({"param": tr.learner.flat_param.cpu(), "acts": tr.buffer.act_buf.cpu(), "scalars": s2, "step": tr.global_step_idx,
+                "captured": tr.learner._epoch_graph is not None},
+               os.path.join(out_dir, f"r{rank}_{int(use_graphs)}_{exchange}.pt"))
     tr.close()
     dist.destroy_process_group()
 
@@ -358,12 +359,35 @@ def test_two_ranks_on_one_gpu_keep_replicas_identical(tmp_path, use_graphs):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), use_graphs), nprocs=2, join=True)
-    r0 = torch.load(tmp_path / f"r0_{int(use_graphs)}.pt")
-    r1 = torch.load(tmp_path / f"r1_{int(use_graphs)}.pt")
+    r0 = torch.load(tmp_path / f"r0_{int(use_graphs)}_rccl.pt")
+    r1 = torch.load(tmp_path / f"r1_{int(use_graphs)}_rccl.pt")
     assert torch.equal(r0["param"], r1["param"])                 # replicas bit-identical after 2 epochs
     assert not torch.equal(r0["acts"], r1["acts"])               # but the shards sampled different actions
     assert r0["step"] == r1["step"] == 2 * 2 * 512 * 64          # global_step counts the whole job (train.py:174)
     assert r0["scalars"]["charts/avg_reward"] == pytest.approx(r1["scalars"]["charts/avg_reward"])   # all-reduced scalars
+
+
+@pytest.mark.parametrize("use_graphs", [True, False])
+def test_one_shot_p2p_exchange_between_two_ranks_on_one_gpu(tmp_path, use_graphs):
+    """PPOConfig.exchange = "p2p": the per-minibatch gradient all-reduce as the library's one-shot exchange over hipIpc-mapped
+    staging buffers (pc_xchg_*), two processes sharing cuda:0 (an IPC mapping works between processes on one device, so
+    correctness and bit-identity are provable here; the xGMI latency is not).  Replicas stay bit-identical, the result equals
+    the all_reduce path's bit for bit (two ranks: a + b is the same sum in either order), and with graphs the whole epoch's
+    update -- exchanges included -- is ONE captured graph even over gloo.  (train.py:259-260)"""
+    import socket
+    import torch.multiprocessing as mp
+    res = {}
+    for exchange in ("p2p", "rccl"):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), use_graphs, exchange), nprocs=2, join=True)
+        res[exchange] = [torch.load(tmp_path / f"r{r}_{int(use_graphs)}_{exchange}.pt") for r in (0, 1)]
+    p0, p1 = res["p2p"]
+    assert torch.equal(p0["param"], p1["param"])                          # replicas bit-identical
+    assert not torch.equal(p0["acts"], p1["acts"])
+    assert torch.equal(p0["param"], res["rccl"][0]["param"])              # and the very bits of the all_reduce path
+    assert p0["captured"] == use_graphs and not res["rccl"][0]["captured"]
 
 
 @pytest.mark.parametrize("B,D,A", [(512, 23, 9), (100, 18, 9), (1024, 39, 9), (256, 23, 6), (64, 39, 13)])
