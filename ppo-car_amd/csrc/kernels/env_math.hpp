@@ -16,13 +16,16 @@ struct TrackHdr {        // one per track, read with scalar loads
     int n_chain;         // F32: chain vertices before the padding to a multiple of 4 (vtx[n_chain .. nV) are sentinels)
     unsigned idx_mask;   // F32: (1 << b) - 1, b = max(5, ceil(log2(nV))): the low bits of a sweep candidate carry its vertex index
     double start_x, start_y, start_rot;
-    float bx0, bx1, by0, by1;   // F32: bounding box of the wall vertices (the sweep's acceptance window is priced from it)
+    double ax0, ay0;            // F32: the anchor of the sweep's float32 coordinates: the centre of the wall vertices' bounding box
+    float bx0, bx1, by0, by1;   // F32: that bounding box (the sweep's flag threshold is priced from it)
 };
 
 // One wall / gate segment as the reference holds it (Boundary.get_points, car_env.py:74): 32 bytes.
 struct Seg { double x1, y1, x2, y2; };
 
-// F32 wall sweep: the walls as chains of vertices.  Vertex k closes the segment (k-1, k) unless it
+// F32 wall sweep: the walls as chains of vertices, (xr, yr) = the vertex relative to the track's anchor (TrackHdr::ax0, ay0: the
+// centre of its bounding box), rounded from float64 -- the sweep only SELECTS, so it can afford float32 coordinates as long as
+// the flag threshold prices their rounding (flag_threshold).  Vertex k closes the segment (k-1, k) unless it
 // starts a new chain: then its edge (ex, ey) is (0, 0) (a real wall has length).  (ex, ey) = the UNIT vector along p[k-1] - p[k]
 // rounded from float64 -- the selector's u = cross(e, a) / cross(e, dir) does not depend on the edge's length, and with a unit
 // edge cross(e, a) is the car's distance from the wall line in pixels, which makes its rounding threshold one number per car --,
@@ -32,7 +35,7 @@ struct Seg { double x1, y1, x2, y2; };
 // opposite sides of the ray line".  Evaluated per VERTEX -- one cross product c_k = cross(p_k - pos, dir)
 // shared by the two segments that meet there -- a float32 ray cannot slip between two adjacent walls
 // through the rounding-wide crack that two independently rounded t's leave at their common corner.
-struct Vtx { double x, y; float ex, ey, exs, eys; };
+struct Vtx { float xr, yr, ex, ey, exs, eys, pad0, pad1; };
 __device__ __forceinline__ bool vtx_brk(const Vtx& v) {   // chain start / padding sentinel: a zero edge (integer test: stays on the SALU)
     return ((__float_as_uint(v.ex) | __float_as_uint(v.ey)) << 1) == 0u;
 }

@@ -112,13 +112,15 @@ __device__ __forceinline__ f32x2 pk_mul_clamp(const f32x2 a, const f32x2 b) {
     asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
-// The flag thresholds for a car at (npx, npy).  With u = 2^-24: a_k, dir and the unit edge are rounded to float32 (relative u
-// each), a cross product is a multiply and an fma, so |c~_k - c_k| and |un~ - un| stay below 8 u M_k, M_k = |a_k|_inf <= R = the
-// largest |coordinate difference| between the car and the track's bounding box.  tau = 16 u R = 2^-20 R.
+// The flag thresholds for a car at (npx, npy).  With u = 2^-24: dir and the unit edge are rounded to float32 (relative u each), a
+// cross product is a multiply and an fma; a_k = p_k - pos is the float32 difference of the vertex and the car, both taken
+// relative to the track's anchor and rounded (each within u of a half-extent of the bounding box).  With M_k = |a_k|_inf <= R =
+// the largest |coordinate difference| between the car and the track's bounding box (>= its half-extents), |c~_k - c_k| and
+// |un~ - un| stay below 14 u R.  tau = 32 u R = 2^-19 R.
 __device__ __forceinline__ float flag_threshold(const TrackHdr& h, const double npx, const double npy) {
     const float px = (float)npx, py = (float)npy;
     const float rx = fmaxf(fabsf(h.bx0 - px), fabsf(h.bx1 - px)), ry = fmaxf(fabsf(h.by0 - py), fabsf(h.by1 - py));
-    return fmaxf(rx, ry) * 0x1p-20f;
+    return fmaxf(rx, ry) * 0x1p-19f;
 }
 
 // The per-lane sweep state shared by the three forms of the sweep (scalar-load loop, unrolled, LDS copy of the chain)
@@ -139,11 +141,12 @@ template <int RPL, bool TAB> struct Sweep {
         um = 1e30f;
         keep = ~idx_mask;
     }
-    // side values of a vertex at (vx, vy): a = p - pos (float64, then rounded), c = cross(a, dir) per ray slot
-    __device__ __forceinline__ void side(const double vx, const double vy, const double npx, const double npy, float& ax, float& ay,
+    // side values of a vertex at (vx, vy) for a car at (px, py), both relative to the track's anchor: a = p - pos, c = cross(a, dir)
+    // per ray slot
+    __device__ __forceinline__ void side(const float vx, const float vy, const float px, const float py, float& ax, float& ay,
                                          f32x2 (&c)[NP]) {
-        ax = (float)(vx - npx);
-        ay = (float)(vy - npy);
+        ax = vx - px;
+        ay = vy - py;
         const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay};
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
@@ -194,7 +197,7 @@ template <int RPL, bool TAB> struct Sweep {
 // PARTS.  dx / dy = the slots' directions, didx = their lattice indices (TAB: rows of the 1/den table `rdl` in LDS; ADDR: didx
 // holds the LDS BYTE ADDRESSES of those rows instead).  bb = the slots' selections (candidate bit patterns).
 template <int RPL, int PARTS, bool TAB, bool ADDR = false>
-__device__ __forceinline__ void wall_sweep_f32(const Vtx* vt, const int nV, const int part, const double npx, const double npy,
+__device__ __forceinline__ void wall_sweep_f32(const Vtx* vt, const int nV, const int part, const float pxr, const float pyr,
                                                const float (&dx)[RPL], const float (&dy)[RPL], const int (&didx)[RPL], lds_cfp rdl,
                                                const float tau, const unsigned idx_mask, unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
     constexpr int NP = (RPL + 1) / 2;
@@ -223,7 +226,7 @@ __device__ __forceinline__ void wall_sweep_f32(const Vtx* vt, const int nV, cons
     for (int j = 0; j < NP; ++j) cA[j] = cB[j] = (f32x2){0.0f, 0.0f};
     if (PARTS > 1 && gbeg > 0) {
         const Vtx v = cload(vt + 4 * gbeg - 1);
-        sw.side(v.x, v.y, npx, npy, axA, ayA, cA);
+        sw.side(v.xr, v.yr, pxr, pyr, axA, ayA, cA);
     }
     // TAB: one 16-byte LDS read per ray slot and group = the slot's 1/den for the group's four vertices
     typedef const __attribute__((address_space(3))) f32x4* lds_row;
@@ -240,7 +243,7 @@ __device__ __forceinline__ void wall_sweep_f32(const Vtx* vt, const int nV, cons
     {                                                                                                                \
         const Vtx v = nxt;                                                                                           \
         nxt = cload(vt + (k + I + 1 < 4 * gend ? k + I + 1 : k + I));                                                \
-        sw.side(v.x, v.y, npx, npy, NAX, NAY, NC);                                                                   \
+        sw.side(v.xr, v.yr, pxr, pyr, NAX, NAY, NC);                                                                   \
         if (!vtx_brk(v)) close(v, k + I, PAX, PAY, PC, NC, RD, I);                                                   \
     }
     for (int gq = gbeg; gq < gend; ++gq) {
@@ -269,7 +272,7 @@ __device__ __forceinline__ void wall_sweep_f32(const Vtx* vt, const int nV, cons
 //     the candidate can never win the unsigned minimum.  Only the trailing padding pair(s) are skipped (n_chain).
 // The minimum is exact, so the result is the very same bits as wall_sweep_f32's.
 template <int RPL, bool TAB, int NGRP, bool ADDR = false>
-__device__ __forceinline__ void wall_sweep_unrolled(const Vtx* vt, const int n_chain, const double npx, const double npy,
+__device__ __forceinline__ void wall_sweep_unrolled(const Vtx* vt, const int n_chain, const float pxr, const float pyr,
                                                     const float (&dx)[RPL], const float (&dy)[RPL], const int (&didx)[RPL], lds_cfp rdl,
                                                     const float tau, unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
     constexpr int NP = (RPL + 1) / 2, nV = 4 * NGRP;
@@ -294,9 +297,9 @@ __device__ __forceinline__ void wall_sweep_unrolled(const Vtx* vt, const int n_c
         constexpr int K = decltype(KC)::value, I = K & 3;
         const Vtx v0 = cload(vt + K), v1 = cload(vt + K + 1);
         float u0[2 * NP], u1[2 * NP];
-        sw.side(v0.x, v0.y, npx, npy, axB, ayB, cB);
+        sw.side(v0.xr, v0.yr, pxr, pyr, axB, ayB, cB);
         sw.cand(v0.ex, v0.ey, v0.exs, v0.eys, axA, ayA, cA, cB, rd, I, u0);
-        sw.side(v1.x, v1.y, npx, npy, axA, ayA, cA);
+        sw.side(v1.xr, v1.yr, pxr, pyr, axA, ayA, cA);
         sw.cand(v1.ex, v1.ey, v1.exs, v1.eys, axB, ayB, cB, cA, rd, I + 1, u1);
 #pragma unroll
         for (int s = 0; s < RPL; ++s)
@@ -446,7 +449,7 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
     // ---- wall sweep: Car.get_distances (:360-374) -- also serves Car.check_collision (E2)
     if constexpr (sizeof(T) == 4) {
         unsigned bb[2 * ((RPL + 1) / 2)];
-        wall_sweep_f32<RPL, PARTS, TAB>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dx, dy, didx, rdl, flag_threshold(h, npx, npy),
+        wall_sweep_f32<RPL, PARTS, TAB>(p.vtx + h.vtx_off, h.nV, part, (float)(npx - h.ax0), (float)(npy - h.ay0), dx, dy, didx, rdl, flag_threshold(h, npx, npy),
                                         h.idx_mask, bb);
         if constexpr (PARTS > 1) {   // the parts' selections meet in LDS (the minimum is exact: the same bits as one wave sweeping everything)
             unsigned* ex = reinterpret_cast<unsigned*>(exch);

@@ -60,7 +60,7 @@ struct FastTabs {        // LDS addresses of the staged tables (wave-uniform)
     lds_f4c dir;         // [720] direction lattice, twice around: (cos, sin, LDS byte address of the direction's 1/den row,
                          //       LDS byte address of the direction's float64 (cos, sin) in dir64)
     lds_cfp reset;       // [D] the track's reset observation
-    lds_cd2 vtx;         // [nV] the wall vertex chain, 32 bytes each: (x, y) float64 then (ex, ey, exs, eys) -- small form only (nV <= 64)
+    lds_cd2 vtx;         // [nV] the wall vertex chain, 32-byte Vtx records: (xr, yr, ex, ey), (exs, eys, -, -) -- small form only (nV <= 64)
     lds_cd2 seg;         // [nV] the chain for the float64 refinement: SegD records, 48 bytes each (nV <= 64)
     lds_cd2 dir64;       // [360] (cos, sin) float64 of the direction lattice
     lds_cfp rden;        // [361][nV] or unused
@@ -169,7 +169,7 @@ __device__ __forceinline__ int swap_pair(int v) { return __builtin_amdgcn_update
 // values are independent instruction chains, chain-start vertices are computed rather than branched around (their candidates
 // are NaN: see wall_sweep_unrolled), and two vertices share a v_min3_u32.  Same bits as wall_sweep_f32<RPL, PARTS, TAB>.
 template <int RPL, int PARTS, bool TAB, bool ADDR = false>
-__device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const int part, const double npx, const double npy,
+__device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const int part, const float pxr, const float pyr,
                                                const float (&dx)[RPL], const float (&dy)[RPL], const int (&didx)[RPL], lds_cfp rdl,
                                                const float tau, const unsigned idx_mask, unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
     constexpr int NP = (RPL + 1) / 2;
@@ -184,8 +184,8 @@ __device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const i
 #pragma unroll
     for (int j = 0; j < NP; ++j) cA[j] = cB[j] = (f32x2){0.0f, 0.0f};
     if (PARTS > 1 && gbeg > 0) {   // the vertex before the range: the chain's previous side values
-        const f64x2 xy = vt[2 * (4 * gbeg - 1)];
-        sw.side(xy.x, xy.y, npx, npy, axA, ayA, cA);
+        const f32x4 xy = *(lds_f4)(vt + 2 * (4 * gbeg - 1));
+        sw.side(xy.x, xy.y, pxr, pyr, axA, ayA, cA);
     }
     lds_f4 rrow[2 * NP];
     if constexpr (TAB) {
@@ -202,22 +202,22 @@ __device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const i
             rd[s] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             if constexpr (TAB) { if (s < RPL) rd[s] = rrow[s][gq]; }
         }
-        f64x2 xy[4];
-        f32x4 ee[4];
+        f32x4 xy[4];    // (xr, yr, ex, ey)
+        f32x2 es[4];    // (exs, eys)
 #pragma unroll
         for (int I = 0; I < 4; ++I) {
-            xy[I] = vt[2 * (4 * gq + I)];
-            ee[I] = *(lds_f4)(vt + 2 * (4 * gq + I) + 1);      // (ex, ey, exs, eys)
+            xy[I] = *(lds_f4)(vt + 2 * (4 * gq + I));
+            es[I] = *(lds_cf2)(vt + 2 * (4 * gq + I) + 1);
         }
         unsigned kv;
         asm("v_mov_b32 %0, %1" : "=v"(kv) : "s"(4 * gq));
 #pragma unroll
         for (int I = 0; I < 4; I += 2) {
             float u0[2 * NP], u1[2 * NP];
-            sw.side(xy[I].x, xy[I].y, npx, npy, axB, ayB, cB);
-            sw.cand(ee[I].x, ee[I].y, ee[I].z, ee[I].w, axA, ayA, cA, cB, rd, I, u0);
-            sw.side(xy[I + 1].x, xy[I + 1].y, npx, npy, axA, ayA, cA);
-            sw.cand(ee[I + 1].x, ee[I + 1].y, ee[I + 1].z, ee[I + 1].w, axB, ayB, cB, cA, rd, I + 1, u1);
+            sw.side(xy[I].x, xy[I].y, pxr, pyr, axB, ayB, cB);
+            sw.cand(xy[I].z, xy[I].w, es[I].x, es[I].y, axA, ayA, cA, cB, rd, I, u0);
+            sw.side(xy[I + 1].x, xy[I + 1].y, pxr, pyr, axA, ayA, cA);
+            sw.cand(xy[I + 1].z, xy[I + 1].w, es[I + 1].x, es[I + 1].y, axB, ayB, cB, cA, rd, I + 1, u1);
 #pragma unroll
             for (int s = 0; s < RPL; ++s)   // (index = 4 gq + I: the group's base in a register, I as an inline constant; v_min3_u32)
                 bb[s] = min(min(bb[s], and_or(__float_as_uint(u0[s]), sw.keep, kv + I)), and_or(__float_as_uint(u1[s]), sw.keep, kv + I + 1));
@@ -296,6 +296,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     constexpr int R1 = RPL > 12 ? (RPL + 1) / 2 : RPL, R2 = RPL - R1;
     unsigned bb[RPL + 2];
     const float tau = flag_threshold(h, npx, npy);
+    const float pxr = (float)(npx - h.ax0), pyr = (float)(npy - h.ay0);   // the car relative to the track's anchor (see Vtx)
     PC_STAMP(4)
     {
         const float(&dxa)[R1] = *reinterpret_cast<const float(*)[R1]>(&dx[0]);
@@ -303,11 +304,11 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         const int(&dia)[R1] = *reinterpret_cast<const int(*)[R1]>(&didx[0]);
         unsigned ba[2 * ((R1 + 1) / 2)];
         if (PARTS > 1)                  // small form: latency-oriented sweep over the LDS copy of the chain
-            wall_sweep_lds<R1, PARTS, TAB, true>(ft.vtx, h.nV, part, npx, npy, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
+            wall_sweep_lds<R1, PARTS, TAB, true>(ft.vtx, h.nV, part, pxr, pyr, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
         else if (SWP == 7 || h.nV == 28)   // (wave-uniform) big_track's chain: the unrolled sweep.  SWP == 7: the host guarantees that
-            wall_sweep_unrolled<R1, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxa, dya, dia, ft.rden, tau, ba);   // chain length
+            wall_sweep_unrolled<R1, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);   // chain length
         else if constexpr (SWP == 0)       // and the generic loop is not even compiled in (1 % from the shorter kernel alone)
-            wall_sweep_f32<R1, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
+            wall_sweep_f32<R1, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, pxr, pyr, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
 #pragma unroll
         for (int s = 0; s < R1; ++s) bb[s] = ba[s];
     }
@@ -318,11 +319,11 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         const int(&dib)[R2] = *reinterpret_cast<const int(*)[R2]>(&didx[R1]);
         unsigned bc[2 * ((R2 + 1) / 2)];
         if (PARTS > 1)
-            wall_sweep_lds<R2, PARTS, TAB, true>(ft.vtx, h.nV, part, npx, npy, dxb, dyb, dib, ft.rden, tau, h.idx_mask, bc);
+            wall_sweep_lds<R2, PARTS, TAB, true>(ft.vtx, h.nV, part, pxr, pyr, dxb, dyb, dib, ft.rden, tau, h.idx_mask, bc);
         else if (SWP == 7 || h.nV == 28)
-            wall_sweep_unrolled<R2, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, npx, npy, dxb, dyb, dib, ft.rden, tau, bc);
+            wall_sweep_unrolled<R2, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, pxr, pyr, dxb, dyb, dib, ft.rden, tau, bc);
         else if constexpr (SWP == 0)
-            wall_sweep_f32<R2, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, npx, npy, dxb, dyb, dib, ft.rden, tau, h.idx_mask, bc);
+            wall_sweep_f32<R2, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, pxr, pyr, dxb, dyb, dib, ft.rden, tau, h.idx_mask, bc);
 #pragma unroll
         for (int s = 0; s < R2; ++s) bb[R1 + s] = bc[s];
     }

@@ -314,6 +314,7 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
     std::vector<float2> dirtab;
     std::vector<double2> dirtab64;
     std::vector<SegD> seg64;
+    std::vector<double2> vpos;      // host only: the chain vertices' exact positions (indexed like vtx)
     size_t rden_floats = 0;
     e->hdr_host.resize(e->n_tracks);
     for (int k = 0; k < e->n_tracks; ++k) {
@@ -325,29 +326,46 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
         for (size_t i = 0; i < t->walls.size(); i += 4) segs.push_back(Seg{t->walls[i], t->walls[i + 1], t->walls[i + 2], t->walls[i + 3]});
         h.gate_off = (int)segs.size();
         for (size_t i = 0; i < t->gates.size(); i += 4) segs.push_back(Seg{t->gates[i], t->gates[i + 1], t->gates[i + 2], t->gates[i + 3]});
-        // walls as vertex chains: a segment continues the chain iff it starts exactly where the previous ended
+        // walls as vertex chains: a segment continues the chain iff it starts exactly where the previous ended.  The sweep's
+        // float32 coordinates are relative to the ANCHOR = the centre of the vertices' bounding box.
         h.vtx_off = (int)vtx.size();
-        // the sweep's view of a wall: the UNIT vector along (x1 - x2, y1 - y2) (car_env.py:171) in float32, and its copy scaled by 2^-40
-        const auto edge = [](const Seg& sg) {
+        {
+            double bx0 = 1e300, bx1 = -1e300, by0 = 1e300, by1 = -1e300;
+            for (int w = 0; w < h.S; ++w) {
+                const Seg& sg = segs[h.wall_off + w];
+                bx0 = std::min({bx0, sg.x1, sg.x2}); bx1 = std::max({bx1, sg.x1, sg.x2});
+                by0 = std::min({by0, sg.y1, sg.y2}); by1 = std::max({by1, sg.y1, sg.y2});
+            }
+            h.ax0 = 0.5 * (bx0 + bx1);
+            h.ay0 = 0.5 * (by0 + by1);
+            h.bx0 = (float)bx0; h.bx1 = (float)bx1; h.by0 = (float)by0; h.by1 = (float)by1;
+        }
+        // the sweep's view of a wall's closing vertex: its anchor-relative position, the UNIT vector along (x1 - x2, y1 - y2)
+        // (car_env.py:171) in float32, and that vector's copy scaled by 2^-40
+        const auto edge = [&h](const Seg& sg) {
             const double ex = sg.x1 - sg.x2, ey = sg.y1 - sg.y2, len = std::hypot(ex, ey);
-            if (len == 0.0) return Vtx{sg.x2, sg.y2, 0.f, 0.f, 1.f, 0.f};     // a wall without length is never hit: a chain start
+            const float xr = (float)(sg.x2 - h.ax0), yr = (float)(sg.y2 - h.ay0);
+            if (len == 0.0) return Vtx{xr, yr, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f};     // a wall without length is never hit: a chain start
             const float fx = (float)(ex / len), fy = (float)(ey / len);
-            return Vtx{sg.x2, sg.y2, fx, fy, fx * 0x1p-40f, fy * 0x1p-40f};
+            return Vtx{xr, yr, fx, fy, fx * 0x1p-40f, fy * 0x1p-40f, 0.f, 0.f};
         };
         for (int w = 0; w < h.S; ++w) {
             const Seg& sg = segs[h.wall_off + w];
             const bool cont = w > 0 && segs[h.wall_off + w - 1].x2 == sg.x1 && segs[h.wall_off + w - 1].y2 == sg.y1;
             if (!cont) {
-                vtx.push_back(Vtx{sg.x1, sg.y1, 0.f, 0.f, 1.f, 0.f});            // chain start: zero edge (scaled copy (1, 0): see Sweep::cand)
+                vtx.push_back(Vtx{(float)(sg.x1 - h.ax0), (float)(sg.y1 - h.ay0), 0.f, 0.f, 1.f, 0.f, 0.f, 0.f});   // chain start: zero edge (scaled copy (1, 0): see Sweep::cand)
                 seg64.push_back(SegD{sg.x1, sg.y1, 0.0, 0.0, -1.0, 0, 0});
+                vpos.push_back(make_double2(sg.x1, sg.y1));
             }
             vtx.push_back(edge(sg));
             seg64.push_back(SegD{sg.x1, sg.y1, sg.x1 - sg.x2, sg.y1 - sg.y2, -1.0, 0, 0});
+            vpos.push_back(make_double2(sg.x2, sg.y2));
         }
         h.n_chain = (int)vtx.size() - h.vtx_off;
         while ((vtx.size() - h.vtx_off) % 4) {  // the sweep walks vertex groups of four: pad with chain-start sentinels
-            vtx.push_back(Vtx{vtx.back().x, vtx.back().y, 0.f, 0.f, 1.f, 0.f});
-            seg64.push_back(SegD{vtx.back().x, vtx.back().y, 0.0, 0.0, -1.0, 0, 0});
+            vtx.push_back(Vtx{vtx.back().xr, vtx.back().yr, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f});
+            seg64.push_back(SegD{seg64.back().x1, seg64.back().y1, 0.0, 0.0, -1.0, 0, 0});
+            vpos.push_back(vpos.back());
         }
         h.nV = (int)vtx.size() - h.vtx_off;
         if (h.nV > 65535) return PC_ERR_UNSUPPORTED;
@@ -360,19 +378,13 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
         {
             const int n = h.nV, o = h.vtx_off;
             const auto is_start = [&](int k) { return seg64[o + k].ex == 0.0 && seg64[o + k].ey == 0.0; };
-            double bx0 = 1e300, bx1 = -1e300, by0 = 1e300, by1 = -1e300;
-            for (int k = 0; k < n; ++k) {
-                bx0 = std::min(bx0, vtx[o + k].x); bx1 = std::max(bx1, vtx[o + k].x);
-                by0 = std::min(by0, vtx[o + k].y); by1 = std::max(by1, vtx[o + k].y);
-            }
-            h.bx0 = (float)bx0; h.bx1 = (float)bx1; h.by0 = (float)by0; h.by1 = (float)by1;
             for (int k = 0; k < n; ++k) {
                 if (is_start(k)) continue;     // chain starts / padding: no segment (h = -1: |t - 0.5| < h never holds)
                 int c0 = k;     // first vertex of this chain, and its last
                 while (!is_start(c0)) --c0;
                 int c1 = k;
                 while (c1 + 1 < h.n_chain && !is_start(c1 + 1)) ++c1;
-                const bool closed = c1 > c0 && vtx[o + c0].x == vtx[o + c1].x && vtx[o + c0].y == vtx[o + c1].y;
+                const bool closed = c1 > c0 && vpos[o + c0].x == vpos[o + c1].x && vpos[o + c0].y == vpos[o + c1].y;
                 const int prev = k - 1 > c0 ? k - 1 : (closed && c1 != k ? c1 : 0);       // shares this segment's first endpoint
                 const int next = k + 1 <= c1 ? k + 1 : (closed && c0 + 1 != k ? c0 + 1 : 0);   // shares its second endpoint
                 seg64[o + k].prev_next = prev | (next << 16);
