@@ -88,7 +88,7 @@ def parse_args():
                     "communicator, clip+Adam) -- the multi-GPU update's cost minus the xGMI transport")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "p2p"], help="multi-rank gradient exchange per minibatch: torch.distributed all_reduce (RCCL) "
                     "or the library's one-shot all-reduce over peer-mapped buffers (pc_xchg_*)")
-    ap.add_argument("--capture-collectives", action="store_true", help="multi-rank, backend nccl: capture the per-minibatch all-reduce into the epoch's update graph "
+    ap.add_argument("--capture-collectives", action="store_true", help="multi-rank, backend nccl or --exchange p2p: capture the per-minibatch all-reduce into the epoch's update graph "
                     "(off by default: the minibatch steps are enqueued eagerly around an eager all-reduce)")
     return ap.parse_args()
 

@@ -320,8 +320,8 @@ int pc_ppo_minibatch_prepared(int device, const float* prepared_mb, int B, int D
  *                                                   := sum over ranks (rank order) of their buckets.  Every rank must make the
  *                                                   same sequence of calls;
  *   pc_xchg_status(x)                               synchronises the device; PC_ERR_TIMEOUT if a wait inside any call gave up
- *                                                   (~2 s without a peer's flag: the kernel then finishes with a wrong sum
- *                                                   rather than hang the GPU);
+ *                                                   (~20 s without a peer's flag: the kernel then finishes with a wrong sum
+ *                                                   rather than hang the GPU, and later calls on the handle do not wait again);
  *   pc_xchg_destroy(x)                              after every rank has finished using it (the caller synchronises the ranks). */
 #define PC_XCHG_HANDLE_BYTES 64
 int pc_xchg_create(int device, int rank, int world, int64_t n_floats, pc_xchg** out);

@@ -204,10 +204,10 @@ __device__ __forceinline__ void wall_sweep_f32(const Vtx* vt, const int nV, cons
     Sweep<RPL, TAB> sw;
     sw.init(dx, dy, idx_mask, bb);
     // vertex k closes the segment (k-1, k): (axp, ayp, cp) belong to k-1, c to k; rd = the slots' 1/den rows (TAB)
-    auto close = [&](const Vtx& v, const int k, const float axp, const float ayp, const f32x2 (&cp)[NP], const f32x2 (&c)[NP],
-                     const f32x4 (&rd)[2 * NP], const int I) {
+    auto close = [&](const float ex, const float ey, const float exs, const float eys, const int k, const float axp, const float ayp,
+                     const f32x2 (&cp)[NP], const f32x2 (&c)[NP], const f32x4 (&rd)[2 * NP], const int I) {
         float u[2 * NP];
-        sw.cand(v.ex, v.ey, v.exs, v.eys, axp, ayp, cp, c, rd, I, u);
+        sw.cand(ex, ey, exs, eys, axp, ayp, cp, c, rd, I, u);
         unsigned kv;
         asm("v_mov_b32 %0, %1" : "=v"(kv) : "s"(k));
 #pragma unroll
@@ -244,7 +244,7 @@ __device__ __forceinline__ void wall_sweep_f32(const Vtx* vt, const int nV, cons
         const Vtx v = nxt;                                                                                           \
         nxt = cload(vt + (k + I + 1 < 4 * gend ? k + I + 1 : k + I));                                                \
         sw.side(v.xr, v.yr, pxr, pyr, NAX, NAY, NC);                                                                   \
-        if (!vtx_brk(v)) close(v, k + I, PAX, PAY, PC, NC, RD, I);                                                   \
+        if (!vtx_brk(v)) close(v.ex, v.ey, v.exs, v.eys, k + I, PAX, PAY, PC, NC, RD, I);                                                \
     }
     for (int gq = gbeg; gq < gend; ++gq) {
         f32x4 rd[2 * NP];

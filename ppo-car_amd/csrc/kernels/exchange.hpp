@@ -12,12 +12,15 @@
 // its own epoch counter, its own flags -- no grid-wide barrier.  Double buffered by epoch parity: a rank can start epoch k + 1
 // (other parity) while a peer still sums epoch k, and cannot start k + 2 before that peer has raised its k + 1 flags, i.e. has
 // finished summing k.  The staging memory is allocated uncached / fine-grained (hipExtMallocWithFlags) so that remote writes
-// are visible to a running kernel; flags are released / acquired at system scope.  A wait that sees no flag for ~2 s raises the
-// handle's error word and lets the kernel finish (pc_xchg_status reports it): the grid always drains.
+// are visible to a running kernel; flags are released / acquired at system scope.  Ranks reach an exchange at different times
+// (one may still be capturing its graph while the other already replays): a wait is patient -- XCHG_TIMEOUT_TICKS of
+// s_memtime, ~20 s -- but not endless: when it expires it raises the handle's error word and the kernel finishes with a wrong
+// sum (pc_xchg_status reports PC_ERR_TIMEOUT), and every later exchange on that handle skips its wait: the grid always drains.
 #pragma once
 
 constexpr int XCHG_MAX_RANKS = 8;
 constexpr int XCHG_CHUNK = 1024;   // floats per workgroup
+constexpr unsigned long long XCHG_TIMEOUT_TICKS = 40000000000ull;   // s_memtime runs at about the shader clock (~2 GHz)
 
 struct XchgView {
     float* data[XCHG_MAX_RANKS];       // data[r]: rank r's staging area [2 parities][W writers][n_pad floats] (data[rank] is local)
@@ -54,11 +57,12 @@ __global__ __launch_bounds__(256) void xchg_allreduce_kernel(const XchgView v, f
     if (tid < W) {
         const unsigned* f = v.flags[v.rank] + (par * W + tid) * v.n_chunks + c;
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != ep) {
-            __builtin_amdgcn_s_sleep(8);
-            if (__builtin_amdgcn_s_memtime() - t0 > 200000000ull) {   // ~2 s of the 100 MHz reference clock: give up, say so
+        bool dead = __hip_atomic_load(v.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;   // an earlier exchange gave up: do not wait again
+        while (!dead && __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != ep) {
+            __builtin_amdgcn_s_sleep(32);
+            if (__builtin_amdgcn_s_memtime() - t0 > XCHG_TIMEOUT_TICKS) {   // give up, say so
                 __hip_atomic_store(v.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
+                dead = true;
             }
         }
     }

@@ -227,15 +227,18 @@ __device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const i
 }
 
 // LG = log2 of the lanes per env (1: K9, a wave owns 32 envs; 2: K9s, 16 envs per wave).  PARTS > 1 (K9s): the wall sweep is split
-// over PARTS waves of the workgroup -- this wave sweeps vertex part `part`, the per-ray minima meet in LDS (`exch`: the env's
-// [rays][PARTS] floats) across ONE workgroup barrier (every thread of the workgroup must make the call), and all waves finish
+// over PARTS waves of the workgroup -- this wave sweeps vertex part `part`, the per-ray selections meet in LDS (`exch`: the env's
+// [rays][PARTS] words) across a workgroup barrier, the float64 refinement is DEALT over the same waves (ray slot s is refined by
+// part s % PARTS, which also writes that ray's column of the observation row), the parts' collision verdicts meet in LDS (`hitw`:
+// the env's [PARTS] words) across a second barrier (every thread of the workgroup must make the call), and all waves finish
 // the step on identical values; only `write_row` waves store the observation row.
 template <int RPL, bool TAB, int LG = 1, int PARTS = 1, int SWP = 0, bool TWICE = true>
 __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const TrackHdr& h, const FastTabs& ft, const FastLane& fl,
                                               const int (&gq)[2], const int g,
                                               EnvRegs& st, int& k72, const int a, const double reward_scale, lds_fp lrow,
                                               float& reward_f, float& term_f, float& trunc_f, const int t = 0, const int lane = 0,
-                                              const int wave = 0, const int part = 0, float* exch = nullptr, const bool write_row = true) {
+                                              const int wave = 0, const int part = 0, float* exch = nullptr, const bool write_row = true,
+                                              int* hitw = nullptr) {
     constexpr int G = 1 << LG;
     // the float64 twin of the lattice entry at LDS byte address m (see FT_D64_BYTES)
     const unsigned dir_b = (unsigned)(size_t)ft.dir;
@@ -340,11 +343,13 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         ray = g;
 #pragma unroll
         for (int s = 0; s < RPL; ++s) {
-            const int r = s + 1 < RPL ? ray : min(ray, p.R - 1);
-            unsigned m = ex[r * PARTS];
+            if (s % PARTS == part) {     // (wave-uniform) this part refines slot s
+                const int r = s + 1 < RPL ? ray : min(ray, p.R - 1);
+                unsigned m = ex[r * PARTS];
 #pragma unroll
-            for (int q = 1; q < PARTS; ++q) m = min(m, ex[r * PARTS + q]);
-            bb[s] = m;
+                for (int q = 1; q < PARTS; ++q) m = min(m, ex[r * PARTS + q]);
+                bb[s] = m;
+            }
             ray += G;
         }
     }
@@ -369,7 +374,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     uint64_t hit_mask = 0;
     // Slots in batches: every LDS read of a batch -- the selected segments' records, the slots' float64 directions -- is issued
     // before the first float64 instruction, so that the wave pays the LDS round trip once per batch, not once per slot.
-    constexpr int NB = RPL <= 9 ? RPL : (RPL + 1) / 2;
+    constexpr int NB = RPL <= 5 ? RPL : (RPL <= 9 ? (RPL + 1) / 2 : (RPL + 3) / 4);   // (14 registers per slot in flight: all nine of the 17-ray kernel at once spill)
 #pragma unroll
     for (int s0 = 0; s0 < RPL; s0 += NB) {
         SegD sg[NB];
@@ -377,7 +382,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int s = s0 + j;
-            if (s < RPL) {
+            if (s < RPL && (PARTS == 1 || s % PARTS == part)) {
                 const int m = m0 + s * fl.rstep;
                 sg[j] = segs((int)(bb[s] & h.idx_mask));
                 d64[j] = dir64_at(s + 1 < RPL ? m : min(m, m_last));
@@ -387,7 +392,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int s = s0 + j;
-            if (s < RPL) {
+            if (s < RPL && (PARTS == 1 || s % PARTS == part)) {
                 bool ok;
                 const double d = refine_fast(sg[j], npx, npy, d64[j].x, d64[j].y, ok);
                 todo |= ok ? 0u : 1u << s;
@@ -396,7 +401,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
                 for (int gg = 0; gg < G; ++gg) col_lanes |= ((colm_g[gg] >> s) & 1) ? LANES_G0 << gg : 0ull;
                 hit_mask |= __builtin_amdgcn_ballot_w64(ok & (d < 10.0)) & col_lanes;           // :387-390 on Car.check_collision's rays
                 const float o = obs_dist(d);                                                    // :593
-                if (write_row) {   // ray slot s -> column 6 + ray(s): G floats apart from the lane's first; the clamped last slot apart
+                if (write_row || PARTS > 1) {   // ray slot s -> column 6 + ray(s): G floats apart from the lane's first; the clamped last slot apart
                     if (s + 1 < RPL) fl.lray[G * s] = o;
                     else fl.llast[0] = o;
                 }
@@ -415,7 +420,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
             const f64x2 d64 = dir64_at(s0 + 1 < RPL ? ms : min(ms, m_last));
             const double d = refine_careful((int)(sel & h.idx_mask), segs, h.nV, npx, npy, d64.x, d64.y);
             wall_hit |= (bool)((fl.colmask >> s0) & 1) & (d < 10.0);
-            if (write_row) {
+            if (write_row || PARTS > 1) {
                 const lds_fp dst = s0 + 1 < RPL ? fl.lray + G * s0 : fl.llast;
                 dst[0] = obs_dist(d);
             }
@@ -426,6 +431,12 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     flags |= swap_pair(flags);                                          // any() over the env's G lanes
     if constexpr (G == 4) flags |= __builtin_amdgcn_update_dpp(0, flags, 0x4e, 0xf, 0xf, false);   // quad_perm [2, 3, 0, 1]
     static_assert(G == 2 || G == 4, "2 or 4 lanes per env");
+    if constexpr (PARTS > 1) {   // every part has judged its own ray slots: the env's verdict is the OR over the parts
+        if (g == 0) hitw[part] = flags;
+        lds_barrier();
+#pragma unroll
+        for (int q = 0; q < PARTS; ++q) flags |= hitw[q];
+    }
     gate_hit = flags & 1;
     const bool destroyed = ((flags & 2) != 0) | (h.start_collides != 0);
     // ---- bookkeeping (car_env.py:694-750): float64 reward in the reference's order of accumulation
@@ -841,7 +852,8 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     float* sOut = lds + IMG;                       // [8 waves][EPW envs][LDO] partial output tiles
     float* sObs = sOut + 8 * EPW * LDO;            // [EPW envs][LDX]
     int* sAct = reinterpret_cast<int*>(sObs + EPW * (FAST ? 40 : LDX));   // (FAST: room for the widest row, so the tables stay 16-byte aligned)
-    float* sTab = reinterpret_cast<float*>(sAct + 32);     // staged per-track tables
+    int* sHit = sAct + 32;                                 // [EPW envs][PARTS]: the sweep parts' collision / gate verdicts (128 words)
+    float* sTab = reinterpret_cast<float*>(sHit + 128);    // staged per-track tables
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, lk = lane >> 4;
     policy_stage_image<IMG>(image, lds, tid);
@@ -984,8 +996,8 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 float rw, tf, cf;
                 const int a = e_valid ? sAct[el] : 8;
                 const bool done = rden_lds   // (uniform)
-                    ? env_step_fast<RPL, true, 2, PARTS>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0)
-                    : env_step_fast<RPL, false, 2, PARTS>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0);
+                    ? env_step_fast<RPL, true, 2, PARTS>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0, sHit + el * PARTS)
+                    : env_step_fast<RPL, false, 2, PARTS>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0, sHit + el * PARTS);
                 rsum += rw;
                 if (__builtin_amdgcn_ballot_w64(done) != 0) {
                     if (done) {

@@ -1011,9 +1011,9 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
     const size_t lds_fast_big = (size_t)(img + 256 * e->D + 256 + ft_floats(false, KS != 10)) * sizeof(float);   // (33 rays: one turn of the float64 lattice)
     const bool fast = !small && fast_shape && max_nV <= FT_VTX_MAX && (!e->track_id || e->track_block >= epw) && lds_fast_big <= 160 * 1024;
     const size_t lds_big = fast ? lds_fast_big : (size_t)(img + 256 * (4 * KS + 1) + 256 + TAB_FLOATS) * sizeof(float);
-    const size_t lds_fast_small = (size_t)(img + 8 * 32 * 17 + 32 * 40 + 32 + ft_floats(true, true)) * sizeof(float);
+    const size_t lds_fast_small = (size_t)(img + 8 * 32 * 17 + 32 * 40 + 32 + 128 + ft_floats(true, true)) * sizeof(float);
     const bool fast_small = small && fast_shape && max_nV <= FT_VTX_MAX && lds_fast_small <= 160 * 1024;     // (a small-form workgroup is 16 or 32 envs)
-    const size_t lds_small = fast_small ? lds_fast_small : (size_t)(img + 8 * 32 * 17 + 32 * (4 * KS + 1) + 32 + TAB_FLOATS) * sizeof(float);
+    const size_t lds_small = fast_small ? lds_fast_small : (size_t)(img + 8 * 32 * 17 + 32 * (4 * KS + 1) + 32 + 128 + TAB_FLOATS) * sizeof(float);
     size_t lds = small ? lds_small : lds_big;
     if (lds > 160 * 1024) return PC_ERR_UNSUPPORTED;
     // the track's 1/den table rides along in LDS when it fits (big_track: 361 x 28 floats = 40 KB); else the sweep forms

@@ -72,7 +72,7 @@ class PPOConfig:
                                            # backend nccl; whatever the process group's backend is otherwise); "p2p" = the library's one-shot
                                            # all-reduce over peer-mapped buffers (pc_xchg_*: every rank writes its bucket into every peer's slot,
                                            # sums locally in rank order) -- one xGMI hop of latency instead of a ring / tree schedule, a plain
-                                           # kernel, so it is captured into the epoch graph with any backend
+                                           # kernel, so capture_collectives can put it into the epoch graph with any backend
     policy_precision: int = -1             # arithmetic of the fused policy step's GEMMs: 2 fp16x2, 1 bf16x3, 0 fp32-input MFMA;
                                            # -1 = the library's default (fp16x2).  Per Trainer (a pc_policy handle), not process-wide
 
@@ -352,10 +352,10 @@ class PPOLearner:
         itself can be captured -- backend nccl (RCCL records its kernels into the capturing stream), not gloo."""
         if not self.collective:
             return True
-        if self.p2p is not None or (self.world_size == 1 and self.cfg.exchange == "p2p"):
-            return True         # the one-shot exchange is an ordinary kernel launch
         if self._capture_failed or not self.cfg.capture_collectives:
             return False
+        if self.p2p is not None:
+            return True         # the one-shot exchange is an ordinary kernel launch: capturable with any backend
         import torch.distributed as dist
         return dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
 

@@ -336,7 +336,8 @@ def _two_rank_worker(rank, world, port, out_dir, use_graphs, exchange="rccl"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)     # both ranks share cuda:0 here; RCCL needs one GPU per rank
     torch.cuda.set_device(0)
-    cfg = _cfg(n_envs=512, n_steps=64, batch_size=32, train_iters=2, use_graphs=use_graphs, seed=11, exchange=exchange)
+    cfg = _cfg(n_envs=512, n_steps=64, batch_size=32, train_iters=2, use_graphs=use_graphs, seed=11, exchange=exchange,
+               capture_collectives=exchange == "p2p")
     tr = Trainer(cfg, device="cuda:0", rank=rank, world_size=world)
     s1 = tr.run_epoch()
     s2 = tr.run_epoch()
@@ -373,7 +374,7 @@ def test_one_shot_p2p_exchange_between_two_ranks_on_one_gpu(tmp_path, use_graphs
     staging buffers (pc_xchg_*), two processes sharing cuda:0 (an IPC mapping works between processes on one device, so
     correctness and bit-identity are provable here; the xGMI latency is not).  Replicas stay bit-identical, the result equals
     the all_reduce path's bit for bit (two ranks: a + b is the same sum in either order), and with graphs the whole epoch's
-    update -- exchanges included -- is ONE captured graph even over gloo.  (train.py:259-260)"""
+    update -- exchanges included -- can be ONE captured graph (capture_collectives) even over gloo.  (train.py:259-260)"""
     import socket
     import torch.multiprocessing as mp
     res = {}
