@@ -3,7 +3,7 @@
 # PMC passes of the persistent rollout kernel (separate passes, --kernel-trace + --pmc only).  Usage: tools/collect_profiles.sh <tag>
 # Output: gpurun_out/<tag>/...; summarise with tools/pmc_summary.py and copy what is cited into profiles/.
 set -o pipefail
-TAG=${1:-r2}
+TAG=${1:-r3}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
