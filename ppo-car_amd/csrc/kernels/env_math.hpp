@@ -18,6 +18,7 @@ struct TrackHdr {        // one per track, read with scalar loads
     double start_x, start_y, start_rot;
     double ax0, ay0;            // F32: the anchor of the sweep's float32 coordinates: the centre of the wall vertices' bounding box
     float bx0, bx1, by0, by1;   // F32: that bounding box (the sweep's flag threshold is priced from it)
+    int brk2, pad2_;            // F32: index of the chain's SECOND chain-start vertex when the walls are exactly two chains (-1 otherwise)
 };
 
 // One wall / gate segment as the reference holds it (Boundary.get_points, car_env.py:74): 32 bytes.

@@ -308,8 +308,8 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         unsigned ba[2 * ((R1 + 1) / 2)];
         if (PARTS > 1)                  // small form: latency-oriented sweep over the LDS copy of the chain
             wall_sweep_lds<R1, PARTS, TAB, true>(ft.vtx, h.nV, part, pxr, pyr, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
-        else if (SWP == 7 || h.nV == 28)   // (wave-uniform) big_track's chain: the unrolled sweep.  SWP == 7: the host guarantees that
-            wall_sweep_unrolled<R1, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);   // chain length
+        else if (SWP == 7 || h.nV == 28)   // (wave-uniform) big_track's chain: the unrolled sweep.  SWP == 7: the host guarantees that chain's whole layout (28 vertices: two loops of 12 walls, chain starts at 0 and 13)
+            wall_sweep_unrolled<R1, TAB, 7, true, (SWP == 7 ? 13 : -1)>(p.vtx + h.vtx_off, h.n_chain, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);   // chain length
         else if constexpr (SWP == 0)       // and the generic loop is not even compiled in (1 % from the shorter kernel alone)
             wall_sweep_f32<R1, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, pxr, pyr, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
 #pragma unroll
@@ -324,7 +324,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         if (PARTS > 1)
             wall_sweep_lds<R2, PARTS, TAB, true>(ft.vtx, h.nV, part, pxr, pyr, dxb, dyb, dib, ft.rden, tau, h.idx_mask, bc);
         else if (SWP == 7 || h.nV == 28)
-            wall_sweep_unrolled<R2, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, pxr, pyr, dxb, dyb, dib, ft.rden, tau, bc);
+            wall_sweep_unrolled<R2, TAB, 7, true, (SWP == 7 ? 13 : -1)>(p.vtx + h.vtx_off, h.n_chain, pxr, pyr, dxb, dyb, dib, ft.rden, tau, bc);
         else if constexpr (SWP == 0)
             wall_sweep_f32<R2, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, pxr, pyr, dxb, dyb, dib, ft.rden, tau, h.idx_mask, bc);
 #pragma unroll

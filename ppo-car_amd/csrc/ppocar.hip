@@ -378,6 +378,13 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
         {
             const int n = h.nV, o = h.vtx_off;
             const auto is_start = [&](int k) { return seg64[o + k].ex == 0.0 && seg64[o + k].ey == 0.0; };
+            {   // exactly two chains?  (what the kernels compiled for big_track's layout rely on: TrackHdr::brk2)
+                int n_starts = 0, second = -1;
+                for (int k = 0; k < h.n_chain; ++k)
+                    if (is_start(k) && ++n_starts == 2) second = k;
+                h.brk2 = n_starts == 2 ? second : -1;
+                h.pad2_ = 0;
+            }
             for (int k = 0; k < n; ++k) {
                 if (is_start(k)) continue;     // chain starts / padding: no segment (h = -1: |t - 0.5| < h never holds)
                 int c0 = k;     // first vertex of this chain, and its last
@@ -1034,7 +1041,7 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
     const int vec_ok = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
     const int mode = (fast || fast_small) ? (rden_lds ? 2 : 1) : 0;
     bool all_nv28 = o.nv28 != 0;
-    for (const TrackHdr& h : e->hdr_host) all_nv28 = all_nv28 && h.nV == 28;
+    for (const TrackHdr& h : e->hdr_host) all_nv28 = all_nv28 && h.nV == 28 && h.n_chain == 26 && h.brk2 == 13;   // big_track's layout: two loops of 12 walls
     hipStream_t st = (hipStream_t)stream;
     EnvParams<float> prm = e->params<float>();
     prm.lg = small ? 2 : 1;

@@ -393,3 +393,81 @@ def test_start_pose_inside_a_wall_terminates_every_step():
         O, R, TE, TR = ora.step(np.array([a, a]))
         o, r, te, tr, _, _ = _step(env, np.array([a, a]))
         assert te.all() and TE.all() and np.array_equal(o, O) and np.array_equal(r, R.astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+# adversarial geometry for F32 mode's rare paths (flags, corner neighbours, float64 chain scan)
+# ------------------------------------------------------------------------------------------------
+def _wedge_track():
+    """A closed outer box and, inside it, a closed wedge whose tip V = (300, 200) points at the car: for a ray along +x from
+    (100, 200 + eps) the tip is a SILHOUETTE vertex -- both of its neighbours lie on the same side of the ray line -- so the
+    ray either crosses both walls that meet at the tip or misses both and travels on to the far wall."""
+    box = [[50, 50, 650, 50], [650, 50, 650, 350], [650, 350, 50, 350], [50, 350, 50, 50]]
+    wedge = [[300, 200, 400, 260], [400, 260, 400, 320], [400, 320, 300, 200]]          # tip (300, 200), both neighbours above it
+    gates = [[60, 60, 61, 60]]
+    return np.array(box + wedge, np.float64), np.array(gates, np.float64)
+
+
+def _oracle_track(walls, gates, start):
+    ot = oracle.Track.__new__(oracle.Track)
+    ot.walls, ot.gates, ot.S, ot.G = walls, gates, len(walls), len(gates)
+    ot.start_x, ot.start_y, ot.start_rot = start
+    return ot
+
+
+@pytest.mark.parametrize("n", [12, 16])
+def test_f32_rays_grazing_a_silhouette_vertex_match_the_oracle_exactly(n):
+    """Rays that pass a wedge's tip at +-1e-12 ... +-1e-1 px: a float32 side test cannot tell which side the tip is on once
+    the offset is below ~1e-4 px, and a wrong guess would report the far wall (550 px) instead of the tip (200 px) or vice
+    versa.  The sweep FLAGS such rays and a float64 scan decides: every observation entry must be the float64 oracle's
+    float32 value (within one ulp), for the ray along +x and for all the others."""
+    walls, gates = _wedge_track()
+    eps = np.array([s * 10.0 ** e for e in range(-12, 0) for s in (+1.0, -1.0)] + [0.0])
+    M = len(eps)
+    start = (100.0, 200.0, 0.0)
+    ot = _oracle_track(walls, gates, start)
+    ora = oracle.OracleVecEnv(ot, M, num_rays=n, reward_scaling=1.0)
+    ora.reset()
+    st = {k: getattr(ora, k).copy() for k in STATE}
+    st["py"] = 200.0 + eps                 # the tip at y = 200: above / below / exactly on the ray along +x
+    ora.set_state(**st)
+    O, R, TE, TR, F = ora.step(np.full(M, 8), want_final_obs=True)
+    hit_tip = np.abs(F[:, 6] * 1000.0 - 200.0) < 1.0
+    assert hit_tip.any() and (~hit_tip).any()                                   # both outcomes occur in the oracle itself
+    for dtype in ("f64", "f32"):
+        env = pc.VecCarEnv(M, pc.Track(walls=walls, gates=gates, start=start), num_rays=n, reward_scaling=1.0, dtype=dtype)
+        env.reset()
+        env.set_state(**st)
+        o, r, te, tr, f, _ = _step(env, np.full(M, 8))
+        assert np.array_equal(te, TE) and np.array_equal(tr, TR), dtype
+        assert np.all(np.abs(f.astype(np.float64) - F) <= np.spacing(np.maximum(np.abs(F), np.float32(1e-3)))), (dtype, np.abs(f - F).max())
+        assert np.array_equal(np.abs(f[:, 6] * 1000.0 - 200.0) < 1.0, hit_tip), dtype   # tip vs far wall: the same decision everywhere
+        env.close()
+
+
+def test_f32_car_on_a_wall_line_and_rays_through_corners_match_the_oracle():
+    """More of the float32-undecidable: the car within 1e-9 ... 1e-3 px of a wall's supporting line (the sign of u), rays
+    exactly through and 1e-9 px beside a shared corner of two collinear walls, rays exactly along a wall (parallel, den == 0)."""
+    walls = np.array([[50, 50, 650, 50], [650, 50, 650, 350], [650, 350, 50, 350], [50, 350, 50, 50],      # box
+                      [300, 120, 300, 200], [300, 200, 300, 280]], np.float64)                             # two collinear walls, corner (300, 200)
+    gates = np.array([[60, 60, 61, 60]], np.float64)
+    start = (100.0, 200.0, 0.0)
+    offs = [0.0] + [s * 10.0 ** e for e in (-9, -6, -4, -3) for s in (1.0, -1.0)]
+    px = np.array([100.0] * len(offs) + [300.0 + o for o in offs])     # second half: the car ON / beside the line x = 300
+    py = np.array([200.0 + o for o in offs] + [240.0] * len(offs))     # first half: ray along +x through / beside the corner
+    M = len(px)
+    ot = _oracle_track(walls, gates, start)
+    ora = oracle.OracleVecEnv(ot, M, num_rays=12, reward_scaling=1.0)
+    ora.reset()
+    st = {k: getattr(ora, k).copy() for k in STATE}
+    st["px"], st["py"] = px, py
+    ora.set_state(**st)
+    O, R, TE, TR, F = ora.step(np.full(M, 8), want_final_obs=True)
+    for dtype in ("f64", "f32"):
+        env = pc.VecCarEnv(M, pc.Track(walls=walls, gates=gates, start=start), num_rays=12, reward_scaling=1.0, dtype=dtype)
+        env.reset()
+        env.set_state(**st)
+        o, r, te, tr, f, _ = _step(env, np.full(M, 8))
+        assert np.array_equal(te, TE) and np.array_equal(tr, TR), dtype
+        assert np.all(np.abs(f.astype(np.float64) - F) <= np.spacing(np.maximum(np.abs(F), np.float32(1e-3)))), (dtype, np.abs(f - F).max())
+        env.close()
