@@ -126,6 +126,9 @@ __device__ __forceinline__ float flag_threshold(const TrackHdr& h, const double 
 // The per-lane sweep state shared by the three forms of the sweep (scalar-load loop, unrolled, LDS copy of the chain)
 template <int RPL, bool TAB> struct Sweep {
     static constexpr int NP = (RPL + 1) / 2;
+#ifdef PC_AB_NOUM
+    static constexpr bool UM = RPL != 4;
+#endif
     f32x2 dx2[NP], dy2[NP];
     float cm[NP];     // per pair of ray slots: the smallest |c_k| over the vertices seen
     float um;         // the smallest |un'| over the segments seen
@@ -163,10 +166,23 @@ template <int RPL, bool TAB> struct Sweep {
         const float un = __builtin_fmaf(eys, axp, -(exs * ayp));
         // (a chain start's record carries (exs, eys) = (1, 0) beside its zero edge: |un'| = |ayp| there -- never small -- and its
         // candidate is still +-inf or NaN, (un' or 0) * (1 / 0))
+#ifdef PC_AB_NOUM
+        if (UM)
+#endif
         um = __builtin_fminf(um, __builtin_fabsf(un));
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const f32x2 P = pk_mul_clamp(cp[j], c[j]);
+#ifdef PC_AB_PKU
+            if constexpr (TAB) {
+                const f32x4 q = rd[2 * j + (I >> 1)];
+                const f32x2 r2 = (I & 1) ? (f32x2){q[2], q[3]} : (f32x2){q[0], q[1]};
+                const f32x2 u2 = __builtin_elementwise_fma((f32x2){un, un}, r2, P);
+                u[2 * j] = u2.x;
+                u[2 * j + 1] = u2.y;
+                continue;
+            }
+#endif
             float r0, r1 = 0.0f;
             if constexpr (TAB) {
                 r0 = rd[2 * j][I];

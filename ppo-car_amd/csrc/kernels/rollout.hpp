@@ -12,10 +12,14 @@ __device__ unsigned long long g_stamps[8 * STAMP_NT * STAMP_NPH];
 #define PC_STAMP(ph)                                                                                                      \
     if (blockIdx.x == 0 && t >= STAMP_T0 && t < STAMP_T0 + STAMP_NT && lane == 0)                                        \
         g_stamps[((wave * STAMP_NT) + (t - STAMP_T0)) * STAMP_NPH + (ph)] = __builtin_amdgcn_s_memtime();
+// the two stamps inside the env step: small form only (in the big form they cost registers the kernel does not have -- with
+// them it spilled 400 VGPRs and the timeline measured the spills)
+#define PC_STAMP_E(ph) if constexpr (PARTS > 1) { PC_STAMP(ph) }
 __device__ unsigned long long g_stamps_u[16];    // the minibatch kernel (K10), workgroup 0, thread 0, of the last launch
 #define PC_STAMP_U(ph) if (wg == 0 && threadIdx.x == 0) g_stamps_u[ph] = __builtin_amdgcn_s_memtime();
 #else
 #define PC_STAMP(ph)
+#define PC_STAMP_E(ph)
 #define PC_STAMP_U(ph)
 #endif
 // ------------------------------------------------------------------------------------------
@@ -300,7 +304,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     unsigned bb[RPL + 2];
     const float tau = flag_threshold(h, npx, npy);
     const float pxr = (float)(npx - h.ax0), pyr = (float)(npy - h.ay0);   // the car relative to the track's anchor (see Vtx)
-    PC_STAMP(4)
+    PC_STAMP_E(4)
     {
         const float(&dxa)[R1] = *reinterpret_cast<const float(*)[R1]>(&dx[0]);
         const float(&dya)[R1] = *reinterpret_cast<const float(*)[R1]>(&dy[0]);
@@ -353,7 +357,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
             ray += G;
         }
     }
-    PC_STAMP(5)
+    PC_STAMP_E(5)
     // ---- float64 refinement of every slot's selection (refine_fast / refine_careful, env_math.hpp): the distance the observation
     // reports and Car.check_collision (:376-392) tests against 10 px.  The chain tables are read from LDS; a slot's float64
     // direction is found through its lattice entry (re-read: nine addresses are cheaper to keep than nine more live registers in

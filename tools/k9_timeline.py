@@ -5,7 +5,8 @@
 
 Workgroup 0's eight waves stamp s_memtime at the phase boundaries of steps 64..71.  Waves w and w + 4 share a SIMD.
 Phases: 0 step start, 1 operand split done / policy pass starts, 2 policy pass done, 3 draw + action stores done,
-4 env pre-sweep done (action decode, physics, directions, gate casts), 5 sweep done, 6 bookkeeping + LDS row writes done,
+4 env pre-sweep done (action decode, physics, directions, gate casts), 5 sweep done (4 and 5: small form only -- the big
+form has no registers to spare for stamps inside its env step), 6 refinement + bookkeeping + LDS row writes done,
 7 reset fix-up + copy-out + flag stores done.
 """
 import ctypes as C
@@ -37,6 +38,10 @@ st = np.array(buf, dtype=np.uint64).reshape(8, NT, NPH).astype(np.int64)
 t0 = st.min()
 names = (["split", "policy", "draw", "env-pre", "sweep", "post", "copy-out"] if tr.cfg.n_envs > 16384 else
          ["tiles", "barrier1", "draw+bar2", "env-pre", "sweep part", "xchg+post", "barrier3"])
+big = tr.cfg.n_envs > 16384
+if big:                  # the big form carries no stamps inside the env step (they made it spill): phases 3..6 are one
+    st = st[:, :, [0, 1, 2, 3, 6, 7]]
+    names = ["split", "policy", "draw", "env step", "copy-out"]
 print(f"rollout mode {tr.rollout_mode}; cycles (s_memtime ticks) per phase, mean over {NT} steps")
 print("wave " + " ".join(f"{n:>9s}" for n in names) + "   step total")
 for w in range(8):
