@@ -18,7 +18,9 @@ struct TrackHdr {        // one per track, read with scalar loads
     double start_x, start_y, start_rot;
     double ax0, ay0;            // F32: the anchor of the sweep's float32 coordinates: the centre of the wall vertices' bounding box
     float bx0, bx1, by0, by1;   // F32: that bounding box (the sweep's flag threshold is priced from it)
-    int brk2, pad2_;            // F32: index of the chain's SECOND chain-start vertex when the walls are exactly two chains (-1 otherwise)
+    int brk2;                   // F32: index of the chain's SECOND chain-start vertex when the walls are exactly two chains (-1 otherwise)
+    int vtxp_off;               // F32: those two chains have the same length (n_chain = 2 brk2): their vertices again, packed by
+                                //      position in the chain, vtxp[vtxp_off .. vtxp_off + brk2) (-1 otherwise)
 };
 
 // One wall / gate segment as the reference holds it (Boundary.get_points, car_env.py:74): 32 bytes.
@@ -37,6 +39,12 @@ struct Seg { double x1, y1, x2, y2; };
 // shared by the two segments that meet there -- a float32 ray cannot slip between two adjacent walls
 // through the rounding-wide crack that two independently rounded t's leave at their common corner.
 struct Vtx { float xr, yr, ex, ey, exs, eys, pad0, pad1; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Walls that are exactly two chains of the same length L (big_track.json: the outer and the inner loop, 13 vertices each):
+// record i holds vertex i of BOTH chains -- component 0 = chain vertex i, component 1 = chain vertex L + i -- so that the
+// sweep's packed-fp32 instructions advance both chains at once (wall_sweep_loops).  Same values as the two Vtx records.
+struct VtxP { f32x2 xr, yr, ex, ey, exs, eys; };   // 48 bytes
 __device__ __forceinline__ bool vtx_brk(const Vtx& v) {   // chain start / padding sentinel: a zero edge (integer test: stays on the SALU)
     return ((__float_as_uint(v.ex) | __float_as_uint(v.ey)) << 1) == 0u;
 }
@@ -63,6 +71,7 @@ template <typename T> struct EnvParams {
     const TrackHdr* __restrict__ hdr;       // [n_tracks]
     const Seg* __restrict__ segs;           // walls and gates of all tracks
     const Vtx* __restrict__ vtx;            // F32 only: wall vertex chains of all tracks
+    const VtxP* __restrict__ vtxp;          // F32 only: the chains of two-equal-loop tracks, packed (TrackHdr::vtxp_off)
     const double2* __restrict__ headtab;    // F32 only: (cos, sin) of radians(start_rot + 5 j), j < 72, per track
     // F32 only.  A ray's direction angle is start_rot + 5 k + step_deg * ray degrees (k = integer turn count): an integer
     // offset from start_rot, so all directions live on a 360-entry lattice per track.
@@ -72,9 +81,6 @@ template <typename T> struct EnvParams {
     const SegD* __restrict__ seg64;         // F32 only: the wall chains for the refinement, indexed like vtx
     const float* __restrict__ reset_obs;    // [n_tracks][D]
 };
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define PC_PI 3.141592653589793238462643383279502884 /* NPY_PI */
 

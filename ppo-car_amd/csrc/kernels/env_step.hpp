@@ -126,9 +126,6 @@ __device__ __forceinline__ float flag_threshold(const TrackHdr& h, const double 
 // The per-lane sweep state shared by the three forms of the sweep (scalar-load loop, unrolled, LDS copy of the chain)
 template <int RPL, bool TAB> struct Sweep {
     static constexpr int NP = (RPL + 1) / 2;
-#ifdef PC_AB_NOUM
-    static constexpr bool UM = RPL != 4;
-#endif
     f32x2 dx2[NP], dy2[NP];
     float cm[NP];     // per pair of ray slots: the smallest |c_k| over the vertices seen
     float um;         // the smallest |un'| over the segments seen
@@ -166,23 +163,10 @@ template <int RPL, bool TAB> struct Sweep {
         const float un = __builtin_fmaf(eys, axp, -(exs * ayp));
         // (a chain start's record carries (exs, eys) = (1, 0) beside its zero edge: |un'| = |ayp| there -- never small -- and its
         // candidate is still +-inf or NaN, (un' or 0) * (1 / 0))
-#ifdef PC_AB_NOUM
-        if (UM)
-#endif
         um = __builtin_fminf(um, __builtin_fabsf(un));
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const f32x2 P = pk_mul_clamp(cp[j], c[j]);
-#ifdef PC_AB_PKU
-            if constexpr (TAB) {
-                const f32x4 q = rd[2 * j + (I >> 1)];
-                const f32x2 r2 = (I & 1) ? (f32x2){q[2], q[3]} : (f32x2){q[0], q[1]};
-                const f32x2 u2 = __builtin_elementwise_fma((f32x2){un, un}, r2, P);
-                u[2 * j] = u2.x;
-                u[2 * j + 1] = u2.y;
-                continue;
-            }
-#endif
             float r0, r1 = 0.0f;
             if constexpr (TAB) {
                 r0 = rd[2 * j][I];
@@ -347,6 +331,100 @@ __device__ __forceinline__ void wall_sweep_unrolled(const Vtx* vt, const int n_c
     };
     [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, NGRP>{});
     sw.apply_flags(tau, bb);
+}
+
+// The same sweep for a track whose walls are exactly TWO chains of L vertices each (TrackHdr::vtxp_off; big_track.json: L = 13,
+// the outer and the inner loop), packed BY CHAIN: every packed-fp32 instruction carries position i of chain 0 in its low half
+// and position i of chain 1 (vertex L + i) in its high half.  Against wall_sweep_unrolled -- which packs two RAY SLOTS per
+// instruction --
+//   * the per-vertex work that does not depend on the ray slot (a = p - pos, un', its flag) is packed as well: half the count;
+//   * the candidate u = fma(un', 1/den, P) is ONE v_pk_fma_f32 per slot and pair of vertices, its 1/den operand one aligned
+//     register pair of the slot's table row -- the table's LDS copy holds each row in the order (0, L, 1, L + 1, ...)
+//     (rden_stage_loops);
+//   * an odd slot count wastes nothing (5 + 4 slots used to cost 6 + 4), and the flags are per slot instead of per slot pair;
+//   * both chain starts are position 0: their candidates are not formed, no sentinel is computed.
+// Every candidate is the same arithmetic on the same operands as in wall_sweep_f32: the same bits, and the minimum is exact.
+// Vertex records: wave-uniform scalar loads of VtxP (48 bytes).  rdl rows: [4 * ((L + 1) / 2)] floats.
+template <int RPL, bool TAB, int L, bool ADDR = false>
+__device__ __forceinline__ void wall_sweep_loops(const VtxP* vp, const float pxr, const float pyr, const float (&dx)[RPL],
+                                                 const float (&dy)[RPL], const int (&didx)[RPL], lds_cfp rdl, const float tau,
+                                                 unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
+    static_assert(2 * L <= 32, "five index bits");
+    constexpr int NG = (L + 1) / 2, ROW = 4 * NG;
+    const unsigned keep = sgpr_const(0xffffffe0u);
+    const f32x2 px2 = {pxr, pxr}, py2 = {pyr, pyr};
+    f32x2 axA, ayA, axB, ayB, cA[RPL], cB[RPL];
+    float cm[RPL], um = 1e30f;
+#pragma unroll
+    for (int s = 0; s < 2 * ((RPL + 1) / 2); ++s) bb[s] = SEL_INIT;
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) cm[s] = 1e30f;
+    typedef const __attribute__((address_space(3))) f32x4* lds_row;
+    lds_row rrow[RPL];
+    if constexpr (TAB) {
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            if constexpr (ADDR) rrow[s] = (lds_row)(size_t)(unsigned)didx[s];
+            else rrow[s] = (lds_row)(rdl + __umul24(didx[s], ROW));
+        }
+    }
+    // side values of position i of both chains: a = p - pos, c[s] = cross(a, dir_s), and the smallest |c| per slot
+    auto side = [&](const VtxP& v, f32x2& ax, f32x2& ay, f32x2(&c)[RPL]) {
+        ax = v.xr - px2;
+        ay = v.yr - py2;
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const f32x2 dxs = {dx[s], dx[s]}, dys = {dy[s], dy[s]};
+            c[s] = __builtin_elementwise_fma(ay, dxs, -(ax * dys));
+            cm[s] = __builtin_fminf(__builtin_fminf(cm[s], __builtin_fabsf(c[s].x)), __builtin_fabsf(c[s].y));   // v_min3_f32 |.|
+        }
+    };
+    // the two segments closed by position I (vertices I and L + I): (axp, ayp, cp) belong to position I - 1, c to I
+    auto cand = [&](auto IC, const VtxP& v, const f32x2 axp, const f32x2 ayp, const f32x2(&cp)[RPL], const f32x2(&c)[RPL],
+                    const f32x4(&rd)[RPL]) {
+        constexpr int I = decltype(IC)::value;
+        const f32x2 un = __builtin_elementwise_fma(v.eys, axp, -(v.exs * ayp));
+        um = __builtin_fminf(__builtin_fminf(um, __builtin_fabsf(un.x)), __builtin_fabsf(un.y));
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const f32x2 P = pk_mul_clamp(cp[s], c[s]);
+            f32x2 r;
+            if constexpr (TAB) {
+                r = (I & 1) ? (f32x2){rd[s][2], rd[s][3]} : (f32x2){rd[s][0], rd[s][1]};
+            } else {
+                const f32x2 dxs = {dx[s], dx[s]}, dys = {dy[s], dy[s]};
+                const f32x2 den = __builtin_elementwise_fma(v.ey, dxs, -(v.ex * dys));   // = rden_build_kernel's
+                r = (f32x2){__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+            }
+            const f32x2 u = __builtin_elementwise_fma(un, r, P);
+            bb[s] = min(min(bb[s], and_or_k<I>(__float_as_uint(u.x), keep)), and_or_k<L + I>(__float_as_uint(u.y), keep));   // v_min3_u32
+        }
+    };
+    auto group = [&](auto GC) {      // positions 2 gq (set A) and 2 gq + 1 (set B)
+        constexpr int gq = decltype(GC)::value;
+        f32x4 rd[RPL];
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            rd[s] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (TAB) rd[s] = rrow[s][gq];
+        }
+        {
+            const VtxP v = cload(vp + 2 * gq);
+            side(v, axA, ayA, cA);
+            if constexpr (gq > 0) cand(std::integral_constant<int, 2 * gq>{}, v, axB, ayB, cB, cA, rd);
+        }
+        if constexpr (2 * gq + 1 < L) {
+            const VtxP v = cload(vp + 2 * gq + 1);
+            side(v, axB, ayB, cB);
+            cand(std::integral_constant<int, 2 * gq + 1>{}, v, axA, ayA, cA, cB, rd);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one scheduling region per group (see wall_sweep_unrolled)
+    };
+    [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, NG>{});
+    // selection 0 ("nothing certified") for a flagged slot / every slot of a flagged lane
+    const bool lane_bad = um < tau * SEL_SCALE;
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) bb[s] = (lane_bad | (cm[s] < tau)) ? 0u : bb[s];
 }
 
 // One CarEnv.step (car_env.py:693-760) + TransformReward + same-step auto-reset for the env whose state the

@@ -312,8 +312,10 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         unsigned ba[2 * ((R1 + 1) / 2)];
         if (PARTS > 1)                  // small form: latency-oriented sweep over the LDS copy of the chain
             wall_sweep_lds<R1, PARTS, TAB, true>(ft.vtx, h.nV, part, pxr, pyr, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
-        else if (SWP == 7 || h.nV == 28)   // (wave-uniform) big_track's chain: the unrolled sweep.  SWP == 7: the host guarantees that chain's whole layout (28 vertices: two loops of 12 walls, chain starts at 0 and 13)
-            wall_sweep_unrolled<R1, TAB, 7, true, (SWP == 7 ? 13 : -1)>(p.vtx + h.vtx_off, h.n_chain, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);   // chain length
+        else if constexpr (SWP == 7)       // the host guarantees big_track's layout (two loops of 13 vertices, packed: TrackHdr::vtxp_off)
+            wall_sweep_loops<R1, TAB, 13, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);
+        else if (h.nV == 28)               // (wave-uniform) a chain of 28: the unrolled sweep
+            wall_sweep_unrolled<R1, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);   // chain length
         else if constexpr (SWP == 0)       // and the generic loop is not even compiled in (1 % from the shorter kernel alone)
             wall_sweep_f32<R1, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, pxr, pyr, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
 #pragma unroll
@@ -327,8 +329,10 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         unsigned bc[2 * ((R2 + 1) / 2)];
         if (PARTS > 1)
             wall_sweep_lds<R2, PARTS, TAB, true>(ft.vtx, h.nV, part, pxr, pyr, dxb, dyb, dib, ft.rden, tau, h.idx_mask, bc);
-        else if (SWP == 7 || h.nV == 28)
-            wall_sweep_unrolled<R2, TAB, 7, true, (SWP == 7 ? 13 : -1)>(p.vtx + h.vtx_off, h.n_chain, pxr, pyr, dxb, dyb, dib, ft.rden, tau, bc);
+        else if constexpr (SWP == 7)
+            wall_sweep_loops<R2, TAB, 13, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxb, dyb, dib, ft.rden, tau, bc);
+        else if (h.nV == 28)
+            wall_sweep_unrolled<R2, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, pxr, pyr, dxb, dyb, dib, ft.rden, tau, bc);
         else if constexpr (SWP == 0)
             wall_sweep_f32<R2, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, pxr, pyr, dxb, dyb, dib, ft.rden, tau, h.idx_mask, bc);
 #pragma unroll
@@ -592,7 +596,18 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(p.rden + h0.rden_off);
         const int n4 = rden_lds ? 361 * h0.nV / 4 : 0;     // nV is a multiple of 4
-        for (int i = tid; i < n4; i += 512) reinterpret_cast<f32x4*>(sRden)[i] = src[i];
+        if constexpr (MODE == 3) {
+            // the two-loop sweep (wall_sweep_loops) reads a row in the order (0, L, 1, L + 1, ...): entry 2 i = vertex i, entry
+            // 2 i + 1 = vertex L + i (L = 13, rows of 28; the last two entries are the padding vertices')
+            const float* g = p.rden + h0.rden_off;
+            for (int i = tid; i < 4 * n4; i += 512) {
+                const int row = i / 28, e = i - 28 * row;
+                const int k = e < 26 ? (e >> 1) + ((e & 1) ? 13 : 0) : e;
+                sRden[i] = g[28 * row + k];
+            }
+        } else {
+            for (int i = tid; i < n4; i += 512) reinterpret_cast<f32x4*>(sRden)[i] = src[i];
+        }
     }
     const lds_cfp rdl = (lds_cfp)sRden;
 

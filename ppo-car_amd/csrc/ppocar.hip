@@ -141,6 +141,7 @@ struct pc_env {
     TrackHdr* hdr = nullptr;
     Seg* segs = nullptr;
     Vtx* vtx = nullptr;
+    VtxP* vtxp = nullptr;
     double2* headtab = nullptr;
     float2* dirtab = nullptr;
     float* rden = nullptr;
@@ -167,6 +168,7 @@ struct pc_env {
         p.hdr = hdr;
         p.segs = segs;
         p.vtx = vtx;
+        p.vtxp = vtxp;
         p.headtab = headtab;
         p.dirtab = dirtab;
         p.rden = rden;
@@ -296,6 +298,7 @@ void pc_env_destroy(pc_env* e) {
     (void)hipFree(e->hdr);
     (void)hipFree(e->segs);
     (void)hipFree(e->vtx);
+    (void)hipFree(e->vtxp);
     (void)hipFree(e->headtab);
     (void)hipFree(e->dirtab);
     (void)hipFree(e->rden);
@@ -310,6 +313,7 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
     // ---- host images of the track table
     std::vector<Seg> segs;
     std::vector<Vtx> vtx;
+    std::vector<VtxP> vtxp;
     std::vector<double2> headtab;
     std::vector<float2> dirtab;
     std::vector<double2> dirtab64;
@@ -383,7 +387,14 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
                 for (int k = 0; k < h.n_chain; ++k)
                     if (is_start(k) && ++n_starts == 2) second = k;
                 h.brk2 = n_starts == 2 ? second : -1;
-                h.pad2_ = 0;
+                h.vtxp_off = -1;
+                if (h.brk2 > 0 && h.n_chain == 2 * h.brk2) {     // ... of the same length: the packed copy (VtxP)
+                    h.vtxp_off = (int)vtxp.size();
+                    for (int i = 0; i < h.brk2; ++i) {
+                        const Vtx &a = vtx[o + i], &b = vtx[o + h.brk2 + i];
+                        vtxp.push_back(VtxP{{a.xr, b.xr}, {a.yr, b.yr}, {a.ex, b.ex}, {a.ey, b.ey}, {a.exs, b.exs}, {a.eys, b.eys}});
+                    }
+                }
             }
             for (int k = 0; k < n; ++k) {
                 if (is_start(k)) continue;     // chain starts / padding: no segment (h = -1: |t - 0.5| < h never holds)
@@ -440,6 +451,11 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
     HIPCHK(hipMemcpy(e->segs, segs.data(), segs.size() * sizeof(Seg), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&e->vtx, vtx.size() * sizeof(Vtx)));
     HIPCHK(hipMemcpy(e->vtx, vtx.data(), vtx.size() * sizeof(Vtx), hipMemcpyHostToDevice));
+    static_assert(sizeof(VtxP) == 48, "packed vertex records: 48 bytes");
+    if (!vtxp.empty()) {
+        HIPCHK(hipMalloc((void**)&e->vtxp, vtxp.size() * sizeof(VtxP)));
+        HIPCHK(hipMemcpy(e->vtxp, vtxp.data(), vtxp.size() * sizeof(VtxP), hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMalloc((void**)&e->headtab, headtab.size() * sizeof(double2)));
     HIPCHK(hipMemcpy(e->headtab, headtab.data(), headtab.size() * sizeof(double2), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&e->dirtab, dirtab.size() * sizeof(float2)));
@@ -1041,7 +1057,7 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
     const int vec_ok = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
     const int mode = (fast || fast_small) ? (rden_lds ? 2 : 1) : 0;
     bool all_nv28 = o.nv28 != 0;
-    for (const TrackHdr& h : e->hdr_host) all_nv28 = all_nv28 && h.nV == 28 && h.n_chain == 26 && h.brk2 == 13;   // big_track's layout: two loops of 12 walls
+    for (const TrackHdr& h : e->hdr_host) all_nv28 = all_nv28 && h.nV == 28 && h.n_chain == 26 && h.brk2 == 13 && h.vtxp_off >= 0;   // big_track's layout: two loops of 12 walls
     hipStream_t st = (hipStream_t)stream;
     EnvParams<float> prm = e->params<float>();
     prm.lg = small ? 2 : 1;
