@@ -12,6 +12,8 @@ struct TrackHdr {        // one per track, read with scalar loads
     int start_collides;  // Car.update at reset already hits a wall (car_env.py:686,468-469)
     int vtx_off, nV;     // F32: the walls again as vertex chains, vtx[vtx_off .. vtx_off+nV); nV is padded to a multiple of 4
     int dir_off;         // F32: ray direction table [361] of this track in dirtab / dirtab64 (entry 360 = (0, 0): no ray)
+                         // F64: first slot of the track's angle -> (cos, sin) hash table in dirhash (Math<double>; head_off = its slot
+                         //      mask), -1 = none
     int rden_off;        // F32: 1/den table [361][nV] of this track in rden (row 360 = +inf: never hits)
     int n_chain;         // F32: chain vertices before the padding to a multiple of 4 (vtx[n_chain .. nV) are sentinels)
     unsigned idx_mask;   // F32: (1 << b) - 1, b = max(5, ceil(log2(nV))): the low bits of a sweep candidate carry its vertex index
@@ -79,6 +81,7 @@ template <typename T> struct EnvParams {
     const float* __restrict__ rden;         // [n_tracks][361][nV] 1 / (ey*dx - ex*dy) exactly as the sweep computes it (device-built)
     const double2* __restrict__ dirtab64;   // [n_tracks][361] the same lattice in float64 (libm): the refinement's ray directions
     const SegD* __restrict__ seg64;         // F32 only: the wall chains for the refinement, indexed like vtx
+    const struct F64Dir* __restrict__ dirhash;   // F64 only: glibc's cos / sin of every angle an episode can reach (Math<double>)
     const float* __restrict__ reset_obs;    // [n_tracks][D]
 };
 
@@ -198,17 +201,53 @@ __device__ __forceinline__ double cast_d(const Seg& s, const double px, const do
 
 template <typename T> struct Math;
 
+// F64 mode's directions.  The reference forms np.cos / np.sin of np.radians(angle) (car_env.py:426-427, :463-466, :584) for
+// angle = rotation [+ a], rotation = the start rotation after a sequence of +-5.0 (each sum rounded: :440-442), a = the ray's
+// whole-degree offset (:269).  Inside an episode (at most 1000 turns) only a few thousand distinct float64 rotations can occur
+// -- the roundings merge the paths -- and ~15 k distinct angles: the host enumerates them, evaluates cos / sin with glibc (the
+// reference's own libm) and the device LOOKS THEM UP by the angle's bit pattern: the reference's bits by construction, where the
+// device's own cos / sin (ocml) differ from glibc in the last place for some arguments.  An angle that is not in the table
+// (set_state with a rotation no episode reaches; more than 16 tracks: dir_off < 0) is evaluated on the device as before.
+struct F64Dir { unsigned long long key; double c, s; unsigned long long pad; };     // 32 bytes; key = the angle's bits (degrees)
+constexpr unsigned long long F64DIR_EMPTY = 0x7ff8dead00000000ull;                  // (a NaN pattern no sum produces)
+constexpr int F64DIR_MAX_PROBE = 8;                                                 // the host sizes the table so that this holds
+__host__ __device__ inline unsigned f64dir_hash(unsigned long long k) {
+    k ^= k >> 29;
+    k *= 0xBF58476D1CE4E5B9ull;
+    return (unsigned)(k >> 32);
+}
 template <> struct Math<double> {
-    // heading (cos, sin): computed from the float64 heading as the reference does (:426-427, :584)
-    static __device__ __forceinline__ void heading(const EnvParams<double>&, const TrackHdr&, int, double rot, double& c,
+    static __device__ __forceinline__ bool lookup(const EnvParams<double>& p, const TrackHdr& h, const double angle, double& c,
+                                                  double& s) {
+        if (h.dir_off < 0) return false;
+        const unsigned long long key = (unsigned long long)__double_as_longlong(angle);
+        const unsigned mask = (unsigned)h.head_off;       // F64 mode: the table's slot mask
+        unsigned slot = f64dir_hash(key) & mask;
+        for (int probe = 0; probe < F64DIR_MAX_PROBE; ++probe) {
+            const F64Dir e = p.dirhash[h.dir_off + slot];
+            if (e.key == key) {
+                c = e.c;
+                s = e.s;
+                return true;
+            }
+            if (e.key == F64DIR_EMPTY) return false;
+            slot = (slot + 1) & mask;
+        }
+        return false;
+    }
+    // heading (cos, sin) of the float64 heading, as the reference forms it (:426-427, :584)
+    static __device__ __forceinline__ void heading(const EnvParams<double>& p, const TrackHdr& h, int, double rot, double& c,
                                                    double& s) {
+        if (lookup(p, h, rot, c, s)) return;
         const double a = d_radians(rot);
         c = cos(a);
         s = sin(a);
     }
-    static __device__ __forceinline__ void ray_dir(const EnvParams<double>& p, const TrackHdr&, int ray, int, double rot,
+    static __device__ __forceinline__ void ray_dir(const EnvParams<double>& p, const TrackHdr& h, int ray, int, double rot,
                                                    double& dx, double& dy) {
-        const double a = d_radians(rot + (double)(ray * p.step_deg));  // Ray.update(x, y, rot + a) :463-466, :153
+        const double deg = rot + (double)(ray * p.step_deg);   // Ray.update(x, y, rot + a) :463-466, :153
+        if (lookup(p, h, deg, dx, dy)) return;
+        const double a = d_radians(deg);
         dx = cos(a);
         dy = sin(a);
     }

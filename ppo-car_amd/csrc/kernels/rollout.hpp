@@ -7,7 +7,7 @@
 // eight waves write s_memtime at every phase boundary of steps 64..71 into a device array that tools/k9_timeline.py reads back.
 // The product build contains none of this.
 #ifdef PC_STAMPS
-constexpr int STAMP_T0 = 64, STAMP_NT = 8, STAMP_NPH = 8;
+constexpr int STAMP_T0 = 64, STAMP_NT = 8, STAMP_NPH = 12;
 __device__ unsigned long long g_stamps[8 * STAMP_NT * STAMP_NPH];
 #define PC_STAMP(ph)                                                                                                      \
     if (blockIdx.x == 0 && t >= STAMP_T0 && t < STAMP_T0 + STAMP_NT && lane == 0)                                        \
@@ -417,6 +417,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         }
     }
     wall_hit = __builtin_amdgcn_inverse_ballot_w64(hit_mask);
+    PC_STAMP_E(8)
     // the rare rest, one slot of one lane at a time through ONE copy of the careful code (a select chain picks the slot's selection)
     while (__builtin_amdgcn_ballot_w64(todo != 0) != 0) {
         const int s0 = todo ? __builtin_ctz(todo) : -1;
@@ -435,6 +436,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
             todo &= todo - 1;
         }
     }
+    PC_STAMP_E(9)
     int flags = (gate_hit ? 1 : 0) | (wall_hit ? 2 : 0);
     flags |= swap_pair(flags);                                          // any() over the env's G lanes
     if constexpr (G == 4) flags |= __builtin_amdgcn_update_dpp(0, flags, 0x4e, 0xf, 0xf, false);   // quad_perm [2, 3, 0, 1]
@@ -445,6 +447,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
 #pragma unroll
         for (int q = 0; q < PARTS; ++q) flags |= hitw[q];
     }
+    PC_STAMP_E(10)
     gate_hit = flags & 1;
     const bool destroyed = ((flags & 2) != 0) | (h.start_collides != 0);
     // ---- bookkeeping (car_env.py:694-750): float64 reward in the reference's order of accumulation

@@ -55,6 +55,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
@@ -147,6 +148,7 @@ struct pc_env {
     float* rden = nullptr;
     double2* dirtab64 = nullptr;
     SegD* seg64 = nullptr;
+    F64Dir* dirhash = nullptr;
     float* reset_obs = nullptr;
 
     template <typename T> EnvParams<T> params() const {
@@ -174,6 +176,7 @@ struct pc_env {
         p.rden = rden;
         p.dirtab64 = dirtab64;
         p.seg64 = seg64;
+        p.dirhash = dirhash;
         p.reset_obs = reset_obs;
         return p;
     }
@@ -304,9 +307,16 @@ void pc_env_destroy(pc_env* e) {
     (void)hipFree(e->rden);
     (void)hipFree(e->dirtab64);
     (void)hipFree(e->seg64);
+    (void)hipFree(e->dirhash);
     (void)hipFree(e->reset_obs);
     delete e;
 }
+
+// glibc's cos and sin, each through its own call: an optimiser that sees both of one argument may merge them into sincos(), whose
+// cosine differs from cos() in the last place for some arguments -- and the tables below stand for the reference's separate
+// np.cos / np.sin calls (car_env.py:426-427, :584)
+__attribute__((noinline)) static double libm_cos(double a) { return std::cos(a); }
+__attribute__((noinline)) static double libm_sin(double a) { return std::sin(a); }
 
 static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8_t* track_id) {
     const bool f64 = e->dtype == PC_DTYPE_F64;
@@ -314,6 +324,7 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
     std::vector<Seg> segs;
     std::vector<Vtx> vtx;
     std::vector<VtxP> vtxp;
+    std::vector<F64Dir> dirhash;
     std::vector<double2> headtab;
     std::vector<float2> dirtab;
     std::vector<double2> dirtab64;
@@ -409,24 +420,68 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
                 seg64[o + k].h = 0.5 - 0.05 / std::hypot(seg64[o + k].ex, seg64[o + k].ey);
             }
         }
-        h.dir_off = (int)dirtab.size();
-        for (int j = 0; j < 360; ++j) {  // direction lattice: start_rot + j degrees, np.radians then libm cos/sin
-            const double a = (t->start_rot + (double)j) * (PC_PI / 180.0);
-            dirtab.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
-            dirtab64.push_back(make_double2(std::cos(a), std::sin(a)));
+        if (f64) {
+            // F64 mode: every angle an episode can reach (see Math<double>), glibc's cos / sin of it, hashed by the angle's bits
+            h.dir_off = -1;
+            h.head_off = 0;
+            if (e->n_tracks <= 16) {
+                std::unordered_set<uint64_t> rots, frontier, keys;
+                const auto bits = [](double v) { uint64_t b; std::memcpy(&b, &v, 8); return b; };
+                const auto val = [](uint64_t b) { double v; std::memcpy(&v, &b, 8); return v; };
+                rots.insert(bits(t->start_rot));
+                frontier = rots;
+                for (int turn = 0; turn < 1000 && !frontier.empty(); ++turn) {      // CarEnv truncates at 1000 steps (car_env.py:749)
+                    std::unordered_set<uint64_t> next;
+                    for (const uint64_t b : frontier)
+                        for (const double w : {val(b) + 5.0, val(b) - 5.0})            // :440-442
+                            if (rots.insert(bits(w)).second) next.insert(bits(w));
+                    frontier.swap(next);
+                }
+                const int step_deg = 360 / e->n_nominal;
+                for (const uint64_t b : rots)
+                    for (int ray = 0; ray < e->R; ++ray) keys.insert(bits(val(b) + (double)(ray * step_deg)));   // :269, :465
+                size_t cap = 1024;
+                while (cap < 4 * keys.size()) cap <<= 1;
+                std::vector<F64Dir> tab;
+                for (;; cap <<= 1) {            // (grown until no probe sequence is longer than the device follows)
+                    tab.assign(cap, F64Dir{F64DIR_EMPTY, 0.0, 0.0, 0});
+                    bool ok = true;
+                    for (const uint64_t k : keys) {
+                        size_t slot = f64dir_hash(k) & (cap - 1);
+                        int probe = 0;
+                        while (tab[slot].key != F64DIR_EMPTY && probe < F64DIR_MAX_PROBE) { slot = (slot + 1) & (cap - 1); ++probe; }
+                        if (probe == F64DIR_MAX_PROBE) { ok = false; break; }
+                        const double a = val(k) * (PC_PI / 180.0);   // np.radians
+                        tab[slot] = F64Dir{k, libm_cos(a), libm_sin(a), 0};
+                    }
+                    if (ok) break;
+                }
+                h.dir_off = (int)dirhash.size();
+                h.head_off = (int)(cap - 1);
+                dirhash.insert(dirhash.end(), tab.begin(), tab.end());
+            }
+            if (dirtab64.empty()) dirtab64.push_back(make_double2(0.0, 0.0));
+            if (dirtab.empty()) dirtab.push_back(make_float2(0.f, 0.f));
+        } else {
+            h.dir_off = (int)dirtab.size();
+            for (int j = 0; j < 360; ++j) {  // direction lattice: start_rot + j degrees, np.radians then libm cos/sin
+                const double a = (t->start_rot + (double)j) * (PC_PI / 180.0);
+                dirtab.push_back(make_float2((float)libm_cos(a), (float)libm_sin(a)));
+                dirtab64.push_back(make_double2(libm_cos(a), libm_sin(a)));
+            }
+            dirtab.push_back(make_float2(0.f, 0.f));
+            dirtab64.push_back(make_double2(0.0, 0.0));
         }
-        dirtab.push_back(make_float2(0.f, 0.f));
-        dirtab64.push_back(make_double2(0.0, 0.0));
         h.rden_off = (int)rden_floats;
         rden_floats += (size_t)361 * h.nV;
-        h.head_off = (int)headtab.size();
+        if (!f64) h.head_off = (int)headtab.size();
         h.start_collides = 0;
         h.start_x = t->start_x;
         h.start_y = t->start_y;
         h.start_rot = t->start_rot;
         for (int j = 0; j < 72; ++j) {  // heading grid: start_rot + 5 j degrees, np.radians then libm cos/sin
             const double a = (t->start_rot + 5.0 * j) * (PC_PI / 180.0);
-            headtab.push_back(make_double2(std::cos(a), std::sin(a)));
+            headtab.push_back(make_double2(libm_cos(a), libm_sin(a)));
         }
     }
     // ---- device buffers
@@ -465,6 +520,10 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
     HIPCHK(hipMemcpy(e->dirtab64, dirtab64.data(), dirtab64.size() * sizeof(double2), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&e->seg64, seg64.size() * sizeof(SegD)));
     HIPCHK(hipMemcpy(e->seg64, seg64.data(), seg64.size() * sizeof(SegD), hipMemcpyHostToDevice));
+    if (!dirhash.empty()) {
+        HIPCHK(hipMalloc((void**)&e->dirhash, dirhash.size() * sizeof(F64Dir)));
+        HIPCHK(hipMemcpy(e->dirhash, dirhash.data(), dirhash.size() * sizeof(F64Dir), hipMemcpyHostToDevice));
+    }
     if (!f64) {
         HIPCHK(hipMalloc((void**)&e->rden, rden_floats * sizeof(float)));
         hipLaunchKernelGGL(rden_build_kernel, dim3(64), dim3(256), 0, 0, e->params<float>(), e->n_tracks, e->rden);

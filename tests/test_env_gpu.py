@@ -86,12 +86,9 @@ def test_teacher_forced_f64_bit_exact(track, n, grp):
     st = env.get_state()
     for k in STATE:  # post state where the env was not reset; start state where it was
         ref = g[f"{grp}_post_{k}"].reshape(-1)
-        if k in ("px", "py", "vx", "vy"):
-            # the device's float64 cos/sin (ocml) and glibc's differ by <= 1 ulp on a few arguments, which
-            # reaches the velocity through the thrust term: allow 4 ulp on the float64 state, nothing else
-            assert np.all(np.abs(st[k][~done] - ref[~done]) <= 4 * 2.3e-16 * np.maximum(1.0, np.abs(ref[~done]))), k
-        else:
-            assert np.array_equal(st[k][~done], ref[~done]), k
+        # the float64 state too, bit for bit: the headings' cos / sin are glibc's own values, read from the track's direction
+        # lattice (Math<double>, env_math.hpp) -- the device's own cos / sin differ from glibc in the last place on a few arguments
+        assert np.array_equal(st[k][~done], ref[~done]), k
     assert np.all(st["time_step"][done] == 0) and np.all(st["px"][done] == g["reset_state"][0])
     assert np.all(st["rot"][done] == g["reset_state"][4]) and np.all(st["vx"][done] == 0)
 
@@ -201,13 +198,17 @@ def test_config0_free_running_f64_vs_oracle(n):
     """BASELINE configs[0]: big_track, n_envs=24, n_steps=1024 (12 rays = the reference literal, and 16)."""
     rng = np.random.default_rng(100 + n)
     actions = _biased_actions(rng, 1024, 24)
-    O, R, TE, TR, _ = _oracle_rollout("big_track", n, actions)
+    O, R, TE, TR, oenv = _oracle_rollout("big_track", n, actions)
     env = pc.VecCarEnv(24, TRACKS["big_track"], num_rays=n, reward_scaling=0.1, dtype="f64")
     o, r, te, tr = _hip_rollout(env, actions)
     assert TE.sum() > 50 and (R > 0.09).sum() > 20      # crashes and gate rewards happened
     assert np.array_equal(te, TE) and np.array_equal(tr, TR)
     assert np.array_equal(r, R.astype(np.float32))
     assert np.array_equal(o, O)
+    # ... and the float64 state after 1024 free-running steps, bit for bit (headings' cos / sin = glibc's, looked up: Math<double>)
+    st = env.get_state()
+    for k in STATE:
+        assert np.array_equal(st[k], getattr(oenv, k).astype(st[k].dtype)), k
 
 
 def test_full_size_f64_vs_oracle_and_replication():

@@ -28,7 +28,7 @@ tr = Trainer(PPOConfig(n_envs=N, n_steps=T, num_rays=16, track=f"{ROOT}/tracks/b
 for _ in range(3):
     tr.rollout(); tr.buffer.ptr = 0
 torch.cuda.synchronize()
-NT, NPH = 8, 8
+NT, NPH = 8, 12
 buf = (C.c_ulonglong * (8 * NT * NPH))()
 _capi.lib.pc_debug_read_stamps.restype = C.c_int
 n = _capi.lib.pc_debug_read_stamps(buf, len(buf))
@@ -39,6 +39,9 @@ t0 = st.min()
 names = (["split", "policy", "draw", "env-pre", "sweep", "post", "copy-out"] if tr.cfg.n_envs > 16384 else
          ["tiles", "barrier1", "draw+bar2", "env-pre", "sweep part", "xchg+post", "barrier3"])
 big = tr.cfg.n_envs > 16384
+if not big:              # the small form's env step carries three more stamps: 8 refinement done, 9 rare-path loop done, 10 verdicts met
+    st = st[:, :, [0, 1, 2, 3, 4, 5, 8, 9, 10, 6, 7]]
+    names = ["tiles", "barrier1", "draw+bar2", "env-pre", "sweep+xchg", "refine", "rare loop", "verdict bar", "bookkeeping", "barrier3"]
 if big:                  # the big form carries no stamps inside the env step (they made it spill): phases 3..6 are one
     st = st[:, :, [0, 1, 2, 3, 6, 7]]
     names = ["split", "policy", "draw", "env step", "copy-out"]
