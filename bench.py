@@ -28,6 +28,7 @@ Extra objects on the JSON line:
   parity_check -- one more pc_rollout launch of the same trainer AFTER the timed region, whose first 256 envs x 64 steps
                   are replayed through the CPU oracle (rewards / flags exact, observations within 1e-5).
   strict_fp32_value -- the same metric with the policy GEMMs as exact-fp32 MFMAs (3 epochs, outside the headline timing).
+  fp32_grade_bf16x3_value -- the same with the bf16 x 3 split (six piece products: fp32-grade error, not the fp32 chain's bits).
 """
 import argparse
 import json
@@ -366,6 +367,21 @@ def main():
             del tr2
         except Exception as ex:
             extras["strict_fp32_value"] = {"error": repr(ex)}
+        if args.policy_arith != "bf16x3":
+            # ... and the fp32-GRADE form in between: bf16 x 3 operand split, six piece products on the bf16 matrix cores -- 1.0e-7 against
+            # float64 on the trained-policy fixture where the exact fp32 chain has 0.8e-7 (tests/test_gae_sample_gpu.py), no scaled domains
+            try:
+                cfg3, tr3 = make_trainer(policy_precision=1)
+                for _ in range(2):
+                    tr3.run_epoch(sync=False)
+                dt3 = timed(tr3, 3)
+                extras["fp32_grade_bf16x3_value"] = {"value": cfg3.n_envs * cfg3.n_steps * 3 / dt3, "unit": "env steps/s", "epochs": 3,
+                                                     "ms_per_step": dt3 / 3 * 1e3, "rollout": tr3.rollout_mode,
+                                                     "policy_gemm_arithmetic": "bf16 x 3 split, 6 piece products (fp32-grade: not the fp32 chain's bits), --policy-arith bf16x3"}
+                tr3.close()
+                del tr3
+            except Exception as ex:
+                extras["fp32_grade_bf16x3_value"] = {"error": repr(ex)}
 
     if rank == 0:
         env_steps = cfg.n_envs * cfg.n_steps * args.steps * world

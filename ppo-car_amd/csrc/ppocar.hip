@@ -137,6 +137,7 @@ struct pc_env {
     int4* iv = nullptr;
     double* rot = nullptr;
     uint8_t* track_id = nullptr;
+    bool mixed = false;            // a track_id array was given (known before the geometry is chosen)
     bool track_blocks32 = false;   // mixed tracks: every aligned block of 32 envs holds ONE track (what pc_rollout needs)
     int track_block = 0;           // ... the largest of 256 / 128 / 64 / 32 for which that holds (0: none)
     TrackHdr* hdr = nullptr;
@@ -192,7 +193,9 @@ struct pc_env {
             G = 1;
             while (G < 64 && (int64_t)G * N < target && G < R) G <<= 1;
         }
-        const int max_rpl = dtype == PC_DTYPE_F64 ? 17 : 33;  // F64 keeps 6 VGPRs per ray slot
+        // F64 keeps 6 VGPRs per ray slot; a mixed-track batch reads every table through per-env pointers: 33 slots on one lane
+        // spilled there (564 B of scratch) -- two lanes per env are the better geometry anyway
+        const int max_rpl = (dtype == PC_DTYPE_F64 || mixed) ? 17 : 33;
         while (true) {
             const int need = (R + G - 1) / G;
             const int m = pick_rpl(need);
@@ -214,10 +217,11 @@ struct pc_env {
 template <typename T, int RPL>
 static void launch_step(const pc_env* e, const int64_t* actions, double reward_scale, float* obs, float* reward, float* term,
                         float* trunc, int32_t* gates_passed, float* final_obs, hipStream_t st) {
-    if (e->track_id)
-        hipLaunchKernelGGL((env_step_kernel<T, RPL, true>), dim3(e->blocks), dim3(256), 0, st, e->params<T>(), actions,
-                           reward_scale, obs, reward, term, trunc, gates_passed, final_obs);
-    else
+    if (e->track_id) {
+        if constexpr (RPL <= 17)     // (choose_geometry never gives a mixed-track batch more slots per lane)
+            hipLaunchKernelGGL((env_step_kernel<T, RPL, true>), dim3(e->blocks), dim3(256), 0, st, e->params<T>(), actions,
+                               reward_scale, obs, reward, term, trunc, gates_passed, final_obs);
+    } else
         hipLaunchKernelGGL((env_step_kernel<T, RPL, false>), dim3(e->blocks), dim3(256), 0, st, e->params<T>(), actions,
                            reward_scale, obs, reward, term, trunc, gates_passed, final_obs);
 }
@@ -570,6 +574,7 @@ int pc_env_create(int device, int64_t n_envs, int num_rays_nominal, const pc_tra
     e->R = pc_ray_count(num_rays_nominal);
     e->D = 6 + e->R;
     e->n_tracks = n_tracks;
+    e->mixed = track_id != nullptr;
     int rc = e->choose_geometry();
     if (rc == PC_OK) rc = env_create_impl(e, tracks, track_id);
     if (rc != PC_OK) {

@@ -54,3 +54,9 @@ for w in range(8):
 print("\ntimeline of waves 0 and 4 (same SIMD), step 66: phase start offsets")
 for w in (0, 4):
     print(w, [int(x - st[0, 2, 0]) for x in st[w, 2]], "next step starts at", int(st[w, 3, 0] - st[0, 2, 0]))
+
+if os.environ.get("K9_TIMELINE_PER_STEP"):      # one phase, every stamped step: rows = waves, columns = steps
+    ph = names.index(os.environ["K9_TIMELINE_PER_STEP"])
+    print(f"\nphase '{names[ph]}' per step")
+    for w in range(8):
+        print(w, [int(x) for x in (st[w, :, ph + 1] - st[w, :, ph])])
