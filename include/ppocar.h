@@ -207,8 +207,11 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
  * rew_buf, val_buf, logprob_buf [T][N] rows 0..T-1, term_buf / trunc_buf rows 1..T-1, and next_obs / next_term / next_trunc
  * overwritten with the state after step T-1.  Bit-identical to T x (pc_policy_act; pc_env_step).
  * PC_ERR_UNSUPPORTED for F64 handles, mixed-track handles whose track ids change inside an aligned block of 32 envs, ray
- * counts other than 12 / 16 / 32, and shapes whose LDS footprint exceeds 160 KB (33 rays with the fp32 or bf16x3 weight
- * image): callers fall back to the two-kernel loop. */
+ * counts whose slots per lane are not on the kernel menu (12 / 16 / 32 run the table-driven fast mode; 17 and 18 share the
+ * slots of 16 and run the generic mode), shapes whose LDS footprint exceeds 160 KB (33 rays with the fp32 or bf16x3 weight
+ * image in the large form), and 33 rays in the GENERIC mode with split operands (a mixed-track batch whose workgroups
+ * straddle tracks, or the fast mode switched off: those kernels spilled and are not built): callers fall back to the
+ * two-kernel loop, which fills the same buffers bit for bit. */
 int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
                const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
                float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, void* stream);

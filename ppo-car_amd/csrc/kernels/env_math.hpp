@@ -222,18 +222,21 @@ template <> struct Math<double> {
         if (h.dir_off < 0) return false;
         const unsigned long long key = (unsigned long long)__double_as_longlong(angle);
         const unsigned mask = (unsigned)h.head_off;       // F64 mode: the table's slot mask
-        unsigned slot = f64dir_hash(key) & mask;
+        const unsigned slot = f64dir_hash(key) & mask;
+        // straight-line probes (no loop with an early exit: inside the ray loops that would keep them from unrolling and send
+        // their register arrays to scratch): all keys of the probe window first, then the one entry that matched
+        int at = -1;
+#pragma unroll
         for (int probe = 0; probe < F64DIR_MAX_PROBE; ++probe) {
-            const F64Dir e = p.dirhash[h.dir_off + slot];
-            if (e.key == key) {
-                c = e.c;
-                s = e.s;
-                return true;
-            }
-            if (e.key == F64DIR_EMPTY) return false;
-            slot = (slot + 1) & mask;
+            const unsigned long long k = p.dirhash[h.dir_off + ((slot + probe) & mask)].key;
+            at = (k == key) ? probe : at;      // (a key occurs once)
         }
-        return false;
+        const F64Dir* e = p.dirhash + h.dir_off + ((slot + (at < 0 ? 0 : at)) & mask);
+        const double ec = e->c, es = e->s;
+        if (at < 0) return false;
+        c = ec;
+        s = es;
+        return true;
     }
     // heading (cos, sin) of the float64 heading, as the reference forms it (:426-427, :584)
     static __device__ __forceinline__ void heading(const EnvParams<double>& p, const TrackHdr& h, int, double rot, double& c,

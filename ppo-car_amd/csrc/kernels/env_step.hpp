@@ -431,7 +431,7 @@ __device__ __forceinline__ void wall_sweep_loops(const VtxP* vp, const float pxr
 // 2^lg lanes of this group hold in `st` (updated in place, identically in every lane).  Lane g sweeps rays
 // g, g + G, ...  Observation entries go to orow (global row), frow (pre-reset obs, optional) and lrow (an LDS
 // copy for the persistent rollout kernel, optional).  The per-env scalars come back in registers.
-template <typename T, int RPL, int PARTS = 1, bool TAB = false>
+template <typename T, int RPL, int PARTS = 1, bool TAB = false, bool TWOPASS = false>
 __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int trk, const int g, const int lg, EnvRegs& st,
                                               const int64_t a, const double reward_scale, float* __restrict__ orow,
                                               float* __restrict__ frow, float* lrow, float& reward_f, bool& term, bool& trunc,
@@ -551,9 +551,37 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
 
     // ---- wall sweep: Car.get_distances (:360-374) -- also serves Car.check_collision (E2)
     if constexpr (sizeof(T) == 4) {
-        unsigned bb[2 * ((RPL + 1) / 2)];
-        wall_sweep_f32<RPL, PARTS, TAB>(p.vtx + h.vtx_off, h.nV, part, (float)(npx - h.ax0), (float)(npy - h.ay0), dx, dy, didx, rdl, flag_threshold(h, npx, npy),
-                                        h.idx_mask, bb);
+        unsigned bb[2 * ((RPL + 1) / 2) + 2];
+        if constexpr (TWOPASS && RPL >= 9) {
+            // inside a persistent kernel's generic mode (TWOPASS): the slots in two passes over the chain, as in the fast mode at 33
+            // rays -- one pass keeps ~40 more registers alive than the kernel has beside its policy state (it spilled); the second
+            // pass repeats only the per-vertex position arithmetic.  Same candidates, same minima: same bits.
+            constexpr int R1 = (RPL + 1) / 2, R2 = RPL - R1;
+            const float pxr = (float)(npx - h.ax0), pyr = (float)(npy - h.ay0), tau = flag_threshold(h, npx, npy);
+            {
+                unsigned ba[2 * ((R1 + 1) / 2)];
+                wall_sweep_f32<R1, PARTS, TAB>(p.vtx + h.vtx_off, h.nV, part, pxr, pyr, *reinterpret_cast<const float(*)[R1]>(&dx[0]),
+                                               *reinterpret_cast<const float(*)[R1]>(&dy[0]), *reinterpret_cast<const int(*)[R1]>(&didx[0]), rdl,
+                                               tau, h.idx_mask, ba);
+#pragma unroll
+                for (int s = 0; s < R1; ++s) bb[s] = ba[s];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // the passes one after the other
+            {
+                unsigned bc[2 * ((R2 + 1) / 2)];
+                wall_sweep_f32<R2, PARTS, TAB>(p.vtx + h.vtx_off, h.nV, part, pxr, pyr, *reinterpret_cast<const float(*)[R2]>(&dx[R1]),
+                                               *reinterpret_cast<const float(*)[R2]>(&dy[R1]), *reinterpret_cast<const int(*)[R2]>(&didx[R1]), rdl,
+                                               tau, h.idx_mask, bc);
+#pragma unroll
+                for (int s = 0; s < R2; ++s) bb[R1 + s] = bc[s];
+            }
+        } else {
+            unsigned b0[2 * ((RPL + 1) / 2)];
+            wall_sweep_f32<RPL, PARTS, TAB>(p.vtx + h.vtx_off, h.nV, part, (float)(npx - h.ax0), (float)(npy - h.ay0), dx, dy, didx, rdl,
+                                            flag_threshold(h, npx, npy), h.idx_mask, b0);
+#pragma unroll
+            for (int s = 0; s < RPL; ++s) bb[s] = b0[s];
+        }
         if constexpr (PARTS > 1) {   // the parts' selections meet in LDS (the minimum is exact: the same bits as one wave sweeping everything)
             unsigned* ex = reinterpret_cast<unsigned*>(exch);
 #pragma unroll

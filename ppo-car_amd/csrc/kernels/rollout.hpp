@@ -810,10 +810,10 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
             bool term, trunc;
             int passed;
             if (rden_lds)  // uniform
-                env_step_core<float, RPL, 1, true>(q, trk, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw,
+                env_step_core<float, RPL, 1, true, true>(q, trk, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw,
                                                    term, trunc, passed, 0, nullptr, rdl);
             else
-                env_step_core<float, RPL>(q, trk, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw, term,
+                env_step_core<float, RPL, 1, false, true>(q, trk, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw, term,
                                           trunc, passed);
             rsum += rw;
             if (g == 0) {
@@ -1067,11 +1067,11 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 bool term, trunc;
                 int passed;
                 if (rden_lds)  // uniform
-                    env_step_core<float, RPL, PARTS, true>(q, trk, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
+                    env_step_core<float, RPL, PARTS, true, true>(q, trk, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
                                                            e_valid && part == 0 ? sObs + el * LDX : nullptr, rw, term, trunc, passed, part,
                                                            exch, rdl);
                 else
-                    env_step_core<float, RPL, PARTS>(q, trk, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
+                    env_step_core<float, RPL, PARTS, false, true>(q, trk, g, 2, st, (int64_t)sAct[el], reward_scale, orow, nullptr,
                                                      e_valid && part == 0 ? sObs + el * LDX : nullptr, rw, term, trunc, passed, part, exch);
                 rsum += rw;
                 if (e_valid && g == 0 && part == 0) {

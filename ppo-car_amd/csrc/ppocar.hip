@@ -1168,13 +1168,21 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
     if (small) {
         if (KS == 5 && rpl == 3) { if (prec == 2) PC_ROLLS(5, 3, 2); else if (prec) PC_ROLLS(5, 3, 1); else PC_ROLLS(5, 3, 0); }        // 12 rays
         else if (KS == 6 && rpl == 5) { if (prec == 2) PC_ROLLS(6, 5, 2); else if (prec) PC_ROLLS(6, 5, 1); else PC_ROLLS(6, 5, 0); }   // 16 -> 17 rays
-        else if (KS == 10 && rpl == 9) { if (prec == 2) PC_ROLLS(10, 9, 2); else if (prec) PC_ROLLS(10, 9, 1); else PC_ROLLS(10, 9, 0); }   // 32 -> 33 rays
+        else if (KS == 10 && rpl == 9) {                                                                                                      // 32 -> 33 rays
+            if (prec == 2) PC_ROLLS(10, 9, 2);
+            else if (prec) { if (mode) PC_ROLLS_M(10, 9, 1, 1, 32); else return PC_ERR_UNSUPPORTED; }   // (bf16 x 3 in the generic mode spilled: the caller's per-step kernels take that shape)
+            else PC_ROLLS(10, 9, 0);
+        }
         else return PC_ERR_UNSUPPORTED;
     } else if (KS == 5 && rpl == 6) { if (prec == 2) PC_ROLL(5, 6, 2); else if (prec) PC_ROLL(5, 6, 1); else PC_ROLL(5, 6, 0); }       // 12 rays, D = 18
     else if (KS == 6 && rpl == 9) { if (prec == 2) PC_ROLL(6, 9, 2); else if (prec) PC_ROLL(6, 9, 1); else PC_ROLL(6, 9, 0); }          // 16 -> 17 rays, D = 23
     else if (KS == 10 && rpl == 17 && prec) {                                                                                             // 32 -> 33 rays, D = 39
-        if (prec == 2) { if (mode) PC_ROLL_M(10, 17, 2, 1); else PC_ROLL_M(10, 17, 2, 0); }   // (its chain-of-28 variant spills: not built)
-        else { if (mode) PC_ROLL_M(10, 17, 1, 1); else PC_ROLL_M(10, 17, 1, 0); }
+        // (the chain-of-28 variant spills: not built.  The GENERIC mode at 33 rays -- a mixed-track batch whose workgroups straddle
+        // tracks, fast mode switched off -- spilled 100+ registers beside the split operands' policy state: not built either; that
+        // shape is PC_ERR_UNSUPPORTED here and runs through the per-step kernels, bit-identical by construction)
+        if (!mode) return PC_ERR_UNSUPPORTED;
+        if (prec == 2) PC_ROLL_M(10, 17, 2, 1);
+        else PC_ROLL_M(10, 17, 1, 1);
     }
     else return PC_ERR_UNSUPPORTED;
 #undef PC_ROLL_M

@@ -289,6 +289,19 @@ def test_mixed_track_batches_through_the_persistent_rollout_kernel(n_envs, form)
     tr.close()
 
 
+def test_generic_mode_at_33_rays_is_not_built_and_falls_back_to_the_per_step_kernels():
+    """pc_rollout's generic mode (here: the fast mode switched off on the env handle) exists at 12 and 17 rays; at 33 rays with
+    split operands those kernels spilled and are not built: PC_ERR_UNSUPPORTED, and the trainer runs the two-kernel loop instead
+    (train.py:173-195 either way; the forms are bit-identical wherever both exist)."""
+    for num_rays, want in ((16, "mega"), (32, "steps-eager")):
+        tr = Trainer(_cfg(rollout_kernel="mega", use_graphs=False, n_envs=20000, n_steps=4, num_rays=num_rays), device="cuda")
+        tr.envs.set_option("rollout_fast", 0)
+        tr.rollout()
+        torch.cuda.synchronize()
+        assert tr.rollout_mode == want, (num_rays, tr.rollout_mode)
+        assert torch.isfinite(tr.buffer.obs_buf[:4]).all()
+        tr.close()
+
 
 @pytest.mark.parametrize("num_rays,batch,graphs", [(16, 512, True), (12, 100, False), (32, 64, False)])
 def test_prepared_minibatches_are_bitwise_the_in_kernel_gather(num_rays, batch, graphs):
