@@ -441,6 +441,19 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     flags |= swap_pair(flags);                                          // any() over the env's G lanes
     if constexpr (G == 4) flags |= __builtin_amdgcn_update_dpp(0, flags, 0x4e, 0xf, 0xf, false);   // quad_perm [2, 3, 0, 1]
     static_assert(G == 2 || G == 4, "2 or 4 lanes per env");
+    // PARTS == 8 (16 envs per workgroup: every wave holds ALL of the workgroup's envs): the barrier at which the parts' verdicts
+    // meet is also the one behind which the observation rows are complete -- the step's LAST barrier (the caller adds one more
+    // only in a step in which some env of the workgroup finished: that is the same decision in every wave).  So the six
+    // kinematic columns, which depend on no verdict, are written before it.
+    constexpr bool MERGED = PARTS == 8;
+    if (MERGED && g == 0 && write_row) {
+        lrow[0] = Math<float>::norm(npx, 1280.0);  // :578-581
+        lrow[1] = Math<float>::norm(npy, 720.0);
+        lrow[2] = Math<float>::norm(nvx, 10.0);
+        lrow[3] = Math<float>::norm(nvy, 10.0);
+        lrow[4] = (float)cs1.x;                    // :584-588
+        lrow[5] = (float)cs1.y;
+    }
     if constexpr (PARTS > 1) {   // every part has judged its own ray slots: the env's verdict is the OR over the parts
         if (g == 0) hitw[part] = flags;
         lds_barrier();
@@ -466,7 +479,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     trunc_f = trunc ? 1.0f : 0.0f;
     // ---- observation row -> LDS: the ray columns were written by the refinement loop (the reset observation of a finished env is
     // written by the caller's fix-up)
-    if (g == 0 && write_row) {
+    if (!MERGED && g == 0 && write_row) {
         lrow[0] = Math<float>::norm(npx, 1280.0);  // :578-581
         lrow[1] = Math<float>::norm(npy, 720.0);
         lrow[2] = Math<float>::norm(nvx, 10.0);
@@ -1034,6 +1047,9 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                         }
                         env_reset_fast(h0, st, k72);
                     }
+                    // PARTS == 8: the verdicts' barrier inside env_step_fast was the step's last one; a step in which an env finished
+                    // needs one more behind the row fix-up.  Every wave holds all 16 envs on identical values: the same branch in all.
+                    if constexpr (PARTS == 8) lds_barrier();
                 }
                 if (part == 0) {   // (uniform) the row-writing wave: per-env scalars
                     if (g == 0 && e_valid) {
@@ -1046,7 +1062,7 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 }
             }
             PC_STAMP(6)
-            lds_barrier();
+            if constexpr (!(FAST && PARTS == 8)) lds_barrier();    // (16 envs per workgroup in the fast mode: merged into the verdicts' barrier)
             PC_STAMP(7)
             // rows -> rollout buffer: the workgroup's 32 rows are contiguous there (32 * D floats): waves 0 .. 2 (.. 4) store 64 float4 each
             {
