@@ -264,14 +264,15 @@ __device__ __forceinline__ void wall_sweep_f32(const Vtx* vt, const int nV, cons
 }
 
 // The same sweep for a track whose chain has exactly NGRP groups of four vertices, fully unrolled and WITHOUT a branch per
-// vertex (persistent big-form kernel: big_track has 24 walls in 2 loops = 26 chain vertices, padded to 28):
+// vertex (persistent big-form kernel in modes 1 / 2, a chain of 28 whose layout is not known at compile time; a track that is
+// known to be two equal chains takes wall_sweep_loops in modes 3 / 4):
 //   * the 1/den rows are read with immediate offsets (no address arithmetic per group), the vertex index is an inline constant;
 //   * two consecutive vertices share one v_min3_u32 per ray slot instead of two v_min_u32;
 //   * a chain-start vertex is not skipped but computed: its edge is (0, 0), so un' = 0 and 1/den = +-inf (what
 //     rden_build_kernel's v_rcp_f32 of 0 stores, too), 0 * inf + P = NaN, whose bit pattern lies above every finite distance:
 //     the candidate can never win the unsigned minimum.  Only the trailing padding pair(s) are skipped (n_chain).
 // The minimum is exact, so the result is the very same bits as wall_sweep_f32's.
-template <int RPL, bool TAB, int NGRP, bool ADDR = false, int BRK2 = -1>
+template <int RPL, bool TAB, int NGRP, bool ADDR = false>
 __device__ __forceinline__ void wall_sweep_unrolled(const Vtx* vt, const int n_chain, const float pxr, const float pyr,
                                                     const float (&dx)[RPL], const float (&dy)[RPL], const int (&didx)[RPL], lds_cfp rdl,
                                                     const float tau, unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
@@ -293,23 +294,17 @@ __device__ __forceinline__ void wall_sweep_unrolled(const Vtx* vt, const int n_c
             else rrow[s] = (lds_row)(rdl + __umul24(s < RPL ? didx[s] : 360, nV));
         }
     }
-    // BRK2 >= 0: the host guarantees that the chain is exactly two loops -- chain starts at vertices 0 and BRK2, n_chain = nV - 2
-    // (big_track.json: 0 and 13 of 26 + 2 padding): those two vertices close no segment and their candidates are not formed at all
     auto pair = [&](auto KC, const f32x4 (&rd)[2 * NP]) {   // vertices K, K + 1 (K even): sets A -> B -> A
         constexpr int K = decltype(KC)::value, I = K & 3;
-        constexpr bool start0 = BRK2 >= 0 && (K == 0 || K == BRK2), start1 = BRK2 >= 0 && K + 1 == BRK2;
         const Vtx v0 = cload(vt + K), v1 = cload(vt + K + 1);
         float u0[2 * NP], u1[2 * NP];
         sw.side(v0.xr, v0.yr, pxr, pyr, axB, ayB, cB);
-        if constexpr (!start0) sw.cand(v0.ex, v0.ey, v0.exs, v0.eys, axA, ayA, cA, cB, rd, I, u0);
+        sw.cand(v0.ex, v0.ey, v0.exs, v0.eys, axA, ayA, cA, cB, rd, I, u0);
         sw.side(v1.xr, v1.yr, pxr, pyr, axA, ayA, cA);
-        if constexpr (!start1) sw.cand(v1.ex, v1.ey, v1.exs, v1.eys, axB, ayB, cB, cA, rd, I + 1, u1);
+        sw.cand(v1.ex, v1.ey, v1.exs, v1.eys, axB, ayB, cB, cA, rd, I + 1, u1);
 #pragma unroll
-        for (int s = 0; s < RPL; ++s) {
-            if constexpr (start0) bb[s] = min(bb[s], and_or_k<K + 1>(__float_as_uint(u1[s]), keep));
-            else if constexpr (start1) bb[s] = min(bb[s], and_or_k<K>(__float_as_uint(u0[s]), keep));
-            else bb[s] = min(min(bb[s], and_or_k<K>(__float_as_uint(u0[s]), keep)), and_or_k<K + 1>(__float_as_uint(u1[s]), keep));   // v_min3_u32
-        }
+        for (int s = 0; s < RPL; ++s)
+            bb[s] = min(min(bb[s], and_or_k<K>(__float_as_uint(u0[s]), keep)), and_or_k<K + 1>(__float_as_uint(u1[s]), keep));   // v_min3_u32
     };
     auto group = [&](auto GC) {
         constexpr int gq = decltype(GC)::value;
@@ -320,11 +315,8 @@ __device__ __forceinline__ void wall_sweep_unrolled(const Vtx* vt, const int n_c
             if constexpr (TAB) { if (s < RPL) rd[s] = rrow[s][gq]; }
         }
         pair(std::integral_constant<int, 4 * gq>{}, rd);
-        if constexpr (BRK2 >= 0) {
-            if constexpr (4 * gq + 2 < nV - 2) pair(std::integral_constant<int, 4 * gq + 2>{}, rd);      // (the last pair is padding)
-        } else if (gq < NGRP - 1 || 4 * gq + 2 < n_chain) {   // (wave-uniform; only the last group can hold a padding pair)
+        if (gq < NGRP - 1 || 4 * gq + 2 < n_chain)   // (wave-uniform; only the last group can hold a padding pair)
             pair(std::integral_constant<int, 4 * gq + 2>{}, rd);
-        }
         // one scheduling region per group: left alone, the scheduler hoists every group's table rows and vertex records
         // to the top of the 1300-instruction block and spills
         __builtin_amdgcn_sched_barrier(0);
