@@ -41,8 +41,11 @@ extern "C" {
 #define PC_ERR_NO_DEVICE (-6)   /* no usable gfx950 device */
 #define PC_ERR_TIMEOUT (-7)     /* pc_xchg: a peer rank did not arrive at the gradient exchange */
 
-#define PC_DTYPE_F32 0 /* float32 ray geometry over a float64 kinematic state: the throughput path            */
-#define PC_DTYPE_F64 1 /* float64 throughout, in the reference's operation order: the exact-parity path      */
+#define PC_DTYPE_F32 0 /* float64 kinematic state; every ray's wall segment SELECTED in float32, its distance (the observation
+                        * entry, the < 10 px tests) recomputed in float64 under the reference's strict test: the throughput path */
+#define PC_DTYPE_F64 1 /* float64 throughout, in the reference's operation order, with glibc's cos / sin values looked up for every
+                        * angle an episode can reach (up to 16 tracks per handle; other angles use the device's): the exact-parity
+                        * path -- observations, rewards, events and the float64 state equal the reference's bit for bit */
 
 typedef struct pc_track pc_track;
 typedef struct pc_env pc_env;
