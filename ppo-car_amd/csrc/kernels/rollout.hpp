@@ -314,6 +314,10 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
             wall_sweep_lds<R1, PARTS, TAB, true>(ft.vtx, h.nV, part, pxr, pyr, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
         else if constexpr (SWP == 7)       // the host guarantees big_track's layout (two loops of 13 vertices, packed: TrackHdr::vtxp_off)
             wall_sweep_loops<R1, TAB, 13, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);
+        else if constexpr (SWP == 5) {     // ... or two loops of 13 or of 9 vertices per track (track.json: 8 walls each): a mixed batch, workgroup-uniform
+            if (h.brk2 == 13) wall_sweep_loops<R1, TAB, 13, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);
+            else wall_sweep_loops<R1, TAB, 9, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);
+        }
         else if (h.nV == 28)               // (wave-uniform) a chain of 28: the unrolled sweep
             wall_sweep_unrolled<R1, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);   // chain length
         else if constexpr (SWP == 0)       // and the generic loop is not even compiled in (1 % from the shorter kernel alone)
@@ -331,6 +335,10 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
             wall_sweep_lds<R2, PARTS, TAB, true>(ft.vtx, h.nV, part, pxr, pyr, dxb, dyb, dib, ft.rden, tau, h.idx_mask, bc);
         else if constexpr (SWP == 7)
             wall_sweep_loops<R2, TAB, 13, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxb, dyb, dib, ft.rden, tau, bc);
+        else if constexpr (SWP == 5) {
+            if (h.brk2 == 13) wall_sweep_loops<R2, TAB, 13, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxb, dyb, dib, ft.rden, tau, bc);
+            else wall_sweep_loops<R2, TAB, 9, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxb, dyb, dib, ft.rden, tau, bc);
+        }
         else if (h.nV == 28)
             wall_sweep_unrolled<R2, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, pxr, pyr, dxb, dyb, dib, ft.rden, tau, bc);
         else if constexpr (SWP == 0)
@@ -563,6 +571,8 @@ __device__ __forceinline__ EnvParams<float> stage_tables(const EnvParams<float>&
 //         MODE 4 / 3 = 1 / 2 for batches whose tracks all have a padded wall chain of 28 vertices (big_track.json): only the
 //         unrolled sweep is compiled in (built for 17 rays and the default arithmetic: ~1 % from the shorter kernel; the 33-ray
 //         kernel schedules worse without the generic branch -- it spills -- and keeps it).
+//         MODE 5 = 2 for batches whose tracks are all two equal chains of 13 OR of 9 vertices (big_track.json and track.json
+//         mixed: BASELINE configs[4]): the chain-packed sweep for both lengths, chosen per workgroup.
 template <int KS, int RPL, int PREC, int MODE>
 __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, const float* __restrict__ image, const int A,
                                                       const int T, const double reward_scale, const uint64_t seed,
@@ -612,14 +622,15 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(p.rden + h0.rden_off);
         const int n4 = rden_lds ? 361 * h0.nV / 4 : 0;     // nV is a multiple of 4
-        if constexpr (MODE == 3) {
+        if constexpr (MODE == 3 || MODE == 5) {
             // the two-loop sweep (wall_sweep_loops) reads a row in the order (0, L, 1, L + 1, ...): entry 2 i = vertex i, entry
-            // 2 i + 1 = vertex L + i (L = 13, rows of 28; the last two entries are the padding vertices')
+            // 2 i + 1 = vertex L + i (L = 13: rows of 28, the last two entries are the padding vertices'; L = 9: rows of 20, two padding entries)
             const float* g = p.rden + h0.rden_off;
+            const int L = h0.brk2, nv = h0.nV;
             for (int i = tid; i < 4 * n4; i += 512) {
-                const int row = i / 28, e = i - 28 * row;
-                const int k = e < 26 ? (e >> 1) + ((e & 1) ? 13 : 0) : e;
-                sRden[i] = g[28 * row + k];
+                const int row = i / nv, e = i - nv * row;
+                const int k = e < 2 * L ? (e >> 1) + ((e & 1) ? L : 0) : e;
+                sRden[i] = g[nv * row + k];
             }
         } else {
             for (int i = tid; i < n4; i += 512) reinterpret_cast<f32x4*>(sRden)[i] = src[i];
@@ -772,7 +783,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 // ---------------- E(t)
                 float rw, tf, cf;
                 const int a = e_valid ? sAct[el] : 8;
-                const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3, 1, 1, (MODE >= 3 ? 7 : 0), RPL != 17>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave);
+                const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3 || MODE == 5, 1, 1, (MODE == 5 ? 5 : (MODE >= 3 ? 7 : 0)), RPL != 17>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave);
                 rsum += rw;
                 PC_STAMP(6)
                 // gymnasium 0.29.1 same-step auto-reset: a finished env returns its reset observation

@@ -1121,7 +1121,11 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
     const int vec_ok = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
     const int mode = (fast || fast_small) ? (rden_lds ? 2 : 1) : 0;
     bool all_nv28 = o.nv28 != 0;
-    for (const TrackHdr& h : e->hdr_host) all_nv28 = all_nv28 && h.nV == 28 && h.n_chain == 26 && h.brk2 == 13 && h.vtxp_off >= 0;   // big_track's layout: two loops of 12 walls
+    bool all_loops = o.nv28 != 0;       // ... or every track is two equal chains of 13 or of 9 vertices (track.json: 8 walls per loop): the mixed form of those kernels
+    for (const TrackHdr& h : e->hdr_host) {
+        all_nv28 = all_nv28 && h.nV == 28 && h.n_chain == 26 && h.brk2 == 13 && h.vtxp_off >= 0;   // big_track's layout: two loops of 12 walls
+        all_loops = all_loops && h.vtxp_off >= 0 && (h.brk2 == 13 || h.brk2 == 9) && h.n_chain == 2 * h.brk2 && h.nV == 4 * ((h.brk2 + 1) / 2);
+    }
     hipStream_t st = (hipStream_t)stream;
     EnvParams<float> prm = e->params<float>();
     prm.lg = small ? 2 : 1;
@@ -1140,6 +1144,7 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
     do {                                                                                                                 \
         if constexpr (PRC == 2 && KSV == 6) {   /* (17 rays, default arithmetic only: the chain-of-28 kernels) */        \
             if (mode == 2 && all_nv28) { PC_ROLL_M(KSV, RPLV, PRC, 3); break; }                                          \
+            if (mode == 2 && all_loops) { PC_ROLL_M(KSV, RPLV, PRC, 5); break; }                                         \
             if (mode == 1 && all_nv28) { PC_ROLL_M(KSV, RPLV, PRC, 4); break; }                                          \
         }                                                                                                                \
         if (mode == 2) PC_ROLL_M(KSV, RPLV, PRC, 2);                                                                     \
