@@ -203,10 +203,15 @@ __device__ __forceinline__ unsigned pk_f16(float a, float b) {  // low half = fp
 // l = fp16(v - h): v_fma_mixlo/mixhi_f16 read h straight out of the packed pair (as fp16), form fma(h, -1, v) -- exact -- and
 // round it once to fp16 into the low / high half: three instructions per pair of values, where converting h back, subtracting
 // and converting again takes five (tools/split_mix_check.hip: the same bits on 4 M pairs, fp16-denormal residuals included).
+// The register the pair ends up in is an MFMA operand, and inline asm is outside the compiler's hazard model: an MFMA that reads
+// it in the very next issue slot gets the stale half (tools/mfma_valu_hazard.hip: one instruction in between is enough in
+// isolation; one experimental schedule of the small form, which had that one instruction, still produced a stale residual --
+// DESIGN.md section 9).  The s_nop keeps two issue slots behind every completed pair: the other wave of the SIMD fills them (no
+// measurable cost in an A/B of the rollout kernel).
 __device__ __forceinline__ void split_pair_h(float a, float b, unsigned& p0, unsigned& p1) {
     p0 = pk_f16(a, b);
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(p1) : "v"(p0), "v"(a));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(p1) : "v"(p0), "v"(b));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n s_nop 1" : "+v"(p1) : "v"(p0), "v"(b));
 }
 
 template <int PREC> __device__ __forceinline__ Pieces<PREC> split8(const float (&v)[8]) {
