@@ -25,8 +25,9 @@ Extra objects on the JSON line:
                   `mfma`, `hbm` price the same launch against each roof; `gae` is the GAE scan's own HBM fraction.
   cpu_baseline -- the CPU oracle (oracle/, the checker -- never the product) driving the same rollout on the
                   host cores of this box for a bounded sample.
-  parity_check -- one more pc_rollout launch of the same trainer AFTER the timed region, whose first 256 envs x 64 steps
-                  are replayed through the CPU oracle (rewards / flags exact, observations within 1e-5).
+  parity_check -- one more pc_rollout launch of the same trainer AFTER the timed region: one env of every 32-env wave x 64 steps
+                  replayed through the CPU oracle (observations within one float32 ulp; rewards / flags exact; an env may leave the
+                  oracle's trajectory only at a step whose threshold margin is below 1e-9 px: 0 departures above that margin).
   strict_fp32_value -- the same metric with the policy GEMMs as exact-fp32 MFMAs (3 epochs, outside the headline timing).
   fp32_grade_bf16x3_value -- the same with the bf16 x 3 split (six piece products: fp32-grade error, not the fp32 chain's bits).
 """
@@ -79,7 +80,7 @@ def parse_args():
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--eager-rollout", action="store_true", help="no rollout graph; bracket env-step launches with events instead")
     ap.add_argument("--rollout-kernel", default="auto", choices=["auto", "mega", "steps"], help="persistent rollout kernel or 2 kernels/step")
-    ap.add_argument("--rollout-form", type=int, default=-1, choices=[-1, 0, 1, 2, 3], help="pc_rollout_set_form: -1 auto; 0/1 force the 32-env-wave / split form; 2/3 the same without the 1/den table in LDS (A/B knob)")
+    ap.add_argument("--rollout-form", type=int, default=-1, choices=[-1, 0, 1, 2, 3], help="PC_OPT_ROLLOUT_FORM of the trainer's env handle: -1 auto; 0/1 force the 32-env-wave / split form; 2/3 the same without the 1/den table in LDS (A/B knob)")
     ap.add_argument("--no-graphs", action="store_true", help="eager update and rollout")
     ap.add_argument("--torch-mlp", action="store_true", help="torch autograd GEMMs for the MLPs inside the minibatch step (fused loss/Adam kernels only)")
     ap.add_argument("--torch-update", action="store_true", help="reference torch ops for the whole minibatch step (no fused loss/Adam kernels)")
@@ -163,8 +164,9 @@ def parity_check(tr, cfg, torch, np, envs=1024, steps=64):
     for k, path in enumerate(tracks):
         mine = np.nonzero(tid == k)[0]
         wave0 = np.unique(mine // 32) * 32                                   # first env of every 32-env wave on this track
-        per_wave = max(1, (envs // nt) // len(wave0))                        # at least one env of EVERY wave
-        offs = (np.arange(per_wave)[None, :] * (32 // per_wave) + (wave0[:, None] // 32) % (32 // per_wave))
+        per_wave = min(32, max(1, (envs // nt) // len(wave0)))               # at least one env of EVERY wave, at most all 32
+        stride = max(1, 32 // per_wave)
+        offs = (np.arange(per_wave)[None, :] * stride + (wave0[:, None] // 32) % stride)
         sel = (wave0[:, None] + offs).reshape(-1)
         sel = np.unique(sel[(sel < cfg.n_envs) & (tid[np.minimum(sel, cfg.n_envs - 1)] == k)])
         P = len(sel)
@@ -200,7 +202,7 @@ def parity_check(tr, cfg, torch, np, envs=1024, steps=64):
             "obs_max_abs_err": worst, "obs_tolerance": OBS_TOL, "obs_entries_bit_equal": n_eq / max(1, n_cmp),
             "envs_left_oracle_trajectory": flips, "largest_threshold_margin_px_of_a_departure": worst_margin, "margin_tolerance_px": MARGIN_PX,
             "rewards_and_flags": "exact on every env still on the oracle's trajectory",
-            "ok": bool(worst <= OBS_TOL and worst_margin <= MARGIN_PX and flips <= max(2, checked // 50)),
+            "ok": bool(worst <= OBS_TOL and worst_margin <= MARGIN_PX),     # i.e. 0 departures above the margin, however many envs
             "checker": "oracle/carenv_oracle.c (float64 restatement of car_env.py:693-760), teacher-forced by the stored actions"}
 
 
@@ -267,10 +269,8 @@ def main():
         cfg_ = PPOConfig(track=track, env_dtype=args.env_dtype, seed=0, policy=args.policy, use_graphs=not args.no_graphs,
                          fused_update=not args.torch_update, custom_mlp=not args.torch_mlp, rollout_kernel=args.rollout_kernel,
                          force_collective=args.force_collective, capture_collectives=bool(args.capture_collectives),
-                         policy_precision=policy_precision, exchange=args.exchange, **wl)
+                         policy_precision=policy_precision, exchange=args.exchange, rollout_form=args.rollout_form, **wl)
         t_ = Trainer(cfg_, device=dev, rank=rank, world_size=world)
-        if args.rollout_form >= 0:
-            t_.envs.set_option("rollout_form", args.rollout_form)
         return cfg_, t_
 
     cfg, tr = make_trainer()

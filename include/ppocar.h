@@ -18,10 +18,9 @@
  *     default stream).  The library never synchronises in reset/step/gae/sample.
  *   - There is NO CPU fallback: every compute entry point needs a gfx950 device and fails
  *     with PC_ERR_NO_DEVICE / PC_ERR_HIP otherwise.
- *   - One handle per device; a handle is not thread-safe; different handles are independent: every launch option lives in a
- *     handle (pc_policy: arithmetic form and work decomposition of the policy step; pc_env: pc_env_set_option).  The
- *     pc_*_set_* entry points marked "process default" only change what handles created AFTERWARDS (and the handle-less
- *     convenience calls) start from.
+ *   - One handle per device; a handle is not thread-safe; different handles are independent.  The library keeps NO process-wide
+ *     state: every launch option lives in a handle (pc_policy: arithmetic form and work decomposition of the policy step;
+ *     pc_env: pc_env_set_option).
  */
 #ifndef PPOCAR_H
 #define PPOCAR_H
@@ -109,10 +108,17 @@ int pc_env_step(pc_env* e, const int64_t* actions, double reward_scale, float* o
  * the finished episode's count is pc_env_step's `gates_passed`).  [N] int32 device arrays, either may be NULL. */
 int pc_env_info(pc_env* e, int32_t* gates_passed, int32_t* time_passed, void* stream);
 
-/* Per-handle launch options of pc_rollout (below); a new handle starts from the process defaults (pc_rollout_set_*).
- *   PC_OPT_ROLLOUT_FORM  -1 automatic, 0..3 as pc_rollout_set_form
- *   PC_OPT_ROLLOUT_EPW   0 automatic, 16 / 32 / 128 / 256 as pc_rollout_set_epw
- *   PC_OPT_ROLLOUT_FAST  0 / 1 / 2 as pc_rollout_set_fast */
+/* Per-handle launch options of pc_rollout (below).  Every choice gives bit-identical buffers; they exist so that the variant a
+ * benchmark size takes can be checked at other batch sizes, and for A/B timing.
+ *   PC_OPT_ROLLOUT_FORM  -1 (default) automatic: above 16384 envs independent waves of 32 envs, 256 envs per workgroup (128 up to
+ *                        32768 envs), else 16 / 32 envs per workgroup with the policy's hidden tiles and the wall sweep split over the
+ *                        waves; 0 / 1 force the first / second form; 2 / 3 = forms 0 / 1 with the env step forming 1/den
+ *                        arithmetically instead of reading the track's 1/den table from LDS (what happens anyway when it does not fit)
+ *   PC_OPT_ROLLOUT_EPW   envs per workgroup: 0 (default) automatic; 128 / 256 force the big form's choice, 16 / 32 the small form's
+ *   PC_OPT_ROLLOUT_FAST  1 (default) = batches whose workgroups each lie on one track take the mode whose gather tables sit in LDS
+ *                        behind LDS pointers -- at 16 (17) rays in the kernels compiled for the chain layout of the reference's tracks
+ *                        when every track of the batch has it; 2 = that mode but never those specialised kernels; 0 = always the
+ *                        generic mode (what mixed-track batches whose workgroups straddle tracks take) */
 #define PC_OPT_ROLLOUT_FORM 1
 #define PC_OPT_ROLLOUT_EPW 2
 #define PC_OPT_ROLLOUT_FAST 3
@@ -145,57 +151,34 @@ int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, 
 
 /* ---- the whole of Agent.get_action_and_value(x) as the rollout calls it (model.py:34-41, train.py:181):
  * both 1-hidden-layer MLPs (actor D->H->A, critic D->H->1, ReLU), the categorical draw, log_prob and the
- * value, in one launch on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products and sums).
+ * value, in one launch on the matrix cores.  A policy step's configuration is a HANDLE: shape (D, H, A), arithmetic form of the
+ * two GEMMs and work decomposition.  Handles are immutable and independent: two of them with different forms can pack and run
+ * side by side in one process; a weight image belongs to the handle that packed it.
+ *   precision  2 (= -1, the default) fp16x2 in scaled domains: every fp32 operand v = h + l, h = fp16(v), l = fp16(v - h); a product
+ *                is a_h b_l + a_l b_h + a_h b_h into ONE fp32 accumulator (v_mfma_f32_16x16x32_f16, three per K block); max error
+ *                vs float64 on this MLP 1.1e-7 (a plain fp32 GEMM: 0.8e-7); operands saturate at fp16's finite range in their
+ *                scaled domain.  Needs D <= 40, A <= 9, else the shape gets form 0.
+ *              1 bf16x3: three bf16 pieces per operand, six piece products (v_mfma_f32_16x16x32_bf16); 1.0e-7; same shapes.
+ *              0 fp32-input MFMA (v_mfma_f32_16x16x4_f32), bit-for-bit an fp32 fmaf chain.
+ *   split      -1 automatic (hidden tiles split across the waves of a workgroup up to 16384 envs), 0 never, 1 always; the two
+ *              forms differ in fp32 summation order (last-bit differences).
+ * pc_policy_create: PC_ERR_UNSUPPORTED unless H == 256, A <= 15, D <= 40 (the caller then uses its own GEMMs + pc_sample).
+ * pc_policy_get reports the form the shape actually got and the number of floats its weight image needs.
  * The weights do not change during a rollout, so they are packed ONCE into the kernel's LDS image:
- *   pc_policy_image_floats(D, H, A)  -> number of floats the image needs (negative: unsupported shape)
- *   pc_policy_pack(...)              -> build the image (device buffer `image`) from the eight
- *                                       torch.nn.Linear tensors: aW1 [H][D], ab1 [H], aW2 [A][H], ab2 [A],
- *                                       cW1 [H][D], cb1 [H], cW2 [1][H], cb2 [1]
- *   pc_policy_act(...)               -> one policy step for obs [N][D] using the image.
- * RNG as pc_sample, with offset = `offset` + *offset_dev when offset_dev != NULL (a device counter, so a
- * captured HIP graph can be replayed with a fresh stream of draws).
- * action [N] int64; action_f32 [N] (the float copy Buffer.act_buf stores, buffer.py:13) or NULL;
- * logprob, value [N]; logits_out [N][A] or NULL.  PC_ERR_UNSUPPORTED unless H == 256, A <= 15, D <= 40
- * (the caller then uses its own GEMMs + pc_sample). */
-int64_t pc_policy_image_floats(int D, int H, int A);
-/* A policy step's configuration as a HANDLE: shape (D, H, A as above), arithmetic form of the two GEMMs (`precision`: 0 / 1 / 2
- * as described at pc_policy_set_precision, -1 = the process default; a shape the split forms do not cover gets form 0) and work
- * decomposition (`split`: -1 automatic by batch size, 0 never, 1 always, -2 = the process default).  Handles are immutable and
- * independent: two of them with different forms can pack and run side by side in one process; a weight image belongs to the
- * handle that packed it.  pc_policy_get reports the form the shape actually got and the image size.
- *   pc_policy_pack_p / pc_policy_act_p = pc_policy_pack / pc_policy_act with the handle's form instead of the process default;
- *   pc_rollout_p = pc_rollout_ex (below) with the handle's form and action count.  (model.py:13-41, train.py:173-195) */
+ *   pc_policy_pack  builds the image (device buffer `image`) from the eight torch.nn.Linear tensors: aW1 [H][D], ab1 [H],
+ *                   aW2 [A][H], ab2 [A], cW1 [H][D], cb1 [H], cW2 [1][H], cb2 [1]
+ *   pc_policy_act   one policy step for obs [N][D] using the image.  RNG as pc_sample, with offset = `offset` + *offset_dev when
+ *                   offset_dev != NULL (a device counter, so a captured HIP graph can be replayed with a fresh stream of draws).
+ *                   action [N] int64; action_f32 [N] (the float copy Buffer.act_buf stores, buffer.py:13) or NULL; logprob,
+ *                   value [N]; logits_out [N][A] or NULL. */
 int pc_policy_create(int device, int D, int H, int A, int precision, int split, pc_policy** out);
 void pc_policy_destroy(pc_policy* p);
 int pc_policy_get(const pc_policy* p, int* precision, int* split, int64_t* image_floats);
-int pc_policy_pack_p(const pc_policy* p, const float* aW1, const float* ab1, const float* aW2, const float* ab2, const float* cW1,
-                     const float* cb1, const float* cW2, const float* cb2, float* image, void* stream);
-int pc_policy_act_p(const pc_policy* p, const float* obs, int64_t N, const float* image, uint64_t seed, uint64_t offset,
-                    const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob, float* value, float* logits_out,
-                    void* stream);
-/* Work decomposition of pc_policy_act: -1 = automatic (hidden tiles split across the waves of a workgroup up to 16384
- * envs), 0 = never split, 1 = always.  The two forms differ in fp32 summation order (last-bit differences).  PROCESS DEFAULT
- * (deprecated as a knob): what pc_policy_create(split = -2) and the handle-less pc_policy_act use. */
-int pc_policy_set_split(int mode);
-/* Arithmetic of the policy step's two GEMMs -- PROCESS DEFAULT (deprecated as a knob): what pc_policy_create(precision = -1) and
- * the handle-less pc_policy_pack / pc_policy_act / pc_rollout use; choose before packing.  All three are fp32-class:
- *   2 (default) = fp16x2: every fp32 operand v = h + 2^-11 l with h = fp16(v), l = fp16((v - h) 2^11) (22 significant
- *       bits at any magnitude); a product is a_h b_h plus the two cross terms in a second, scaled fp32 accumulator
- *       (v_mfma_f32_16x16x32_f16, three per K block).  Max error vs float64 on this MLP 1.3e-7 (a plain fp32 GEMM:
- *       0.8e-7).  Operands saturate at fp16's finite range (|v| <= 65504).  Used when D <= 40 (two K blocks of 32
- *       features above D = 24) and A <= 9, else form 0.
- *   1 = bf16x3: three bf16 pieces per operand, six piece products (v_mfma_f32_16x16x32_bf16); 1.0e-7; same shapes.
- *   0 = fp32-input MFMA (v_mfma_f32_16x16x4_f32), bit-for-bit an fp32 fmaf chain.
- * pc_policy_precision reports the form a (D, H, A) shape will actually get (negative: unsupported shape). */
-int pc_policy_set_precision(int mode);
-int pc_policy_precision(int D, int H, int A);
-/* the two process defaults as they stand (either pointer may be NULL) */
-int pc_policy_defaults(int* precision, int* split);
-int pc_policy_pack(int device, int D, int H, int A, const float* aW1, const float* ab1, const float* aW2, const float* ab2,
-                   const float* cW1, const float* cb1, const float* cW2, const float* cb2, float* image, void* stream);
-int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, const float* image, uint64_t seed,
-                  uint64_t offset, const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob, float* value,
-                  float* logits_out, void* stream);
+int pc_policy_pack(const pc_policy* p, const float* aW1, const float* ab1, const float* aW2, const float* ab2, const float* cW1,
+                   const float* cb1, const float* cW2, const float* cb2, float* image, void* stream);
+int pc_policy_act(const pc_policy* p, const float* obs, int64_t N, const float* image, uint64_t seed, uint64_t offset,
+                  const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob, float* value, float* logits_out,
+                  void* stream);
 
 /* ---- the whole rollout of one epoch (train.py:173-195) as ONE persistent launch: for t in 0..T-1
  *   (action, logprob, value) = Agent.get_action_and_value(obs_t)      [pc_policy_act's arithmetic and RNG, offset + t]
@@ -204,55 +187,26 @@ int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, 
  * Inputs: the env handle (F32; single track, or mixed tracks with every aligned block of 32 envs on one track -- when the
  * blocks are as large as the launch's workgroups, 128 / 256 envs in the large form and 16 / 32 in the small one, each
  * workgroup stages its track's tables in LDS as for a single track, else every wave reads them from global memory), the
- * policy weight image of pc_policy_pack, and next_obs /
- * next_term / next_trunc [N] = observation and flags the rollout starts from (the caller has copied them into row 0 of
- * obs_buf / term_buf / trunc_buf, as Trainer does).  Outputs: obs_buf [T][N][D] rows 1..T-1, act_buf (float32, buffer.py:13),
- * rew_buf, val_buf, logprob_buf [T][N] rows 0..T-1, term_buf / trunc_buf rows 1..T-1, and next_obs / next_term / next_trunc
- * overwritten with the state after step T-1.  Bit-identical to T x (pc_policy_act; pc_env_step).
+ * policy handle and the weight image it packed, and next_obs / next_term / next_trunc [N] = observation and flags the rollout
+ * starts from (the caller has copied them into row 0 of obs_buf / term_buf / trunc_buf, as Trainer does).
+ * Outputs: obs_buf [T][N][D] rows 1..T-1, act_buf (float32, buffer.py:13), rew_buf, val_buf, logprob_buf [T][N] rows 0..T-1,
+ * term_buf / trunc_buf rows 1..T-1, and next_obs / next_term / next_trunc overwritten with the state after step T-1 -- bit-identical
+ * to T x (pc_policy_act; pc_env_step) -- plus two per-env outputs [N] float32 (each may be NULL) so that an epoch needs nothing
+ * else between the rollout and Buffer.calculate_advantages:
+ *   last_value : the critic's value of the FINAL observation -- agent.get_value(next_obs), train.py:200 -- from one more policy
+ *                pass inside the launch (the fused policy step's arithmetic, i.e. what val_buf's rows hold for the other steps);
+ *   reward_sum : the sum over the T steps of the env's (scaled) rewards, accumulated in float32 in step order -- the numerator
+ *                of train.py:272's average reward without re-reading rew_buf.
  * PC_ERR_UNSUPPORTED for F64 handles, mixed-track handles whose track ids change inside an aligned block of 32 envs, ray
  * counts whose slots per lane are not on the kernel menu (12 / 16 / 32 run the table-driven fast mode; 17 and 18 share the
  * slots of 16 and run the generic mode), shapes whose LDS footprint exceeds 160 KB (33 rays with the fp32 or bf16x3 weight
  * image in the large form), and 33 rays in the GENERIC mode with split operands (a mixed-track batch whose workgroups
  * straddle tracks, or the fast mode switched off: those kernels spilled and are not built): callers fall back to the
  * two-kernel loop, which fills the same buffers bit for bit. */
-int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
+int pc_rollout(pc_env* e, const pc_policy* p, const float* image, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
                const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
-               float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, void* stream);
-/* pc_rollout with two more per-env outputs (each may be NULL), both [N] float32, so that an epoch needs nothing else between
- * the rollout and Buffer.calculate_advantages:
- *   last_value : the critic's value of the FINAL observation -- agent.get_value(next_obs), train.py:200 -- from one more policy
- *                pass inside the launch (the fused policy step's arithmetic, i.e. what val_buf's rows hold for the other steps);
- *   reward_sum : the sum over the T steps of the env's (scaled) rewards, accumulated in float32 in step order -- the numerator
- *                of train.py:272's average reward without re-reading rew_buf.
- * Everything else exactly as pc_rollout (same buffers bit for bit). */
-int pc_rollout_ex(pc_env* e, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
-                  const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
-                  float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, float* last_value,
-                  float* reward_sum, void* stream);
-
-int pc_rollout_p(pc_env* e, const pc_policy* p, const float* image, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
-                 const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
-                 float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, float* last_value,
-                 float* reward_sum, void* stream);
-
-/* PROCESS DEFAULTS of pc_env's rollout options (deprecated as knobs: a handle created afterwards starts from them; use
- * pc_env_set_option on the handle).
- * Work decomposition of pc_rollout: -1 = automatic (above 16384 envs: independent waves of 32 envs, 256 envs per workgroup
- * -- 128 up to 32768 envs; else 32 envs per workgroup with the policy's hidden tiles and the wall sweep split over the
- * waves), 0 / 1 force the first / second form; 2 / 3 = forms 0 / 1 with the env step forming 1/den arithmetically instead of
- * reading the track's 1/den table from LDS (what happens anyway when the table does not fit).  All are bit-identical
- * to the per-step kernels.  Tuning / test knob. */
-int pc_rollout_set_form(int form);
-/* Test / tuning knob of pc_rollout: envs per workgroup, 0 = automatic (big form: 128 up to 32768 envs, else 256; small
- * form: 16 up to 4096 envs, else 32); 128 / 256 force the big form's choice, 16 / 32 the small form's -- so that the variant a
- * benchmark size takes can be checked at other batch sizes. */
-int pc_rollout_set_epw(int envs_per_workgroup);
-/* A/B / test knob of pc_rollout: 1 (default) = batches whose workgroups each lie on one track take the mode whose gather
- * tables sit in LDS behind LDS pointers, with a branch-free env step and the wave copying its observation rows out in 16-byte
- * stores -- at 16 (17) rays in the kernels compiled for a padded wall chain of 28 vertices (big_track.json) when every track of
- * the batch has one; 2 = the same mode but never those specialised kernels; 0 = always the generic mode (what mixed-track batches whose
- * workgroups straddle tracks take).  Bit-identical buffers in every case. */
-int pc_rollout_set_fast(int on);
+               float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, float* last_value,
+               float* reward_sum, void* stream);
 
 /* ---- the non-GEMM work of one PPO minibatch step (train.py:230-261), three launches:
  * pc_ppo_gather : traj_*[batch_indices] (train.py:233-238,249): idx [B] int64 into the flattened trajectories

@@ -74,26 +74,14 @@ _sig = {
     "pc_env_set_state": (_i, [_vp] * 9),
     "pc_gae": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _i64, _i64, _vp, _vp, _vp]),
     "pc_sample": (_i, [_i, _vp, _i64, _i, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp]),
-    "pc_policy_image_floats": (_i64, [_i, _i, _i]),
-    "pc_policy_set_split": (_i, [_i]),
-    "pc_policy_set_precision": (_i, [_i]),
-    "pc_policy_precision": (_i, [_i, _i, _i]),
-    "pc_policy_pack": (_i, [_i, _i, _i, _i] + [_vp] * 8 + [_vp, _vp]),
-    "pc_policy_act": (_i, [_i, _vp, _i64, _i, _i, _i, _vp, C.c_uint64, C.c_uint64, _vp] + [_vp] * 5 + [_vp]),
-    "pc_rollout": (_i, [_vp, _vp, _i, _i64, _d, C.c_uint64, C.c_uint64, _vp] + [_vp] * 10 + [_vp]),
-    "pc_rollout_ex": (_i, [_vp, _vp, _i, _i64, _d, C.c_uint64, C.c_uint64, _vp] + [_vp] * 12 + [_vp]),
     "pc_policy_create": (_i, [_i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "pc_policy_destroy": (None, [_vp]),
-    "pc_policy_defaults": (_i, [C.POINTER(_i), C.POINTER(_i)]),
     "pc_policy_get": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64)]),
-    "pc_policy_pack_p": (_i, [_vp] + [_vp] * 8 + [_vp, _vp]),
-    "pc_policy_act_p": (_i, [_vp, _vp, _i64, _vp, C.c_uint64, C.c_uint64, _vp] + [_vp] * 5 + [_vp]),
-    "pc_rollout_p": (_i, [_vp, _vp, _vp, _i64, _d, C.c_uint64, C.c_uint64, _vp] + [_vp] * 12 + [_vp]),
+    "pc_policy_pack": (_i, [_vp] + [_vp] * 8 + [_vp, _vp]),
+    "pc_policy_act": (_i, [_vp, _vp, _i64, _vp, C.c_uint64, C.c_uint64, _vp] + [_vp] * 5 + [_vp]),
+    "pc_rollout": (_i, [_vp, _vp, _vp, _i64, _d, C.c_uint64, C.c_uint64, _vp] + [_vp] * 12 + [_vp]),
     "pc_env_set_option": (_i, [_vp, _i, _i]),
     "pc_env_get_option": (_i, [_vp, _i, C.POINTER(_i)]),
-    "pc_rollout_set_form": (_i, [_i]),
-    "pc_rollout_set_epw": (_i, [_i]),
-    "pc_rollout_set_fast": (_i, [_i]),
     "pc_ppo_gather": (_i, [_i, _vp, _i, _i] + [_vp] * 10 + [_vp]),
     "pc_ppo_loss": (_i, [_i] + [_vp] * 6 + [_i, _i, _d, _d, _d, _vp, _vp, _vp, _vp]),
     "pc_clip_adam": (_i, [_i] + [_vp] * 6 + [_i64, _d, _d, _d, _d, _d, _vp]),

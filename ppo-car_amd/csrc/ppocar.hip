@@ -110,8 +110,8 @@ int pick_rpl(int need) {
 
 }  // namespace
 
-// pc_rollout's dispatch options: per env handle (pc_env_set_option); a new handle starts from the process defaults, which the
-// deprecated pc_rollout_set_* entry points change.
+// pc_rollout's dispatch options: per env handle (pc_env_set_option).  There is no process-wide state: a new handle starts from
+// the member initialisers below.
 struct RolloutOpts {
     int form = -1;        // -1 auto, 0 = 256 envs per workgroup, 1 = 32 envs per workgroup
     int rden = 1;         // stage the 1/den table in LDS when it fits (0: never; test / tuning knob)
@@ -119,13 +119,11 @@ struct RolloutOpts {
     int fast = 1;         // the fast modes (LDS tables behind LDS pointers) when the shape allows them (0: never; A/B knob)
     int nv28 = 1;         // kernels compiled for a padded wall chain of 28 vertices (big_track.json) when every track of the batch has one
 };
-static RolloutOpts g_rollout_defaults;
-static int g_policy_split_mode = -1;  // process default of pc_policy::split: -1 auto (split below 32768 envs), 0 never, 1 always
-static int g_policy_precision = 2;    // process default of pc_policy::precision: 0 = fp32-input MFMA; split forms on the 16-bit matrix cores (need D <= 40, A <= 9): 1 = bf16 x 3, 2 = fp16 x 2
+constexpr int kDefaultPolicyPrecision = 2;   // pc_policy_create(precision = -1): 0 = fp32-input MFMA; split forms on the 16-bit matrix cores (need D <= 40, A <= 9): 1 = bf16 x 3, 2 = fp16 x 2
 
 struct pc_env {
     int device = 0;
-    RolloutOpts opt = g_rollout_defaults;
+    RolloutOpts opt;
     int dtype = PC_DTYPE_F32;
     int64_t N = 0;
     int n_nominal = 12, R = 12, D = 18, n_tracks = 0;
@@ -796,7 +794,7 @@ struct pc_policy {
 extern "C" {
 
 int pc_policy_create(int device, int D, int H, int A, int precision, int split, pc_policy** out) {
-    if (!out || precision < -1 || precision > 2 || split < -2 || split > 1) return PC_ERR_INVALID_ARG;
+    if (!out || precision < -1 || precision > 2 || split < -1 || split > 1) return PC_ERR_INVALID_ARG;
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;  // the caller falls back to its own GEMMs
     pc_policy* p = new (std::nothrow) pc_policy;
     if (!p) return PC_ERR_INVALID_ARG;
@@ -804,8 +802,8 @@ int pc_policy_create(int device, int D, int H, int A, int precision, int split, 
     p->D = D;
     p->H = H;
     p->A = A;
-    p->precision = policy_prec(precision < 0 ? g_policy_precision : precision, D, A);
-    p->split = split == -2 ? g_policy_split_mode : split;
+    p->precision = policy_prec(precision < 0 ? kDefaultPolicyPrecision : precision, D, A);
+    p->split = split;
     *out = p;
     return PC_OK;
 }
@@ -817,53 +815,6 @@ int pc_policy_get(const pc_policy* p, int* precision, int* split, int64_t* image
     if (precision) *precision = p->precision;
     if (split) *split = p->split;
     if (image_floats) *image_floats = p->precision ? polx_image_dwords(p->precision, pol_ng(policy_ks(p->D))) : pol_image_padded(policy_ks(p->D));
-    return PC_OK;
-}
-
-// ---- deprecated process-wide defaults: what a handle created with precision = -1 / split = -2 and a new pc_env start from,
-// and what the handle-less pc_policy_* / pc_rollout* entry points use
-int pc_rollout_set_form(int form) {
-    if (form < -1 || form > 3) return PC_ERR_INVALID_ARG;
-    g_rollout_defaults.rden = form >= 2 ? 0 : 1;              // forms 2 / 3 = forms 0 / 1 without the LDS 1/den table
-    g_rollout_defaults.form = form >= 2 ? form - 2 : form;
-    return PC_OK;
-}
-
-int pc_rollout_set_fast(int on) {
-    if (on < 0 || on > 2) return PC_ERR_INVALID_ARG;
-    g_rollout_defaults.fast = on != 0;
-    g_rollout_defaults.nv28 = on == 1;      // 2: fast mode, but never the kernels specialised for a wall chain of 28 vertices
-    return PC_OK;
-}
-
-int pc_rollout_set_epw(int envs_per_workgroup) {
-    if (envs_per_workgroup != 0 && envs_per_workgroup != 16 && envs_per_workgroup != 32 && envs_per_workgroup != 128 &&
-        envs_per_workgroup != 256)
-        return PC_ERR_INVALID_ARG;
-    g_rollout_defaults.epw_override = envs_per_workgroup;
-    return PC_OK;
-}
-
-int pc_policy_set_precision(int mode) {
-    if (mode < 0 || mode > 2) return PC_ERR_INVALID_ARG;
-    g_policy_precision = mode;
-    return PC_OK;
-}
-
-int pc_policy_precision(int D, int H, int A) {
-    if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
-    return policy_prec(g_policy_precision, D, A);
-}
-
-int pc_policy_set_split(int mode) {
-    if (mode < -1 || mode > 1) return PC_ERR_INVALID_ARG;
-    g_policy_split_mode = mode;
-    return PC_OK;
-}
-
-int pc_policy_defaults(int* precision, int* split) {
-    if (precision) *precision = g_policy_precision;
-    if (split) *split = g_policy_split_mode;
     return PC_OK;
 }
 
@@ -977,34 +928,15 @@ static int policy_act_impl(int device, int prec, int split_mode, const float* ob
     return PC_OK;
 }
 
-int64_t pc_policy_image_floats(int D, int H, int A) {
-    if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
-    return policy_image_floats_impl(policy_prec(g_policy_precision, D, A), D);
-}
-
-int pc_policy_pack(int device, int D, int H, int A, const float* aW1, const float* ab1, const float* aW2, const float* ab2,
-                   const float* cW1, const float* cb1, const float* cW2, const float* cb2, float* image, void* stream) {
-    if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
-    return policy_pack_impl(device, policy_prec(g_policy_precision, D, A), D, H, A, aW1, ab1, aW2, ab2, cW1, cb1, cW2, cb2, image, stream);
-}
-
-int pc_policy_pack_p(const pc_policy* p, const float* aW1, const float* ab1, const float* aW2, const float* ab2, const float* cW1,
-                     const float* cb1, const float* cW2, const float* cb2, float* image, void* stream) {
+int pc_policy_pack(const pc_policy* p, const float* aW1, const float* ab1, const float* aW2, const float* ab2, const float* cW1,
+                   const float* cb1, const float* cW2, const float* cb2, float* image, void* stream) {
     if (!p) return PC_ERR_INVALID_ARG;
     return policy_pack_impl(p->device, p->precision, p->D, p->H, p->A, aW1, ab1, aW2, ab2, cW1, cb1, cW2, cb2, image, stream);
 }
 
-int pc_policy_act(int device, const float* obs, int64_t N, int D, int H, int A, const float* image, uint64_t seed,
-                  uint64_t offset, const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob, float* value,
-                  float* logits_out, void* stream) {
-    if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
-    return policy_act_impl(device, policy_prec(g_policy_precision, D, A), g_policy_split_mode, obs, N, D, H, A, image, seed, offset, offset_dev,
-                           action, action_f32, logprob, value, logits_out, stream);
-}
-
-int pc_policy_act_p(const pc_policy* p, const float* obs, int64_t N, const float* image, uint64_t seed, uint64_t offset,
-                    const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob, float* value, float* logits_out,
-                    void* stream) {
+int pc_policy_act(const pc_policy* p, const float* obs, int64_t N, const float* image, uint64_t seed, uint64_t offset,
+                  const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob, float* value, float* logits_out,
+                  void* stream) {
     if (!p) return PC_ERR_INVALID_ARG;
     return policy_act_impl(p->device, p->precision, p->split, obs, N, p->D, p->H, p->A, image, seed, offset, offset_dev, action, action_f32,
                            logprob, value, logits_out, stream);
@@ -1198,25 +1130,10 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
     return PC_OK;
 }
 
-int pc_rollout(pc_env* e, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
+int pc_rollout(pc_env* e, const pc_policy* p, const float* image, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
                const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
-               float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, void* stream) {
-    return rollout_impl(e, g_policy_precision, image, A, T, reward_scale, seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf,
-                        trunc_buf, logprob_buf, next_obs, next_term, next_trunc, nullptr, nullptr, stream);
-}
-
-int pc_rollout_ex(pc_env* e, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
-                  const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
-                  float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, float* last_value,
-                  float* reward_sum, void* stream) {
-    return rollout_impl(e, g_policy_precision, image, A, T, reward_scale, seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf,
-                        trunc_buf, logprob_buf, next_obs, next_term, next_trunc, last_value, reward_sum, stream);
-}
-
-int pc_rollout_p(pc_env* e, const pc_policy* p, const float* image, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
-                 const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
-                 float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, float* last_value,
-                 float* reward_sum, void* stream) {
+               float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, float* last_value,
+               float* reward_sum, void* stream) {
     if (!e || !p) return PC_ERR_INVALID_ARG;
     if (p->D != e->D || p->device != e->device) return PC_ERR_INVALID_ARG;     // the policy was built for another observation width / device
     return rollout_impl(e, p->precision, image, p->A, T, reward_scale, seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf,

@@ -52,10 +52,11 @@ class Agent(nn.Module):
                    and isinstance(m[2], nn.Linear) for m in (self.actor, self.critic))
 
     # ---- the fused policy step's configuration lives in a pc_policy HANDLE of this agent (include/ppocar.h): arithmetic form
-    # (`policy_precision`: 0 fp32-input MFMA, 1 bf16x3, 2 fp16x2, -1 = the library's process default) and work decomposition
-    # (`policy_split`: -1 automatic by batch size, 0 / 1, -2 = the process default).  Two agents with different forms coexist.
+    # (`policy_precision`: 0 fp32-input MFMA, 1 bf16x3, 2 fp16x2, -1 = the library's default, fp16x2) and work decomposition
+    # (`policy_split`: -1 automatic by batch size, 0 never, 1 always).  Two agents with different forms coexist; the library keeps
+    # no process-wide setting.
     policy_precision = -1
-    policy_split = -2
+    policy_split = -1
 
     def _policy_handle(self):
         """The pc_policy handle for the current (device, shape, policy_precision, policy_split); None outside the kernel's menu.
@@ -65,11 +66,7 @@ class Agent(nn.Module):
         dev = a1.weight.device
         di = dev.index if dev.index is not None else torch.cuda.current_device()
         cache = self.__dict__.setdefault("_policy_handles", {})
-        dp, ds = C.c_int(), C.c_int()
-        lib.pc_policy_defaults(C.byref(dp), C.byref(ds))
-        prec = dp.value if self.policy_precision < 0 else int(self.policy_precision)      # defaults are resolved HERE: the handle is explicit
-        split = ds.value if self.policy_split == -2 else int(self.policy_split)
-        key = (di, a1.in_features, a1.out_features, a2.out_features, prec, split)
+        key = (di, a1.in_features, a1.out_features, a2.out_features, max(-1, int(self.policy_precision)), max(-1, int(self.policy_split)))
         if key not in cache:
             h = C.c_void_p()
             rc = lib.pc_policy_create(*key, C.byref(h))
@@ -107,9 +104,9 @@ class Agent(nn.Module):
         if getattr(self, "_image", None) is None or self._image.numel() != n or self._image.device != dev:
             self._image = torch.empty(n, dtype=torch.float32, device=dev)
         h = self._policy_handle()
-        check(lib.pc_policy_pack_p(h, a1.weight.data_ptr(), a1.bias.data_ptr(), a2.weight.data_ptr(), a2.bias.data_ptr(),
+        check(lib.pc_policy_pack(h, a1.weight.data_ptr(), a1.bias.data_ptr(), a2.weight.data_ptr(), a2.bias.data_ptr(),
                                    c1.weight.data_ptr(), c1.bias.data_ptr(), c2.weight.data_ptr(), c2.bias.data_ptr(),
-                                   self._image.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "pc_policy_pack_p")
+                                   self._image.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "pc_policy_pack")
         self._image_ok = True
         self._image_handle = h       # the image belongs to the handle that packed it
         return True
@@ -140,9 +137,9 @@ class Agent(nn.Module):
             ok = h is not None and (self.pack_policy() if (repack or stale) else True)
             if ok:
                 value = out_value if out_value is not None else torch.empty(N, dtype=torch.float32, device=dev)
-                check(lib.pc_policy_act_p(h, x.data_ptr(), N, self._image.data_ptr(), int(self.rng_seed), int(offset), ptr(offset_dev),
+                check(lib.pc_policy_act(h, x.data_ptr(), N, self._image.data_ptr(), int(self.rng_seed), int(offset), ptr(offset_dev),
                                           action.data_ptr(), ptr(out_action_f32), logprob.data_ptr(), value.data_ptr(), ptr(out_logits),
-                                          stream), "pc_policy_act_p")
+                                          stream), "pc_policy_act")
                 return action, logprob, value
         if offset_dev is not None:
             raise NotImplementedError("a device-side RNG offset needs the fused policy kernel")

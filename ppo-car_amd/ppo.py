@@ -75,6 +75,11 @@ class PPOConfig:
                                            # kernel, so capture_collectives can put it into the epoch graph with any backend
     policy_precision: int = -1             # arithmetic of the fused policy step's GEMMs: 2 fp16x2, 1 bf16x3, 0 fp32-input MFMA;
                                            # -1 = the library's default (fp16x2).  Per Trainer (a pc_policy handle), not process-wide
+    policy_split: int = -1                 # work decomposition of the fused policy step: -1 automatic by batch size, 0 never, 1 always
+                                           # (hidden tiles split over a workgroup's waves; differs in fp32 summation order)
+    rollout_form: int = -1                 # pc_rollout's per-handle options (include/ppocar.h PC_OPT_ROLLOUT_*; every choice gives the
+    rollout_epw: int = 0                   # same bits): form -1 automatic / 0 big / 1 small / 2, 3 without the LDS 1/den table; envs per
+    rollout_fast: int = 1                  # workgroup 0 automatic / 16 / 32 / 128 / 256; fast 1 / 2 / 0 (table-driven modes on / generic sweep / off)
 
 
 def flatten_parameters(module):
@@ -581,6 +586,10 @@ class Trainer:
         self.agent = Agent(self.obs_dim[0], self.act_dim).to(self.device)   # train.py:145
         self.agent.rng_seed = cfg.seed * 1000003 + rank
         self.agent.policy_precision = int(cfg.policy_precision)
+        self.agent.policy_split = int(cfg.policy_split)
+        for name, default in (("rollout_form", -1), ("rollout_epw", 0), ("rollout_fast", 1)):
+            if int(getattr(cfg, name)) != default:
+                self.envs.set_option(name, int(getattr(cfg, name)))
         self.learner = PPOLearner(self.agent, cfg, self.device, rank, world_size)
         self.optimizer, self.scheduler = self.learner.optimizer, self.learner.scheduler
         self.buffer = Buffer(self.obs_dim, cfg.n_steps, cfg.n_envs, self.device, cfg.gamma, cfg.gae_lambda)   # :152
@@ -656,7 +665,7 @@ class Trainer:
         if self._boot_val is None:
             self._boot_val = torch.empty(cfg.n_envs, device=self.device)       # the final observation's value (train.py:200)
             self._rew_sum = torch.empty(cfg.n_envs, device=self.device)        # per-env reward totals (train.py:272)
-        rc = lib.pc_rollout_p(self.envs._h, agent._image_handle, agent._image.data_ptr(), cfg.n_steps, float(cfg.reward_scaling),
+        rc = lib.pc_rollout(self.envs._h, agent._image_handle, agent._image.data_ptr(), cfg.n_steps, float(cfg.reward_scaling),
                               int(agent.rng_seed), 0, self.rng_base.data_ptr(), buf.obs_buf.data_ptr(), buf.act_buf.data_ptr(),
                               buf.rew_buf.data_ptr(), buf.val_buf.data_ptr(), buf.term_buf.data_ptr(), buf.trunc_buf.data_ptr(),
                               buf.logprob_buf.data_ptr(), self.next_obs.data_ptr(), self.next_term.data_ptr(),
@@ -664,7 +673,7 @@ class Trainer:
                               torch.cuda.current_stream(self.device).cuda_stream)
         if rc == -5:       # PC_ERR_UNSUPPORTED: shape outside the persistent kernel's menu
             return False
-        check(rc, "pc_rollout_p")
+        check(rc, "pc_rollout")
         self._aux_valid = True   # the launch also delivered the bootstrap values and the reward totals of THIS rollout
         if ev is not None:
             ev[1].record()

@@ -155,18 +155,31 @@ def test_buffer_store_get_semantics_cpu_storage():
 def test_shape_menus_are_reported_without_a_gpu():
     """The size / precision queries validate shapes on the host: callers use them to decide on their fallbacks."""
     lib = _capi.lib
-    assert lib.pc_policy_image_floats(23, 256, 9) > 0 and lib.pc_policy_image_floats(39, 256, 9) > 0
-    assert lib.pc_policy_image_floats(23, 128, 9) == _capi.PC_ERR_UNSUPPORTED      # hidden size other than 256
-    assert lib.pc_policy_image_floats(41, 256, 9) == _capi.PC_ERR_UNSUPPORTED
-    assert lib.pc_policy_image_floats(23, 256, 16) == _capi.PC_ERR_UNSUPPORTED
-    assert lib.pc_policy_precision(23, 256, 9) == 2 and lib.pc_policy_precision(39, 256, 9) == 2   # the split forms cover D <= 40
-    assert lib.pc_policy_precision(23, 256, 12) == 0                                                 # ... and A <= 9
-    assert lib.pc_policy_set_precision(0) == 0 and lib.pc_policy_precision(23, 256, 9) == 0
-    assert lib.pc_policy_set_precision(1) == 0 and lib.pc_policy_precision(23, 256, 9) == 1
-    assert lib.pc_policy_set_precision(7) == _capi.PC_ERR_INVALID_ARG and lib.pc_policy_set_precision(2) == 0
-    assert lib.pc_policy_image_floats(23, 256, 9) == 32 * 2 * 48 * 4 + 8 * 2 * 4 * 10 * 4 + 512 + 16 + 256
-    assert lib.pc_policy_image_floats(39, 256, 9) == 32 * 2 * 80 * 4 + 8 * 2 * 4 * 10 * 4 + 512 + 16 + 256   # two K blocks, 5 stored groups
-    assert lib.pc_policy_set_split(2) == _capi.PC_ERR_INVALID_ARG and lib.pc_policy_set_split(-1) == 0
+    import ctypes as C
+
+    def form(D, H, A, precision=-1, split=-1):
+        """(status, precision the shape got, split, image floats) of a pc_policy handle -- creation needs no GPU"""
+        h = C.c_void_p()
+        rc = lib.pc_policy_create(0, D, H, A, precision, split, C.byref(h))
+        if rc != 0:
+            return rc, None, None, None
+        pr, sp, n = C.c_int(), C.c_int(), C.c_int64()
+        assert lib.pc_policy_get(h, C.byref(pr), C.byref(sp), C.byref(n)) == 0
+        lib.pc_policy_destroy(h)
+        return rc, pr.value, sp.value, n.value
+
+    assert form(23, 256, 9)[3] > 0 and form(39, 256, 9)[3] > 0
+    assert form(23, 128, 9)[0] == _capi.PC_ERR_UNSUPPORTED      # hidden size other than 256
+    assert form(41, 256, 9)[0] == _capi.PC_ERR_UNSUPPORTED
+    assert form(23, 256, 16)[0] == _capi.PC_ERR_UNSUPPORTED
+    assert form(23, 256, 9)[1] == 2 and form(39, 256, 9)[1] == 2    # the default form is fp16x2; the split forms cover D <= 40
+    assert form(23, 256, 12)[1] == 0                                 # ... and A <= 9
+    assert form(23, 256, 9, precision=0)[1] == 0 and form(23, 256, 9, precision=1)[1] == 1
+    assert form(23, 256, 9, precision=7)[0] == _capi.PC_ERR_INVALID_ARG
+    assert form(23, 256, 9)[3] == 32 * 2 * 48 * 4 + 8 * 2 * 4 * 10 * 4 + 512 + 16 + 256
+    assert form(39, 256, 9)[3] == 32 * 2 * 80 * 4 + 8 * 2 * 4 * 10 * 4 + 512 + 16 + 256   # two K blocks, 5 stored groups
+    assert form(23, 256, 9, split=2)[0] == _capi.PC_ERR_INVALID_ARG and form(23, 256, 9, split=-2)[0] == _capi.PC_ERR_INVALID_ARG
+    assert form(23, 256, 9, split=1)[2] == 1
     n = lib.pc_ppo_workspace_floats(512, 23, 256, 9)
     n_param = 2 * (256 * 23 + 256) + 9 * 256 + 9 + 256 + 1
     n_pad = (n_param + 3) // 4 * 4                      # a partial's row stride: 16-byte aligned rows

@@ -134,15 +134,7 @@ def test_sample_kernel_entropy_and_extreme_logits():
     assert int(act[0]) == 0 and abs(float(ent[1]) - np.log(9)) < 1e-6
 
 
-@pytest.fixture
-def policy_precision(request):
-    from ppo_car_amd._capi import lib
-    lib.pc_policy_set_precision(request.param)
-    yield request.param
-    lib.pc_policy_set_precision(2)
-
-
-@pytest.mark.parametrize("policy_precision", [0, 1, 2], indirect=True)
+@pytest.mark.parametrize("policy_precision", [0, 1, 2])
 @pytest.mark.parametrize("D", [18, 23, 39])
 @pytest.mark.parametrize("N", [1000, 65536])
 def test_fused_policy_kernel_matches_torch_mlp(D, N, policy_precision):
@@ -151,6 +143,7 @@ def test_fused_policy_kernel_matches_torch_mlp(D, N, policy_precision):
     reports, draws distributed as the categorical."""
     torch.manual_seed(D)
     agent = pc.Agent(D, 9).cuda()
+    agent.policy_precision = policy_precision       # this agent's pc_policy handle (nothing process-wide)
     with torch.no_grad():
         for p in agent.parameters():          # non-trivial biases / output weights (the init has zero biases, 0.01 gain)
             p.add_(torch.randn_like(p) * 0.1)
@@ -162,8 +155,7 @@ def test_fused_policy_kernel_matches_torch_mlp(D, N, policy_precision):
     a, lp, v = agent.act(x, out_logits=logits, out_action_f32=af)
     with torch.no_grad():
         ref_logits, ref_v = agent.actor(x), agent.critic(x).view(-1)
-    from ppo_car_amd._capi import lib
-    assert lib.pc_policy_precision(D, 256, 9) == policy_precision   # the split forms cover D <= 40 (two K blocks above 24)
+    assert agent.policy_form()[0] == policy_precision   # the split forms cover D <= 40 (two K blocks above 24)
     assert torch.allclose(logits, ref_logits, atol=1e-5, rtol=1e-5)
     assert torch.allclose(v, ref_v, atol=1e-5, rtol=1e-5)
     # against float64: all three forms are fp32-class
@@ -185,7 +177,7 @@ def test_fused_policy_kernel_matches_torch_mlp(D, N, policy_precision):
         assert np.abs(counts / N - p).max() < 0.01
 
 
-@pytest.mark.parametrize("policy_precision", [2, 1, 0], indirect=True)
+@pytest.mark.parametrize("policy_precision", [2, 1, 0])
 def test_fused_policy_kernel_on_trained_weights_and_harvested_observations(policy_precision):
     """The precision claim of the fused policy kernel on REAL data rather than random weights: tests/golden/policy_trained.npz
     holds the weights after 150 PPO epochs on big_track (tools/make_policy_fixture.py, this repository's own run) and ~3900
@@ -201,6 +193,7 @@ def test_fused_policy_kernel_on_trained_weights_and_harvested_observations(polic
     agent = pc.Agent(23, 9)
     agent.load_state_dict({k: torch.from_numpy(f[k.replace(".", "_")]) for k in agent.state_dict()})
     agent = agent.cuda()
+    agent.policy_precision = policy_precision
     x = torch.from_numpy(obs).cuda()
     logits = torch.empty(n, 9, device="cuda")
     agent.rng_seed = 5
@@ -219,41 +212,42 @@ def test_fused_policy_kernel_on_trained_weights_and_harvested_observations(polic
 
 
 def test_two_policy_handles_with_different_arithmetic_coexist():
-    """Every launch option lives in a handle (include/ppocar.h): two agents with different arithmetic forms of the fused policy
-    step, used ALTERNATELY in one process, each produce exactly what they produce alone under the matching process default --
-    and the two differ from each other (fp16x2 vs the exact fp32 chain).  Same for pc_rollout's per-env options.
-    (model.py:34-41, train.py:173-195)"""
-    from ppo_car_amd._capi import lib
+    """Every launch option lives in a handle (include/ppocar.h; the library keeps no process-wide setting): two agents with
+    different arithmetic forms of the fused policy step, used ALTERNATELY in one process, each produce exactly what a fresh agent of
+    that form produces alone -- and the two forms differ from each other (fp16x2 vs the exact fp32 chain).  Same for pc_rollout's
+    per-env options.  (model.py:34-41, train.py:173-195)"""
     from ppo_car_amd.model import Agent
     torch.manual_seed(3)
     N, D = 4096, 23
     obs = torch.randn(N, D, device="cuda") * 0.5
-    agents = {}
-    for prec in (2, 0):
+
+    def make(prec):
         torch.manual_seed(5)
         a = Agent(D, 9).cuda()
         a.rng_seed = 77
         a.policy_precision = prec
-        agents[prec] = a
+        return a
+
     alone = {}
-    for prec in (2, 0):          # each alone, with the process default set to its form (the pre-handle way)
-        assert lib.pc_policy_set_precision(prec) == 0
-        torch.manual_seed(5)
-        b = Agent(D, 9).cuda()
-        b.rng_seed = 77
-        try:
-            logits = torch.empty(N, 9, device="cuda")
-            _, lp, v = b.act(obs, out_logits=logits, offset=0)
-            alone[prec] = (logits.clone(), lp.clone(), v.clone())
-        finally:
-            lib.pc_policy_set_precision(2)
-    for _ in range(2):           # interleaved, process default untouched (fp16x2)
+    for prec in (2, 0):          # each alone
+        b = make(prec)
+        logits = torch.empty(N, 9, device="cuda")
+        _, lp, v = b.act(obs, out_logits=logits, offset=0)
+        alone[prec] = (logits.clone(), lp.clone(), v.clone())
+        del b
+    agents = {prec: make(prec) for prec in (2, 0)}
+    default = make(-1)           # -1 = the library's default form
+    assert default.policy_form()[0] == 2
+    for _ in range(2):           # interleaved
         for prec in (0, 2):
             logits = torch.empty(N, 9, device="cuda")
             _, lp, v = agents[prec].act(obs, out_logits=logits, offset=0)
             assert agents[prec].policy_form()[0] == prec
             for got, want in zip((logits, lp, v), alone[prec]):
                 assert torch.equal(got, want), prec
+    logits = torch.empty(N, 9, device="cuda")
+    default.act(obs, out_logits=logits, offset=0)
+    assert torch.equal(logits, alone[2][0])
     assert not torch.equal(alone[0][0], alone[2][0])          # the two forms do differ in the last bits
     assert float((alone[0][0] - alone[2][0]).abs().max()) < 1e-5
 

@@ -190,26 +190,19 @@ def test_both_workgroup_sizes_of_the_big_form_at_small_n(n_envs, epw, fast):
     per-step kernels, with the 1/den table in LDS (form 0) -- the configuration the benchmark runs -- in the kernels compiled
     for big_track's chain length (the default), in the fast mode's generic-sweep kernels and in the generic mode."""
     res = {}
-    lib.pc_policy_set_split(0)
-    lib.pc_rollout_set_form(0)
-    lib.pc_rollout_set_epw(epw)
-    assert lib.pc_rollout_set_fast(fast) == 0 and lib.pc_rollout_set_fast(3) != 0
-    try:
-        for mode in ("steps", "mega"):
-            tr = Trainer(PPOConfig(n_envs=n_envs, n_steps=96, num_rays=16, track=TRACKS["big_track"], rollout_kernel=mode,
-                                   use_graphs=False, seed=3), device="cuda")
-            for _ in range(2):
-                tr.rollout()
-                tr.buffer.ptr = 0
-            torch.cuda.synchronize()
-            assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
-            res[mode] = _snap(tr)
-            tr.close()
-    finally:
-        lib.pc_policy_set_split(-1)
-        lib.pc_rollout_set_form(-1)
-        lib.pc_rollout_set_epw(0)
-        lib.pc_rollout_set_fast(1)
+    for mode in ("steps", "mega"):      # every option through this trainer's own handles (pc_policy_create, pc_env_set_option)
+        tr = Trainer(PPOConfig(n_envs=n_envs, n_steps=96, num_rays=16, track=TRACKS["big_track"], rollout_kernel=mode,
+                               use_graphs=False, seed=3, policy_split=0, rollout_form=0, rollout_epw=epw, rollout_fast=fast), device="cuda")
+        assert (tr.envs.get_option("rollout_form"), tr.envs.get_option("rollout_epw"), tr.envs.get_option("rollout_fast")) == (0, epw, fast)
+        with pytest.raises(pc.PpoCarError):
+            tr.envs.set_option("rollout_fast", 3)
+        for _ in range(2):
+            tr.rollout()
+            tr.buffer.ptr = 0
+        torch.cuda.synchronize()
+        assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
+        res[mode] = _snap(tr)
+        tr.close()
     for i, (a, b) in enumerate(zip(res["steps"], res["mega"])):
         assert torch.equal(a, b), i
     assert float(res["mega"][5].sum()) > 0
@@ -222,25 +215,17 @@ def test_both_workgroup_sizes_of_the_small_form(n_envs, num_rays, epw):
     what BASELINE configs[1] (4096 envs) takes: one workgroup on every CU -- and with 32, forced at other batch sizes: bitwise
     the per-step kernels (split policy form), two rollouts so that auto-resets are inside the window."""
     res = {}
-    lib.pc_policy_set_split(1)
-    lib.pc_rollout_set_form(1)
-    lib.pc_rollout_set_epw(epw)
-    try:
-        for mode in ("steps", "mega"):
-            tr = Trainer(PPOConfig(n_envs=n_envs, n_steps=96, num_rays=num_rays, track=TRACKS["big_track"], rollout_kernel=mode,
-                                   use_graphs=False, seed=4), device="cuda")
-            for _ in range(2):
-                tr.rollout()
-                tr.buffer.ptr = 0
-            torch.cuda.synchronize()
-            assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
-            res[mode] = _snap(tr)
-            res[mode + "_state"] = tr.envs.get_state()
-            tr.close()
-    finally:
-        lib.pc_policy_set_split(-1)
-        lib.pc_rollout_set_form(-1)
-        lib.pc_rollout_set_epw(0)
+    for mode in ("steps", "mega"):
+        tr = Trainer(PPOConfig(n_envs=n_envs, n_steps=96, num_rays=num_rays, track=TRACKS["big_track"], rollout_kernel=mode,
+                               use_graphs=False, seed=4, policy_split=1, rollout_form=1, rollout_epw=epw), device="cuda")
+        for _ in range(2):
+            tr.rollout()
+            tr.buffer.ptr = 0
+        torch.cuda.synchronize()
+        assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
+        res[mode] = _snap(tr)
+        res[mode + "_state"] = tr.envs.get_state()
+        tr.close()
     for i, (a, b) in enumerate(zip(res["steps"], res["mega"])):
         assert torch.equal(a, b), i
     for k in res["mega_state"]:
@@ -250,8 +235,9 @@ def test_both_workgroup_sizes_of_the_small_form(n_envs, num_rays, epw):
 
 @pytest.mark.parametrize("n_envs,num_rays,n_steps", [(65536, 16, 64), (4096, 16, 200), (1000, 32, 50), (3000, 12, 33)])
 def test_rollout_ex_delivers_bootstrap_values_and_reward_totals(n_envs, num_rays, n_steps):
-    """pc_rollout_ex = pc_rollout (same buffers, bit for bit) + the critic's value of the final observation (train.py:200) and
-    every env's reward total (train.py:272's numerator), from inside the same launch -- big and small form."""
+    """pc_rollout with its two optional outputs = pc_rollout without them (same buffers, bit for bit) + the critic's value of the
+    final observation (train.py:200) and every env's reward total (train.py:272's numerator), from inside the same launch -- big
+    and small form."""
     outs = {}
     for ex in (True, False):
         cfg = PPOConfig(n_envs=n_envs, n_steps=n_steps, num_rays=num_rays, track=TRACKS["big_track"], rollout_kernel="mega",
@@ -268,16 +254,16 @@ def test_rollout_ex_delivers_bootstrap_values_and_reward_totals(n_envs, num_rays
             assert float((rsum.double() - ref_sum).abs().max()) <= 1e-4 * max(1.0, float(ref_sum.abs().max()))
             mean_k = float(rsum.sum() / (n_steps * n_envs))
             assert mean_k == pytest.approx(float(tr.buffer.rew_buf.mean()), rel=1e-4, abs=1e-7)
-        else:               # the plain entry point, called directly
+        else:               # without the two optional outputs, called directly
             agent, buf = tr.agent, tr.buffer
             assert agent.pack_policy()
             buf.obs_buf[0].copy_(tr.next_obs)
             buf.term_buf[0].copy_(tr.next_term)
             buf.trunc_buf[0].copy_(tr.next_trunc)
-            rc = lib.pc_rollout(tr.envs._h, agent._image.data_ptr(), tr.act_dim, cfg.n_steps, float(cfg.reward_scaling), int(agent.rng_seed),
+            rc = lib.pc_rollout(tr.envs._h, agent._image_handle, agent._image.data_ptr(), cfg.n_steps, float(cfg.reward_scaling), int(agent.rng_seed),
                                 0, tr.rng_base.data_ptr(), buf.obs_buf.data_ptr(), buf.act_buf.data_ptr(), buf.rew_buf.data_ptr(),
                                 buf.val_buf.data_ptr(), buf.term_buf.data_ptr(), buf.trunc_buf.data_ptr(), buf.logprob_buf.data_ptr(),
-                                tr.next_obs.data_ptr(), tr.next_term.data_ptr(), tr.next_trunc.data_ptr(),
+                                tr.next_obs.data_ptr(), tr.next_term.data_ptr(), tr.next_trunc.data_ptr(), None, None,
                                 torch.cuda.current_stream().cuda_stream)
             assert rc == 0
         torch.cuda.synchronize()

@@ -194,35 +194,28 @@ def test_persistent_rollout_kernel_is_bitwise_the_two_kernel_rollout(num_rays, n
     of its forms: 0 = 256 envs per workgroup, every wave independent (the whole-tile policy kernel's summation order);
     1 = 32 envs per workgroup, hidden tiles split over the waves (the split policy kernel's summation order); 2 / 3 = the
     same two without the 1/den table in LDS (the sweep forms den and its reciprocal itself: same bits by construction)."""
-    from ppo_car_amd._capi import lib
     res = {}
-    lib.pc_policy_set_split(form & 1)   # same fp32 summation order in the per-step policy kernel as in this rollout form
-    lib.pc_policy_set_precision(precision)
-    lib.pc_rollout_set_form(form)
-    try:
-        for mode in ("steps", "mega"):
-            cfg = _cfg(rollout_kernel=mode, use_graphs=False, n_envs=n_envs, n_steps=80, num_rays=num_rays)
-            tr = Trainer(cfg, device="cuda")
-            snaps = []
-            for ep in range(3):
-                tr.rollout()
-                torch.cuda.synchronize()
-                # 32 -> 33 rays with the fp32 weight image: image + a 256-env observation tile exceed 160 KB of LDS -> form 0
-                # reports PC_ERR_UNSUPPORTED and the trainer falls back to the two-kernel loop; form 1 fits.  The 95 KB fp16x2
-                # image fits both forms, the 141 KB bf16x3 image (two K blocks at D = 39) neither.
-                mega_ok = mode == "mega" and (num_rays != 32 or precision == 2 or (precision == 0 and form & 1))
-                assert tr.rollout_mode == ("mega" if mega_ok else "steps-eager")
-                b = tr.buffer
-                snaps.append([t.clone() for t in (b.obs_buf, b.act_buf, b.rew_buf, b.val_buf, b.logprob_buf, b.term_buf,
-                                                  b.trunc_buf, tr.next_obs, tr.next_term, tr.next_trunc)])
-                tr.buffer.ptr = 0
-            st = tr.envs.get_state()
-            res[mode] = (snaps, st)
-            tr.close()
-    finally:
-        lib.pc_policy_set_split(-1)
-        lib.pc_policy_set_precision(2)
-        lib.pc_rollout_set_form(-1)
+    for mode in ("steps", "mega"):
+        # policy_split = form & 1: the same fp32 summation order in the per-step policy kernel as in this rollout form
+        cfg = _cfg(rollout_kernel=mode, use_graphs=False, n_envs=n_envs, n_steps=80, num_rays=num_rays, policy_split=form & 1,
+                   policy_precision=precision, rollout_form=form)
+        tr = Trainer(cfg, device="cuda")
+        snaps = []
+        for ep in range(3):
+            tr.rollout()
+            torch.cuda.synchronize()
+            # 32 -> 33 rays with the fp32 weight image: image + a 256-env observation tile exceed 160 KB of LDS -> form 0
+            # reports PC_ERR_UNSUPPORTED and the trainer falls back to the two-kernel loop; form 1 fits.  The 95 KB fp16x2
+            # image fits both forms, the 141 KB bf16x3 image (two K blocks at D = 39) neither.
+            mega_ok = mode == "mega" and (num_rays != 32 or precision == 2 or (precision == 0 and form & 1))
+            assert tr.rollout_mode == ("mega" if mega_ok else "steps-eager")
+            b = tr.buffer
+            snaps.append([t.clone() for t in (b.obs_buf, b.act_buf, b.rew_buf, b.val_buf, b.logprob_buf, b.term_buf,
+                                              b.trunc_buf, tr.next_obs, tr.next_term, tr.next_trunc)])
+            tr.buffer.ptr = 0
+        st = tr.envs.get_state()
+        res[mode] = (snaps, st)
+        tr.close()
     for ep in range(3):
         for i, (a, b) in enumerate(zip(res["steps"][0][ep], res["mega"][0][ep])):
             assert torch.equal(a, b), (ep, i)
@@ -255,26 +248,20 @@ def test_mixed_track_batches_through_the_persistent_rollout_kernel(n_envs, form)
     one track (it stages that track's tables in LDS: 4096 / 65536 default dispatch, 8192 big form, 1000 small form), else
     with every wave reading its own track's tables from global memory (1000 envs, big form: the halves meet at env 480);
     with the tracks interleaved env by env it reports PC_ERR_UNSUPPORTED and the trainer takes the per-step path."""
-    from ppo_car_amd._capi import lib
     tracks = [TRACKS["track"], TRACKS["big_track"]]
     res = {}
-    lib.pc_rollout_set_form(form)
-    lib.pc_policy_set_split(-1 if form < 0 else form & 1)
-    try:
-        for mode in ("steps", "mega"):
-            tr = Trainer(_cfg(track=tracks, rollout_kernel=mode, use_graphs=False, n_envs=n_envs, n_steps=48, num_rays=16), device="cuda")
-            for _ in range(2):
-                tr.rollout()
-                tr.buffer.ptr = 0
-            torch.cuda.synchronize()
-            assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
-            b = tr.buffer
-            res[mode] = [t.clone() for t in (b.obs_buf, b.act_buf, b.rew_buf, b.val_buf, b.logprob_buf, b.term_buf, tr.next_obs)]
-            res[mode + "_state"] = tr.envs.get_state()
-            tr.close()
-    finally:
-        lib.pc_rollout_set_form(-1)
-        lib.pc_policy_set_split(-1)
+    for mode in ("steps", "mega"):
+        tr = Trainer(_cfg(track=tracks, rollout_kernel=mode, use_graphs=False, n_envs=n_envs, n_steps=48, num_rays=16,
+                          rollout_form=form, policy_split=-1 if form < 0 else form & 1), device="cuda")
+        for _ in range(2):
+            tr.rollout()
+            tr.buffer.ptr = 0
+        torch.cuda.synchronize()
+        assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
+        b = tr.buffer
+        res[mode] = [t.clone() for t in (b.obs_buf, b.act_buf, b.rew_buf, b.val_buf, b.logprob_buf, b.term_buf, tr.next_obs)]
+        res[mode + "_state"] = tr.envs.get_state()
+        tr.close()
     for i, (a, b) in enumerate(zip(res["steps"], res["mega"])):
         assert torch.equal(a, b), i
     for k in res["steps_state"]:
