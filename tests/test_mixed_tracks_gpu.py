@@ -35,7 +35,7 @@ def _track_ids(n_envs, interleave):
 def _replay_per_track(cfg, snaps, first, n_envs, interleave, what, limit=1024):
     tid = _track_ids(n_envs, interleave)
     # one env out of every 32-env wave (rotating offsets; with interleaved tracks the offsets alternate between the tracks)
-    sel = strided_population(n_envs, per_wave=2 if interleave else 1, limit=limit)
+    sel = strided_population(n_envs, per_wave=(2 if interleave else 1) * (4 if n_envs < 4096 else 1), limit=limit)
     out = {}
     for k, path in enumerate(MIXED):
         mine = sel[tid[sel] == k]
