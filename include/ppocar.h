@@ -77,7 +77,12 @@ int pc_ray_count(int num_rays_nominal);
 /* Create n_envs environments on `device` (HIP ordinal).  `tracks`/`n_tracks`: the track table;
  * `track_id` (host, [n_envs], may be NULL = all on track 0) picks each env's track -- the
  * reference allows a different track per env through reset(options=...) (car_env.py:621-628).
- * Replaces: CarEnv.__init__ (car_env.py:475-533) x N + AsyncVectorEnv construction. */
+ * Replaces: CarEnv.__init__ (car_env.py:475-533) x N + AsyncVectorEnv construction.
+ * F32 handles check what their float32 selector assumes of a track (car_env.py:155-184 puts no constraint on the walls): the
+ * walls' bounding box must fit 2000 px and a track may have at most 8192 chain vertices (PC_ERR_UNSUPPORTED, pc_last_hip_error
+ * says which: use PC_DTYPE_F64); walls that cross or touch without being chain neighbours, spikes sharper than ~13 degrees and
+ * walls shorter than the corner margin are accepted and resolved exactly (every ray that selects one of them takes the float64
+ * scan of the whole chain): slower on those rays, never different from the reference. */
 int pc_env_create(int device, int64_t n_envs, int num_rays_nominal, const pc_track* const* tracks, int n_tracks,
                   const uint8_t* track_id, int dtype, pc_env** out);
 void pc_env_destroy(pc_env* e); /* envs.close() (train.py:296) */
@@ -292,7 +297,8 @@ int pc_xchg_status(pc_xchg* x);
 void pc_xchg_destroy(pc_xchg* x);
 
 const char* pc_strerror(int code);
-/* Last HIP error string seen by this thread (diagnostics for PC_ERR_HIP). */
+/* Detail of the last error on this thread: the HIP error string behind a PC_ERR_HIP, or what made pc_env_create answer
+ * PC_ERR_UNSUPPORTED (e.g. an F32 handle for a track that does not fit 2000 px).  Empty when there is none. */
 const char* pc_last_hip_error(void);
 /* 0 in every shipped build.  Non-zero only in the separate developer library `make ablate` builds
  * (libppocar_ablate.so, -DPC_ABLATE=n: timing ablations that skip parts of the rollout kernel); bench.py and the

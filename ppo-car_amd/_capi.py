@@ -24,8 +24,9 @@ class PpoCarError(RuntimeError):
     def __init__(self, code, what):
         self.code = code
         msg = f"{what}: {lib.pc_strerror(code).decode()} (code {code})"
-        if code == PC_ERR_HIP:
-            msg += f" [{lib.pc_last_hip_error().decode()}]"
+        detail = lib.pc_last_hip_error().decode()
+        if detail and code in (PC_ERR_HIP, PC_ERR_UNSUPPORTED):
+            msg += f" [{detail}]"
         super().__init__(msg)
 
 

@@ -20,6 +20,7 @@ struct TrackHdr {        // one per track, read with scalar loads
     double start_x, start_y, start_rot;
     double ax0, ay0;            // F32: the anchor of the sweep's float32 coordinates: the centre of the wall vertices' bounding box
     float bx0, bx1, by0, by1;   // F32: that bounding box (the sweep's flag threshold is priced from it)
+    int n_scan;                 // F32: how many segments carry PC_SEG_SCAN (diagnostic)
     int brk2;                   // F32: index of the chain's SECOND chain-start vertex when the walls are exactly two chains (-1 otherwise)
     int vtxp_off;               // F32: those two chains have the same length (n_chain = 2 brk2): their vertices again, packed by
                                 //      position in the chain, vtxp[vtxp_off .. vtxp_off + brk2) (-1 otherwise)
@@ -55,7 +56,11 @@ __device__ __forceinline__ bool vtx_brk(const Vtx& v) {   // chain start / paddi
 // (car_env.py:171); h = 0.5 - (0.05 px) / |e|: a refined hit whose parameter t satisfies |t - 0.5| < h lies at least 0.05 px
 // inside the segment's ends (-1 for chain starts / padding, which have a zero edge: no segment); prev / next = the chain
 // neighbours of the segment -- prev shares its first endpoint, next its second (0: none; a closed loop wraps).
-struct SegD { double x1, y1, ex, ey, h; int prev_next, pad; };   // prev in the low 16 bits, next in the high 16
+struct SegD { double x1, y1, ex, ey, h; int prev_next, pad; };   // prev in bits 0..14, PC_SEG_SCAN, next in bits 16..30
+// PC_SEG_SCAN: this wall comes closer to another one than float32 can order hits, without the two being plain chain neighbours
+// (walls that cross or touch -- a T-junction, an X --, a spike sharper than ~13 degrees, a wall shorter than the end margin;
+// found on the host at pc_env_create): h = -1, and a ray whose selection lands here is resolved by the float64 scan of the chain
+constexpr int PC_SEG_SCAN = 0x8000;
 
 template <typename T> struct EnvParams {
     int64_t N;
@@ -178,12 +183,12 @@ __device__ __forceinline__ double refine_careful(const int k, const LoadSeg& seg
     if (k != 0) {
         const SegD sg = segs(k);
         const CastD c = cast_terms(sg, px, py, dx, dy);
-        if (strict_hit(c)) {   // the selection is a hit: is a chain neighbour's hit (around the corner it lies next to) nearer?
+        if (strict_hit(c) && !(sg.prev_next & PC_SEG_SCAN)) {   // the selection is a hit: is a chain neighbour's hit (around the corner it lies next to) nearer?
             d = c.un * rcp_d(c.den);
             any = true;
-            const CastD cp = cast_terms(segs(sg.prev_next & 0xffff), px, py, dx, dy);   // (index 0 = no neighbour: zero edge, never a hit)
+            const CastD cp = cast_terms(segs(sg.prev_next & 0x7fff), px, py, dx, dy);   // (index 0 = no neighbour: zero edge, never a hit)
             if (strict_hit(cp)) d = __builtin_fmin(d, cp.un * rcp_d(cp.den));
-            const CastD cn = cast_terms(segs((int)((unsigned)sg.prev_next >> 16)), px, py, dx, dy);
+            const CastD cn = cast_terms(segs((int)(((unsigned)sg.prev_next >> 16) & 0x7fff)), px, py, dx, dy);
             if (strict_hit(cn)) d = __builtin_fmin(d, cn.un * rcp_d(cn.den));
         }
     }

@@ -200,18 +200,38 @@ __device__ __forceinline__ unsigned pk_f16(float a, float b) {  // low half = fp
     const f32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2v));
 }
-// l = fp16(v - h): v_fma_mixlo/mixhi_f16 read h straight out of the packed pair (as fp16), form fma(h, -1, v) -- exact -- and
-// round it once to fp16 into the low / high half: three instructions per pair of values, where converting h back, subtracting
-// and converting again takes five (tools/split_mix_check.hip: the same bits on 4 M pairs, fp16-denormal residuals included).
-// The register the pair ends up in is an MFMA operand, and inline asm is outside the compiler's hazard model: an MFMA that reads
-// it in the very next issue slot gets the stale half (tools/mfma_valu_hazard.hip: one instruction in between is enough in
-// isolation; one experimental schedule of the small form, which had that one instruction, still produced a stale residual --
-// DESIGN.md section 9).  The s_nop keeps two issue slots behind every completed pair: the other wave of the SIMD fills them (no
-// measurable cost in an A/B of the rollout kernel).
+// l = fp16(v - h) as fp16(fma(h, -1, v)): the product and the sum are exact in fp32 (h is v rounded to 11 bits), so the one
+// rounding is the conversion to fp16 -- and written like this the compiler selects v_fma_mixlo_f16 / v_fma_mixhi_f16, which read h
+// straight out of the packed pair, form the fma and round it into the low / high half of the destination: THREE instructions per
+// pair of values (v_cvt_pk_f16_f32 + the two) where convert-back, subtract, convert takes five; the same bits
+// (tools/split_mix_check.hip, fp16-denormal residuals included).  Rounds 2-3 wrote the two mix instructions as inline asm, which
+// is outside the compiler's hazard model: the register they complete is an MFMA operand, and on gfx950 a VALU write needs TWO wait
+// states before an MFMA reads it (hipcc inserts the s_nop itself between compiler-generated instructions; tools/mfma_valu_hazard.hip)
+// -- one schedule of the small form read a stale half.  Here every instruction that writes an MFMA operand is the compiler's own.
+// Two details keep the optimiser from undoing the form:
+//   * the multiplier -1.0 arrives in an SGPR the optimiser cannot see through (as a literal, fma(h, -1, v) is folded into a
+//     subtraction before instruction selection and the fp16 source operand is lost);
+//   * the low half is an fma, the high half a contracted multiply-add (llvm.fma vs llvm.fmuladd: the same fused operation on
+//     this target): two identical expressions are merged by the SLP vectoriser into v_pk_fma_f32 + v_cvt_pk_f16_f32 behind two
+//     conversions back to fp32 -- five instructions again.
+// tests/test_capi_host.py compiles this function alone and checks the instruction selection.
+__device__ __forceinline__ float opaque_neg_one() {
+    float m;
+    asm("s_mov_b32 %0, 0xbf800000" : "=s"(m));     // (a scalar constant only: no vector register is written from inline asm)
+    return m;
+}
 __device__ __forceinline__ void split_pair_h(float a, float b, unsigned& p0, unsigned& p1) {
-    p0 = pk_f16(a, b);
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(p1) : "v"(p0), "v"(a));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n s_nop 1" : "+v"(p1) : "v"(p0), "v"(b));
+    const f32x2 v = {a, b};
+    const f16x2v h = __builtin_convertvector(v, f16x2v);        // round-to-nearest-even, both halves: v_cvt_pk_f16_f32
+    p0 = __builtin_bit_cast(unsigned, h);
+    const float m1 = opaque_neg_one();
+    f16x2v l;
+    l.x = (_Float16)__builtin_fmaf((float)h.x, m1, a);          // v_fma_mixlo_f16
+    {
+#pragma clang fp contract(fast)
+        l.y = (_Float16)((float)h.y * m1 + b);                  // v_fma_mixhi_f16
+    }
+    p1 = __builtin_bit_cast(unsigned, l);
 }
 
 template <int PREC> __device__ __forceinline__ Pieces<PREC> split8(const float (&v)[8]) {

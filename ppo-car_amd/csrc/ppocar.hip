@@ -339,6 +339,7 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
         TrackHdr& h = e->hdr_host[k];
         h.S = t->n_walls();
         h.G = t->n_gates();
+        h.n_scan = 0;
         h.wall_off = (int)segs.size();
         for (size_t i = 0; i < t->walls.size(); i += 4) segs.push_back(Seg{t->walls[i], t->walls[i + 1], t->walls[i + 2], t->walls[i + 3]});
         h.gate_off = (int)segs.size();
@@ -366,6 +367,7 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
             const float fx = (float)(ex / len), fy = (float)(ey / len);
             return Vtx{xr, yr, fx, fy, fx * 0x1p-40f, fy * 0x1p-40f, 0.f, 0.f};
         };
+        std::vector<int> wall_k(h.S);      // host only: wall w = the segment closed by chain vertex wall_k[w]
         for (int w = 0; w < h.S; ++w) {
             const Seg& sg = segs[h.wall_off + w];
             const bool cont = w > 0 && segs[h.wall_off + w - 1].x2 == sg.x1 && segs[h.wall_off + w - 1].y2 == sg.y1;
@@ -377,6 +379,7 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
             vtx.push_back(edge(sg));
             seg64.push_back(SegD{sg.x1, sg.y1, sg.x1 - sg.x2, sg.y1 - sg.y2, -1.0, 0, 0});
             vpos.push_back(make_double2(sg.x2, sg.y2));
+            wall_k[w] = (int)vtx.size() - 1 - h.vtx_off;
         }
         h.n_chain = (int)vtx.size() - h.vtx_off;
         while ((vtx.size() - h.vtx_off) % 4) {  // the sweep walks vertex groups of four: pad with chain-start sentinels
@@ -385,7 +388,17 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
             vpos.push_back(vpos.back());
         }
         h.nV = (int)vtx.size() - h.vtx_off;
-        if (h.nV > 65535) return PC_ERR_UNSUPPORTED;
+        // F32 mode: the selector's "nothing selected" pattern (SEL_INIT) carries vertex index 0 only while the index takes at
+        // most 13 of the candidate's mantissa bits; the float32 coordinates (relative to the track's anchor) and the flag
+        // thresholds are priced for a track that fits 2000 px.  F64 mode has neither limit.
+        if (h.nV > 65535 || (!f64 && h.nV > 8192)) {
+            g_hip_err = "track " + std::to_string(k) + ": " + std::to_string(h.nV) + " chain vertices; dtype f32 takes at most 8192 (use dtype f64)";
+            return PC_ERR_UNSUPPORTED;
+        }
+        if (!f64 && (h.bx1 - h.bx0 > 2000.0f || h.by1 - h.by0 > 2000.0f)) {
+            g_hip_err = "track " + std::to_string(k) + ": the walls' bounding box exceeds 2000 px; dtype f32 is priced for tracks that fit (use dtype f64)";
+            return PC_ERR_UNSUPPORTED;
+        }
         {   // low bits of a sweep candidate that carry the vertex index (at least 5: the unrolled 28-vertex sweep's constant)
             int b = 5;
             while ((1 << b) < h.nV) ++b;
@@ -409,6 +422,21 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
                     }
                 }
             }
+            // What float32 can get wrong is the ORDER of two hits that lie within its resolution of each other.  The selector
+            // keeps 23 - b mantissa bits of a candidate (b index bits): two hits closer than sel_res = 1001 px * 2^-(23 - b) along
+            // a ray (beyond 1000 px the reported distance is 1000 either way) may be taken in the wrong order.
+            //   * Two walls that share a vertex V at an angle of at least ~13 degrees: such hits lie within sel_res / sin(13 deg) of
+            //     V, so a refined hit within `margin` = max(0.05 px, 4.6 sel_res) of a segment's end is compared with the chain
+            //     neighbours under the strict test (SegD::h; refine_careful).
+            //   * Anything else that brings two walls within `near` = max(0.05 px, 1.5 sel_res) of each other -- walls that cross
+            //     or touch without being chain neighbours (a T-junction, an X), a spike sharper than 13 degrees, a wall shorter than
+            //     2 margin (its neighbours' neighbours are that close) -- cannot be settled by looking at two neighbours: those
+            //     segments carry PC_SEG_SCAN and every ray whose selection lands on one of them is resolved by the float64 scan of
+            //     the whole chain under the reference's strict test (car_env.py:178), i.e. exactly.
+            int bits = 5;
+            while ((1 << bits) < h.nV) ++bits;
+            const double sel_res = 1001.0 * std::ldexp(1.0, -(23 - bits));
+            const double margin = std::max(0.05, 4.6 * sel_res), near = std::max(0.05, 1.5 * sel_res);
             for (int k = 0; k < n; ++k) {
                 if (is_start(k)) continue;     // chain starts / padding: no segment (h = -1: |t - 0.5| < h never holds)
                 int c0 = k;     // first vertex of this chain, and its last
@@ -419,7 +447,50 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
                 const int prev = k - 1 > c0 ? k - 1 : (closed && c1 != k ? c1 : 0);       // shares this segment's first endpoint
                 const int next = k + 1 <= c1 ? k + 1 : (closed && c0 + 1 != k ? c0 + 1 : 0);   // shares its second endpoint
                 seg64[o + k].prev_next = prev | (next << 16);
-                seg64[o + k].h = 0.5 - 0.05 / std::hypot(seg64[o + k].ex, seg64[o + k].ey);
+                const double len = std::hypot(seg64[o + k].ex, seg64[o + k].ey);
+                seg64[o + k].h = 0.5 - margin / len;
+                if (len < 2.0 * margin) seg64[o + k].prev_next |= PC_SEG_SCAN;
+            }
+            if (!f64) {
+                const auto seg_of = [&](int w) { return segs[h.wall_off + w]; };
+                const auto pt_seg = [](double px, double py, const Seg& s) {     // distance of a point from a segment
+                    const double ex = s.x2 - s.x1, ey = s.y2 - s.y1, l2 = ex * ex + ey * ey;
+                    double t = l2 > 0.0 ? ((px - s.x1) * ex + (py - s.y1) * ey) / l2 : 0.0;
+                    t = std::min(1.0, std::max(0.0, t));
+                    return std::hypot(px - (s.x1 + t * ex), py - (s.y1 + t * ey));
+                };
+                const auto orient = [](const Seg& s, double px, double py) { return (s.x2 - s.x1) * (py - s.y1) - (s.y2 - s.y1) * (px - s.x1); };
+                for (int a = 0; a < h.S; ++a) {
+                    const Seg sa = seg_of(a);
+                    const int ka = wall_k[a];
+                    if (is_start(ka)) continue;     // (a wall without length is a chain start: never hit)
+                    const int pa = seg64[o + ka].prev_next & 0x7fff, na = (int)(((unsigned)seg64[o + ka].prev_next >> 16) & 0x7fff);
+                    for (int b = a + 1; b < h.S; ++b) {
+                        const Seg sb = seg_of(b);
+                        const int kb = wall_k[b];
+                        if (is_start(kb)) continue;
+                        bool bad;
+                        if (pa == kb || na == kb) {
+                            // chain neighbours: a spike sharper than ~13 degrees (|sin| < 0.22 with the walls folding back on each other)
+                            const double ax = sa.x2 - sa.x1, ay = sa.y2 - sa.y1, bx = sb.x2 - sb.x1, by = sb.y2 - sb.y1;
+                            const double la = std::hypot(ax, ay), lb = std::hypot(bx, by);
+                            const double sn = std::fabs(ax * by - ay * bx) / (la * lb), cs = (ax * bx + ay * by) / (la * lb);
+                            // consecutive walls run head to tail: folding back = their directions nearly opposite
+                            bad = sn < 0.22 && cs < 0.0;
+                        } else {
+                            const double o1 = orient(sa, sb.x1, sb.y1), o2 = orient(sa, sb.x2, sb.y2), o3 = orient(sb, sa.x1, sa.y1), o4 = orient(sb, sa.x2, sa.y2);
+                            const bool cross = ((o1 > 0) != (o2 > 0)) && ((o3 > 0) != (o4 > 0));
+                            const double d = cross ? 0.0 : std::min({pt_seg(sa.x1, sa.y1, sb), pt_seg(sa.x2, sa.y2, sb), pt_seg(sb.x1, sb.y1, sa), pt_seg(sb.x2, sb.y2, sa)});
+                            bad = d < near;
+                        }
+                        if (bad) {
+                            seg64[o + ka].prev_next |= PC_SEG_SCAN;
+                            seg64[o + kb].prev_next |= PC_SEG_SCAN;
+                        }
+                    }
+                }
+                for (int k = 0; k < n; ++k)
+                    if (seg64[o + k].prev_next & PC_SEG_SCAN) { seg64[o + k].h = -1.0; ++h.n_scan; }
             }
         }
         if (f64) {
@@ -563,6 +634,7 @@ int pc_env_create(int device, int64_t n_envs, int num_rays_nominal, const pc_tra
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1 || device < 0 || device >= count) return PC_ERR_NO_DEVICE;
     DeviceGuard guard(device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
+    g_hip_err.clear();
     pc_env* e = new (std::nothrow) pc_env;
     if (!e) return PC_ERR_INVALID_ARG;
     e->device = device;

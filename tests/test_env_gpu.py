@@ -472,3 +472,97 @@ def test_f32_car_on_a_wall_line_and_rays_through_corners_match_the_oracle():
         assert np.array_equal(te, TE) and np.array_equal(tr, TR), dtype
         assert np.all(np.abs(f.astype(np.float64) - F) <= np.spacing(np.maximum(np.abs(F), np.float32(1e-3)))), (dtype, np.abs(f - F).max())
         env.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# what F32 mode assumes of a track is CHECKED at pc_env_create (car_env.py:155-184 puts no constraint on the walls)
+# ------------------------------------------------------------------------------------------------
+def _junction_track_json(path):
+    """A box (outer loop) and an inner polyline T0 -> T1 -> A -> B -> C -> D whose first point lies in the INTERIOR of the box's
+    bottom wall (a T-junction: two walls touch without being chain neighbours) and whose segments AB and CD CROSS each other (an
+    X): both are outside what a float32 selector can order by looking at chain neighbours."""
+    import json
+    W, H = 1280.0, 720.0
+    n = lambda pts: [[x / W, y / H] for x, y in pts]
+    outer = [(50, 50), (650, 50), (650, 350), (50, 350), (50, 50)]
+    inner = [(300, 50), (300, 150), (420, 180), (520, 280), (520, 180), (420, 280)]
+    gates = [(60, 60), (61, 60), (70, 60), (71, 60)]
+    json.dump({"outer_track_points": n(outer), "inner_track_points": n(inner), "reward_gates": n(gates),
+               "initial_position": [150 / W, 200 / H], "initial_angle": 0.0}, open(path, "w"))
+    return path
+
+
+@pytest.mark.parametrize("n", [12, 16])
+def test_f32_t_junction_and_crossing_walls_match_the_oracle(tmp_path, n):
+    """Cars on a fine grid around the T-junction's foot and around the crossing point, and on a coarse grid over the whole box:
+    every observation entry within one float32 ulp of the float64 oracle's, flags equal -- in F32 mode as in F64."""
+    path = _junction_track_json(str(tmp_path / "junction.json"))
+    ot = oracle.Track(path)
+    pts = [(300.0 + dx, 50.0 + dy) for dx in np.linspace(-30, 30, 25) for dy in np.linspace(0.5, 40, 12)]       # around the T's foot
+    pts += [(470.0 + dx, 230.0 + dy) for dx in np.linspace(-40, 40, 33) for dy in np.linspace(-40, 40, 33)]     # around the X
+    pts += [(300.0 + s * 10.0 ** e, 60.0) for e in range(-9, 0) for s in (1.0, -1.0)]                            # beside the T wall's line
+    pts += [(x, y) for x in np.linspace(60, 640, 30) for y in np.linspace(60, 340, 15)]
+    M = len(pts)
+    ora = oracle.OracleVecEnv(ot, M, num_rays=n, reward_scaling=1.0, threads=8)
+    ora.reset()
+    st = {k: getattr(ora, k).copy() for k in STATE}
+    st["px"], st["py"] = np.array([p[0] for p in pts]), np.array([p[1] for p in pts])
+    st["rot"] = ot.start_rot + 5.0 * (np.arange(M) % 72)                                                         # every heading of the lattice
+    ora.set_state(**st)
+    O, R, TE, TR, F = ora.step(np.full(M, 8), want_final_obs=True)
+    assert TE.any() and (~TE).any()
+    for dtype in ("f64", "f32"):
+        env = pc.VecCarEnv(M, path, num_rays=n, reward_scaling=1.0, dtype=dtype)
+        env.reset()
+        env.set_state(**st)
+        o, r, te, tr, f, _ = _step(env, np.full(M, 8))
+        wall_margin = np.abs(F[:, 6:6 + n:n // 4] * 1000.0 - 10.0).min(1)
+        bad = (te != TE) | (tr != TR)
+        assert not (bad & (wall_margin > MARGIN_PX)).any(), dtype
+        assert np.all(np.abs(f.astype(np.float64) - F) <= np.spacing(np.maximum(np.abs(F), np.float32(1e-3)))), (dtype, np.abs(f - F).max())
+        if dtype == "f64":
+            assert np.array_equal(f, F) and not bad.any()
+        env.close()
+
+
+@pytest.mark.parametrize("n_envs", [2048, 20000])
+def test_f32_junction_track_through_the_persistent_rollout_kernel(tmp_path, n_envs):
+    """The same track through pc_rollout (small and big form: the flagged segments sit in the LDS copy of the chain) and the
+    per-step kernels: bitwise each other, and the oracle replayed on the stored actions."""
+    from ppo_car_amd.ppo import PPOConfig, Trainer
+    from test_rollout_baseline_gpu import _oracle_replay_check, _snap, strided_population
+    path = _junction_track_json(str(tmp_path / "junction.json"))
+    res, first = {}, None
+    for mode in ("mega", "steps"):
+        cfg = PPOConfig(n_envs=n_envs, n_steps=200, num_rays=16, track=path, rollout_kernel=mode, use_graphs=False, seed=19)
+        tr = Trainer(cfg, device="cuda")
+        if first is None:
+            first = tr.next_obs.clone()
+        tr.rollout()
+        torch.cuda.synchronize()
+        assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
+        res[mode] = _snap(tr)
+        tr.close()
+    for i, (a, b) in enumerate(zip(res["mega"], res["steps"])):
+        assert torch.equal(a, b), i
+    _oracle_replay_check(cfg, res["mega"], first, f"junction track N={n_envs}", sel=strided_population(n_envs, per_wave=2, limit=512))
+
+
+def test_f32_handles_refuse_tracks_outside_their_pricing_and_say_why():
+    """F32 mode's float32 coordinates and flag thresholds are priced for a track that fits 2000 px, its selector for at most
+    8192 chain vertices: pc_env_create answers PC_ERR_UNSUPPORTED with a message that names dtype f64, which takes both."""
+    gates = np.array([[60.0, 60.0, 61.0, 60.0]])
+    wide = np.array([[0, 0, 2500, 0], [2500, 0, 2500, 300], [2500, 300, 0, 300], [0, 300, 0, 0]], np.float64)
+    with pytest.raises(pc.PpoCarError) as ei:
+        pc.VecCarEnv(4, pc.Track(walls=wide, gates=gates, start=(100.0, 100.0, 0.0)), num_rays=12, dtype="f32")
+    assert ei.value.code == -5 and "2000 px" in str(ei.value) and "f64" in str(ei.value)
+    env = pc.VecCarEnv(4, pc.Track(walls=wide, gates=gates, start=(100.0, 100.0, 0.0)), num_rays=12, dtype="f64")
+    obs, _ = env.reset()
+    assert obs.shape == (4, 18)
+    env.close()
+    t = np.linspace(0, 2 * np.pi, 8300)
+    ring = np.stack([600 + 400 * np.cos(t), 350 + 300 * np.sin(t)], 1)
+    many = np.concatenate([ring[:-1], ring[1:]], 1)                      # 8299 walls in one chain
+    with pytest.raises(pc.PpoCarError) as ei:
+        pc.VecCarEnv(4, pc.Track(walls=many, gates=gates, start=(600.0, 350.0, 0.0)), num_rays=12, dtype="f32")
+    assert ei.value.code == -5 and "8192" in str(ei.value)

@@ -1,4 +1,9 @@
-// mfma_valu_hazard.hip -- developer probe: does v_mfma_f32_16x16x32_f16 on gfx950 see a VGPR that a VALU instruction wrote
+// mfma_valu_hazard.hip -- developer probe (round 3; HISTORICAL -- its conclusion "one instruction in between is enough" was an
+// observation on these particular timings, NOT the rule).  The gfx950 rule is TWO wait states between a VALU write of a VGPR and an
+// MFMA that reads it: hipcc emits `s_nop 1` between a compiler-generated VALU write and the dependent MFMA, and LLVM's hazard
+// recogniser does not see instructions inside inline asm.  Since round 4 the operand split is compiler-generated
+// (policy.hpp: split_pair_h) and tests/test_isa_static.py checks the two-wait-state rule statically over every kernel of the library.
+// The probe's question: does v_mfma_f32_16x16x32_f16 on gfx950 see a VGPR that a VALU instruction wrote
 // N instructions earlier?  (Inline asm is outside the compiler's hazard handling: the operand split of the policy pass writes MFMA
 // operands with v_fma_mixlo/mixhi_f16 from inline asm.)  For N = 0..4 independent instructions between the write and the MFMA:
 // B operand = all ones (fp16 1.0) except that its last dword is rewritten from `stale` to `fresh` right before the MFMA.

@@ -1,4 +1,5 @@
-// developer probe: tools/mfma_valu_hazard.hip's question under CONTENTION -- two waves per SIMD (512 threads), each looping over
+// developer probe (round 3; HISTORICAL: see the header of tools/mfma_valu_hazard.hip -- the rule is two wait states, what this
+// probe observed with one is timing luck): tools/mfma_valu_hazard.hip's question under CONTENTION -- two waves per SIMD (512 threads), each looping over
 //   [independent MFMAs] ; v_fma_mixhi (rewrites the high halves of two dwords of the next MFMA's B operand) ; N fillers ; MFMA ; check
 // counts the iterations in which the MFMA did not see the fresh halves.
 #include <hip/hip_runtime.h>
