@@ -304,7 +304,9 @@ def main():
         for _ in range(n_epochs):
             trn.run_epoch(sync=False)
         barrier()
-        return time.perf_counter() - t0
+        dt_ = time.perf_counter() - t0
+        trn.check_exchange()        # --exchange p2p: a timed-out exchange invalidates the run (raises, non-zero exit)
+        return dt_
 
     for _ in range(max(args.warmup, 2 if cfg.use_graphs else 0)):   # graphs: 1 eager epoch, then capture, then replay
         tr.run_epoch(sync=False)
@@ -442,7 +444,7 @@ def main():
                                    f"train_iters={cfg.train_iters}; one step = one PPO epoch (rollout + GAE + update)",
                        "n_envs_total": cfg.n_envs * world, "parallelism": f"env-sharded dp{world}, 1 flat grad all-reduce/minibatch",
                        "ranks": dist.get_world_size() if dist is not None else 1,
-                       "rccl_ranks": (dist.get_world_size() if (dist is not None and dist.get_backend() == "nccl") else 0) if dist is not None else 1,
+                       "rccl_ranks": dist.get_world_size() if (dist is not None and dist.get_backend() == "nccl") else 0,   # 0: no RCCL communicator exists
                        "update_path": ("multi-rank (all-reduce + clip/Adam per minibatch), " + ("captured in the epoch graph" if captured else "enqueued eagerly"))
                        if (world > 1 or args.force_collective) else "single-rank epoch graph",
                        "backend": (dist.get_backend() if dist is not None else None),

@@ -280,18 +280,23 @@ int pc_ppo_minibatch_prepared(int device, const float* prepared_mb, int B, int D
  *   pc_xchg_create(device, rank, world, n_floats)   allocates this rank's staging buffer (uncached device memory);
  *   pc_xchg_local_handle(x, out)                    PC_XCHG_HANDLE_BYTES bytes (a hipIpcMemHandle_t) for the other ranks -- the
  *                                                   caller carries them across (e.g. torch.distributed.all_gather_object);
- *   pc_xchg_connect(x, all)                         `all` = world x PC_XCHG_HANDLE_BYTES bytes in rank order: maps the peers;
+ *   pc_xchg_connect(x, all)                         `all` = world x PC_XCHG_HANDLE_BYTES bytes in rank order: maps the peers and
+ *                                                   verifies / enables peer access to each peer's device (PC_ERR_UNSUPPORTED with a
+ *                                                   message in pc_last_hip_error when a peer is unreachable);
+ *   pc_xchg_set_timeout(x, seconds)                 patience of a wait inside the exchange kernel (default 20 s);
  *   pc_xchg_allreduce(x, bucket, stream)            in place, asynchronous on `stream`, capturable into a HIP graph: bucket[0..n)
  *                                                   := sum over ranks (rank order) of their buckets.  Every rank must make the
  *                                                   same sequence of calls;
  *   pc_xchg_status(x)                               synchronises the device; PC_ERR_TIMEOUT if a wait inside any call gave up
- *                                                   (~20 s without a peer's flag: the kernel then finishes with a wrong sum
- *                                                   rather than hang the GPU, and later calls on the handle do not wait again);
+ *                                                   (the timeout passed without a peer's flag: the kernel then finishes with a
+ *                                                   WRONG sum rather than hang the GPU, and later calls on the handle do not wait
+ *                                                   again): the caller must check it wherever it synchronises and abort the job;
  *   pc_xchg_destroy(x)                              after every rank has finished using it (the caller synchronises the ranks). */
 #define PC_XCHG_HANDLE_BYTES 64
 int pc_xchg_create(int device, int rank, int world, int64_t n_floats, pc_xchg** out);
 int pc_xchg_local_handle(pc_xchg* x, void* handle_out);
 int pc_xchg_connect(pc_xchg* x, const void* all_handles);
+int pc_xchg_set_timeout(pc_xchg* x, double seconds);
 int pc_xchg_allreduce(pc_xchg* x, float* bucket, void* stream);
 int pc_xchg_status(pc_xchg* x);
 void pc_xchg_destroy(pc_xchg* x);

@@ -145,17 +145,57 @@ __device__ __forceinline__ double rcp_d(const double den) {
 __device__ __forceinline__ bool strict_hit(const CastD& c) {
     return (c.tn * c.den > 0.0) & (__builtin_fabs(c.tn) < __builtin_fabs(c.den)) & (c.un * c.den > 0.0);
 }
+// ... but the reference does not evaluate that test in exact arithmetic: it forms (x4, y4) = pos + dir (car_env.py:169) and works
+// with the ROUNDED differences (x3 - x4), (y3 - y4), i.e. with a direction perturbed by up to an ulp of the car's position (for
+// dir = (cos 90 deg, 1) = (6e-17, 1) the x component vanishes altogether), and two rounded quotients.  Away from a tie that
+// changes nothing (3e-14 rad; the test's margins are relative 1e-13).  AT a tie -- a ray that passes exactly through a vertex,
+// a car exactly on a wall's line, exactly parallel: what axis-aligned tracks with integer coordinates produce at will -- hit or
+// miss is decided by those roundings, and the two walls that meet at the vertex can both say "miss" (the ray passes between them
+// and reports whatever lies behind: 100s of pixels away).  near_tie says when one of the test's comparisons is within 1e-9
+// (relative; ~1e4 x the reference's rounding) of flipping; cast_lit then repeats the reference's arithmetic LITERALLY
+// (car_env.py:166-181,:205; the float64 kernel's cast_ref), so that the decision is the reference's own.
+__device__ __forceinline__ bool near_tie(const SegD& sg, const CastD& c) {
+    const double ad = __builtin_fabs(c.den), at = __builtin_fabs(c.tn), g = ad * 1e-9;
+    const double m = __builtin_fmin(__builtin_fmin(at, __builtin_fabs(ad - at)), __builtin_fabs(c.un));   // t ~ 0, t ~ 1, u ~ 0 (u in px)
+    return (m <= g) | (ad <= (__builtin_fabs(sg.ex) + __builtin_fabs(sg.ey)) * 1e-9);                     // ... or (nearly) parallel
+}
+// Ray.cast + np.linalg.norm exactly as the reference evaluates them (cast_ref), for the segment (x1, y1) -> (x1 - ex, y1 - ey):
+// (x1 - x2) = ex and (x2 - x1) = -ex as the reference rounds them.  Returns the distance; `hit` = the reference's verdict.
+__device__ __forceinline__ double cast_lit(const SegD& sg, const double px, const double py, const double dx, const double dy, bool& hit) {
+    const double x4 = px + dx, y4 = py + dy;                                   // :169
+    const double mx = px - x4, my = py - y4;                                   // (x3 - x4), (y3 - y4)
+    const double den = sg.ex * my - sg.ey * mx;                                // :171
+    hit = false;
+    if (den == 0) return 1000.0;                                               // :172
+    const double t = ((sg.x1 - px) * my - (sg.y1 - py) * mx) / den;            // :175
+    const double u = -(sg.ex * (sg.y1 - py) - sg.ey * (sg.x1 - px)) / den;     // :176
+    if (0 < t && t < 1 && u > 0) {                                             // :178
+        hit = true;
+        const double ptx = sg.x1 + t * -sg.ex, pty = sg.y1 + t * -sg.ey;       // :180-181
+        const double d0 = px - ptx, d1 = py - pty;
+        return sqrt(fma(d1, d1, d0 * d0));                                     // np.linalg.norm (see cast_ref)
+    }
+    return 1000.0;
+}
+// one ray against one segment, the reference's verdict and distance (1000.0 = Ray.get_distance's `largest_distance` for a miss):
+// the numerators' test and un / den wherever that is safe, the literal arithmetic at a tie
+struct CastR { double d; bool hit; };
+__device__ __forceinline__ CastR cast_exact(const SegD& sg, const double px, const double py, const double dx, const double dy) {
+    const CastD c = cast_terms(sg, px, py, dx, dy);
+    CastR r;
+    r.hit = strict_hit(c);
+    r.d = c.un * rcp_d(c.den);
+    if (near_tie(sg, c)) r.d = cast_lit(sg, px, py, dx, dy, r.hit);            // (rare: a branch the wave skips)
+    r.d = r.hit ? r.d : 1000.0;
+    return r;
+}
 // Ray.get_distance (car_env.py:186-213) of ONE ray against a whole wall chain in float64: the refinement's exhaustive form,
 // taken only by the rare lanes whose float32 selection could not be certified (see refine_careful).  segs(1 .. n - 1).
 template <typename LoadSeg>
 __device__ __forceinline__ double scan_chain_d(const LoadSeg& segs, const int n, const double px, const double py, const double dx,
                                                const double dy) {
     double best = 1000.0;                                          // :198
-    for (int k = 1; k < n; ++k) {
-        const SegD sg = segs(k);
-        const CastD c = cast_terms(sg, px, py, dx, dy);
-        if (strict_hit(c)) best = __builtin_fmin(best, c.un * rcp_d(c.den));   // :203-207
-    }
+    for (int k = 1; k < n; ++k) best = __builtin_fmin(best, cast_exact(segs(k), px, py, dx, dy).d);   // :203-207
     return best;
 }
 // ---- the float64 distance of one ray, given the float32 sweep's selection (candidate bits: vertex index k in the low bits;
@@ -178,30 +218,36 @@ __device__ __forceinline__ double refine_fast(const SegD& sg, const double px, c
 template <typename LoadSeg>
 __device__ __forceinline__ double refine_careful(const int k, const LoadSeg& segs, const int nV, const double px, const double py,
                                                  const double dx, const double dy) {
-    double d = 1000.0;
-    bool any = false;
-    if (k != 0) {
-        const SegD sg = segs(k);
-        const CastD c = cast_terms(sg, px, py, dx, dy);
-        if (strict_hit(c) && !(sg.prev_next & PC_SEG_SCAN)) {   // the selection is a hit: is a chain neighbour's hit (around the corner it lies next to) nearer?
-            d = c.un * rcp_d(c.den);
-            any = true;
-            const CastD cp = cast_terms(segs(sg.prev_next & 0x7fff), px, py, dx, dy);   // (index 0 = no neighbour: zero edge, never a hit)
-            if (strict_hit(cp)) d = __builtin_fmin(d, cp.un * rcp_d(cp.den));
-            const CastD cn = cast_terms(segs((int)(((unsigned)sg.prev_next >> 16) & 0x7fff)), px, py, dx, dy);
-            if (strict_hit(cn)) d = __builtin_fmin(d, cn.un * rcp_d(cn.den));
+    // ONE call site of cast_exact (its literal branch is a few hundred instructions of float64 division and square root: the
+    // persistent kernels pay for code size) driven by a per-lane state machine: first the selection and its two chain
+    // neighbours -- unless the selection is no hit after all, or flagged PC_SEG_SCAN --, else every segment of the chain.
+    bool scan = k == 0;
+    int j = 0, prev = 0, next = 0;
+    double d = 1000.0;                                             // :198
+    while (true) {
+        const int idx = scan ? j + 1 : (j == 0 ? k : (j == 1 ? prev : next));
+        const SegD sg = segs(idx);
+        const CastR c = cast_exact(sg, px, py, dx, dy);
+        if (!scan && j == 0) {
+            if (!c.hit || (sg.prev_next & PC_SEG_SCAN)) {          // nothing certified: scan (nV >= 4: the chain has segments)
+                scan = true;
+                continue;
+            }
+            prev = sg.prev_next & 0x7fff;                          // (index 0 = no neighbour: zero edge, never a hit)
+            next = (int)(((unsigned)sg.prev_next >> 16) & 0x7fff);
         }
+        d = __builtin_fmin(d, c.d);                                // :203-207
+        ++j;
+        if (j == (scan ? nV - 1 : 3)) break;
     }
-    if (!any) d = scan_chain_d(segs, nV, px, py, dx, dy);
     return d;
 }
 // min(1000, d) / 1000 as the observation holds it (Ray.get_distance :198,:210-211; car_env.py:593,:595)
 __device__ __forceinline__ float obs_dist(const double d) { return (float)(__builtin_fmin(d, 1000.0) * 0.001); }
-// one ray against one segment (the reward gates: Car.check_collision(gate), car_env.py:387-390), float64, strict
+// one ray against one segment (the reward gates: Car.check_collision(gate), car_env.py:387-390), float64, the reference's verdict
 __device__ __forceinline__ double cast_d(const Seg& s, const double px, const double py, const double dx, const double dy) {
     const SegD sg = {s.x1, s.y1, s.x1 - s.x2, s.y1 - s.y2, 0.0, 0, 0};
-    const CastD c = cast_terms(sg, px, py, dx, dy);
-    return strict_hit(c) ? __builtin_fmin(c.un * rcp_d(c.den), 1000.0) : 1000.0;
+    return __builtin_fmin(cast_exact(sg, px, py, dx, dy).d, 1000.0);
 }
 
 template <typename T> struct Math;

@@ -529,15 +529,13 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
         // lane can cast any ray (directions come from the lattice table), so the casts are dealt round-robin to the env's lanes
         // instead of falling on whichever lane owns those rays (with rays strided over the lanes: all on lane 0).
         const int k5o = 5 * Math<float>::mod72(st.k);
-#pragma unroll
-        for (int jj = 0; jj < 7; ++jj) {
+#pragma unroll 1
+        for (int jj = 0; jj * G < p.nc; ++jj) {  // (uniform trip count; rolled: one copy of cast_exact's literal branch)
             const int j = g + jj * G;
-            if (jj * G < p.nc) {  // uniform
-                const unsigned m = (unsigned)(k5o + (j < p.nc ? j : 0) * p.q * p.step_deg);
-                const double2 cs = p.dirtab64[h.dir_off + (int)min(m, m - 360u)];
-                const bool hit = cast_d(gate, opx, opy, cs.x, cs.y) < 10.0;  // :387,:390
-                gate_hit |= hit & (j < p.nc);
-            }
+            const unsigned m = (unsigned)(k5o + (j < p.nc ? j : 0) * p.q * p.step_deg);
+            const double2 cs = p.dirtab64[h.dir_off + (int)min(m, m - 360u)];
+            const bool hit = cast_d(gate, opx, opy, cs.x, cs.y) < 10.0;  // :387,:390
+            gate_hit |= hit & (j < p.nc);
         }
     }
 

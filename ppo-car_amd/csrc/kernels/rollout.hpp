@@ -291,9 +291,9 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     const Seg gate = {gv.x, gv.y, gv.z, gv.w};
     const int k80o = 80 * k72;
     bool gate_hit = false;
-#pragma unroll
-    for (int jj = 0; jj < 4 / G; ++jj) {
-        const f64x2 cs = dir64_at(k80o + gq[jj]);
+#pragma unroll 1
+    for (int jj = 0; jj < 4 / G; ++jj) {      // (rolled: ONE copy of cast_exact's literal branch in the kernel)
+        const f64x2 cs = dir64_at(k80o + (jj == 0 ? gq[0] : gq[1]));
         gate_hit |= cast_d(gate, opx, opy, cs.x, cs.y) < 10.0;  // :387,:390
     }
     // ---- wall sweep (float32 selector, env_step.hpp).  More than 12 ray slots per lane (33 rays: 17) are swept in TWO passes over

@@ -1308,6 +1308,7 @@ struct pc_xchg {
     char* local = nullptr;                       // this rank's staging allocation (uncached device memory)
     char* peer[XCHG_MAX_RANKS] = {nullptr};      // every rank's allocation as mapped here (peer[rank] == local)
     bool connected = false;
+    double timeout_s = 20.0;
     size_t data_bytes() const { return (size_t)2 * world * n_pad * sizeof(float); }
     size_t flag_bytes() const { return (size_t)2 * world * n_chunks * sizeof(unsigned); }
     size_t total_bytes() const { return data_bytes() + flag_bytes() + (size_t)n_chunks * sizeof(unsigned) + 64; }
@@ -1325,6 +1326,7 @@ struct pc_xchg {
         v.n = (int)n;
         v.n_pad = n_pad;
         v.n_chunks = n_chunks;
+        v.timeout_ticks = (unsigned long long)(timeout_s * XCHG_TICKS_PER_SECOND);
         return v;
     }
 };
@@ -1379,6 +1381,8 @@ int pc_xchg_local_handle(pc_xchg* x, void* handle_out) {
 int pc_xchg_connect(pc_xchg* x, const void* all_handles) {
     if (!x || !all_handles) return PC_ERR_INVALID_ARG;
     DeviceGuard guard(x->device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    g_hip_err.clear();
     for (int r = 0; r < x->world; ++r) {
         if (r == x->rank || x->peer[r]) continue;
         hipIpcMemHandle_t h;
@@ -1386,8 +1390,31 @@ int pc_xchg_connect(pc_xchg* x, const void* all_handles) {
         void* q = nullptr;
         HIPCHK(hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess));
         x->peer[r] = static_cast<char*>(q);
+        // The exchange kernel WRITES into this mapping from a running kernel: make sure the peer's device is reachable from ours
+        // NOW (a distinct error at connect time) rather than as a 20-second wait for a flag that can never arrive.
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, q) == hipSuccess && attr.device != x->device && attr.device >= 0) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, x->device, attr.device) != hipSuccess || !can) {
+                g_hip_err = "pc_xchg_connect: device " + std::to_string(x->device) + " has no peer access to rank " + std::to_string(r) +
+                            "'s device " + std::to_string(attr.device) + " (xGMI / PCIe P2P unavailable): use PPOConfig.exchange = \"rccl\"";
+                return PC_ERR_UNSUPPORTED;
+            }
+            const hipError_t pe = hipDeviceEnablePeerAccess(attr.device, 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+                g_hip_err = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe);
+                return PC_ERR_HIP;
+            }
+            (void)hipGetLastError();     // (hipErrorPeerAccessAlreadyEnabled is sticky otherwise)
+        }
     }
     x->connected = true;
+    return PC_OK;
+}
+
+int pc_xchg_set_timeout(pc_xchg* x, double seconds) {
+    if (!x || !(seconds > 0.0) || seconds > 3600.0) return PC_ERR_INVALID_ARG;
+    x->timeout_s = seconds;
     return PC_OK;
 }
 

@@ -73,6 +73,9 @@ class PPOConfig:
                                            # all-reduce over peer-mapped buffers (pc_xchg_*: every rank writes its bucket into every peer's slot,
                                            # sums locally in rank order) -- one xGMI hop of latency instead of a ring / tree schedule, a plain
                                            # kernel, so capture_collectives can put it into the epoch graph with any backend
+    exchange_timeout_s: float = 20.0       # exchange = "p2p": how long an exchange kernel waits for a peer's flag before it gives up; the
+                                           # Trainer checks for that wherever it synchronises (run_epoch(sync=True), check_exchange(), close())
+                                           # and raises ExchangeTimeout
     policy_precision: int = -1             # arithmetic of the fused policy step's GEMMs: 2 fp16x2, 1 bf16x3, 0 fp32-input MFMA;
                                            # -1 = the library's default (fp16x2).  Per Trainer (a pc_policy handle), not process-wide
     policy_split: int = -1                 # work decomposition of the fused policy step: -1 automatic by batch size, 0 never, 1 always
@@ -115,20 +118,33 @@ class GradExchange:
             self.flat_grad.div_(self.world_size)
 
 
+class ExchangeTimeout(RuntimeError):
+    """A peer rank did not arrive at a gradient exchange within the timeout: the sums of that exchange (and every later one on
+    the handle) are WRONG and this rank's replica has diverged.  The job must stop; the launcher tears the other ranks down."""
+
+
 class P2PExchange:
     """pc_xchg_*: the flat gradient bucket summed over the ranks of one node by a one-shot exchange over hipIpc-mapped staging
     buffers (include/ppocar.h).  The IPC handles travel through torch.distributed (any backend); the exchange itself is one
     kernel launch on the caller's stream, in place, bit-identical on every rank."""
 
-    def __init__(self, flat_grad, rank, world_size, device):
+    def __init__(self, flat_grad, rank, world_size, device, timeout_s=20.0):
         import ctypes as C
+        import socket
         import torch.distributed as dist
         self.flat_grad, self.rank, self.world = flat_grad, rank, world_size
         self.device = torch.device(device)
+        self._h = None
+        self.failed = False
+        hosts = [None] * world_size
+        dist.all_gather_object(hosts, socket.gethostname())
+        if len(set(hosts)) != 1:       # hipIpc handles are meaningful inside one node only
+            raise ValueError(f"PPOConfig.exchange = 'p2p' needs all ranks on one node (got hosts {sorted(set(hosts))}): use exchange = 'rccl'")
         di = self.device.index if self.device.index is not None else torch.cuda.current_device()
         h = C.c_void_p()
         check(lib.pc_xchg_create(di, rank, world_size, flat_grad.numel(), C.byref(h)), "pc_xchg_create")
         self._h = h
+        check(lib.pc_xchg_set_timeout(h, float(timeout_s)), "pc_xchg_set_timeout")
         mine = (C.c_char * 64)()
         check(lib.pc_xchg_local_handle(h, mine), "pc_xchg_local_handle")
         handles = [None] * world_size
@@ -142,14 +158,21 @@ class P2PExchange:
               "pc_xchg_allreduce")
 
     def status(self):
-        check(lib.pc_xchg_status(self._h), "pc_xchg_status")
+        """Synchronises the device.  Raises ExchangeTimeout if any exchange so far gave up waiting for a peer."""
+        rc = lib.pc_xchg_status(self._h)
+        if rc == -7:
+            self.failed = True
+            raise ExchangeTimeout(f"rank {self.rank}: a peer did not arrive at a gradient exchange (pc_xchg: PC_ERR_TIMEOUT); the reduced "
+                                  "gradients since then are wrong -- aborting instead of training on them")
+        check(rc, "pc_xchg_status")
 
     def close(self):
         if self._h is not None:
             import torch.distributed as dist
             torch.cuda.synchronize(self.device)
-            if dist.is_initialized():
+            if dist.is_initialized() and not self.failed:
                 dist.barrier()      # no rank frees its staging buffer while a peer may still write into it
+            # (after a timeout the peers are gone or hung: a barrier would hang this rank too; its buffer is released as it is)
             lib.pc_xchg_destroy(self._h)
             self._h = None
 
@@ -190,7 +213,8 @@ class PPOLearner:
             raise ValueError(f"PPOConfig.exchange must be 'rccl' or 'p2p', not {cfg.exchange!r}")
         self.p2p = None
         if cfg.exchange == "p2p" and world_size > 1 and self.device.type == "cuda":
-            self.p2p = P2PExchange(self.flat_grad, rank, world_size, self.device)
+            self.p2p = P2PExchange(self.flat_grad, rank, world_size, self.device, timeout_s=cfg.exchange_timeout_s)
+            self.exchange = self._exchange_and_average      # the torch-op update paths (fused_update off) exchange through it too
         self._capture_failed = False
         self.graphs = bool(cfg.use_graphs) and self.device.type == "cuda"
         self.fused = bool(cfg.fused_update) and self.device.type == "cuda" and 2 <= cfg.batch_size <= 1024
@@ -265,6 +289,11 @@ class PPOLearner:
                                self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(), self.lr_dev.data_ptr(),
                                self.flat_param.numel(), cfg.max_grad_norm, 1.0 / self.world_size, 0.9, 0.999, 1e-5,
                                self._stream()), "pc_clip_adam")
+
+    def _exchange_and_average(self):
+        """GradExchange's contract (flat_grad := the MEAN over ranks) on top of the configured transport."""
+        self._sum_gradients()
+        self.flat_grad.div_(self.world_size)
 
     def _sum_gradients(self):
         """The one exchange step per minibatch: flat_grad := SUM over ranks (the 1/W is folded into the clip + Adam kernels)."""
@@ -743,6 +772,7 @@ class Trainer:
         self.epoch += 1
         if not sync:
             return None
+        self.check_exchange()       # (synchronises; the scalars below are fetched anyway) a timed-out exchange stops the job HERE
         m = (self.learner.metrics / self.cfg.train_iters).tolist()   # divided by train_iters, not by #minibatches
         avg_reward = float(rew_mean) / self.cfg.reward_scaling       # train.py:272-274
         if self.world_size > 1:
@@ -791,8 +821,17 @@ class Trainer:
         self.start_time = time.time() - float(sd.get("elapsed", 0.0))     # charts/SPS = global_step / elapsed (train.py:292)
         self.agent._rng_offset = sd["agent_rng_offset"]
 
-    def close(self):
+    def check_exchange(self):
+        """exchange = "p2p": synchronise and raise ExchangeTimeout if an exchange kernel gave up waiting for a peer (its sums, and
+        every later one's, are wrong).  Called by run_epoch(sync=True) and close(); a caller that queues epochs without
+        synchronising (bench.py) calls it where it synchronises."""
         if self.learner.p2p is not None:
-            self.learner.p2p.status()       # a peer that never arrived at an exchange surfaces here as PC_ERR_TIMEOUT
-            self.learner.p2p.close()
-        self.envs.close()
+            self.learner.p2p.status()
+
+    def close(self):
+        try:
+            self.check_exchange()           # a peer that never arrived at an exchange surfaces here at the latest
+        finally:                            # ... and the handles are released either way
+            if self.learner.p2p is not None:
+                self.learner.p2p.close()
+            self.envs.close()

@@ -175,32 +175,66 @@ def test_gradient_all_reduce_is_captured_into_the_update_graph(tmp_path):
     assert torch.allclose(res["captured"][0], res["single"][0], atol=2e-6, rtol=1e-5)
 
 
-def _two_rank_nccl_worker(rank, world, port, out_dir):
+def _two_gpu_worker(rank, world, port, out_dir, exchange, capture):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
-    cfg = PPOConfig(n_envs=512, n_steps=64, batch_size=32, train_iters=2, track=TRACKS["big_track"], num_rays=16, seed=11)
+    cfg = PPOConfig(n_envs=512, n_steps=64, batch_size=32, train_iters=2, track=TRACKS["big_track"], num_rays=16, seed=11,
+                    exchange=exchange, capture_collectives=capture)
     tr = Trainer(cfg, device=f"cuda:{rank}", rank=rank, world_size=world)
     tr.run_epoch()
     s2 = tr.run_epoch()
     torch.cuda.synchronize()
     torch.save({"param": tr.learner.flat_param.cpu(), "acts": tr.buffer.act_buf.cpu(), "scalars": s2,
-                "captured": tr.learner._epoch_graph is not None}, os.path.join(out_dir, f"r{rank}.pt"))
+                "captured": tr.learner._epoch_graph is not None}, os.path.join(out_dir, f"r{rank}_{exchange}_{int(capture)}.pt"))
     tr.close()
     dist.destroy_process_group()
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (one RCCL rank per GPU)")
-def test_two_rccl_ranks_keep_replicas_identical(tmp_path):
+# What the two tests below verify ON A BOX WITH TWO GPUs (this pool's boxes have one; the driver's 8-GPU node runs bench.py, not
+# pytest): SURVEY 8(e)'s one exchange step per minibatch ACROSS DEVICES -- one process per GPU, RCCL communicator of world size 2
+# over xGMI, or the library's one-shot exchange writing into the peer GPU's hipIpc-mapped staging buffer (system-scope release /
+# acquire across the fabric, peer access enabled by pc_xchg_connect) -- eager and captured into the epoch's update graph: replicas
+# bit-identical after two epochs, different action streams per shard, all-reduced scalars equal, and p2p == RCCL bit for bit (two
+# ranks: a + b in either order).  Same-device rehearsals of all of this run in tests/test_trainer_gpu.py.
+_TWO_GPU_REASON = ("needs two GPUs (found %d): would run one rank per GPU and check that replicas stay bit-identical through %s "
+                   "across devices (xGMI); the same-device rehearsal is test_trainer_gpu.py::%s")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2,
+                    reason=_TWO_GPU_REASON % (torch.cuda.device_count(), "an RCCL all-reduce of world size 2, eager and captured",
+                                              "test_two_ranks_on_one_gpu_keep_replicas_identical"))
+@pytest.mark.parametrize("capture", [False, True])
+def test_two_rccl_ranks_keep_replicas_identical(tmp_path, capture):
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_two_rank_nccl_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    mp.spawn(_two_gpu_worker, args=(2, port, str(tmp_path), "rccl", capture), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"r{r}_rccl_{int(capture)}.pt") for r in (0, 1))
     assert torch.equal(r0["param"], r1["param"]) and not torch.equal(r0["acts"], r1["acts"])
     assert r0["scalars"]["charts/avg_reward"] == pytest.approx(r1["scalars"]["charts/avg_reward"])
+    assert r0["captured"] == capture
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2,
+                    reason=_TWO_GPU_REASON % (torch.cuda.device_count(), "the one-shot p2p exchange (pc_xchg_*) over peer-mapped buffers, eager and captured",
+                                              "test_one_shot_p2p_exchange_between_two_ranks_on_one_gpu"))
+@pytest.mark.parametrize("capture", [False, True])
+def test_one_shot_p2p_exchange_across_two_gpus(tmp_path, capture):
+    import torch.multiprocessing as mp
+    res = {}
+    for exchange in ("p2p", "rccl"):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mp.spawn(_two_gpu_worker, args=(2, port, str(tmp_path), exchange, capture and exchange == "p2p"), nprocs=2, join=True)
+        res[exchange] = [torch.load(tmp_path / f"r{r}_{exchange}_{int(capture and exchange == 'p2p')}.pt") for r in (0, 1)]
+    p0, p1 = res["p2p"]
+    assert torch.equal(p0["param"], p1["param"]) and not torch.equal(p0["acts"], p1["acts"])
+    assert torch.equal(p0["param"], res["rccl"][0]["param"])              # the very bits of the RCCL path
+    assert p0["captured"] == capture
 
 
 def test_bench_starts_its_own_ranks(tmp_path):
