@@ -545,7 +545,12 @@ def test_f32_junction_track_through_the_persistent_rollout_kernel(tmp_path, n_en
         tr.close()
     for i, (a, b) in enumerate(zip(res["mega"], res["steps"])):
         assert torch.equal(a, b), i
-    _oracle_replay_check(cfg, res["mega"], first, f"junction track N={n_envs}", sel=strided_population(n_envs, per_wave=2, limit=512))
+    # bit-equal fraction 99.9 % here instead of 99.99 %: this track starts at heading 0 with walls on integer coordinates, so the
+    # reference produces exact cancellations (vy + sin(5 deg) 0.8 - sin(5 deg) 0.8 = 0.0) and cos / sin of +-90 deg (6e-17), where
+    # F32 mode's heading table -- angles reduced mod 360: sin(355 deg) for the reference's sin(-5 deg), one float64 ulp apart --
+    # leaves residues of 1e-17 ... 3e-16 in the velocity and heading columns: far below the one-ulp bar, but not the same bits
+    _oracle_replay_check(cfg, res["mega"], first, f"junction track N={n_envs}", sel=strided_population(n_envs, per_wave=2, limit=512),
+                         bit_equal=0.999)
 
 
 def test_f32_handles_refuse_tracks_outside_their_pricing_and_say_why():

@@ -66,7 +66,7 @@ def strided_population(n_envs, per_wave=4, wave=32, limit=None):
     return np.unique(sel)
 
 
-def _oracle_replay_check(cfg, snaps, first_obs, what, sel=None, stats=None):
+def _oracle_replay_check(cfg, snaps, first_obs, what, sel=None, stats=None, bit_equal=BIT_EQUAL):
     """Replay the stored actions of the envs `sel` (default: the first REPLAY) through the oracle and compare with the buffers
     of the persistent rollout.  `stats` (a dict) receives the observation-error histogram and the list of departures."""
     obs_buf, act_buf, rew_buf, _val, _lp, term_buf, trunc_buf, next_obs, next_term, next_trunc = snaps
@@ -110,7 +110,7 @@ def _oracle_replay_check(cfg, snaps, first_obs, what, sel=None, stats=None):
     assert worst <= OBS_TOL, f"{what}: obs error {worst} before the first near-tie"
     assert alive.mean() > 0.97, f"{what}: {P - alive.sum()} of {P} envs left the oracle's trajectory"
     assert n_done > 0                       # episodes ended (auto-reset rows were compared)
-    assert n_eq >= BIT_EQUAL * n_cmp, f"{what}: only {n_eq} of {n_cmp} observation entries bit-equal"
+    assert n_eq >= bit_equal * n_cmp, f"{what}: only {n_eq} of {n_cmp} observation entries bit-equal"
     if stats is not None:
         stats.update(envs=P, steps=T, entries=n_cmp, bit_equal=n_eq, obs_max_err=worst, hist_edges=[float(x) for x in edges[:-1]],
                      hist=[int(x) for x in hist], departures=departures, episodes_ended=n_done, on_trajectory=float(alive.mean()))
