@@ -73,6 +73,17 @@
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// Developer-only quick build (tools/ab_run.sh with -DPC_DEV_MIN=<mask>; never the product: the host layer refuses it like the
+// ablation build): the dispatch tables keep only the benchmarked kernels -- bit 0: rollout_kernel<6, 9, 2, 3> (target), bit 1:
+// rollout_small_kernel<6, 5, 2, 1, 16> (cfg1), bit 2: rollout_kernel<10, 17, 2, 1> (cfg2); the fp16x2 policy kernels, the
+// float32 env-step kernels and the update kernels stay -- so that one kernel experiment compiles in seconds instead of 75.
+#ifdef PC_DEV_MIN
+#define PC_FULL(...) return PC_ERR_UNSUPPORTED
+#define PC_DEV(bit, ...) do { if constexpr (((PC_DEV_MIN) >> (bit)) & 1) { __VA_ARGS__; } else return PC_ERR_UNSUPPORTED; } while (0)
+#else
+#define PC_FULL(...) __VA_ARGS__
+#define PC_DEV(bit, ...) __VA_ARGS__
+#endif
 static thread_local std::string g_hip_err;
 
 #define HIPCHK(expr)                                                                       \
@@ -706,8 +717,10 @@ int pc_env_step(pc_env* e, const int64_t* actions, double reward_scale, float* o
         break;
     if (e->dtype == PC_DTYPE_F64) {
         switch (e->rpl) {
+#ifndef PC_DEV_MIN
             PC_CASE(double, 1) PC_CASE(double, 2) PC_CASE(double, 3) PC_CASE(double, 5) PC_CASE(double, 6)
             PC_CASE(double, 9) PC_CASE(double, 12) PC_CASE(double, 17)
+#endif
             default: return PC_ERR_UNSUPPORTED;
         }
     } else {
@@ -732,7 +745,11 @@ int pc_env_info(pc_env* e, int32_t* gates_passed, int32_t* time_passed, void* st
     return PC_OK;
 }
 
+#ifdef PC_DEV_MIN
+int pc_build_ablate(void) { return 0x100 | PC_ABLATE; }     // a developer quick build is refused by the host layer like an ablation build
+#else
 int pc_build_ablate(void) { return PC_ABLATE; }
+#endif
 
 #ifdef PC_STAMPS
 // developer build only (not declared in ppocar.h): copy the phase stamps of the last pc_rollout launch to the host
@@ -937,12 +954,12 @@ static int policy_pack_impl(int device, int prec, int D, int H, int A, const flo
     hipLaunchKernelGGL((policy_pack16_kernel<PRC, NGV>), dim3(64), dim3(256), 0, (hipStream_t)stream, D, A, aW1, ab1, aW2, ab2, cW1, \
                        cb1, cW2, cb2, reinterpret_cast<unsigned*>(image))
     const int ng = pol_ng(policy_ks(D));
-    if (prec == 1) { if (ng == 5) PC_PACK(1, 5); else PC_PACK(1, 3); }
+    if (prec == 1) { PC_FULL(if (ng == 5) PC_PACK(1, 5); else PC_PACK(1, 3)); }
     else if (prec == 2) { if (ng == 5) PC_PACK(2, 5); else PC_PACK(2, 3); }
 #undef PC_PACK
     else
-        hipLaunchKernelGGL(policy_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, policy_ks(D), D, A, aW1, ab1, aW2, ab2,
-                           cW1, cb1, cW2, cb2, image);
+        PC_FULL(hipLaunchKernelGGL(policy_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, policy_ks(D), D, A, aW1, ab1, aW2, ab2,
+                                   cW1, cb1, cW2, cb2, image));
     HIPCHK(hipGetLastError());
     return PC_OK;
 }
@@ -981,19 +998,19 @@ static int policy_act_impl(int device, int prec, int split_mode, const float* ob
                            action, action_f32, logprob, value, logits_out);                                              \
     } while (0)
     if (prec == 1) {
-        if (split) { if (KS == 5) PC_POL(5, true, 1); else if (KS == 6) PC_POL(6, true, 1); else PC_POL(10, true, 1); }
-        else { if (KS == 5) PC_POL(5, false, 1); else if (KS == 6) PC_POL(6, false, 1); else PC_POL(10, false, 1); }
+        PC_FULL(if (split) { if (KS == 5) PC_POL(5, true, 1); else if (KS == 6) PC_POL(6, true, 1); else PC_POL(10, true, 1); }
+                else { if (KS == 5) PC_POL(5, false, 1); else if (KS == 6) PC_POL(6, false, 1); else PC_POL(10, false, 1); });
     } else if (prec == 2) {
-        if (split) { if (KS == 5) PC_POL(5, true, 2); else if (KS == 6) PC_POL(6, true, 2); else PC_POL(10, true, 2); }
-        else { if (KS == 5) PC_POL(5, false, 2); else if (KS == 6) PC_POL(6, false, 2); else PC_POL(10, false, 2); }
+        if (split) { if (KS == 5) PC_FULL(PC_POL(5, true, 2)); else if (KS == 6) PC_POL(6, true, 2); else PC_POL(10, true, 2); }
+        else { if (KS == 5) PC_FULL(PC_POL(5, false, 2)); else if (KS == 6) PC_POL(6, false, 2); else PC_POL(10, false, 2); }
     } else if (split) {
-        if (KS == 5) PC_POL(5, true, 0);
-        else if (KS == 6) PC_POL(6, true, 0);
-        else PC_POL(10, true, 0);
+        PC_FULL(if (KS == 5) PC_POL(5, true, 0);
+                else if (KS == 6) PC_POL(6, true, 0);
+                else PC_POL(10, true, 0));
     } else {
-        if (KS == 5) PC_POL(5, false, 0);
-        else if (KS == 6) PC_POL(6, false, 0);
-        else PC_POL(10, false, 0);
+        PC_FULL(if (KS == 5) PC_POL(5, false, 0);
+                else if (KS == 6) PC_POL(6, false, 0);
+                else PC_POL(10, false, 0));
     }
 #undef PC_POL
     HIPCHK(hipGetLastError());
@@ -1147,13 +1164,13 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
 #define PC_ROLL(KSV, RPLV, PRC)                                                                                          \
     do {                                                                                                                 \
         if constexpr (PRC == 2 && KSV == 6) {   /* (17 rays, default arithmetic only: the chain-of-28 kernels) */        \
-            if (mode == 2 && all_nv28) { PC_ROLL_M(KSV, RPLV, PRC, 3); break; }                                          \
-            if (mode == 2 && all_loops) { PC_ROLL_M(KSV, RPLV, PRC, 5); break; }                                         \
-            if (mode == 1 && all_nv28) { PC_ROLL_M(KSV, RPLV, PRC, 4); break; }                                          \
+            if (mode == 2 && all_nv28) { PC_DEV(0, PC_ROLL_M(KSV, RPLV, PRC, 3)); break; }                               \
+            if (mode == 2 && all_loops) { PC_FULL(PC_ROLL_M(KSV, RPLV, PRC, 5)); break; }                                \
+            if (mode == 1 && all_nv28) { PC_FULL(PC_ROLL_M(KSV, RPLV, PRC, 4)); break; }                                 \
         }                                                                                                                \
-        if (mode == 2) PC_ROLL_M(KSV, RPLV, PRC, 2);                                                                     \
-        else if (mode == 1) PC_ROLL_M(KSV, RPLV, PRC, 1);                                                                \
-        else PC_ROLL_M(KSV, RPLV, PRC, 0);                                                                               \
+        if (mode == 2) PC_FULL(PC_ROLL_M(KSV, RPLV, PRC, 2));                                                            \
+        else if (mode == 1) PC_FULL(PC_ROLL_M(KSV, RPLV, PRC, 1));                                                       \
+        else PC_FULL(PC_ROLL_M(KSV, RPLV, PRC, 0));                                                                      \
     } while (0)
 #define PC_ROLLS_M(KSV, RPLV, PRC, MD, EPWV)                                                                             \
     do {                                                                                                                 \
@@ -1169,29 +1186,29 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
 #define PC_ROLLS(KSV, RPLV, PRC)                                                                                         \
     do {                                                                                                                 \
         if constexpr (PRC != 0 && RPLV <= 5) {                                                                           \
-            if (mode && epw_small == 16) { PC_ROLLS_M(KSV, RPLV, PRC, 1, 16); break; }                                   \
+            if (mode && epw_small == 16) { if constexpr (PRC == 2 && KSV == 6) PC_DEV(1, PC_ROLLS_M(KSV, RPLV, PRC, 1, 16)); else PC_FULL(PC_ROLLS_M(KSV, RPLV, PRC, 1, 16)); break; } \
         }                                                                                                                \
-        if (mode) PC_ROLLS_M(KSV, RPLV, PRC, 1, 32);    /* (the small form takes the 1/den table as a run-time branch) */   \
-        else PC_ROLLS_M(KSV, RPLV, PRC, 0, 32);                                                                          \
+        if (mode) PC_FULL(PC_ROLLS_M(KSV, RPLV, PRC, 1, 32));    /* (the small form takes the 1/den table as a run-time branch) */   \
+        else PC_FULL(PC_ROLLS_M(KSV, RPLV, PRC, 0, 32));                                                                 \
     } while (0)
     if (small) {
-        if (KS == 5 && rpl == 3) { if (prec == 2) PC_ROLLS(5, 3, 2); else if (prec) PC_ROLLS(5, 3, 1); else PC_ROLLS(5, 3, 0); }        // 12 rays
-        else if (KS == 6 && rpl == 5) { if (prec == 2) PC_ROLLS(6, 5, 2); else if (prec) PC_ROLLS(6, 5, 1); else PC_ROLLS(6, 5, 0); }   // 16 -> 17 rays
+        if (KS == 5 && rpl == 3) { PC_FULL(if (prec == 2) PC_ROLLS(5, 3, 2); else if (prec) PC_ROLLS(5, 3, 1); else PC_ROLLS(5, 3, 0)); }        // 12 rays
+        else if (KS == 6 && rpl == 5) { if (prec == 2) PC_ROLLS(6, 5, 2); else PC_FULL(if (prec) PC_ROLLS(6, 5, 1); else PC_ROLLS(6, 5, 0)); }   // 16 -> 17 rays
         else if (KS == 10 && rpl == 9) {                                                                                                      // 32 -> 33 rays
-            if (prec == 2) PC_ROLLS(10, 9, 2);
-            else if (prec) { if (mode) PC_ROLLS_M(10, 9, 1, 1, 32); else return PC_ERR_UNSUPPORTED; }   // (bf16 x 3 in the generic mode spilled: the caller's per-step kernels take that shape)
-            else PC_ROLLS(10, 9, 0);
+            PC_FULL(if (prec == 2) PC_ROLLS(10, 9, 2);
+                    else if (prec) { if (mode) PC_ROLLS_M(10, 9, 1, 1, 32); else return PC_ERR_UNSUPPORTED; }   // (bf16 x 3 in the generic mode spilled: the caller's per-step kernels take that shape)
+                    else PC_ROLLS(10, 9, 0));
         }
         else return PC_ERR_UNSUPPORTED;
-    } else if (KS == 5 && rpl == 6) { if (prec == 2) PC_ROLL(5, 6, 2); else if (prec) PC_ROLL(5, 6, 1); else PC_ROLL(5, 6, 0); }       // 12 rays, D = 18
-    else if (KS == 6 && rpl == 9) { if (prec == 2) PC_ROLL(6, 9, 2); else if (prec) PC_ROLL(6, 9, 1); else PC_ROLL(6, 9, 0); }          // 16 -> 17 rays, D = 23
+    } else if (KS == 5 && rpl == 6) { PC_FULL(if (prec == 2) PC_ROLL(5, 6, 2); else if (prec) PC_ROLL(5, 6, 1); else PC_ROLL(5, 6, 0)); }       // 12 rays, D = 18
+    else if (KS == 6 && rpl == 9) { if (prec == 2) PC_ROLL(6, 9, 2); else PC_FULL(if (prec) PC_ROLL(6, 9, 1); else PC_ROLL(6, 9, 0)); }          // 16 -> 17 rays, D = 23
     else if (KS == 10 && rpl == 17 && prec) {                                                                                             // 32 -> 33 rays, D = 39
         // (the chain-of-28 variant spills: not built.  The GENERIC mode at 33 rays -- a mixed-track batch whose workgroups straddle
         // tracks, fast mode switched off -- spilled 100+ registers beside the split operands' policy state: not built either; that
         // shape is PC_ERR_UNSUPPORTED here and runs through the per-step kernels, bit-identical by construction)
         if (!mode) return PC_ERR_UNSUPPORTED;
-        if (prec == 2) PC_ROLL_M(10, 17, 2, 1);
-        else PC_ROLL_M(10, 17, 1, 1);
+        if (prec == 2) PC_DEV(2, PC_ROLL_M(10, 17, 2, 1));
+        else PC_FULL(PC_ROLL_M(10, 17, 1, 1));
     }
     else return PC_ERR_UNSUPPORTED;
 #undef PC_ROLL_M

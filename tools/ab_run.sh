@@ -1,6 +1,8 @@
 #!/bin/bash
 # Developer tool: A/B timing of the persistent rollout kernel between builds of the working tree.
-#   tools/ab_run.sh build <name> [flags]    (here, hipcc)  -> build/ab_<name>_pkg: the package around a library built from the tree as it is now
+#   [AB_MIN=mask] tools/ab_run.sh build <name> [flags]    (here, hipcc)  -> build/ab_<name>_pkg: the package around a library built from the tree as it is
+#                                           now, as a developer QUICK build (-DPC_DEV_MIN=mask, default 1: only the target's rollout kernel; 2: cfg1's, 4: cfg2's;
+#                                           AB_MIN=0: every kernel, 75 s) -- the copies' _capi.py has the check that refuses such builds removed
 #   [AB_MIXED=1] tools/ab_run.sh run [n_envs] [n_steps] [rays]  (on the GPU box; AB_MIXED: track.json + big_track.json in halves) -> every build/ab_*_pkg in turn, three rounds, inside a short training
 #                                           run so that the policy is not the random initial one; the product library is not used.
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -8,9 +10,11 @@ cd $ROOT
 if [ "$1" = "build" ]; then
   d=build/ab_${2}_pkg
   mkdir -p $d/ppo-car_amd $d/ppo_car_amd
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++20 -ffp-contract=off -Wno-unused-function -Iinclude -Ippo-car_amd/csrc $3 -shared \
+  MIN=${AB_MIN:-1}; if [ "$MIN" != "0" ]; then MINFLAG="-DPC_DEV_MIN=$MIN"; else MINFLAG=""; fi
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++20 -ffp-contract=off -Wno-unused-function -Iinclude -Ippo-car_amd/csrc $MINFLAG $3 -shared \
       -o $d/ppo-car_amd/libppocar.so ppo-car_amd/csrc/ppocar.hip ppo-car_amd/csrc/track_json.cpp || exit 1
   cp ppo-car_amd/*.py $d/ppo-car_amd/ && cp ppo_car_amd/__init__.py $d/ppo_car_amd/
+  sed -i 's/^if lib.pc_build_ablate() != 0:/if False:/' $d/ppo-car_amd/_capi.py
   exit 0
 fi
 N=${2:-65536}; T=${3:-1024}; R=${4:-16}
