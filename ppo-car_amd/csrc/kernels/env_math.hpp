@@ -2,6 +2,11 @@
 // device-side data (track header, env parameters) and the reference's ray / segment arithmetic in float64 and float32.
 #pragma once
 
+// Developer-only timing ablations (a SEPARATE library the product never loads: rollout.hpp, tools/ab_run.sh); 0 in every shipped build
+#ifndef PC_ABLATE
+#define PC_ABLATE 0
+#endif
+
 // ------------------------------------------------------------------------------------------
 // device-side data
 // ------------------------------------------------------------------------------------------
@@ -248,6 +253,44 @@ __device__ __forceinline__ float obs_dist(const double d) { return (float)(__bui
 __device__ __forceinline__ double cast_d(const Seg& s, const double px, const double py, const double dx, const double dy) {
     const SegD sg = {s.x1, s.y1, s.x1 - s.x2, s.y1 - s.y2, 0.0, 0, 0};
     return __builtin_fmin(cast_exact(sg, px, py, dx, dy).d, 1000.0);
+}
+
+// ---- Car.get_passed_gate's casts (car_env.py:387-390: one ray against gate[next], `distance < 10`) decided in FLOAT32 where
+// float32 can decide them.  The answer is a boolean, so a certified float32 verdict IS the exact one: with u = 2^-24, the
+// car-relative endpoint a = p1 - pos and the gate's edge e = p1 - p2 rounded from float64 (|a|_inf = m, |e|_inf = E) and the
+// float32 lattice direction, the numerators of Ray.cast carry absolute errors below
+//     |tn~ - tn| <= 6 u m,   |den~ - den| <= 6 u E,   |un~ - un| <= 7 u E m        (a multiply and an fma each),
+// priced here as eps_t = 2^-20 m, eps_d = 2^-20 E, eps_u = 2^-19 E m.  `0 < t < 1 and 0 < u < 10` (t = tn / den, u = un / den = the
+// hit distance) is CERTAINLY true when every sign is certain (magnitudes above their eps, products positive) and both
+// |den| - |tn| and 10 |den| - |un| clear the summed errors; CERTAINLY false when tn or un has the certain opposite sign of den, or
+// |tn| - |den| or |un| - 10 |den| clears the errors (|t| > 1 resp. |u| > 10; den = 0 included).  Anything else -- a verdict within
+// ~1e-5 (relative) of flipping: t at a gate end, u at 0 or at 10 px, a near-parallel ray -- is UNDECIDED and goes to the float64
+// cast (cast_d: the reference's own arithmetic at a tie).  ~1 cast in 1e5.
+struct GateF32 { float ax, ay, ex, ey, un, eps_t, eps_d, eps_u; };
+__device__ __forceinline__ GateF32 gate_f32(const Seg& g, const double px, const double py) {
+    GateF32 q;
+    q.ax = (float)(g.x1 - px);
+    q.ay = (float)(g.y1 - py);
+    q.ex = (float)(g.x1 - g.x2);
+    q.ey = (float)(g.y1 - g.y2);
+    const float m = __builtin_fmaxf(__builtin_fabsf(q.ax), __builtin_fabsf(q.ay)), E = __builtin_fmaxf(__builtin_fabsf(q.ex), __builtin_fabsf(q.ey));
+    q.un = __builtin_fmaf(q.ey, q.ax, -(q.ex * q.ay));
+    q.eps_t = m * 0x1p-20f;
+    q.eps_d = E * 0x1p-20f;
+    q.eps_u = m * E * 0x1p-19f;
+    return q;
+}
+// hit = the cast certainly hits within 10 px; returns false when the verdict is certain (hit or not), true when undecided
+__device__ __forceinline__ bool gate_cast_f32(const GateF32& q, const float dx, const float dy, bool& hit) {
+    const float den = __builtin_fmaf(q.ey, dx, -(q.ex * dy)), tn = __builtin_fmaf(q.ay, dx, -(q.ax * dy));
+    const float ad = __builtin_fabsf(den), at = __builtin_fabsf(tn), au = __builtin_fabsf(q.un);
+    const float sT = tn * den, sU = q.un * den;
+    const float A = ad - at, B = __builtin_fmaf(ad, 10.0f, -au);
+    const float et = q.eps_t + q.eps_d, eu = __builtin_fmaf(q.eps_d, 10.0f, q.eps_u);
+    const bool bigT = at > q.eps_t, bigD = ad > q.eps_d, bigU = au > q.eps_u;
+    hit = bigT & bigD & bigU & (sT > 0.0f) & (sU > 0.0f) & (A > et) & (B > eu);
+    const bool miss = (bigT & bigD & (sT < 0.0f)) | (A < -et) | (bigU & bigD & (sU < 0.0f)) | (B < -eu);
+    return !(hit | miss);
 }
 
 template <typename T> struct Math;

@@ -368,7 +368,7 @@ __device__ __forceinline__ void wall_sweep_loops(const VtxP* vp, const float pxr
         for (int s = 0; s < RPL; ++s) {
             const f32x2 dxs = {dx[s], dx[s]}, dys = {dy[s], dy[s]};
             c[s] = __builtin_elementwise_fma(ay, dxs, -(ax * dys));
-            cm[s] = __builtin_fminf(__builtin_fminf(cm[s], __builtin_fabsf(c[s].x)), __builtin_fabsf(c[s].y));   // v_min3_f32 |.|
+            if constexpr (!(PC_ABLATE & 32)) cm[s] = __builtin_fminf(__builtin_fminf(cm[s], __builtin_fabsf(c[s].x)), __builtin_fabsf(c[s].y));   // v_min3_f32 |.|
         }
     };
     // the two segments closed by position I (vertices I and L + I): (axp, ayp, cp) belong to position I - 1, c to I

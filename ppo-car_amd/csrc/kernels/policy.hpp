@@ -568,6 +568,68 @@ __device__ __forceinline__ void policy_tail(const float (&v)[16], const int A_rt
     }
 }
 
+// The same draw for Discrete(9) (car_env.py:525) on the TWO lanes that own an env (lane = 2 env + g: the env step's mapping, so the
+// action never leaves the lane pair): lane 0 holds logits 0..3 and the value (output 9), lane 1 logits 4..8 -- four / five
+// exponentials per lane instead of nine on half of the wave's lanes, every reduction one exchange with the neighbouring lane
+// (DPP quad_perm [1, 0, 3, 2]).  The arithmetic (policy_tail's with the sums associated by lane): max and sum = lane 0's
+// sequential partial (+) lane 1's; the CDF runs sequentially through lane 0's bins and continues from its total through lane
+// 1's; the action = the number of bins the uniform has passed, the last bin absorbing rounding.  Used by BOTH the per-step policy
+// kernel and the persistent rollout kernel whenever A == 9, so the two stay bit-identical.
+// w[0..4] = this lane's outputs as described (already scaled back and biased); act / lp / val are returned in both lanes.
+__device__ __forceinline__ float dpp_swap_pair_f(const float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));
+}
+__device__ __forceinline__ void policy_tail_pair(const float (&w)[5], const int g, const float u, int& act, float& lp, float& val) {
+    const bool hi = g != 0;
+    float l[5];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) l[j] = w[j];
+    l[4] = hi ? w[4] : -INFINITY;                  // lane 0's fifth output is the value, not a logit
+    float mx = fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3]));
+    mx = fmaxf(mx, l[4]);
+    mx = fmaxf(mx, dpp_swap_pair_f(mx));
+    float ex[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) ex[j] = softmax_exp(l[j] - mx);     // (exp2(-inf) = 0 for lane 0's fifth slot)
+    const float part = (((ex[0] + ex[1]) + ex[2]) + ex[3]) + ex[4];
+    const float sum = part + dpp_swap_pair_f(part);                  // (a + b on one lane, b + a on the other: the same float)
+    const float lse = mx + logf(sum);  // Categorical(logits=...) normalises: logits - logsumexp
+    const float inv = 1.0f / sum;
+    float c[5];
+    c[0] = ex[0] * inv;
+#pragma unroll
+    for (int j = 1; j < 5; ++j) c[j] = c[j - 1] + ex[j] * inv;
+    const float other_total = dpp_swap_pair_f(c[4]);
+    const float base = hi ? other_total : 0.0f;                      // lane 1's bins continue from lane 0's total
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) n += (!(u < base + c[j]) && (j < 4 || hi)) ? 1 : 0;   // bins the uniform has passed (inverse CDF)
+    const int n_other = __builtin_amdgcn_update_dpp(0, n, 0xb1, 0xf, 0xf, false);
+    const int n_lo = hi ? n_other : n, n_hi = hi ? n : n_other;
+    act = n_lo < 4 ? n_lo : 4 + (n_hi < 4 ? n_hi : 4);               // last bin absorbs rounding
+    const int li = act - (hi ? 4 : 0);                               // index among this lane's logits (if it is this lane's)
+    float mine = l[0];
+#pragma unroll
+    for (int j = 1; j < 5; ++j) mine = li == j ? l[j] : mine;
+    mine -= lse;
+    const float theirs = dpp_swap_pair_f(mine);
+    lp = ((act >= 4) == hi) ? mine : theirs;
+    const float v_other = dpp_swap_pair_f(w[4]);
+    val = hi ? v_other : w[4];
+}
+// this lane's five outputs of env row `row` of an output tile with row stride LDO (a multiple of 4 floats: 16-byte reads):
+// columns 0..3 + 9 (g = 0) or 4..8 (g = 1), back from their scaled domain and biased (sB2: the 16 output biases)
+template <int LDO>
+__device__ __forceinline__ void pair_outputs(const float* tile, const int row, const int g, const float so_inv, const float* sB2, float (&w)[5]) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(tile + row * LDO + 4 * g);
+    const float x = tile[row * LDO + (g ? 8 : 9)];
+    const f32x4 b = *reinterpret_cast<const f32x4*>(sB2 + 4 * g);
+    const float bx = sB2[g ? 8 : 9];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = __builtin_fmaf(q[j], so_inv, b[j]);
+    w[4] = __builtin_fmaf(x, so_inv, bx);
+}
+
 // The same draw with 16 lanes per env (the split forms, where the 32 envs of a workgroup would otherwise be drawn by half
 // of ONE wave while seven wait): lane i of a 16-lane row holds output i of its env (logits 0..A-1, the value at A).
 // Row-wide max / sum by DPP rotations, the CDF by a DPP scan, the action = number of bins the uniform has passed.  The
@@ -639,7 +701,7 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
                                                      float* __restrict__ action_f, float* __restrict__ logprob,
                                                      float* __restrict__ value, float* __restrict__ logits_out) {
     constexpr int HID = 256, NT = 2 * HID / 16;  // 32 hidden tiles: 16 actor + 16 critic
-    constexpr int LD1 = pol_ld1(KS), LDO = 17, ET = 2;
+    constexpr int LD1 = pol_ld1(KS), LDO = SPLIT ? 17 : 20, ET = 2;     // (non-split: 16-byte rows for the pair draw's reads)
     constexpr int ENVS_PER_WG = SPLIT ? 32 : 256;
     constexpr int NG = pol_ng(KS), KB = pol_kb(KS);
     constexpr int IMG = PREC ? polx_image_dwords(PREC, NG) : pol_image_padded(KS);
@@ -709,9 +771,13 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
         // ---- out tile -> LDS so that lane = env
         __syncthreads();  // previous pass's readers are done with sOut
 #pragma unroll
-        for (int et = 0; et < ET; ++et)
+        for (int et = 0; et < ET; ++et) {
+            if constexpr (LDO % 4 == 0) *reinterpret_cast<f32x4*>(myOut + (16 * et + lc) * LDO + 4 * lk) = out[et];
+            else {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) myOut[(16 * et + lc) * LDO + 4 * lk + reg] = out[et][reg];
+                for (int reg = 0; reg < 4; ++reg) myOut[(16 * et + lc) * LDO + 4 * lk + reg] = out[et][reg];
+            }
+        }
         __syncthreads();
         if constexpr (SPLIT) {
             // every wave draws for 4 of the 32 envs, 16 lanes (= outputs) per env: sum the 8 waves' partial tiles in a fixed
@@ -728,6 +794,27 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
             if (e < N) {
                 if (logits_out && oi < A) logits_out[e * A + oi] = t;
                 if (oi == 0) {
+                    action[e] = act;
+                    if (action_f) action_f[e] = (float)act;
+                    logprob[e] = lp;
+                    value[e] = val;
+                }
+            }
+        } else if (A == 9) {     // (uniform) Discrete(9): the two lanes of an env draw together (policy_tail_pair)
+            const int row = lane >> 1, g = lane & 1;
+            const int64_t e = env0 + row;
+            if (e < N) {
+                float w[5];
+                pair_outputs<LDO>(myOut, row, g, PolScale<PREC>::so_inv, sB2, w);
+                int act;
+                float lp, val;
+                policy_tail_pair(w, g, philox_uniform(seed, off, (uint64_t)e), act, lp, val);
+                if (logits_out) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j)
+                        if (j < 4 || g) logits_out[e * A + 4 * g + j] = w[j];
+                }
+                if (g == 0) {
                     action[e] = act;
                     if (action_f) action_f[e] = (float)act;
                     logprob[e] = lp;

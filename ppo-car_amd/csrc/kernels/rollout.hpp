@@ -285,16 +285,34 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
             m += fl.rstep;
         }
     }
-    // ---- Car.get_passed_gate (:394-408): the four collision rays at the PREVIOUS pose against gate[next], dealt over the lanes,
-    // cast in float64 (the lattice entry names its float64 twin)
+    // ---- Car.get_passed_gate (:394-408): the four collision rays at the PREVIOUS pose against gate[next], dealt over the lanes.
+    // The verdict `distance < 10` is taken in float32 wherever float32 can certify it (gate_cast_f32); the rare undecided cast --
+    // a verdict within ~1e-5 of flipping -- is repeated in float64 (cast_d: the lattice entry names its float64 twin), in a
+    // block the wave skips unless one of its lanes needs it.  Either way the boolean is the exact one: the same as the per-step
+    // kernel's, which casts in float64 throughout.
     const f64x4 gv = ft.gates[st.next];
     const Seg gate = {gv.x, gv.y, gv.z, gv.w};
     const int k80o = 80 * k72;
     bool gate_hit = false;
+    if constexpr (!(PC_ABLATE & 8)) {
+        const GateF32 gf = gate_f32(gate, opx, opy);
+        unsigned und = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4 / G; ++jj) {
+            const f32x4 cs = *(lds_f4c)(size_t)(unsigned)(k80o + gq[jj]);
+            bool hit;
+            und |= gate_cast_f32(gf, cs.x, cs.y, hit) ? 1u << jj : 0u;
+            gate_hit |= hit;
+        }
+        if (__builtin_amdgcn_ballot_w64(und != 0) != 0) {
 #pragma unroll 1
-    for (int jj = 0; jj < 4 / G; ++jj) {      // (rolled: ONE copy of cast_exact's literal branch in the kernel)
-        const f64x2 cs = dir64_at(k80o + (jj == 0 ? gq[0] : gq[1]));
-        gate_hit |= cast_d(gate, opx, opy, cs.x, cs.y) < 10.0;  // :387,:390
+            for (int jj = 0; jj < 4 / G; ++jj) {      // (rolled: ONE copy of cast_exact's literal branch in the kernel)
+                if ((und >> jj) & 1) {
+                    const f64x2 cs = dir64_at(k80o + gq[0] + jj * (gq[G == 2 ? 1 : 0] - gq[0]));     // (no indexed register array: that went to scratch)
+                    gate_hit |= cast_d(gate, opx, opy, cs.x, cs.y) < 10.0;  // :387,:390
+                }
+            }
+        }
     }
     // ---- wall sweep (float32 selector, env_step.hpp).  More than 12 ray slots per lane (33 rays: 17) are swept in TWO passes over
     // the vertex chain, 9 + 8 slots: one pass would need ~40 more registers than the 256 a wave has at two waves per SIMD (it
@@ -305,6 +323,10 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     const float tau = flag_threshold(h, npx, npy);
     const float pxr = (float)(npx - h.ax0), pyr = (float)(npy - h.ay0);   // the car relative to the track's anchor (see Vtx)
     PC_STAMP_E(4)
+    if constexpr (PC_ABLATE & 64) {
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) bb[s] = 1u + (unsigned)s;
+    } else
     {
         const float(&dxa)[R1] = *reinterpret_cast<const float(*)[R1]>(&dx[0]);
         const float(&dya)[R1] = *reinterpret_cast<const float(*)[R1]>(&dy[0]);
@@ -409,8 +431,9 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         for (int j = 0; j < NB; ++j) {
             const int s = s0 + j;
             if (s < RPL && (PARTS == 1 || s % PARTS == part)) {
-                bool ok;
-                const double d = refine_fast(sg[j], npx, npy, d64[j].x, d64[j].y, ok);
+                bool ok = true;
+                double d = 500.0 + sg[j].x1 * 1e-9 + d64[j].x * 1e-9;
+                if constexpr (!(PC_ABLATE & 16)) d = refine_fast(sg[j], npx, npy, d64[j].x, d64[j].y, ok);
                 todo |= ok ? 0u : 1u << s;
                 uint64_t col_lanes = 0;
 #pragma unroll
@@ -516,11 +539,9 @@ __device__ __forceinline__ void env_reset_fast(const TrackHdr& h, EnvRegs& st, i
 }
 
 // Developer-only timing ablation of the persistent rollout kernels: a SEPARATE build (make ABLATE=n -> libppocar_ablate.so,
-// never loaded by the product or the tests) compiled with -DPC_ABLATE=n skips the policy MFMAs (1), the env step (2) or
-// the draw (4).  The shipped library is built with PC_ABLATE = 0: there is no run-time switch that makes a kernel do less.
-#ifndef PC_ABLATE
-#define PC_ABLATE 0
-#endif
+// never loaded by the product or the tests) compiled with -DPC_ABLATE=n skips the policy MFMAs (1), the env step (2), the draw
+// (4), the gate casts (8), the float64 refinement (16), the sweep's flag minima (32), the whole sweep (64) or the copy-out (256).
+// The shipped library is built with PC_ABLATE = 0 (env_math.hpp): there is no run-time switch that makes a kernel do less.
 // K9: the whole rollout (train.py:173-195) as ONE persistent launch.
 // A workgroup (8 waves) owns 256 envs for all T steps: the policy weights stay in LDS, the env state in
 // registers, the observation of step t passes from the env step to the policy step through LDS; per step an
@@ -585,10 +606,13 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                                                       const int rden_lds, const int epw, const int vec_ok,
                                                       float* __restrict__ last_val, float* __restrict__ rew_sum) {
     constexpr int dbg = PC_ABLATE;  // 0 in the product build (see PC_ABLATE)
-    constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), LDO = 17, ET = 2;
+    constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), ET = 2;
     constexpr int NG = pol_ng(KS), KB = pol_kb(KS);
     constexpr int IMG = PREC ? polx_image_dwords(PREC, NG) : pol_image_padded(KS);
     constexpr bool FAST = MODE != 0;
+    // row stride of a wave's output tile [32 envs][LDO]: 16-byte rows (one ds_write_b128 per env tile, 16-byte reads in the draw);
+    // the tile aliases the wave's 32 observation rows, so at 12 rays (18 floats per dense row) the stride is 16, else 20
+    constexpr int LDO = (FAST && RPL == 6) ? 16 : 20;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sW1 = lds;
     float* sB1 = PREC ? lds + polx_w1_dwords(PREC, NG) + polx_w2_dwords(PREC) : sW1 + 2 * HID * LD1;
@@ -653,7 +677,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     for (int f = g; f < (FAST ? D : 4 * KS); f += 2) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
     // this wave's output tile [32 envs][LDO] lives in its own observation rows: they are dead from the policy pass's
     // operand load until the env step stores the next observation (32 * LDX >= 32 * LDO floats: D >= 17 on the host's menu)
-    static_assert(4 * KS + 1 >= 17, "the output tile must fit the wave's observation rows");
+    static_assert(4 * KS + 1 >= 20, "the output tile must fit the wave's observation rows");
     float* myOut = sObs + wave * 32 * LDX;
     const uint64_t off0 = offset + (offset_dev ? *offset_dev : 0);
     PhiloxBlock rnd = {};  // the sampling lanes' current Philox block (4 steps' draws)
@@ -682,6 +706,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     // and every env's reward total rides along in a register (train.py:272's average reward without re-reading rew_buf).
     const int TT = last_val ? T + 1 : T;
     float rsum = 0.0f;
+    int act_reg = 8;     // the action drawn for this lane pair's env (the pair draw leaves it in both lanes)
 #pragma unroll 1
     for (int t = 0; t < TT; ++t) {
         const bool tail = t == T;      // (uniform)
@@ -745,30 +770,49 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 }
             }
 #pragma unroll
-            for (int et = 0; et < ET; ++et)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) myOut[(16 * et + lc) * LDO + 4 * lk + reg] = out[et][reg];
+            for (int et = 0; et < ET; ++et) *reinterpret_cast<f32x4*>(myOut + (16 * et + lc) * LDO + 4 * lk) = out[et];
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the tile is written and read by this wave only
             __builtin_amdgcn_wave_barrier();
-            const int64_t e = e_wave + lane;
-            if (lane < 32 && e < N) {
-                float v[16];
+            const uint64_t o = off0 + (uint64_t)t;
+            if (FAST || A == 9) {     // Discrete(9): the env's two lanes draw together (policy_tail_pair); the action stays with them
+                if (e_valid) {
+                    float w[5];
+                    pair_outputs<LDO>(myOut, lane >> 1, g, PolScale<PREC>::so_inv, sB2, w);
+                    float lp, val;
+                    if (t == 0 || (o & 3) == 0) rnd = philox_block(seed, o >> 2, (uint64_t)e_env);  // uniform: ten rounds per 4 steps
+                    if constexpr (PC_ABLATE & 4) { act_reg = (int)(o & 7); lp = w[0]; val = w[4]; }
+                    else policy_tail_pair(w, g, philox_word_uniform(rnd, (unsigned)(o & 3)), act_reg, lp, val);
+                    if constexpr (!FAST) { if (g == 0) sAct[el] = act_reg; }
+                    if (g == 0) {
+                        if (tail) {
+                            last_val[e_env] = val;
+                        } else {
+                            const int64_t row = (int64_t)t * N + e_env;
+                            act_buf[row] = (float)act_reg;     // stored as float32 like the reference (buffer.py:13)
+                            logprob_buf[row] = lp;
+                            val_buf[row] = val;
+                        }
+                    }
+                }
+            } else {
+                const int64_t e = e_wave + lane;
+                if (lane < 32 && e < N) {
+                    float v[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = __builtin_fmaf(myOut[lane * LDO + i], PolScale<PREC>::so_inv, sB2[i]);   // outputs back from their scaled domain
-                int act;
-                float lp, val;
-                const uint64_t o = off0 + (uint64_t)t;
-                if (t == 0 || (o & 3) == 0) rnd = philox_block(seed, o >> 2, (uint64_t)e);  // uniform: ten rounds per 4 steps
-                if constexpr (FAST) policy_tail<9>(v, 9, philox_word_uniform(rnd, (unsigned)(o & 3)), act, lp, val, nullptr);
-                else policy_tail(v, A, philox_word_uniform(rnd, (unsigned)(o & 3)), act, lp, val, nullptr);
-                sAct[pbase + lane] = act;
-                if (tail) {
-                    last_val[e] = val;
-                } else {
-                    const int64_t row = (int64_t)t * N + e;
-                    act_buf[row] = (float)act;     // stored as float32 like the reference (buffer.py:13)
-                    logprob_buf[row] = lp;
-                    val_buf[row] = val;
+                    for (int i = 0; i < 16; ++i) v[i] = __builtin_fmaf(myOut[lane * LDO + i], PolScale<PREC>::so_inv, sB2[i]);   // outputs back from their scaled domain
+                    int act;
+                    float lp, val;
+                    if (t == 0 || (o & 3) == 0) rnd = philox_block(seed, o >> 2, (uint64_t)e);  // uniform: ten rounds per 4 steps
+                    policy_tail(v, A, philox_word_uniform(rnd, (unsigned)(o & 3)), act, lp, val, nullptr);
+                    sAct[pbase + lane] = act;
+                    if (tail) {
+                        last_val[e] = val;
+                    } else {
+                        const int64_t row = (int64_t)t * N + e;
+                        act_buf[row] = (float)act;     // stored as float32 like the reference (buffer.py:13)
+                        logprob_buf[row] = lp;
+                        val_buf[row] = val;
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -782,7 +826,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 __builtin_amdgcn_s_setprio(2);
                 // ---------------- E(t)
                 float rw, tf, cf;
-                const int a = e_valid ? sAct[el] : 8;
+                const int a = e_valid ? act_reg : 8;
                 const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3 || MODE == 5, 1, 1, (MODE == 5 ? 5 : (MODE >= 3 ? 7 : 0)), RPL != 17>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave);
                 rsum += rw;
                 PC_STAMP(6)
@@ -815,7 +859,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 const int64_t left = N - e_wave;                       // valid envs from this wave's first on
                 const int n_rows = left >= 32 ? 32 : (int)left;
                 const float* srcl = sObs + pbase * LDX;
-                if (vec_ok && n_rows == 32) {
+                if constexpr (PC_ABLATE & 256) {
+                } else if (vec_ok && n_rows == 32) {
 #pragma unroll
                     for (int j = 0; j < (8 * DC + 63) / 64; ++j) {      // 8 * D float4s: 3 (D = 18, 23) or 5 (D = 39) stores per lane
                         const int i = lane + 64 * j;

@@ -974,7 +974,7 @@ static int policy_act_impl(int device, int prec, int split_mode, const float* ob
     DeviceGuard guard(device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
     const int KS = policy_ks(D);
-    const size_t lds = (size_t)((prec ? polx_image_dwords(prec, pol_ng(KS)) : pol_image_padded(KS)) + 8 * 32 * 17) * sizeof(float);
+    const size_t lds = (size_t)((prec ? polx_image_dwords(prec, pol_ng(KS)) : pol_image_padded(KS)) + 8 * 32 * 20) * sizeof(float);
     static int n_cu[64] = {0};
     if (device < 64 && n_cu[device] == 0) {
         hipDeviceProp_t prop;

@@ -18,7 +18,7 @@ if [ "$1" = "build" ]; then
   exit 0
 fi
 N=${2:-65536}; T=${3:-1024}; R=${4:-16}
-for round in 1 2 3; do
+for round in $(seq 1 ${AB_ROUNDS:-4}); do
   for P in $ROOT/build/ab_*_pkg; do
     python3 - $P $N $T $R <<'PY'
 import sys, os
@@ -33,13 +33,18 @@ for _ in range(4):
     tr.run_epoch(sync=False)
 torch.cuda.synchronize()
 ts = []
-for _ in range(6):
+for _ in range(int(os.environ.get("AB_REPS", "24"))):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); tr.rollout(); e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1) * 1e3 / T)
     tr.update()
 ts.sort()
-print(f"{os.path.basename(pkg):24s} {ts[0]:.3f} (min) {ts[len(ts)//2]:.3f} (median) us per vector step of {N} envs, {R} rays", flush=True)
+import time
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10):
+    tr.run_epoch(sync=False)
+torch.cuda.synchronize(); ep = (time.perf_counter() - t0) / 10 * 1e3
+print(f"{os.path.basename(pkg):24s} {ts[0]:.3f} (min) {ts[len(ts)//2]:.3f} (median) us per vector step of {N} envs, {R} rays; then 10 epochs back to back: {ep:.2f} ms per epoch = {N * T / ep / 1e3:.0f} M env-steps/s", flush=True)
 PY
   done
 done
