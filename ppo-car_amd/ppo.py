@@ -73,6 +73,10 @@ class PPOConfig:
                                            # all-reduce over peer-mapped buffers (pc_xchg_*: every rank writes its bucket into every peer's slot,
                                            # sums locally in rank order) -- one xGMI hop of latency instead of a ring / tree schedule, a plain
                                            # kernel, so capture_collectives can put it into the epoch graph with any backend
+    bootstrap_value: str = "kernel"        # the value of the final observation for GAE (agent.get_value(next_obs), train.py:200): "kernel" = the
+                                           # persistent rollout kernel's own critic pass (the fused policy step's arithmetic: fp16x2 by default,
+                                           # within 4e-6 of float64 -- what val_buf's other rows hold); "fp32" = torch's fp32 Linear on next_obs,
+                                           # the reference's very call
     exchange_timeout_s: float = 20.0       # exchange = "p2p": how long an exchange kernel waits for a peer's flag before it gives up; the
                                            # Trainer checks for that wherever it synchronises (run_epoch(sync=True), check_exchange(), close())
                                            # and raises ExchangeTimeout
@@ -209,6 +213,8 @@ class PPOLearner:
             dist.broadcast(self.flat_param, src=0)       # every rank starts from rank 0's parameters
         self.exchange = GradExchange(self.flat_grad, world_size)
         self.collective = world_size > 1 or bool(cfg.force_collective)     # the update has an exchange step
+        if cfg.bootstrap_value not in ("kernel", "fp32"):
+            raise ValueError(f"PPOConfig.bootstrap_value must be 'kernel' or 'fp32', not {cfg.bootstrap_value!r}")
         if cfg.exchange not in ("rccl", "p2p"):
             raise ValueError(f"PPOConfig.exchange must be 'rccl' or 'p2p', not {cfg.exchange!r}")
         self.p2p = None
@@ -748,7 +754,8 @@ class Trainer:
         buf, agent = self.buffer, self.agent
         with torch.no_grad():
             # train.py:200 -- the persistent rollout kernel has already evaluated the critic on the final observation
-            next_values = (self._boot_val if self._aux_valid else agent.get_value(self.next_obs)).reshape(1, -1)
+            in_kernel = self._aux_valid and self.cfg.bootstrap_value == "kernel"
+            next_values = (self._boot_val if in_kernel else agent.get_value(self.next_obs)).reshape(1, -1)
             adv, ret = buf.calculate_advantages(next_values, self.next_term.reshape(1, -1),
                                                 self.next_trunc.reshape(1, -1))                   # :203
         obs, act, _val, logprob = buf.get()                                                      # :206

@@ -582,3 +582,29 @@ def test_evaluate_entry_point(tmp_path):
     assert out["frames"] == len(files) >= 1
     head = files[0].read_bytes()[:24]
     assert head[:8] == b"\x89PNG\r\n\x1a\n" and int.from_bytes(head[16:20], "big") == 640 and int.from_bytes(head[20:24], "big") == 360
+
+
+def test_bootstrap_value_switch_takes_the_reference_call_in_fp32():
+    """PPOConfig.bootstrap_value = "fp32": Buffer.calculate_advantages gets agent.get_value(next_obs) (train.py:200) from torch's
+    fp32 Linear instead of the rollout launch's own critic pass; the two agree within the fused policy step's tolerance, and the
+    advantages that come out differ by no more than that."""
+    outs = {}
+    for mode in ("kernel", "fp32"):
+        tr = Trainer(_cfg(n_envs=1024, n_steps=32, bootstrap_value=mode, rollout_kernel="mega"), device="cuda")
+        tr.rollout()
+        assert tr.rollout_mode == "mega" and tr._aux_valid
+        with torch.no_grad():
+            ref = tr.agent.get_value(tr.next_obs).reshape(-1)
+            in_kernel = tr._aux_valid and tr.cfg.bootstrap_value == "kernel"
+            nv = (tr._boot_val if in_kernel else ref).reshape(1, -1).clone()
+            adv, _ = tr.buffer.calculate_advantages(nv, tr.next_term.reshape(1, -1), tr.next_trunc.reshape(1, -1))
+        outs[mode] = (nv.clone(), adv.clone(), ref.clone())
+        tr.buffer.ptr = tr.cfg.n_steps
+        tr.update()              # runs with the configured bootstrap
+        tr.close()
+    assert torch.equal(outs["fp32"][0].reshape(-1), outs["fp32"][2])             # the reference's call, bit for bit
+    assert not torch.equal(outs["kernel"][0], outs["fp32"][0])
+    assert float((outs["kernel"][0] - outs["fp32"][0]).abs().max()) <= 1e-5
+    assert float((outs["kernel"][1] - outs["fp32"][1]).abs().max()) <= 1e-5
+    with pytest.raises(ValueError):
+        Trainer(_cfg(bootstrap_value="bf16"), device="cuda")

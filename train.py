@@ -44,6 +44,10 @@ def parse_args(argv=None):
     p.add_argument("--env-dtype", default="f32", choices=["f32", "f64"], help="ray-geometry precision of the env kernel")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--full-sweep", action="store_true", help="use every sample each train iter instead of train.py:228's loop bound")
+    p.add_argument("--policy-arith", default="fp16x2", choices=["fp16x2", "bf16x3", "fp32"],
+                   help="arithmetic of the rollout policy step's GEMMs on the matrix cores: fp16x2 / bf16x3 operand splits (fp32-grade) or the exact fp32 chain")
+    p.add_argument("--bootstrap-value", default="kernel", choices=["kernel", "fp32"],
+                   help="agent.get_value(next_obs) for GAE (train.py:200): from inside the rollout launch, or torch's fp32 Linear")
     p.add_argument("--out-dir", default=".", help="where checkpoints/ and logs/ are created")
     p.add_argument("--resume", default=None, help="trainer_<epoch>.pt written by an earlier run: continue it exactly")
     return p.parse_args(argv)
@@ -85,7 +89,8 @@ def main(argv=None):
                     ent_coef=args.ent_coef, vf_coef=args.vf_coef, learning_rate=args.learning_rate,
                     learning_rate_decay=args.learning_rate_decay, max_grad_norm=args.max_grad_norm,
                     reward_scaling=args.reward_scaling, track=args.track, num_rays=args.num_rays, env_dtype=args.env_dtype,
-                    seed=args.seed, full_sweep=args.full_sweep)
+                    seed=args.seed, full_sweep=args.full_sweep, bootstrap_value=args.bootstrap_value,
+                    policy_precision={"fp16x2": 2, "bf16x3": 1, "fp32": 0}[args.policy_arith])
     trainer = Trainer(cfg, device=torch.device("cuda", local_rank), rank=rank, world_size=world)
     first_epoch = 1
     if args.resume:
