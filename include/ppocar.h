@@ -271,6 +271,20 @@ int pc_ppo_minibatch_prepared(int device, const float* prepared_mb, int B, int D
                               float* workspace, int apply, void* stream);
 
 
+/* The whole minibatch loop of one epoch (train.py:223-261) over n_mb prepared minibatches (consecutive blocks of
+ * pc_ppo_prepared_floats(B, D) floats at `prepared`), with the clip + Adam step of minibatch i taken by the forward / backward
+ * launch of minibatch i + 1 as it loads the parameters (every workgroup needs all of them anyway; workgroup 0 writes the new
+ * generation into the other of two state buffers): TWO launches per minibatch instead of three, plus one clip + Adam launch for
+ * the last gradient, which also brings the state home.  Bit-identical to n_mb x pc_ppo_minibatch_prepared(apply = 1): param,
+ * exp_avg, exp_avg_sq, step_count and metrics; `grad` ends as the LAST minibatch's clipped gradient.  state2: device scratch of
+ * pc_ppo_epoch_state_floats(D, H, A) floats; param / grad / exp_avg / exp_avg_sq / state2 16-byte aligned.  Single-rank only
+ * (the multi-rank step has the gradient exchange between the backward pass and the clip). */
+int64_t pc_ppo_epoch_state_floats(int D, int H, int A);
+int pc_ppo_epoch_prepared(int device, const float* prepared, int n_mb, int B, int D, int H, int A, float* param, float* grad, float* exp_avg,
+                          float* exp_avg_sq, float* step_count, const float* lr_dev, double clip_ratio, double vf_coef, double ent_coef,
+                          double max_norm, double beta1, double beta2, double eps, float* metrics, float* workspace, float* state2,
+                          void* stream);
+
 /* ---- the per-minibatch gradient exchange (one all-reduce(SUM) of the flat gradient bucket between
  * loss.backward() and clip_grad_norm_, train.py:259-260) as a ONE-SHOT all-reduce over peer-mapped buffers -- the
  * latency-proof alternative to an RCCL all_reduce for a 49 - 92 KB message: every rank writes its bucket straight into a

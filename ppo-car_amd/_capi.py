@@ -91,6 +91,8 @@ _sig = {
     "pc_ppo_prepared_floats": (_i64, [_i, _i]),
     "pc_ppo_prepare": (_i, [_i, _vp, _i64, _i, _i, _i] + [_vp] * 5 + [_vp, _vp]),
     "pc_ppo_minibatch_prepared": (_i, [_i, _vp, _i, _i, _i, _i] + [_vp] * 6 + [_d] * 7 + [_vp, _vp, _i, _vp]),
+    "pc_ppo_epoch_state_floats": (_i64, [_i, _i, _i]),
+    "pc_ppo_epoch_prepared": (_i, [_i, _vp, _i, _i, _i, _i, _i] + [_vp] * 6 + [_d] * 7 + [_vp, _vp, _vp, _vp]),
     "pc_ppo_minibatch": (_i, [_i, _vp, _i, _i, _i, _i] + [_vp] * 5 + [_vp] * 6 + [_d] * 7 + [_vp, _vp, _i, _vp]),
     "pc_xchg_create": (_i, [_i, _i, _i, _i64, C.POINTER(_vp)]),
     "pc_xchg_local_handle": (_i, [_vp, _vp]),

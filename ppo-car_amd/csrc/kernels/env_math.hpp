@@ -152,46 +152,33 @@ __device__ __forceinline__ bool strict_hit(const CastD& c) {
 }
 // ... but the reference does not evaluate that test in exact arithmetic: it forms (x4, y4) = pos + dir (car_env.py:169) and works
 // with the ROUNDED differences (x3 - x4), (y3 - y4), i.e. with a direction perturbed by up to an ulp of the car's position (for
-// dir = (cos 90 deg, 1) = (6e-17, 1) the x component vanishes altogether), and two rounded quotients.  Away from a tie that
-// changes nothing (3e-14 rad; the test's margins are relative 1e-13).  AT a tie -- a ray that passes exactly through a vertex,
-// a car exactly on a wall's line, exactly parallel: what axis-aligned tracks with integer coordinates produce at will -- hit or
-// miss is decided by those roundings, and the two walls that meet at the vertex can both say "miss" (the ray passes between them
-// and reports whatever lies behind: 100s of pixels away).  near_tie says when one of the test's comparisons is within 1e-9
-// (relative; ~1e4 x the reference's rounding) of flipping; cast_lit then repeats the reference's arithmetic LITERALLY
-// (car_env.py:166-181,:205; the float64 kernel's cast_ref), so that the decision is the reference's own.
-__device__ __forceinline__ bool near_tie(const SegD& sg, const CastD& c) {
-    const double ad = __builtin_fabs(c.den), at = __builtin_fabs(c.tn), g = ad * 1e-9;
-    const double m = __builtin_fmin(__builtin_fmin(at, __builtin_fabs(ad - at)), __builtin_fabs(c.un));   // t ~ 0, t ~ 1, u ~ 0 (u in px)
-    return (m <= g) | (ad <= (__builtin_fabs(sg.ex) + __builtin_fabs(sg.ey)) * 1e-9);                     // ... or (nearly) parallel
-}
-// Ray.cast + np.linalg.norm exactly as the reference evaluates them (cast_ref), for the segment (x1, y1) -> (x1 - ex, y1 - ey):
-// (x1 - x2) = ex and (x2 - x1) = -ex as the reference rounds them.  Returns the distance; `hit` = the reference's verdict.
-__device__ __forceinline__ double cast_lit(const SegD& sg, const double px, const double py, const double dx, const double dy, bool& hit) {
-    const double x4 = px + dx, y4 = py + dy;                                   // :169
-    const double mx = px - x4, my = py - y4;                                   // (x3 - x4), (y3 - y4)
-    const double den = sg.ex * my - sg.ey * mx;                                // :171
-    hit = false;
-    if (den == 0) return 1000.0;                                               // :172
-    const double t = ((sg.x1 - px) * my - (sg.y1 - py) * mx) / den;            // :175
-    const double u = -(sg.ex * (sg.y1 - py) - sg.ey * (sg.x1 - px)) / den;     // :176
-    if (0 < t && t < 1 && u > 0) {                                             // :178
-        hit = true;
-        const double ptx = sg.x1 + t * -sg.ex, pty = sg.y1 + t * -sg.ey;       // :180-181
-        const double d0 = px - ptx, d1 = py - pty;
-        return sqrt(fma(d1, d1, d0 * d0));                                     // np.linalg.norm (see cast_ref)
-    }
-    return 1000.0;
-}
-// one ray against one segment, the reference's verdict and distance (1000.0 = Ray.get_distance's `largest_distance` for a miss):
-// the numerators' test and un / den wherever that is safe, the literal arithmetic at a tie
+// dir = (cos 90 deg, 1) = (6e-17, 1) the x component vanishes altogether).  Away from a tie that changes nothing (3e-14 rad; the
+// test's margins are relative 1e-13).  AT a tie -- a ray that passes exactly through a vertex, a car exactly on a wall's line,
+// exactly parallel: what axis-aligned tracks with integer coordinates produce at will -- hit or miss is decided by those
+// roundings, and the two walls that meet at the vertex can both say "miss" (the ray passes between them and reports whatever
+// lies behind: 100s of pixels away).  So wherever a verdict is taken in float64 outside refine_fast's certified interior --
+// the gate casts, the corner neighbours, the chain scan -- it is taken on the reference's OWN numerators and denominator, formed
+// literally (car_env.py:166-176; cast_exact).  No quotient is needed for the verdict: with IEEE division, 0 < fl(n / d) <=> n and d
+// have the same sign (nothing here underflows), fl(n / d) < 1 <=> |n| < |d| (the largest quotient of two doubles with |n| < |d| is
+// 1 - 2^-53, which does not round up to 1), and u > 0 likewise by signs.  The DISTANCE of a hit is refine_fast's very expression
+// (cast_terms' numerators, un / den to 2^-46: within a few float64 ulps of the reference's norm of the hit point): a ray reports the
+// same bits whether its slot was certified by the sweep or flagged and resolved here -- which depends on how the rays are dealt
+// to lanes (flags are kept per pair of slots) -- so the result does not depend on the launch geometry.
 struct CastR { double d; bool hit; };
 __device__ __forceinline__ CastR cast_exact(const SegD& sg, const double px, const double py, const double dx, const double dy) {
-    const CastD c = cast_terms(sg, px, py, dx, dy);
+    const double x4 = px + dx, y4 = py + dy;                                   // :169
+    const double mx = px - x4, my = py - y4;                                   // (x3 - x4), (y3 - y4)
+    const double ax = sg.x1 - px, ay = sg.y1 - py;                             // (x1 - x3), (y1 - y3)
+    const double den = sg.ex * my - sg.ey * mx;                                // :171 (the translation unit is compiled without contraction)
+    const double tn = ax * my - ay * mx;                                       // :175 numerator
+    const double un = -(sg.ex * ay - sg.ey * ax);                              // :176 numerator
+    const bool dpos = den > 0.0, dneg = den < 0.0;                             // den == 0: None (:172)
+    const bool t_ok = ((tn > 0.0) & dpos) | ((tn < 0.0) & dneg);               // 0 < t
+    const bool u_ok = ((un > 0.0) & dpos) | ((un < 0.0) & dneg);               // u > 0
     CastR r;
-    r.hit = strict_hit(c);
-    r.d = c.un * rcp_d(c.den);
-    if (near_tie(sg, c)) r.d = cast_lit(sg, px, py, dx, dy, r.hit);            // (rare: a branch the wave skips)
-    r.d = r.hit ? r.d : 1000.0;
+    r.hit = t_ok & (__builtin_fabs(tn) < __builtin_fabs(den)) & u_ok;          // t < 1
+    const CastD c = cast_terms(sg, px, py, dx, dy);
+    r.d = r.hit ? c.un * rcp_d(c.den) : 1000.0;                                // (1000.0 = Ray.get_distance's `largest_distance` for a miss)
     return r;
 }
 // Ray.get_distance (car_env.py:186-213) of ONE ray against a whole wall chain in float64: the refinement's exhaustive form,
@@ -223,28 +210,19 @@ __device__ __forceinline__ double refine_fast(const SegD& sg, const double px, c
 template <typename LoadSeg>
 __device__ __forceinline__ double refine_careful(const int k, const LoadSeg& segs, const int nV, const double px, const double py,
                                                  const double dx, const double dy) {
-    // ONE call site of cast_exact (its literal branch is a few hundred instructions of float64 division and square root: the
-    // persistent kernels pay for code size) driven by a per-lane state machine: first the selection and its two chain
-    // neighbours -- unless the selection is no hit after all, or flagged PC_SEG_SCAN --, else every segment of the chain.
-    bool scan = k == 0;
-    int j = 0, prev = 0, next = 0;
-    double d = 1000.0;                                             // :198
-    while (true) {
-        const int idx = scan ? j + 1 : (j == 0 ? k : (j == 1 ? prev : next));
-        const SegD sg = segs(idx);
+    double d = 1000.0;
+    bool any = false;
+    if (k != 0) {
+        const SegD sg = segs(k);
         const CastR c = cast_exact(sg, px, py, dx, dy);
-        if (!scan && j == 0) {
-            if (!c.hit || (sg.prev_next & PC_SEG_SCAN)) {          // nothing certified: scan (nV >= 4: the chain has segments)
-                scan = true;
-                continue;
-            }
-            prev = sg.prev_next & 0x7fff;                          // (index 0 = no neighbour: zero edge, never a hit)
-            next = (int)(((unsigned)sg.prev_next >> 16) & 0x7fff);
+        if (c.hit && !(sg.prev_next & PC_SEG_SCAN)) {   // the selection is a hit: is a chain neighbour's hit (around the corner it lies next to) nearer?
+            any = true;
+            d = c.d;
+            d = __builtin_fmin(d, cast_exact(segs(sg.prev_next & 0x7fff), px, py, dx, dy).d);   // (index 0 = no neighbour: zero edge, never a hit)
+            d = __builtin_fmin(d, cast_exact(segs((int)(((unsigned)sg.prev_next >> 16) & 0x7fff)), px, py, dx, dy).d);
         }
-        d = __builtin_fmin(d, c.d);                                // :203-207
-        ++j;
-        if (j == (scan ? nV - 1 : 3)) break;
     }
+    if (!any) d = scan_chain_d(segs, nV, px, py, dx, dy);
     return d;
 }
 // min(1000, d) / 1000 as the observation holds it (Ray.get_distance :198,:210-211; car_env.py:593,:595)
@@ -253,44 +231,6 @@ __device__ __forceinline__ float obs_dist(const double d) { return (float)(__bui
 __device__ __forceinline__ double cast_d(const Seg& s, const double px, const double py, const double dx, const double dy) {
     const SegD sg = {s.x1, s.y1, s.x1 - s.x2, s.y1 - s.y2, 0.0, 0, 0};
     return __builtin_fmin(cast_exact(sg, px, py, dx, dy).d, 1000.0);
-}
-
-// ---- Car.get_passed_gate's casts (car_env.py:387-390: one ray against gate[next], `distance < 10`) decided in FLOAT32 where
-// float32 can decide them.  The answer is a boolean, so a certified float32 verdict IS the exact one: with u = 2^-24, the
-// car-relative endpoint a = p1 - pos and the gate's edge e = p1 - p2 rounded from float64 (|a|_inf = m, |e|_inf = E) and the
-// float32 lattice direction, the numerators of Ray.cast carry absolute errors below
-//     |tn~ - tn| <= 6 u m,   |den~ - den| <= 6 u E,   |un~ - un| <= 7 u E m        (a multiply and an fma each),
-// priced here as eps_t = 2^-20 m, eps_d = 2^-20 E, eps_u = 2^-19 E m.  `0 < t < 1 and 0 < u < 10` (t = tn / den, u = un / den = the
-// hit distance) is CERTAINLY true when every sign is certain (magnitudes above their eps, products positive) and both
-// |den| - |tn| and 10 |den| - |un| clear the summed errors; CERTAINLY false when tn or un has the certain opposite sign of den, or
-// |tn| - |den| or |un| - 10 |den| clears the errors (|t| > 1 resp. |u| > 10; den = 0 included).  Anything else -- a verdict within
-// ~1e-5 (relative) of flipping: t at a gate end, u at 0 or at 10 px, a near-parallel ray -- is UNDECIDED and goes to the float64
-// cast (cast_d: the reference's own arithmetic at a tie).  ~1 cast in 1e5.
-struct GateF32 { float ax, ay, ex, ey, un, eps_t, eps_d, eps_u; };
-__device__ __forceinline__ GateF32 gate_f32(const Seg& g, const double px, const double py) {
-    GateF32 q;
-    q.ax = (float)(g.x1 - px);
-    q.ay = (float)(g.y1 - py);
-    q.ex = (float)(g.x1 - g.x2);
-    q.ey = (float)(g.y1 - g.y2);
-    const float m = __builtin_fmaxf(__builtin_fabsf(q.ax), __builtin_fabsf(q.ay)), E = __builtin_fmaxf(__builtin_fabsf(q.ex), __builtin_fabsf(q.ey));
-    q.un = __builtin_fmaf(q.ey, q.ax, -(q.ex * q.ay));
-    q.eps_t = m * 0x1p-20f;
-    q.eps_d = E * 0x1p-20f;
-    q.eps_u = m * E * 0x1p-19f;
-    return q;
-}
-// hit = the cast certainly hits within 10 px; returns false when the verdict is certain (hit or not), true when undecided
-__device__ __forceinline__ bool gate_cast_f32(const GateF32& q, const float dx, const float dy, bool& hit) {
-    const float den = __builtin_fmaf(q.ey, dx, -(q.ex * dy)), tn = __builtin_fmaf(q.ay, dx, -(q.ax * dy));
-    const float ad = __builtin_fabsf(den), at = __builtin_fabsf(tn), au = __builtin_fabsf(q.un);
-    const float sT = tn * den, sU = q.un * den;
-    const float A = ad - at, B = __builtin_fmaf(ad, 10.0f, -au);
-    const float et = q.eps_t + q.eps_d, eu = __builtin_fmaf(q.eps_d, 10.0f, q.eps_u);
-    const bool bigT = at > q.eps_t, bigD = ad > q.eps_d, bigU = au > q.eps_u;
-    hit = bigT & bigD & bigU & (sT > 0.0f) & (sU > 0.0f) & (A > et) & (B > eu);
-    const bool miss = (bigT & bigD & (sT < 0.0f)) | (A < -et) | (bigU & bigD & (sU < 0.0f)) | (B < -eu);
-    return !(hit | miss);
 }
 
 template <typename T> struct Math;

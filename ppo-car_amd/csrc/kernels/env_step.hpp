@@ -530,7 +530,7 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
         // instead of falling on whichever lane owns those rays (with rays strided over the lanes: all on lane 0).
         const int k5o = 5 * Math<float>::mod72(st.k);
 #pragma unroll 1
-        for (int jj = 0; jj * G < p.nc; ++jj) {  // (uniform trip count; rolled: one copy of cast_exact's literal branch)
+        for (int jj = 0; jj * G < p.nc; ++jj) {  // (uniform trip count)
             const int j = g + jj * G;
             const unsigned m = (unsigned)(k5o + (j < p.nc ? j : 0) * p.q * p.step_deg);
             const double2 cs = p.dirtab64[h.dir_off + (int)min(m, m - 360u)];
@@ -606,7 +606,7 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
         }
         // the rare rest, one slot of one lane at a time through ONE copy of the careful code (select chains instead of
         // dynamically indexed registers)
-        while (__builtin_amdgcn_ballot_w64(todo != 0) != 0) {
+        while (__builtin_expect(__builtin_amdgcn_ballot_w64(todo != 0) != 0, 0)) {
             const int s0 = todo ? __builtin_ctzll(todo) : -1;
             unsigned sel = 0;
             int di = 360;

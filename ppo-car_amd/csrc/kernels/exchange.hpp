@@ -14,14 +14,17 @@
 // finished summing k.  The staging memory is allocated uncached / fine-grained (hipExtMallocWithFlags) so that remote writes
 // are visible to a running kernel; flags are released / acquired at system scope.  Ranks reach an exchange at different times
 // (one may still be capturing its graph while the other already replays): a wait is patient -- the handle's timeout, 20 s of
-// s_memtime by default (pc_xchg_set_timeout) -- but not endless: when it expires it raises the handle's error word and the kernel
+// the device's real-time counter by default (pc_xchg_set_timeout) -- but not endless: when it expires it raises the handle's error word and the kernel
 // finishes with a wrong sum (pc_xchg_status reports PC_ERR_TIMEOUT; the host layer checks it wherever it synchronises and aborts
 // the job), and every later exchange on that handle skips its wait: the grid always drains.
 #pragma once
 
 constexpr int XCHG_MAX_RANKS = 8;
 constexpr int XCHG_CHUNK = 1024;   // floats per workgroup
-constexpr double XCHG_TICKS_PER_SECOND = 2.0e9;   // s_memtime runs at about the shader clock (~2 GHz)
+// The patience is measured with s_memrealtime: the 100 MHz reference clock, one counter for the whole device.  (s_memtime is a
+// per-XCD shader-clock counter: a wave that the driver saves and restores while two processes time-slice one GPU -- the
+// same-device rehearsal -- can resume where the counter reads something unrelated, and a "20 s" wait then expires at once.)
+constexpr double XCHG_TICKS_PER_SECOND = 1.0e8;
 
 struct XchgView {
     float* data[XCHG_MAX_RANKS];       // data[r]: rank r's staging area [2 parities][W writers][n_pad floats] (data[rank] is local)
@@ -29,7 +32,7 @@ struct XchgView {
     unsigned* epoch;                   // local [n_chunks]: this rank's call count per chunk
     int* error;                        // local [1]
     int rank, world, n, n_pad, n_chunks;
-    unsigned long long timeout_ticks;  // patience of a wait, in s_memtime ticks
+    unsigned long long timeout_ticks;  // patience of a wait, in s_memrealtime ticks (100 MHz)
 };
 
 __global__ __launch_bounds__(256) void xchg_allreduce_kernel(const XchgView v, float* __restrict__ bucket) {
@@ -58,11 +61,12 @@ __global__ __launch_bounds__(256) void xchg_allreduce_kernel(const XchgView v, f
     // ---- phase 2: wait for the W writers of my chunk, then sum their slots in rank order
     if (tid < W) {
         const unsigned* f = v.flags[v.rank] + (par * W + tid) * v.n_chunks + c;
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         bool dead = __hip_atomic_load(v.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;   // an earlier exchange gave up: do not wait again
         while (!dead && __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != ep) {
             __builtin_amdgcn_s_sleep(32);
-            if (__builtin_amdgcn_s_memtime() - t0 > v.timeout_ticks) {   // give up, say so
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (now > t0 && now - t0 > v.timeout_ticks) {   // give up, say so
                 __hip_atomic_store(v.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 dead = true;
             }

@@ -285,33 +285,17 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
             m += fl.rstep;
         }
     }
-    // ---- Car.get_passed_gate (:394-408): the four collision rays at the PREVIOUS pose against gate[next], dealt over the lanes.
-    // The verdict `distance < 10` is taken in float32 wherever float32 can certify it (gate_cast_f32); the rare undecided cast --
-    // a verdict within ~1e-5 of flipping -- is repeated in float64 (cast_d: the lattice entry names its float64 twin), in a
-    // block the wave skips unless one of its lanes needs it.  Either way the boolean is the exact one: the same as the per-step
-    // kernel's, which casts in float64 throughout.
+    // ---- Car.get_passed_gate (:394-408): the four collision rays at the PREVIOUS pose against gate[next], dealt over the lanes,
+    // cast in float64 (cast_d: the lattice entry names its float64 twin; the reference's own verdict at a tie)
     const f64x4 gv = ft.gates[st.next];
     const Seg gate = {gv.x, gv.y, gv.z, gv.w};
     const int k80o = 80 * k72;
     bool gate_hit = false;
     if constexpr (!(PC_ABLATE & 8)) {
-        const GateF32 gf = gate_f32(gate, opx, opy);
-        unsigned und = 0;
 #pragma unroll
         for (int jj = 0; jj < 4 / G; ++jj) {
-            const f32x4 cs = *(lds_f4c)(size_t)(unsigned)(k80o + gq[jj]);
-            bool hit;
-            und |= gate_cast_f32(gf, cs.x, cs.y, hit) ? 1u << jj : 0u;
-            gate_hit |= hit;
-        }
-        if (__builtin_amdgcn_ballot_w64(und != 0) != 0) {
-#pragma unroll 1
-            for (int jj = 0; jj < 4 / G; ++jj) {      // (rolled: ONE copy of cast_exact's literal branch in the kernel)
-                if ((und >> jj) & 1) {
-                    const f64x2 cs = dir64_at(k80o + gq[0] + jj * (gq[G == 2 ? 1 : 0] - gq[0]));     // (no indexed register array: that went to scratch)
-                    gate_hit |= cast_d(gate, opx, opy, cs.x, cs.y) < 10.0;  // :387,:390
-                }
-            }
+            const f64x2 cs = dir64_at(k80o + gq[jj]);
+            gate_hit |= cast_d(gate, opx, opy, cs.x, cs.y) < 10.0;  // :387,:390
         }
     }
     // ---- wall sweep (float32 selector, env_step.hpp).  More than 12 ray slots per lane (33 rays: 17) are swept in TWO passes over
@@ -450,7 +434,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     wall_hit = __builtin_amdgcn_inverse_ballot_w64(hit_mask);
     PC_STAMP_E(8)
     // the rare rest, one slot of one lane at a time through ONE copy of the careful code (a select chain picks the slot's selection)
-    while (__builtin_amdgcn_ballot_w64(todo != 0) != 0) {
+    while (__builtin_expect(__builtin_amdgcn_ballot_w64(todo != 0) != 0, 0)) {
         const int s0 = todo ? __builtin_ctz(todo) : -1;
         unsigned sel = 0;
 #pragma unroll

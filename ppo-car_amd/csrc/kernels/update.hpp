@@ -151,6 +151,59 @@ __global__ __launch_bounds__(1024) void clip_adam_kernel(float* __restrict__ par
 // ------------------------------------------------------------------------------------------
 constexpr int FB_S = 8;  // samples per workgroup
 
+// clip_grad_norm_ + Adam for ONE element, shared by K12 (adam_kernel), K12m (clip_adam_mb_kernel) and K10's deferred form: the
+// same instruction sequence wherever a parameter is updated, so every path gives the same bits.  torch's update is
+//   g = grad * clip_coef;  m = m + (1 - b1)(g - m);  v = b2 v + (1 - b2) g g;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+// (train.py:260-261, Adam(eps = 1e-5) train.py:146).  The square root and the two divisions are v_sqrt_f32 / v_rcp_f32 (one ulp
+// each) and a multiply by the exactly computed 1 / sqrt(bc2): the update term (<= lr ~ 3e-4) moves by 2.4e-7 of itself, 7e-11
+// absolute per step against the 2e-6 the parameters are held to against torch -- where the IEEE forms cost ~35 instructions
+// per element, which K10's deferred form would pay 58 times per thread at the head of its critical path.
+struct AdamCoef { float coef, step_size, inv_bc2_sqrt, beta1, beta2, eps; };
+__device__ __forceinline__ AdamCoef adam_coef(const float norm_sq, const float step, const float lr, const float max_norm, const float beta1,
+                                              const float beta2, const float eps) {
+    AdamCoef c;
+    c.coef = fminf(max_norm / (sqrtf(norm_sq) + 1e-6f), 1.0f);                 // clip_coef_clamped
+    const float bc1 = 1.0f - powf(beta1, step), bc2 = 1.0f - powf(beta2, step);
+    c.step_size = lr / bc1;
+    c.inv_bc2_sqrt = 1.0f / sqrtf(bc2);
+    c.beta1 = beta1;
+    c.beta2 = beta2;
+    c.eps = eps;
+    return c;
+}
+__device__ __forceinline__ void adam_elem(const AdamCoef& c, const float g_raw, float& p, float& m, float& v) {
+    const float g = g_raw * c.coef;
+    m = m + (1.0f - c.beta1) * (g - m);                                        // exp_avg.lerp_(grad, 1 - beta1)
+    v = c.beta2 * v + (1.0f - c.beta2) * g * g;                                // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+    const float denom = __builtin_amdgcn_sqrtf(v) * c.inv_bc2_sqrt + c.eps;
+    p = p - c.step_size * (m * __builtin_amdgcn_rcpf(denom));                  // param.addcdiv_(exp_avg, denom, -step_size)
+}
+// the squared gradient norm from K11's per-block partials, summed in index order (every thread, every workgroup: the same float)
+__device__ __forceinline__ float norm_sq_from_partials(const float* __restrict__ norm_partial, const int n_norm) {
+    float ss = 0.0f;
+    for (int j = 0; j < n_norm; ++j) ss += norm_partial[j];
+    return ss;
+}
+// K10's deferred form: the clip + Adam step of the PREVIOUS minibatch (K12) is taken by the next forward / backward launch as it
+// loads the parameters -- every workgroup needs all of them anyway, and every thread exactly the 2 D + 12 + ... elements of its own
+// hidden unit: it reads (param, grad, exp_avg, exp_avg_sq) of generation i, updates them in registers (adam_elem) and runs on the
+// result; workgroup 0 also writes generation i + 1 into the OTHER of two state buffers (readers and the writer of one launch never
+// meet).  Per minibatch the chain is two launches (K10, K11) instead of three; the last gradient of an epoch is applied by one
+// K12 launch that also brings the state home to the caller's tensors.
+struct AdamDefer {
+    const float* __restrict__ grad;          // the previous minibatch's raw gradient (K11's output); nullptr = nothing to apply
+    const float* __restrict__ m_in;
+    const float* __restrict__ v_in;
+    float* __restrict__ p_out;
+    float* __restrict__ m_out;
+    float* __restrict__ v_out;
+    const float* __restrict__ norm_partial;
+    int n_norm;
+    const float* __restrict__ step_count;
+    const float* __restrict__ lr_dev;
+    float max_norm, beta1, beta2, eps;
+};
+
 // 64-lane sum with DPP row operations (VALU only; the __shfl_xor butterfly goes through the LDS crossbar
 // with ~100 cycles of dependent latency per step).  The total lands in lane 63; readlane broadcasts it.
 __device__ __forceinline__ float wave_sum(float v) {
@@ -225,14 +278,14 @@ __global__ __launch_bounds__(256) void ppo_prepare_kernel(const int64_t* __restr
 // unrolled 16-slot loops is a v_cndmask per slot and sample and the FMAs of the unused slots are executed (backward: 219
 // selects + 112 FMAs per thread); the same operations in the same order either way.
 // DC > 0: likewise the observation width (6 + 12 / 17 / 33 rays).
-template <int DMAX, int AC = 0, int DC = 0>
+template <int DMAX, int AC = 0, int DC = 0, bool DEFER = false>
 __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __restrict__ idx, const int B, const int D_rt, const int A_rt,
                                                 const float* __restrict__ obs, const float* __restrict__ act,
                                                 const float* __restrict__ old_lp, const float* __restrict__ adv,
                                                 const float* __restrict__ ret, const float* __restrict__ param,
                                                 const float clip, const float vf, const float ec,
                                                 float* __restrict__ partial, float* __restrict__ metric_partial,
-                                                const float* __restrict__ prep) {
+                                                const float* __restrict__ prep, const AdamDefer df) {
     constexpr int H = 256, S = FB_S, LDT = DMAX + 1, LDH = H + 1;
     const int A = AC > 0 ? AC : A_rt, D = DC > 0 ? DC : D_rt;
     static_assert(DC <= DMAX, "observation width");
@@ -268,30 +321,122 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
 #pragma unroll
         for (int j = 0; j < 4; ++j) a_src[j] = u + j * 256 < B ? idx[u + j * 256] : 0;
     }
-    float w2a[16];
+    // defer (uniform): `param` holds generation i, the previous minibatch's clip + Adam step has not been taken yet (AdamDefer):
+    // every parameter element this thread loads is loaded with its gradient and moments, updated in registers, and -- by
+    // workgroup 0 -- written to generation i + 1.  All loads of the phase are issued before the first wait either way.
+    // DEFER is compiled in for CarEnv's shapes only (the generic kernels take the three-launch step).
+    const bool defer = DEFER && df.grad != nullptr;
+    const bool wr = defer && wg == 0;
+    float w2a[16], w2a_g[16], w2a_m[16], w2a_v[16];
 #pragma unroll
-    for (int o = 0; o < 16; ++o) w2a[o] = o < A ? param[o_aW2 + o * H + u] : 0.0f;
-    const float w2c = param[o_cW2 + u], b1a = param[o_ab1 + u], b1c = param[o_cb1 + u];
+    for (int o = 0; o < 16; ++o) {
+        w2a[o] = o < A ? param[o_aW2 + o * H + u] : 0.0f;
+        w2a_g[o] = w2a_m[o] = w2a_v[o] = 0.0f;
+        if (defer && o < A) {
+            w2a_g[o] = df.grad[o_aW2 + o * H + u];
+            w2a_m[o] = df.m_in[o_aW2 + o * H + u];
+            w2a_v[o] = df.v_in[o_aW2 + o * H + u];
+        }
+    }
+    float w2c = param[o_cW2 + u], b1a = param[o_ab1 + u], b1c = param[o_cb1 + u];
     const int ob = u & 15;                                                // my output index in the layer-2 epilogue
-    const float b2 = ob < A ? param[o_ab2 + ob] : (ob == A ? param[o_cb2] : 0.0f);
+    const int o_b2 = ob < A ? o_ab2 + ob : o_cb2;                         // (ob > A: a dummy slot, value unused)
+    float b2 = ob <= A ? param[o_b2] : 0.0f;
+    float sc_g[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sc_m[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sc_v[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // w2c, b1a, b1c, b2
+    const int sc_i[4] = {o_cW2 + u, o_ab1 + u, o_cb1 + u, o_b2};
+    if (defer) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < 3 || ob <= A) {
+                sc_g[q] = df.grad[sc_i[q]];
+                sc_m[q] = df.m_in[sc_i[q]];
+                sc_v[q] = df.v_in[sc_i[q]];
+            }
+        }
+    }
     // W1 of both nets with 16-byte loads: the [H][D] block at parameter offset `off` is fetched as the aligned float4 window
     // [off & ~3, off + H D) -- NV4 loads per thread and net instead of D dword loads (the kernel's memory instructions were a
     // third of its time: profiles/, K10 phase stamps) -- and goes through the LDS tile in that same natural order.
     constexpr int NV4 = (H * DMAX + 3 + 1023) / 1024 + 1;
-    f32x4 w1raw4[2][NV4];
-    int w1_shift[2], w1_n4[2];
+    constexpr int NVD = DEFER ? NV4 : 1;
+    f32x4 w1raw4[2][NV4], w1g[2][NVD], w1m[2][NVD], w1v[2][NVD];
+    int w1_shift[2], w1_n4[2], w1_b4[2];
 #pragma unroll
     for (int net = 0; net < 2; ++net) {
         const int off = net == 0 ? o_aW1 : o_cW1, b4 = off & ~3;
         w1_shift[net] = off - b4;
+        w1_b4[net] = b4;
         w1_n4[net] = (off + H * D - b4 + 3) >> 2;
         const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(param + b4);
 #pragma unroll
         for (int j = 0; j < NV4; ++j) {
             const int i4 = u + 256 * j;
-            w1raw4[net][j] = i4 < w1_n4[net] ? src[i4] : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+            w1raw4[net][j] = i4 < w1_n4[net] ? src[i4] : z;
+            if constexpr (DEFER) {
+                w1g[net][j] = w1m[net][j] = w1v[net][j] = z;
+                if (defer && i4 < w1_n4[net]) {
+                    w1g[net][j] = reinterpret_cast<const f32x4*>(df.grad + b4)[i4];
+                    w1m[net][j] = reinterpret_cast<const f32x4*>(df.m_in + b4)[i4];
+                    w1v[net][j] = reinterpret_cast<const f32x4*>(df.v_in + b4)[i4];
+                }
+            }
         }
     }
+    if constexpr (DEFER) if (defer) {      // (uniform) the deferred clip + Adam step, element by element in registers
+        const AdamCoef ac = adam_coef(norm_sq_from_partials(df.norm_partial, df.n_norm), df.step_count[0], df.lr_dev[0], df.max_norm, df.beta1,
+                                      df.beta2, df.eps);
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            if (o < A) {
+                adam_elem(ac, w2a_g[o], w2a[o], w2a_m[o], w2a_v[o]);
+                if (wr) {
+                    df.p_out[o_aW2 + o * H + u] = w2a[o];
+                    df.m_out[o_aW2 + o * H + u] = w2a_m[o];
+                    df.v_out[o_aW2 + o * H + u] = w2a_v[o];
+                }
+            }
+        }
+        float sc_p[4] = {w2c, b1a, b1c, b2};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < 3 || ob <= A) {
+                adam_elem(ac, sc_g[q], sc_p[q], sc_m[q], sc_v[q]);
+                if (wr && (q < 3 || u <= A)) {     // (the 16 copies of an output bias: one writer)
+                    df.p_out[sc_i[q]] = sc_p[q];
+                    df.m_out[sc_i[q]] = sc_m[q];
+                    df.v_out[sc_i[q]] = sc_v[q];
+                }
+            }
+        }
+        w2c = sc_p[0];
+        b1a = sc_p[1];
+        b1c = sc_p[2];
+        b2 = sc_p[3];
+#pragma unroll
+        for (int net = 0; net < 2; ++net) {
+#pragma unroll
+            for (int j = 0; j < NV4; ++j) {
+                const int i4 = u + 256 * j;
+                if (i4 < w1_n4[net]) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {      // (a vector element does not bind to a reference)
+                        float pe = w1raw4[net][j][c], me = w1m[net][j][c], ve = w1v[net][j][c];
+                        adam_elem(ac, w1g[net][j][c], pe, me, ve);
+                        w1raw4[net][j][c] = pe;
+                        w1m[net][j][c] = me;
+                        w1v[net][j][c] = ve;
+                    }
+                    if (wr) {      // (the window's few elements outside the block belong to its neighbours: the same values again)
+                        reinterpret_cast<f32x4*>(df.p_out + w1_b4[net])[i4] = w1raw4[net][j];
+                        reinterpret_cast<f32x4*>(df.m_out + w1_b4[net])[i4] = w1m[net][j];
+                        reinterpret_cast<f32x4*>(df.v_out + w1_b4[net])[i4] = w1v[net][j];
+                    }
+                }
+            }
+        }
+    }
+    if (ob > A) b2 = 0.0f;
     // ---- second-level loads (addresses came from idx)
     float a_loc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, a_sum = 0.0f;
     float pre_mean = 0.0f, pre_sd = 1.0f;
@@ -554,15 +699,15 @@ __device__ __forceinline__ void ppo_fwdbwd_body(const int wg, const int64_t* __r
     PC_STAMP_U(7)
 }
 
-template <int DMAX, int AC = 0, int DC = 0>
+template <int DMAX, int AC = 0, int DC = 0, bool DEFER = false>
 __global__ __launch_bounds__(256) void ppo_fwdbwd_kernel(const int64_t* __restrict__ idx, const int B, const int D, const int A,
                                                          const float* __restrict__ obs, const float* __restrict__ act,
                                                          const float* __restrict__ old_lp, const float* __restrict__ adv,
                                                          const float* __restrict__ ret, const float* __restrict__ param,
                                                          const float clip, const float vf, const float ec,
                                                          float* __restrict__ partial, float* __restrict__ metric_partial,
-                                                         const float* __restrict__ prep) {
-    ppo_fwdbwd_body<DMAX, AC, DC>(blockIdx.x, idx, B, D, A, obs, act, old_lp, adv, ret, param, clip, vf, ec, partial, metric_partial, prep);
+                                                         const float* __restrict__ prep, const AdamDefer df) {
+    ppo_fwdbwd_body<DMAX, AC, DC, DEFER>(blockIdx.x, idx, B, D, A, obs, act, old_lp, adv, ret, param, clip, vf, ec, partial, metric_partial, prep, df);
 }
 
 // K11: flat_grad[i] = sum_p partial[p][i] (fixed order: deterministic); block-wise squared-norm partials for the clip;
@@ -648,18 +793,18 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restric
 
 // K12: clip_grad_norm_ + Adam, one element per thread; the squared norm arrives as per-block partials of K11 and
 // the step counter has already been advanced there.
-__device__ __forceinline__ void adam_body(const int blk, float* __restrict__ param, float* __restrict__ grad, float* __restrict__ exp_avg,
-                                                   float* __restrict__ exp_avg_sq, const float* __restrict__ step_count,
-                                                   const float* __restrict__ lr_dev, const float* __restrict__ norm_partial,
-                                                   const int n_norm, const int n, const float max_norm, const float beta1,
-                                                   const float beta2, const float eps) {
+__device__ __forceinline__ void adam_body(const int blk, const float* __restrict__ p_in, const float* __restrict__ m_in, const float* __restrict__ v_in,
+                                          float* __restrict__ grad, float* __restrict__ p_out, float* __restrict__ m_out, float* __restrict__ v_out,
+                                          const float* __restrict__ step_count, const float* __restrict__ lr_dev,
+                                          const float* __restrict__ norm_partial, const int n_norm, const int n, const float max_norm,
+                                          const float beta1, const float beta2, const float eps) {
     // all loads first (cold misses: the operands were written by other workgroups), the norm partials once per
     // workgroup through LDS; every thread then sums them in index order
     __shared__ float sNorm[256];
     const int i = blk * blockDim.x + threadIdx.x;
     const bool live = i < n;
-    const float g_raw = live ? grad[i] : 0.0f, m0 = live ? exp_avg[i] : 0.0f, v0 = live ? exp_avg_sq[i] : 0.0f;
-    const float p0 = live ? param[i] : 0.0f;
+    const float g_raw = live ? grad[i] : 0.0f;
+    float m = live ? m_in[i] : 0.0f, v = live ? v_in[i] : 0.0f, p = live ? p_in[i] : 0.0f;
     const float step = step_count[0], lr = lr_dev[0];
     float ss = 0.0f;
     for (int j0 = 0; j0 < n_norm; j0 += 256) {
@@ -669,25 +814,24 @@ __device__ __forceinline__ void adam_body(const int blk, float* __restrict__ par
         const int cnt = n_norm - j0 < 256 ? n_norm - j0 : 256;
         for (int j = 0; j < cnt; ++j) ss += sNorm[j];
     }
-    const float coef = fminf(max_norm / (sqrtf(ss) + 1e-6f), 1.0f);
-    const float bc1 = 1.0f - powf(beta1, step), bc2_sqrt = sqrtf(1.0f - powf(beta2, step));
-    const float step_size = lr / bc1;
+    const AdamCoef ac = adam_coef(ss, step, lr, max_norm, beta1, beta2, eps);
     if (!live) return;
-    const float g = g_raw * coef;
-    grad[i] = g;
-    const float m = m0 + (1.0f - beta1) * (g - m0);
-    const float v = beta2 * v0 + (1.0f - beta2) * g * g;
-    exp_avg[i] = m;
-    exp_avg_sq[i] = v;
-    param[i] = p0 - step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
+    grad[i] = g_raw * ac.coef;             // clip_grad_norm_ scales the grads in place
+    adam_elem(ac, g_raw, p, m, v);
+    m_out[i] = m;
+    v_out[i] = v;
+    p_out[i] = p;
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ exp_avg,
-                                                   float* __restrict__ exp_avg_sq, const float* __restrict__ step_count,
+// (state in -> state out: the same tensors for the classic three-launch step, the deferred chain's current generation -> the
+// caller's tensors at the end of an epoch)
+__global__ __launch_bounds__(256) void adam_kernel(const float* __restrict__ p_in, const float* __restrict__ m_in, const float* __restrict__ v_in,
+                                                   float* __restrict__ grad, float* __restrict__ p_out, float* __restrict__ m_out,
+                                                   float* __restrict__ v_out, const float* __restrict__ step_count,
                                                    const float* __restrict__ lr_dev, const float* __restrict__ norm_partial,
                                                    const int n_norm, const int n, const float max_norm, const float beta1,
                                                    const float beta2, const float eps) {
-    adam_body(blockIdx.x, param, grad, exp_avg, exp_avg_sq, step_count, lr_dev, norm_partial, n_norm, n, max_norm, beta1, beta2, eps);
+    adam_body(blockIdx.x, p_in, m_in, v_in, grad, p_out, m_out, v_out, step_count, lr_dev, norm_partial, n_norm, n, max_norm, beta1, beta2, eps);
 }
 
 
@@ -723,16 +867,12 @@ __global__ __launch_bounds__(256) void clip_adam_mb_kernel(float* __restrict__ p
         }
     }
     for (int j = 4 * n4 + threadIdx.x; j < n; j += 256) { const float a = grad[j] * grad_scale; ss += a * a; }
-    const float total_norm = sqrtf(block_sum(ss, sh));
-    const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);   // clip_coef_clamped
-    const float bc1 = 1.0f - powf(beta1, step), bc2_sqrt = sqrtf(1.0f - powf(beta2, step));
-    const float step_size = lr / bc1;
+    const AdamCoef ac = adam_coef(block_sum(ss, sh), step, lr, max_norm, beta1, beta2, eps);
     if (!live) return;
     // (the bucket itself is left as the all-reduce delivered it: other workgroups may still be reading it for their norm)
-    const float g = g_own * coef;
-    const float m = m0 + (1.0f - beta1) * (g - m0);
-    const float v = beta2 * v0 + (1.0f - beta2) * g * g;
+    float p = p0, m = m0, v = v0;
+    adam_elem(ac, g_own, p, m, v);
     exp_avg[i] = m;
     exp_avg_sq[i] = v;
-    param[i] = p0 - step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
+    param[i] = p;
 }

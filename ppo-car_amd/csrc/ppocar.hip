@@ -1236,6 +1236,52 @@ int64_t pc_ppo_workspace_floats(int B, int D, int H, int A) {
     return n_part * ((n_param + 3) & ~(int64_t)3) + n_part * 4 + (n_param + 255) / 256;
 }
 
+// the layout of pc_ppo_minibatch's workspace and the launches of one minibatch step
+struct MbPlan {
+    int n_param, n_part, n_blk, n_pad, HD, mid_end;
+    float *partial, *metric_partial, *norm_partial;
+    MbPlan(int B, int D, int H, int A, float* workspace) {
+        n_param = 2 * (H * D + H) + A * H + A + H + 1;
+        n_part = (B + FB_S - 1) / FB_S;
+        n_blk = (n_param + 255) / 256;
+        n_pad = (n_param + 3) & ~3;          // a partial's row stride: 16-byte aligned rows
+        HD = H * D;
+        mid_end = HD + H + A * H + A;        // natural offset of critic.0.weight (ppo_fwdbwd_body's o_cW1)
+        partial = workspace;
+        metric_partial = partial + (size_t)n_part * n_pad;
+        norm_partial = metric_partial + n_part * 4;
+    }
+};
+
+static void launch_fwdbwd(const MbPlan& pl, const int64_t* idx, const float* prep, int B, int D, int A, const float* obs, const float* act,
+                          const float* old_logprob, const float* adv, const float* ret, const float* param, double clip_ratio, double vf_coef,
+                          double ent_coef, const AdamDefer& df, hipStream_t st) {
+#define PC_FB(DM, ACV, DCV, DF)                                                                                          \
+    hipLaunchKernelGGL((ppo_fwdbwd_kernel<DM, ACV, DCV, DF>), dim3(pl.n_part), dim3(256), 0, st, idx, B, D, A, obs, act, old_logprob, adv, ret, param, \
+                       (float)clip_ratio, (float)vf_coef, (float)ent_coef, pl.partial, pl.metric_partial, prep, df)
+    // CarEnv's shapes (Discrete(9); 6 + 12 / 17 / 33 rays) have their action count and observation width compiled in -- and the
+    // deferred clip + Adam prologue (mb_defer_shape)
+    if (A == 9 && D == 23) { if (df.grad) PC_FB(24, 9, 23, true); else PC_FB(24, 9, 23, false); }
+    else if (A == 9 && D == 18) { if (df.grad) PC_FB(24, 9, 18, true); else PC_FB(24, 9, 18, false); }
+    else if (A == 9 && D == 39) { if (df.grad) PC_FB(40, 9, 39, true); else PC_FB(40, 9, 39, false); }
+    else if (D <= 24) PC_FB(24, 0, 0, false);
+    else PC_FB(40, 0, 0, false);
+#undef PC_FB
+}
+static bool mb_defer_shape(int D, int A) { return A == 9 && (D == 18 || D == 23 || D == 39); }
+
+static void launch_reduce(const MbPlan& pl, int B, double vf_coef, double ent_coef, float* grad, float* metrics, float* step_count, hipStream_t st) {
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3(pl.n_blk), dim3(256), 0, st, pl.partial, pl.n_part, pl.n_param, pl.HD, pl.mid_end, pl.n_pad, grad,
+                       pl.norm_partial, pl.metric_partial, B, (float)vf_coef, (float)ent_coef, metrics, step_count);
+}
+
+static void launch_adam(const MbPlan& pl, const float* p_in, const float* m_in, const float* v_in, float* grad, float* p_out, float* m_out,
+                        float* v_out, const float* step_count, const float* lr_dev, double max_norm, double beta1, double beta2, double eps,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(adam_kernel, dim3(pl.n_blk), dim3(256), 0, st, p_in, m_in, v_in, grad, p_out, m_out, v_out, step_count, lr_dev,
+                       pl.norm_partial, pl.n_blk, pl.n_param, (float)max_norm, (float)beta1, (float)beta2, (float)eps);
+}
+
 static int ppo_minibatch_impl(int device, const int64_t* idx, const float* prep, int B, int D, int H, int A, const float* obs,
                               const float* act, const float* old_logprob, const float* adv, const float* ret, float* param, float* grad,
                               float* exp_avg, float* exp_avg_sq, float* step_count, const float* lr_dev, double clip_ratio,
@@ -1249,30 +1295,11 @@ static int ppo_minibatch_impl(int device, const int64_t* idx, const float* prep,
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40 || B < 2 || B > 1024) return PC_ERR_UNSUPPORTED;
     DeviceGuard guard(device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
-    const int n_param = 2 * (H * D + H) + A * H + A + H + 1;
-    const int n_part = (B + FB_S - 1) / FB_S;
-    const int n_blk = (n_param + 255) / 256;
-    const int n_pad = (n_param + 3) & ~3;          // a partial's row stride: 16-byte aligned rows
-    const int HD = H * D, mid_end = HD + H + A * H + A;   // natural offset of critic.0.weight (ppo_fwdbwd_body's o_cW1)
-    float* partial = workspace;
-    float* metric_partial = partial + (size_t)n_part * n_pad;
-    float* norm_partial = metric_partial + n_part * 4;
+    const MbPlan pl(B, D, H, A, workspace);
     hipStream_t st = (hipStream_t)stream;
-#define PC_FB(DM, ACV, DCV)                                                                                              \
-    hipLaunchKernelGGL((ppo_fwdbwd_kernel<DM, ACV, DCV>), dim3(n_part), dim3(256), 0, st, idx, B, D, A, obs, act, old_logprob, adv, ret, param, \
-                       (float)clip_ratio, (float)vf_coef, (float)ent_coef, partial, metric_partial, prep)
-    // CarEnv's shapes (Discrete(9); 6 + 12 / 17 / 33 rays) have their action count and observation width compiled in
-    if (A == 9 && D == 23) PC_FB(24, 9, 23);
-    else if (A == 9 && D == 18) PC_FB(24, 9, 18);
-    else if (A == 9 && D == 39) PC_FB(40, 9, 39);
-    else if (D <= 24) PC_FB(24, 0, 0);
-    else PC_FB(40, 0, 0);
-#undef PC_FB
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3(n_blk), dim3(256), 0, st, partial, n_part, n_param, HD, mid_end, n_pad, grad, norm_partial, metric_partial, B,
-                       (float)vf_coef, (float)ent_coef, metrics, apply ? step_count : nullptr);
-    if (apply == 1)
-        hipLaunchKernelGGL(adam_kernel, dim3(n_blk), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, step_count, lr_dev, norm_partial,
-                           n_blk, n_param, (float)max_norm, (float)beta1, (float)beta2, (float)eps);
+    launch_fwdbwd(pl, idx, prep, B, D, A, obs, act, old_logprob, adv, ret, param, clip_ratio, vf_coef, ent_coef, AdamDefer{}, st);
+    launch_reduce(pl, B, vf_coef, ent_coef, grad, metrics, apply ? step_count : nullptr, st);
+    if (apply == 1) launch_adam(pl, param, exp_avg, exp_avg_sq, grad, param, exp_avg, exp_avg_sq, step_count, lr_dev, max_norm, beta1, beta2, eps, st);
     HIPCHK(hipGetLastError());
     return PC_OK;
 }
@@ -1314,6 +1341,61 @@ int pc_ppo_minibatch_prepared(int device, const float* prepared_mb, int B, int D
                               workspace, apply, stream);
 }
 
+
+int64_t pc_ppo_epoch_state_floats(int D, int H, int A) {
+    if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
+    const int64_t n_param = 2 * ((int64_t)H * D + H) + (int64_t)A * H + A + H + 1;
+    return 3 * ((n_param + 3) & ~(int64_t)3);
+}
+
+int pc_ppo_epoch_prepared(int device, const float* prepared, int n_mb, int B, int D, int H, int A, float* param, float* grad, float* exp_avg,
+                          float* exp_avg_sq, float* step_count, const float* lr_dev, double clip_ratio, double vf_coef, double ent_coef,
+                          double max_norm, double beta1, double beta2, double eps, float* metrics, float* workspace, float* state2,
+                          void* stream) {
+    if (!prepared || !param || !grad || !exp_avg || !exp_avg_sq || !step_count || !lr_dev || !metrics || !workspace || !state2 || n_mb < 1)
+        return PC_ERR_INVALID_ARG;
+    if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40 || B < 2 || B > 1024) return PC_ERR_UNSUPPORTED;
+    if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)state2) & 15) != 0) return PC_ERR_INVALID_ARG;   // 16-byte loads / stores
+    DeviceGuard guard(device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    const MbPlan pl(B, D, H, A, workspace);
+    hipStream_t st = (hipStream_t)stream;
+    // two generations of (param, exp_avg, exp_avg_sq): the caller's tensors and `state2`
+    float* P[2] = {param, state2};
+    float* M[2] = {exp_avg, state2 + pl.n_pad};
+    float* V[2] = {exp_avg_sq, state2 + 2 * (size_t)pl.n_pad};
+    const int64_t pf = (int64_t)B * (D + 4) + 4;
+    int cur = 0;
+    const bool defer = mb_defer_shape(D, A);     // (other shapes: the generic kernels, three launches per minibatch -- the same bits)
+    for (int m = 0; m < n_mb; ++m) {
+        AdamDefer df{};
+        if (!defer && m > 0) launch_adam(pl, param, exp_avg, exp_avg_sq, grad, param, exp_avg, exp_avg_sq, step_count, lr_dev, max_norm, beta1, beta2, eps, st);
+        if (defer && m > 0) {     // the previous minibatch's gradient is applied by this launch as it loads the parameters
+            df.grad = grad;
+            df.m_in = M[cur];
+            df.v_in = V[cur];
+            df.p_out = P[cur ^ 1];
+            df.m_out = M[cur ^ 1];
+            df.v_out = V[cur ^ 1];
+            df.norm_partial = pl.norm_partial;
+            df.n_norm = pl.n_blk;
+            df.step_count = step_count;
+            df.lr_dev = lr_dev;
+            df.max_norm = (float)max_norm;
+            df.beta1 = (float)beta1;
+            df.beta2 = (float)beta2;
+            df.eps = (float)eps;
+        }
+        launch_fwdbwd(pl, nullptr, prepared + (size_t)m * pf, B, D, A, nullptr, nullptr, nullptr, nullptr, nullptr, P[cur], clip_ratio, vf_coef, ent_coef,
+                      df, st);
+        if (defer && m > 0) cur ^= 1;
+        launch_reduce(pl, B, vf_coef, ent_coef, grad, metrics, step_count, st);
+    }
+    // the last gradient, and the state home to the caller's tensors
+    launch_adam(pl, P[cur], M[cur], V[cur], grad, param, exp_avg, exp_avg_sq, step_count, lr_dev, max_norm, beta1, beta2, eps, st);
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
 
 // ---- pc_xchg: one-shot all-reduce over peer-mapped staging buffers (kernels/exchange.hpp) --------------------------------
 }  // extern "C"

@@ -59,6 +59,10 @@ class PPOConfig:
     custom_mlp: bool = True                # with fused_update: the MLP forward/backward too are HIP kernels (pc_ppo_minibatch,
                                            # no library GEMM); False = torch autograd GEMMs between the fused loss / Adam kernels
     prepared_minibatches: bool = True      # gather all minibatches of an epoch in one launch (pc_ppo_prepare) before the steps
+    deferred_adam: bool = False            # single rank + prepared minibatches: the epoch's minibatch loop as pc_ppo_epoch_prepared -- the clip + Adam
+                                           # step of minibatch i is taken by the forward / backward launch of minibatch i + 1 (two launches per
+                                           # minibatch instead of three; the same bits).  OFF: measured SLOWER on MI355X (update 2.28 vs 1.92 ms
+                                           # per epoch at the target shape, 2.07 vs 1.73 at configs[1])
     rollout_kernel: str = "auto"           # "mega": the whole rollout as one persistent launch (pc_rollout); "steps": two
                                            # kernels per step (HIP-graph replayed); "auto": mega whenever pc_rollout supports the shape
     policy: str = "fused"                  # rollout policy step: "fused" (one MFMA kernel: MLPs + draw),
@@ -368,6 +372,18 @@ class PPOLearner:
             self._sum_gradients()
             self._custom_apply()
 
+    def _epoch_chain(self, n_mb_total):
+        """pc_ppo_epoch_prepared: all minibatch steps of the epoch on the prepared blocks, two launches per minibatch (the clip +
+        Adam step deferred into the next forward / backward launch) + one for the last gradient."""
+        cfg, a1, a2 = self.cfg, self.agent.actor[0], self.agent.actor[2]
+        if getattr(self, "_state2", None) is None:
+            self._state2 = torch.empty(lib.pc_ppo_epoch_state_floats(a1.in_features, a1.out_features, a2.out_features), device=self.device)
+        check(lib.pc_ppo_epoch_prepared(self._dev_index(), self._prep.data_ptr(), n_mb_total, cfg.batch_size, a1.in_features, a1.out_features,
+                                        a2.out_features, self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                        self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(), self.lr_dev.data_ptr(), cfg.clip_ratio,
+                                        cfg.vf_coef, cfg.ent_coef, cfg.max_grad_norm, 0.9, 0.999, 1e-5, self.metrics.data_ptr(),
+                                        self._ws.data_ptr(), self._state2.data_ptr(), self._stream()), "pc_ppo_epoch_prepared")
+
     def fused_minibatch_step(self, idx, obs, act, logprob, adv, ret):
         self._fused_fwd_bwd(idx, obs, act, logprob, adv, ret)
         if self.world_size > 1:
@@ -380,6 +396,9 @@ class PPOLearner:
         B = cfg.batch_size
         if cfg.prepared_minibatches:
             pf = self.prepare_minibatches(idx_all, n_mb, *args)
+            if cfg.deferred_adam and not self.collective:
+                self._epoch_chain(cfg.train_iters * n_mb)
+                return
             for m in range(cfg.train_iters * n_mb):
                 self.prepared_minibatch_step(m, pf)
         else:
@@ -560,6 +579,10 @@ class PPOLearner:
                     torch.cuda.synchronize(self.device)
                     if cfg.prepared_minibatches:
                         self.prepare_minibatches(idx_all, n_mb, *args)      # (allocates outside the capture)
+                        if getattr(self, "_state2", None) is None and cfg.deferred_adam and not self.collective:
+                            a1_, a2_ = self.agent.actor[0], self.agent.actor[2]
+                            self._state2 = torch.empty(lib.pc_ppo_epoch_state_floats(a1_.in_features, a1_.out_features, a2_.out_features),
+                                                       device=self.device)
                         torch.cuda.synchronize(self.device)
                     self._epoch_graph = self._capture_epoch(idx_all, n_mb, args)
                     self._epoch_key = key

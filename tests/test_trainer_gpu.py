@@ -608,3 +608,27 @@ def test_bootstrap_value_switch_takes_the_reference_call_in_fp32():
     assert float((outs["kernel"][1] - outs["fp32"][1]).abs().max()) <= 1e-5
     with pytest.raises(ValueError):
         Trainer(_cfg(bootstrap_value="bf16"), device="cuda")
+
+
+@pytest.mark.parametrize("num_rays,batch,graphs", [(16, 512, True), (12, 100, False), (32, 64, False)])
+def test_deferred_adam_epoch_chain_is_bitwise_the_three_launch_steps(num_rays, batch, graphs):
+    """pc_ppo_epoch_prepared (two launches per minibatch: the clip + Adam step of minibatch i rides in the forward / backward launch
+    of minibatch i + 1, state ping-ponged between two buffers) against pc_ppo_minibatch_prepared(apply = 1) per minibatch (three
+    launches): identical parameters, Adam state, step counter, logged sums and last clipped gradient over three epochs
+    (train.py:223-269)."""
+    res = {}
+    for deferred in (False, True):
+        cfg = _cfg(deferred_adam=deferred, use_graphs=graphs, n_envs=256, n_steps=64, batch_size=batch, train_iters=5,
+                   num_rays=num_rays, seed=9)
+        tr = Trainer(cfg, device="cuda")
+        scal = [tr.run_epoch() for _ in range(3)]
+        L = tr.learner
+        res[deferred] = ([t.clone() for t in (L.flat_param, L.exp_avg, L.exp_avg_sq, L.step_count, L.metrics, L.flat_grad)], scal)
+        assert (getattr(L, "_state2", None) is not None) == deferred
+        tr.close()
+    for i, (a, b) in enumerate(zip(res[False][0], res[True][0])):
+        assert torch.equal(a, b), i
+    assert float(res[True][0][3]) == 3 * 5 * len(range(0, 64, batch))
+    for a, b in zip(res[False][1], res[True][1]):
+        for k in ("losses/policy_loss", "losses/value_loss", "losses/entropy", "losses/total_loss", "charts/avg_reward"):
+            assert a[k] == b[k], k

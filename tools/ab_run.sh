@@ -28,23 +28,34 @@ import torch
 from ppo_car_amd.ppo import PPOConfig, Trainer
 root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
 track = [f"{root}/tracks/track.json", f"{root}/tracks/big_track.json"] if os.environ.get("AB_MIXED") else f"{root}/tracks/big_track.json"
-tr = Trainer(PPOConfig(n_envs=N, n_steps=T, num_rays=R, track=track, rollout_kernel="mega", seed=3), device="cuda")
-for _ in range(4):
-    tr.run_epoch(sync=False)
-torch.cuda.synchronize()
-ts = []
-for _ in range(int(os.environ.get("AB_REPS", "24"))):
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); tr.rollout(); e1.record(); torch.cuda.synchronize()
-    ts.append(e0.elapsed_time(e1) * 1e3 / T)
-    tr.update()
-ts.sort()
-import time
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(10):
-    tr.run_epoch(sync=False)
-torch.cuda.synchronize(); ep = (time.perf_counter() - t0) / 10 * 1e3
-print(f"{os.path.basename(pkg):24s} {ts[0]:.3f} (min) {ts[len(ts)//2]:.3f} (median) us per vector step of {N} envs, {R} rays; then 10 epochs back to back: {ep:.2f} ms per epoch = {N * T / ep / 1e3:.0f} M env-steps/s", flush=True)
+import json
+for extra in json.loads(os.environ.get("AB_CFGS", "[{}]")):      # e.g. AB_CFGS='[{"deferred_adam": true}, {"deferred_adam": false}]': PPOConfig variants of one build
+  tag = os.path.basename(pkg) + ("" if not extra else " " + json.dumps(extra))
+  tr = Trainer(PPOConfig(n_envs=N, n_steps=T, num_rays=R, track=track, rollout_kernel="mega", seed=3, **extra), device="cuda")
+  for _ in range(4):
+      tr.run_epoch(sync=False)
+  torch.cuda.synchronize()
+  ts = []
+  for _ in range(int(os.environ.get("AB_REPS", "24"))):
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record(); tr.rollout(); e1.record(); torch.cuda.synchronize()
+      ts.append(e0.elapsed_time(e1) * 1e3 / T)
+      tr.update()
+  ts.sort()
+  import time
+  torch.cuda.synchronize(); t0 = time.perf_counter()
+  for _ in range(10):
+      tr.run_epoch(sync=False)
+  torch.cuda.synchronize(); ep = (time.perf_counter() - t0) / 10 * 1e3
+  ue = []
+  for _ in range(6):      # the update alone (GAE + minibatch loop) between events
+      tr.rollout()
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record(); tr.update(); e1.record(); torch.cuda.synchronize()
+      ue.append(e0.elapsed_time(e1))
+  ue.sort()
+  tr.close()
+  print(f"{tag:44s} {ts[0]:.3f} (min) {ts[len(ts)//2]:.3f} (median) us per vector step of {N} envs, {R} rays; then 10 epochs back to back: {ep:.2f} ms per epoch = {N * T / ep / 1e3:.0f} M env-steps/s; update {ue[len(ue)//2]:.3f} ms", flush=True)
 PY
   done
 done
