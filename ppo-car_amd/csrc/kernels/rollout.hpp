@@ -172,7 +172,8 @@ __device__ __forceinline__ int swap_pair(int v) { return __builtin_amdgcn_update
 // is latency, not issue slots: a group's vertex records and 1/den rows are all requested at its top, the four vertices' side
 // values are independent instruction chains, chain-start vertices are computed rather than branched around (their candidates
 // are NaN: see wall_sweep_unrolled), and two vertices share a v_min3_u32.  Same bits as wall_sweep_f32<RPL, PARTS, TAB>.
-template <int RPL, int PARTS, bool TAB, bool ADDR = false>
+// VPART: `part` differs between the lanes of the wave (env_step_wave: the parts are lane groups, not waves).
+template <int RPL, int PARTS, bool TAB, bool ADDR = false, bool VPART = false>
 __device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const int part, const float pxr, const float pyr,
                                                const float (&dx)[RPL], const float (&dy)[RPL], const int (&didx)[RPL], lds_cfp rdl,
                                                const float tau, const unsigned idx_mask, unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
@@ -214,7 +215,8 @@ __device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const i
             es[I] = *(lds_cf2)(vt + 2 * (4 * gq + I) + 1);
         }
         unsigned kv;
-        asm("v_mov_b32 %0, %1" : "=v"(kv) : "s"(4 * gq));
+        if constexpr (VPART) kv = 4u * (unsigned)gq;
+        else asm("v_mov_b32 %0, %1" : "=v"(kv) : "s"(4 * gq));
 #pragma unroll
         for (int I = 0; I < 4; I += 2) {
             float u0[2 * NP], u1[2 * NP];
@@ -520,6 +522,140 @@ __device__ __forceinline__ void env_reset_fast(const TrackHdr& h, EnvRegs& st, i
     st.px = h.start_x; st.py = h.start_y; st.vx = 0.0; st.vy = 0.0;
     st.k = 0; st.time = 0; st.next = 0; st.passed = 0;
     k72 = 0;
+}
+
+// The env step of K9s at 16 envs per workgroup: a WAVE owns two envs outright, 32 lanes per env = 8 sweep parts x 4 ray groups --
+// env_step_fast<RPL, TAB, 2, 8>'s decomposition with the parts as lane groups of ONE wave instead of the eight waves of the
+// workgroup.  Same per-lane work (a part sweeps at most one group of four vertices of big_track's chain for its RPL ray slots),
+// but nothing crosses a wave: the parts' selections meet through two DPP row rotations and one ds_swizzle per slot (min is
+// exact: the same bits), part s refines ray slot s and writes its observation column, Car.check_collision's verdict is one
+// ballot -- where the eight-wave form paid two LDS exchanges and two workgroup barriers per step (the selections, the verdicts)
+// plus the one between the draw and the env step (a wave draws for exactly the two envs it steps: the action never leaves it).
+// lane = 32 (env of the wave) + 4 part + g.
+template <int RPL, bool TAB>
+__device__ __forceinline__ bool env_step_wave(const EnvParams<float>& p, const TrackHdr& h, const FastTabs& ft, const FastLane& fl,
+                                              const int gq0, const int g, const int part, EnvRegs& st, int& k72, const int a,
+                                              const double reward_scale, lds_fp lrow, float& reward_f, float& term_f, float& trunc_f,
+                                              const int lane) {
+    constexpr int G = 4, PARTS = 8, NP = (RPL + 1) / 2;
+    static_assert(RPL <= PARTS && RPL <= 12, "one refinement per lane, one sweep pass");
+    // ---- action, heading, Car.update physics: env_step_fast's, instruction for instruction
+    const f64x2 Lf = ft.act[2 * a];
+    const i32x2 Li = *(lds_ci2)(ft.act + 2 * a + 1);
+    struct { double thrust, fric; int dk, fwd; } L = {Lf.x, Lf.y, Li.x, Li.y};
+    const f64x2 cs0 = ft.head[k72];
+    const int k72n = ft.wrap[k72 + L.dk + 1];
+    const f64x2 cs1 = ft.head[k72n];
+    double nvx = (st.vx + cs0.x * L.thrust) * L.fric, nvy = (st.vy + cs0.y * L.thrust) * L.fric;
+    nvx = fmin(fmax(nvx, -10.0), 10.0);
+    nvy = fmin(fmax(nvy, -10.0), 10.0);
+    const double opx = st.px, opy = st.py;
+    const double npx = opx + nvx, npy = opy + nvy;
+    float dx[RPL], dy[RPL];
+    int didx[RPL];
+    const int k80n = 80 * k72n;
+    const int m0 = k80n + fl.rs0, m_last = k80n + fl.rs_last;
+    {
+        int m = m0;
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const f32x4 cs = *(lds_f4c)(size_t)(unsigned)(s + 1 < RPL ? m : min(m, m_last));
+            dx[s] = cs.x;
+            dy[s] = cs.y;
+            didx[s] = (int)__float_as_uint(cs.z);
+            m += fl.rstep;
+        }
+    }
+    // ---- Car.get_passed_gate: collision ray j = g at the previous pose against gate[next], float64 (every part: the same values)
+    const f64x4 gv = ft.gates[st.next];
+    const Seg gate = {gv.x, gv.y, gv.z, gv.w};
+    bool gate_hit;
+    {
+        const f64x2 cs = *(lds_cd2)(size_t)(unsigned)(80 * k72 + gq0 + FT_D64_BYTES);
+        gate_hit = cast_d(gate, opx, opy, cs.x, cs.y) < 10.0;
+    }
+    // ---- wall sweep: this lane's part of the chain for its RPL slots, then the minimum over the env's 8 parts (lanes of equal g)
+    unsigned bb[2 * NP];
+    const float tau = flag_threshold(h, npx, npy);
+    const float pxr = (float)(npx - h.ax0), pyr = (float)(npy - h.ay0);
+    wall_sweep_lds<RPL, PARTS, TAB, true, true>(ft.vtx, h.nV, part, pxr, pyr, dx, dy, didx, ft.rden, tau, h.idx_mask, bb);
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) {
+        unsigned m = bb[s];
+        m = min(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, false));      // row_ror:4  } the four parts of
+        m = min(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, false));      // row_ror:8  } the 16-lane row
+        m = min(m, (unsigned)__builtin_amdgcn_ds_swizzle((int)m, 0x401f));                         // lane ^ 16: the env's other row
+        bb[s] = m;
+    }
+    // ---- float64 refinement: part s takes ray slot s (parts >= RPL repeat the last slot and are masked out)
+    const lds_cd2 sgl = ft.seg;
+    const auto segs = [sgl](const int k) {
+        const f64x2 a = sgl[3 * k], b = sgl[3 * k + 1], c = sgl[3 * k + 2];
+        return SegD{a.x, a.y, b.x, b.y, c.x, (int)(unsigned)__double_as_longlong(c.y), 0};
+    };
+    const bool active = part < RPL;
+    const int slot = active ? part : RPL - 1;
+    unsigned sel = bb[0];
+#pragma unroll
+    for (int s = 1; s < RPL; ++s) sel = slot == s ? bb[s] : sel;
+    const int ms = m0 + slot * fl.rstep;
+    const bool is_last = slot == RPL - 1;
+    const f64x2 d64 = *(lds_cd2)(size_t)(unsigned)((is_last ? min(ms, m_last) : ms) + FT_D64_BYTES);
+    const SegD sg = segs((int)(sel & h.idx_mask));
+    bool ok = true;
+    double d = refine_fast(sg, npx, npy, d64.x, d64.y, ok);
+    bool todo = active & !ok;
+    const bool col = (bool)((fl.colmask >> slot) & 1) & active;
+    bool hit = col & ok & (d < 10.0);                                                              // :387-390 on Car.check_collision's rays
+    const lds_fp dst = is_last ? fl.llast : fl.lray + G * slot;
+    if (active) dst[0] = obs_dist(d);                                                              // :593
+    while (__builtin_expect(__builtin_amdgcn_ballot_w64(todo) != 0, 0)) {   // the rare rest: the careful path
+        if (todo) {
+            d = refine_careful((int)(sel & h.idx_mask), segs, h.nV, npx, npy, d64.x, d64.y);
+            hit = col & (d < 10.0);
+            dst[0] = obs_dist(d);
+            todo = false;
+        }
+    }
+    const uint64_t hit_mask = __builtin_amdgcn_ballot_w64(hit);
+    const bool wall_hit = (unsigned)(hit_mask >> (lane & 32)) != 0u;                               // any() over the env's 32 lanes
+    int gflag = gate_hit ? 1 : 0;
+    gflag |= swap_pair(gflag);                                                                     // any() over the four ray groups
+    gflag |= __builtin_amdgcn_update_dpp(0, gflag, 0x4e, 0xf, 0xf, false);                         // quad_perm [2, 3, 0, 1]
+    gate_hit = gflag != 0;
+    const bool destroyed = wall_hit | (h.start_collides != 0);
+    // ---- bookkeeping (car_env.py:694-750): env_step_fast's
+    double rw = L.fwd ? 0.01 : 0.0;
+    const bool lap = gate_hit & (st.next == h.G - 1);
+    rw = rw + (gate_hit ? 1.0 : 0.0);
+    rw = rw + (lap ? 10.0 : 0.0);
+    const int passed = st.passed + (gate_hit ? 1 : 0);
+    const int next = gate_hit ? (lap ? 0 : st.next + 1) : st.next;
+    const int time = st.time + 1;
+    rw = rw + (destroyed ? -3.0 : 0.0);
+    const bool trunc = !destroyed & (time >= 1000);
+    const bool done = destroyed | trunc;
+    reward_f = (float)(rw * reward_scale);
+    term_f = destroyed ? 1.0f : 0.0f;
+    trunc_f = trunc ? 1.0f : 0.0f;
+    if (g == 0 && part == 0) {
+        lrow[0] = Math<float>::norm(npx, 1280.0);
+        lrow[1] = Math<float>::norm(npy, 720.0);
+        lrow[2] = Math<float>::norm(nvx, 10.0);
+        lrow[3] = Math<float>::norm(nvy, 10.0);
+        lrow[4] = (float)cs1.x;
+        lrow[5] = (float)cs1.y;
+    }
+    st.px = npx;
+    st.py = npy;
+    st.vx = nvx;
+    st.vy = nvy;
+    st.k += L.dk;
+    k72 = k72n;
+    st.time = time;
+    st.next = next;
+    st.passed = passed;
+    return done;
 }
 
 // Developer-only timing ablation of the persistent rollout kernels: a SEPARATE build (make ABLATE=n -> libppocar_ablate.so,
@@ -949,10 +1085,14 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     }
     const lds_cfp rdl = (lds_cfp)sRden;
 
-    // env step: wave w sweeps part (w % PARTS) of the wall vertices for 16 envs, 4 lanes (ray groups) per env
+    // env step, 32 envs per workgroup: wave w sweeps part (w % PARTS) of the wall vertices for 16 envs, 4 lanes (ray groups) per env;
+    // 16 envs per workgroup (WOWN): wave w owns envs 2 w and 2 w + 1 outright, 32 lanes per env = 8 sweep parts x 4 ray groups
+    // (env_step_wave) -- the two envs it also draws the actions of
     constexpr int PARTS = 128 / EPW;
-    const int part = __builtin_amdgcn_readfirstlane(wave % PARTS);
-    const int el = (wave / PARTS) * 16 + (lane >> 2), g = lane & 3;
+    constexpr bool WOWN = EPW == 16;
+    const int part = WOWN ? (lane >> 2) & 7 : __builtin_amdgcn_readfirstlane(wave % PARTS);
+    const int el = WOWN ? 2 * wave + (lane >> 5) : (wave / PARTS) * 16 + (lane >> 2);
+    const int g = lane & 3;
     constexpr int EXS = EPW == 16 ? PARTS * (DC - 6) : PARTS * 34;   // floats per env: [rays][PARTS]
     static_assert(EPW * EXS <= 8 * EPW * LDO, "the exchange area aliases the partial output tiles");
     float* exch = sOut + el * EXS;                 // [rays][PARTS] of this env; aliases the partial output tiles (idle now)
@@ -1036,6 +1176,7 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
         PC_STAMP(1)
         lds_barrier();
         PC_STAMP(2)
+        int act = 8;
         if (lk < EPW / 8) {   // every wave draws for EPW / 8 of the envs, 16 lanes (= outputs) per env, exactly as policy_kernel<SPLIT>
             const int dl = wave * (EPW / 8) + lk, oi = lc;
             const int64_t e = e_wg + dl;
@@ -1045,12 +1186,11 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
             const float tsum = __builtin_fmaf(ps, PolScale<PREC>::so_inv, sB2[oi]);   // outputs back from their scaled domain
             const uint64_t o = off0 + (uint64_t)t;
             if (t == 0 || (o & 3) == 0) rnd = philox_block(seed, o >> 2, (uint64_t)e);  // uniform: ten rounds per 4 steps
-            int act;
             float lp, val;
             if (!(dbg & 4)) policy_tail_row(tsum, oi, A, philox_word_uniform(rnd, (unsigned)(o & 3)), lane, act, lp, val);
             else { act = 0; lp = tsum; val = tsum; }
             if (oi == 0 && e < N) {
-                sAct[dl] = act;
+                if constexpr (!WOWN) sAct[dl] = act;
                 if (tail) {
                     last_val[e] = val;
                 } else {
@@ -1061,7 +1201,7 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 }
             }
         }
-        lds_barrier();
+        if constexpr (!WOWN) lds_barrier();   // (WOWN: the wave steps the two envs it drew for -- lanes 0 and 16 hold their actions)
         PC_STAMP(3)
         if (tail) break;
         // ---------------- E(t): 4 waves x 4 lanes per env (one more barrier inside, where the sweep parts meet)
@@ -1069,10 +1209,19 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
         if constexpr (FAST) {
             if (!(dbg & 2)) {
                 float rw, tf, cf;
-                const int a = e_valid ? sAct[el] : 8;
-                const bool done = rden_lds   // (uniform)
-                    ? env_step_fast<RPL, true, 2, PARTS>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0, sHit + el * PARTS)
-                    : env_step_fast<RPL, false, 2, PARTS>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0, sHit + el * PARTS);
+                bool done;
+                if constexpr (WOWN) {
+                    const int a0 = __builtin_amdgcn_readlane(act, 0), a1 = __builtin_amdgcn_readlane(act, 16);
+                    const int a = e_valid ? (lane < 32 ? a0 : a1) : 8;
+                    done = rden_lds   // (uniform)
+                        ? env_step_wave<RPL, true>(p, h0, ft, fl, gq[0], g, part, st, k72, a, reward_scale, lrow, rw, tf, cf, lane)
+                        : env_step_wave<RPL, false>(p, h0, ft, fl, gq[0], g, part, st, k72, a, reward_scale, lrow, rw, tf, cf, lane);
+                } else {
+                    const int a = e_valid ? sAct[el] : 8;
+                    done = rden_lds   // (uniform)
+                        ? env_step_fast<RPL, true, 2, PARTS>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0, sHit + el * PARTS)
+                        : env_step_fast<RPL, false, 2, PARTS>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0, sHit + el * PARTS);
+                }
                 rsum += rw;
                 if (__builtin_amdgcn_ballot_w64(done) != 0) {
                     if (done) {
@@ -1087,9 +1236,6 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                         }
                         env_reset_fast(h0, st, k72);
                     }
-                    // PARTS == 8: the verdicts' barrier inside env_step_fast was the step's last one; a step in which an env finished
-                    // needs one more behind the row fix-up.  Every wave holds all 16 envs on identical values: the same branch in all.
-                    if constexpr (PARTS == 8) lds_barrier();
                 }
                 if (part == 0) {   // (uniform) the row-writing wave: per-env scalars
                     if (g == 0 && e_valid) {
@@ -1102,7 +1248,7 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 }
             }
             PC_STAMP(6)
-            if constexpr (!(FAST && PARTS == 8)) lds_barrier();    // (16 envs per workgroup in the fast mode: merged into the verdicts' barrier)
+            lds_barrier();    // the workgroup's observation rows are complete
             PC_STAMP(7)
             // rows -> rollout buffer: the workgroup's 32 rows are contiguous there (32 * D floats): waves 0 .. 2 (.. 4) store 64 float4 each
             {
