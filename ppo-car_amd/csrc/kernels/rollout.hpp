@@ -536,7 +536,7 @@ template <int RPL, bool TAB>
 __device__ __forceinline__ bool env_step_wave(const EnvParams<float>& p, const TrackHdr& h, const FastTabs& ft, const FastLane& fl,
                                               const int gq0, const int g, const int part, EnvRegs& st, int& k72, const int a,
                                               const double reward_scale, lds_fp lrow, float& reward_f, float& term_f, float& trunc_f,
-                                              const int lane) {
+                                              const int lane, const int t = 0, const int wave = 0) {   // (t, wave: the developer stamps)
     constexpr int G = 4, PARTS = 8, NP = (RPL + 1) / 2;
     static_assert(RPL <= PARTS && RPL <= 12, "one refinement per lane, one sweep pass");
     // ---- action, heading, Car.update physics: env_step_fast's, instruction for instruction
@@ -578,6 +578,7 @@ __device__ __forceinline__ bool env_step_wave(const EnvParams<float>& p, const T
     unsigned bb[2 * NP];
     const float tau = flag_threshold(h, npx, npy);
     const float pxr = (float)(npx - h.ax0), pyr = (float)(npy - h.ay0);
+    PC_STAMP(4)
     wall_sweep_lds<RPL, PARTS, TAB, true, true>(ft.vtx, h.nV, part, pxr, pyr, dx, dy, didx, ft.rden, tau, h.idx_mask, bb);
 #pragma unroll
     for (int s = 0; s < RPL; ++s) {
@@ -587,6 +588,7 @@ __device__ __forceinline__ bool env_step_wave(const EnvParams<float>& p, const T
         m = min(m, (unsigned)__builtin_amdgcn_ds_swizzle((int)m, 0x401f));                         // lane ^ 16: the env's other row
         bb[s] = m;
     }
+    PC_STAMP(5)
     // ---- float64 refinement: part s takes ray slot s (parts >= RPL repeat the last slot and are masked out)
     const lds_cd2 sgl = ft.seg;
     const auto segs = [sgl](const int k) {
@@ -609,6 +611,7 @@ __device__ __forceinline__ bool env_step_wave(const EnvParams<float>& p, const T
     bool hit = col & ok & (d < 10.0);                                                              // :387-390 on Car.check_collision's rays
     const lds_fp dst = is_last ? fl.llast : fl.lray + G * slot;
     if (active) dst[0] = obs_dist(d);                                                              // :593
+    PC_STAMP(8)
     while (__builtin_expect(__builtin_amdgcn_ballot_w64(todo) != 0, 0)) {   // the rare rest: the careful path
         if (todo) {
             d = refine_careful((int)(sel & h.idx_mask), segs, h.nV, npx, npy, d64.x, d64.y);
@@ -617,12 +620,14 @@ __device__ __forceinline__ bool env_step_wave(const EnvParams<float>& p, const T
             todo = false;
         }
     }
+    PC_STAMP(9)
     const uint64_t hit_mask = __builtin_amdgcn_ballot_w64(hit);
     const bool wall_hit = (unsigned)(hit_mask >> (lane & 32)) != 0u;                               // any() over the env's 32 lanes
     int gflag = gate_hit ? 1 : 0;
     gflag |= swap_pair(gflag);                                                                     // any() over the four ray groups
     gflag |= __builtin_amdgcn_update_dpp(0, gflag, 0x4e, 0xf, 0xf, false);                         // quad_perm [2, 3, 0, 1]
     gate_hit = gflag != 0;
+    PC_STAMP(10)
     const bool destroyed = wall_hit | (h.start_collides != 0);
     // ---- bookkeeping (car_env.py:694-750): env_step_fast's
     double rw = L.fwd ? 0.01 : 0.0;
@@ -1214,8 +1219,8 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                     const int a0 = __builtin_amdgcn_readlane(act, 0), a1 = __builtin_amdgcn_readlane(act, 16);
                     const int a = e_valid ? (lane < 32 ? a0 : a1) : 8;
                     done = rden_lds   // (uniform)
-                        ? env_step_wave<RPL, true>(p, h0, ft, fl, gq[0], g, part, st, k72, a, reward_scale, lrow, rw, tf, cf, lane)
-                        : env_step_wave<RPL, false>(p, h0, ft, fl, gq[0], g, part, st, k72, a, reward_scale, lrow, rw, tf, cf, lane);
+                        ? env_step_wave<RPL, true>(p, h0, ft, fl, gq[0], g, part, st, k72, a, reward_scale, lrow, rw, tf, cf, lane, t, wave)
+                        : env_step_wave<RPL, false>(p, h0, ft, fl, gq[0], g, part, st, k72, a, reward_scale, lrow, rw, tf, cf, lane, t, wave);
                 } else {
                     const int a = e_valid ? sAct[el] : 8;
                     done = rden_lds   // (uniform)

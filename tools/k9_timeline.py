@@ -41,7 +41,8 @@ names = (["split", "policy", "draw", "env-pre", "sweep", "post", "copy-out"] if 
 big = tr.cfg.n_envs > 16384
 if not big:              # the small form's env step carries three more stamps: 8 refinement done, 9 rare-path loop done, 10 verdicts met
     st = st[:, :, [0, 1, 2, 3, 4, 5, 8, 9, 10, 6, 7]]
-    names = ["tiles", "barrier1", "draw+bar2", "env-pre", "sweep+xchg", "refine", "rare loop", "verdict bar", "bookkeeping", "barrier3"]
+    names = (["tiles", "barrier1", "draw", "env-pre", "sweep+min", "refine", "rare loop", "verdicts", "bookkeeping", "barrier2"] if N <= 4096 else   # a wave owns two envs
+             ["tiles", "barrier1", "draw+bar2", "env-pre", "sweep+xchg", "refine", "rare loop", "verdict bar", "bookkeeping", "barrier3"])
 if big:                  # the big form carries no stamps inside the env step (they made it spill): phases 3..6 are one
     st = st[:, :, [0, 1, 2, 3, 6, 7]]
     names = ["split", "policy", "draw", "env step", "copy-out"]
