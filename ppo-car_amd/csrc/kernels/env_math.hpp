@@ -146,11 +146,9 @@ __device__ __forceinline__ double rcp_d(const double den) {
     const double r0 = __builtin_amdgcn_rcp(den);
     return __builtin_fma(r0, __builtin_fma(-den, r0, 1.0), r0);
 }
-// the reference's `0 < t < 1 and u > 0` (car_env.py:178) on the numerators: no rounding of a quotient is involved
-__device__ __forceinline__ bool strict_hit(const CastD& c) {
-    return (c.tn * c.den > 0.0) & (__builtin_fabs(c.tn) < __builtin_fabs(c.den)) & (c.un * c.den > 0.0);
-}
-// ... but the reference does not evaluate that test in exact arithmetic: it forms (x4, y4) = pos + dir (car_env.py:169) and works
+// The reference's `0 < t < 1 and u > 0` (car_env.py:178) is decidable on the numerators, without rounding a quotient (t > 0 iff tn
+// and den have the same sign, t < 1 iff |tn| < |den|, u > 0 likewise by signs) -- but the reference does not evaluate that test
+// in exact arithmetic: it forms (x4, y4) = pos + dir (car_env.py:169) and works
 // with the ROUNDED differences (x3 - x4), (y3 - y4), i.e. with a direction perturbed by up to an ulp of the car's position (for
 // dir = (cos 90 deg, 1) = (6e-17, 1) the x component vanishes altogether).  Away from a tie that changes nothing (3e-14 rad; the
 // test's margins are relative 1e-13).  AT a tie -- a ray that passes exactly through a vertex, a car exactly on a wall's line,
