@@ -755,7 +755,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     float* sObs = lds + IMG;
     int* sAct = reinterpret_cast<int*>(sObs + 256 * LDX);
     float* sTab = reinterpret_cast<float*>(sAct + 256);    // staged per-track tables
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform by construction: everything derived from it lives in SGPRs)
     const int lc = lane & 15, lk = lane >> 4;
     policy_stage_image<IMG>(image, lds, tid);
     // FAST with a mixed-track batch: the host checked that every workgroup's envs lie on ONE track, whose tables it stages
@@ -904,13 +904,19 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                     float w[5];
                     pair_outputs<LDO>(myOut, lane >> 1, g, PolScale<PREC>::so_inv, sB2, w);
                     float lp, val;
-                    if (t == 0 || (o & 3) == 0) rnd = philox_block(seed, o >> 2, (uint64_t)e_env);  // uniform: ten rounds per 4 steps
+                    if (t == 0 || (o & 3) == 0) {   // uniform: ten rounds per 4 steps
+                        uint64_t ctr = (uint64_t)e_env;             // (opaque: the first round's products of the lane's counter are formed here,
+                        asm volatile("" : "+v"(ctr));               // not hoisted into four registers that live through all T steps)
+                        rnd = philox_block(seed, o >> 2, ctr);
+                    }
                     if constexpr (PC_ABLATE & 4) { act_reg = (int)(o & 7); lp = w[0]; val = w[4]; }
                     else policy_tail_pair(w, g, philox_word_uniform(rnd, (unsigned)(o & 3)), act_reg, lp, val);
                     if constexpr (!FAST) { if (g == 0) sAct[el] = act_reg; }
                     if (g == 0) {
-                        if (tail) {
-                            last_val[e_env] = val;
+                        if (tail) {   // (once per launch: the address is formed here, not kept in two registers for T steps -- at 33 rays they were spilled)
+                            int64_t ee = e_env;
+                            asm volatile("" : "+v"(ee));
+                            last_val[ee] = val;
                         } else {
                             const int64_t row = (int64_t)t * N + e_env;
                             act_buf[row] = (float)act_reg;     // stored as float32 like the reference (buffer.py:13)
@@ -992,7 +998,14 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                         if (64 * j + 63 < 8 * DC || i < 8 * DC) reinterpret_cast<f32x4*>(dstg)[i] = reinterpret_cast<const f32x4*>(srcl)[i];
                     }
                 } else {
-                    for (int i = lane; i < n_rows * D; i += 64) dstg[i] = srcl[i];
+                    // (the unaligned caller's path: its addresses are formed here from opaque copies, not hoisted into registers that
+                    // live through all T steps -- at 33 rays those were spilled to scratch)
+                    int64_t ew = e_wave;
+                    int pb = pbase, i0 = lane;
+                    asm volatile("" : "+v"(ew), "+v"(pb), "+v"(i0));
+                    float* dg = (last ? next_obs : obs_buf + (int64_t)(t + 1) * N * D) + ew * D;
+                    const float* sl = sObs + pb * LDX;
+                    for (int i = i0; i < n_rows * D; i += 64) dg[i] = sl[i];
                 }
                 PC_STAMP(7)
             }
