@@ -73,7 +73,9 @@ def test_generated_circuits_validate_and_load(tmp_path, points, gates):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("points,gates,n", [(64, 40, 16), (200, 90, 12)])
+# (24 points: two loops of 25 chain vertices = 13 groups of four over the small form's 8 sweep parts -- one or two groups per lane
+# group of the wave-owned env step, and no room for the 1/den table beside the weight image: its arithmetic variant)
+@pytest.mark.parametrize("points,gates,n", [(24, 20, 16), (64, 40, 16), (200, 90, 12)])
 def test_generated_circuit_steps_like_the_oracle_and_through_the_persistent_kernel(tmp_path, points, gates, n):
     from ppo_car_amd.ppo import PPOConfig, Trainer
     path = str(tmp_path / "oval.json")
