@@ -23,8 +23,14 @@ Extra objects on the JSON line:
                   HIP events on the launch stream inside the timed epochs, against the 8 TB/s HBM peak.  `bound` names
                   the roof that actually binds -- "valu": the env step is branchy fp32 geometry, 66 flop/B -- and `valu`,
                   `mfma`, `hbm` price the same launch against each roof; `gae` is the GAE scan's own HBM fraction.
-  cpu_baseline -- the CPU oracle (oracle/, the checker -- never the product) driving the same rollout on the
-                  host cores of this box for a bounded sample.
+  cpu_baseline -- the CPU oracle (oracle/, the checker -- never the product) driving the same rollout on ALL usable host cores of
+                  this box for a bounded sample (`host_cores`, `usable_cores`, `threads` stated; `env_only_value` = CarEnv.step alone,
+                  `value` = env + torch-CPU policy; `env_only_one_thread_value` beside the reference's Python figure per core).
+  exact_f64_value -- the same workload with the env in float64 throughout (dtype "f64": bit-exact against the reference, state included),
+                  3 epochs after the timed region: the throughput of the configuration that is exact BY CONSTRUCTION.
+  other_workloads -- every other single-GPU BASELINE configuration (cfg1 = configs[1], cfg2 = configs[2], cfg4 = the per-GPU shard of
+                  configs[4]; `target` when another workload is the headline), 5 epochs each after the timed region, with its own
+                  ms_per_step, rollout-launch duration by HIP events and roofline fraction.
   parity_check -- one more pc_rollout launch of the same trainer AFTER the timed region: one env of every 32-env wave x 64 steps
                   replayed through the CPU oracle (observations within one float32 ulp; rewards / flags exact; an env may leave the
                   oracle's trajectory only at a step whose threshold margin is below 1e-9 px: 0 departures above that margin).
@@ -52,8 +58,19 @@ WORKLOADS = {
     # the per-GPU shard of BASELINE.json configs[4] (262144 envs on 8 GPUs, track.json and big_track.json in one batch)
     "cfg4": dict(n_envs=32768, n_steps=1024, num_rays=16, batch_size=512, train_iters=40, mixed=True),
 }
-ALGO_BYTES = {12: 156, 16: 176, 32: 240}      # SURVEY 8(d) / BASELINE.md section 4, per env step
-ALGO_FLOPS = {12: 8200, 16: 11600, 32: 22400}  # ditto, big_track (24 wall segments)
+# SURVEY 8(d) / BASELINE.md section 4, per env step: state 64 B + action 8 B + observation 4 (6 + R) B + reward / flags 12 B
+# = 156 / 176 / 240 B at 12 / 17 / 33 actual rays; 28 flop per ray-segment test x (R S + 4 gate tests) + R sincos pairs + ~30 physics
+# = 8.2 / 11.6 / 22.4 kflop on big_track (S = 24 walls).  As FORMULAS of the actual ray count R and the track's wall count S, so
+# that every ray count and every track prices its launch (a mixed batch: the mean over its envs' tracks).
+def algo_bytes(R):
+    return 4 * (6 + R) + 84
+
+
+def algo_flops(R, walls):
+    """walls: the wall count of every track of the batch, weighted equally (ppo.Trainer deals the envs to the tracks in equal blocks)"""
+    return sum(28 * (R * S + 4) + 2 * R + 30 for S in walls) / len(walls)
+
+
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8 TB/s
 VALU_PEAK_TFLOPS = 157.3                       # fp32 vector peak
 MFMA_F16_PEAK_TFLOPS = 2500.0                  # dense fp16 / bf16 matrix peak
@@ -108,16 +125,65 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(cfg, torch, budget_s=12.0):
-    """Rollout of the same workload on the host: torch-CPU policy forward + the C oracle env on all host
-    cores, bounded sample.  The PPO update is not included (it favours the CPU figure)."""
+def usable_cpus():
+    """(host_cores, usable): os.cpu_count() and what this process may actually run on (its affinity mask, cut by a cgroup CPU quota
+    when one is set)."""
+    host = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = host
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            elif float(txt[0]) > 0:
+                quota = float(txt[0]) / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota:
+        usable = max(1, min(usable, int(quota + 0.999)))
+    return host, usable, quota
+
+
+def cpu_baseline(cfg, torch, budget_s=5.0):
+    """The same rollout on the host, by the CPU oracle (oracle/: the checker -- `kind: "port"`, the C restatement of car_env.py; the
+    Python reference cannot travel to the GPU box, its own figure is quoted from BASELINE.md).  Three bounded legs on big_track at
+    the workload's ray count, ALL usable host cores (no cap; the count is stated):
+      env only, 1 thread            -- the per-core figure beside the reference's Python 227 steps/s/core;
+      env only, all usable cores    -- `env_only_value`: CarEnv.step alone, uniform random actions;
+      env + torch-CPU policy        -- `value`: the rollout (policy forward + sample + env step), the PPO update not included."""
+    import numpy as np
+
     import oracle
     from ppo_car_amd.model import Agent
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
-    n_envs = 4096
-    env = oracle.OracleVecEnv(oracle.Track(os.path.join(ROOT, "tracks", "big_track.json")), n_envs,
-                              num_rays=cfg["num_rays"], reward_scaling=0.1, threads=cores)
+    host, usable, quota = usable_cpus()
+    threads = usable
+    track = oracle.Track(os.path.join(ROOT, "tracks", "big_track.json"))
+
+    def env_only(n_threads, n_envs, budget):
+        env = oracle.OracleVecEnv(track, n_envs, num_rays=cfg["num_rays"], reward_scaling=0.1, threads=n_threads)
+        env.reset()
+        rng = np.random.default_rng(0)
+        acts = rng.integers(0, 9, size=(16, n_envs)).astype(np.int64)
+        env.step(acts[0])
+        steps, t0 = 0, time.time()
+        while True:
+            env.step(acts[steps % 16])
+            steps += 1
+            if time.time() - t0 > budget and steps >= 2:
+                break
+        return n_envs * steps / (time.time() - t0), steps
+
+    n_envs = max(4096, 128 * threads)
+    one, steps1 = env_only(1, 1024, budget_s * 0.4)
+    allc, steps_all = env_only(threads, n_envs, budget_s)
+    torch.set_num_threads(threads)
+    env = oracle.OracleVecEnv(track, n_envs, num_rays=cfg["num_rays"], reward_scaling=0.1, threads=threads)
     obs = torch.from_numpy(env.reset())
     agent = Agent(env.D, 9)
     steps, t0 = 0, time.time()
@@ -131,9 +197,12 @@ def cpu_baseline(cfg, torch, budget_s=12.0):
                 break
     dt = time.time() - t0
     py = PY_REFERENCE.get(cfg["num_rays"])
-    return {"value": n_envs * steps / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
-            "sample": f"rollout only (torch-CPU policy + C oracle env, {cores} threads), n_envs={n_envs}, {steps} steps, "
-                      f"{cfg['num_rays']} rays, big_track; PPO update not included",
+    return {"value": n_envs * steps / dt, "unit": "env steps/s", "cores": threads, "kind": "port",
+            "host_cores": host, "usable_cores": usable, "cgroup_cpu_quota": quota, "threads": threads,
+            "env_only_value": allc, "env_only_one_thread_value": one, "env_only_scaling": allc / one / threads,
+            "sample": f"big_track, {cfg['num_rays']} rays: (a) env only, 1 thread, 1024 envs x {steps1} steps; (b) env only, {threads} threads, "
+                      f"{n_envs} envs x {steps_all} steps -> env_only_value; (c) rollout = torch-CPU policy ({threads} threads) + C oracle env "
+                      f"({threads} threads), {n_envs} envs x {steps} steps -> value; PPO update not included; every leg bounded to ~{budget_s:.0f} s",
             "reference_python": {"value": py, "unit": "env steps/s", "cores": 1,
                                  "source": "BASELINE.md section 2: the reference's Python CarEnv on one Xeon 2.1 GHz core of the survey "
                                            "container (env only, big_track); it cannot travel to the GPU box, so it is quoted, not re-timed"}}
@@ -264,14 +333,59 @@ def main():
     track = ([os.path.join(ROOT, "tracks", "track.json"), os.path.join(ROOT, "tracks", "big_track.json")] if mixed
              else os.path.join(ROOT, "tracks", "big_track.json"))
 
-    def make_trainer(policy_precision=PREC[args.policy_arith]):
+    def tracks_of(mixed_):
+        return ([os.path.join(ROOT, "tracks", "track.json"), os.path.join(ROOT, "tracks", "big_track.json")] if mixed_
+                else os.path.join(ROOT, "tracks", "big_track.json"))
+
+    def make_trainer(policy_precision=PREC[args.policy_arith], wl_=None, env_dtype=None, track_=None):
         # every launch option lives in this trainer's handles (pc_policy, pc_env): nothing process-wide is touched
-        cfg_ = PPOConfig(track=track, env_dtype=args.env_dtype, seed=0, policy=args.policy, use_graphs=not args.no_graphs,
+        cfg_ = PPOConfig(track=track if track_ is None else track_, env_dtype=env_dtype or args.env_dtype, seed=0, policy=args.policy,
+                         use_graphs=not args.no_graphs,
                          fused_update=not args.torch_update, custom_mlp=not args.torch_mlp, rollout_kernel=args.rollout_kernel,
                          force_collective=args.force_collective, capture_collectives=bool(args.capture_collectives),
-                         policy_precision=policy_precision, exchange=args.exchange, rollout_form=args.rollout_form, **wl)
+                         policy_precision=policy_precision, exchange=args.exchange, rollout_form=args.rollout_form, **(wl if wl_ is None else wl_))
         t_ = Trainer(cfg_, device=dev, rank=rank, world_size=world)
         return cfg_, t_
+
+    def wall_counts(track_):
+        from ppo_car_amd.env import Track
+        return [Track(t).n_walls for t in (track_ if isinstance(track_, (list, tuple)) else [track_])]
+
+    def side_measurement(name, wl_in, env_dtype="f32", epochs=5):
+        """Another workload (or the same one in another env dtype) AFTER the headline's timed region, same process, same box:
+        2 warm-up epochs (graphs: one eager, then capture), then `epochs` timed epochs bracketed like the headline; the rollout
+        launch by HIP events on the launch stream inside those epochs; the launch priced against the same roofs."""
+        wl_ = dict(wl_in)
+        mixed_ = wl_.pop("mixed", False)
+        trk = tracks_of(mixed_)
+        c_, t_ = make_trainer(wl_=wl_, env_dtype=env_dtype, track_=trk)
+        try:
+            for _ in range(2):
+                t_.run_epoch(sync=False)
+            t_.mega_events, t_.phase_events = [], []
+            d_ = timed(t_, epochs)
+            torch.cuda.synchronize()
+            R_ = t_.obs_dim[0] - 6
+            fl, by = algo_flops(R_, wall_counts(trk)), algo_bytes(R_)
+            units_ = c_.n_envs * c_.n_steps
+            r_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in t_.phase_events]))
+            mega = float(np.mean([a.elapsed_time(b) for a, b in t_.mega_events]) * 1e3) if t_.mega_events else None
+            sec_ = (mega if mega is not None else r_ms * 1e3) * 1e-6     # per-step kernels (f64): the rollout phase of the epoch
+            res = {"workload": f"{name}: {'track.json + big_track.json (halves)' if mixed_ else 'big_track.json'}, num_rays={c_.num_rays} ({R_} actual), "
+                               f"n_envs={c_.n_envs}, n_steps={c_.n_steps}, batch_size={c_.batch_size}, train_iters={c_.train_iters}",
+                   "value": units_ * epochs / d_, "unit": "env steps/s", "epochs": epochs, "ms_per_step": d_ / epochs * 1e3,
+                   "dtype": env_dtype, "rollout": t_.rollout_mode,
+                   "epoch_split": {"rollout_ms": r_ms, "gae_update_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in t_.phase_events]))},
+                   "roofline": {"bound": "valu", "launch_us": sec_ * 1e6,
+                                "launch_us_method": ("HIP events on the launch stream around each pc_rollout launch inside the timed epochs" if mega is not None
+                                                     else "HIP events around the rollout phase (per-step kernels replayed as one HIP graph) inside the timed epochs"),
+                                "achieved": fl * units_ / sec_ / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": fl * units_ / sec_ / 1e12 / VALU_PEAK_TFLOPS, "flops_per_env_step": fl,
+                                "hbm_frac": by * units_ / sec_ / 1e9 / HBM_PEAK_GBS, "bytes_per_env_step": by}}
+            return res
+        finally:
+            t_.mega_events = t_.phase_events = None
+            t_.close()
 
     cfg, tr = make_trainer()
     tr.profile_stride = 0
@@ -334,6 +448,16 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+    replicas_equal = None
+    if dist is not None and world > 1:
+        # the replicas after the timed epochs: every rank's flat parameter buffer against rank 0's, bit for bit (clip + Adam are
+        # replicated on the all-reduced gradient: train.py:259-261 on every rank)
+        mine = tr.learner.flat_param.detach().clone()
+        if dist.get_backend() != "nccl":
+            mine = mine.cpu()
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        replicas_equal = bool(all(torch.equal(every[0], t) for t in every[1:]))
     k1_us = float(np.mean([a.elapsed_time(b) for a, b in probe_events]) * 1e3 / PROBE)
     k1_bracketed_us = float(np.mean([a.elapsed_time(b) for a, b in tr.k1_events]) * 1e3) if tr.k1_events else None
     gae_us = float(np.median([a.elapsed_time(b) for a, b in gae_events]) * 1e3)
@@ -385,11 +509,30 @@ def main():
             except Exception as ex:
                 extras["fp32_grade_bf16x3_value"] = {"error": repr(ex)}
 
+    if world == 1 and not args.no_extras and args.env_dtype == "f32" and args.policy == "fused" and not args.force_collective:
+        # the bit-exact configuration (float64 throughout, the reference's own operation order: observations, rewards, events AND
+        # the float64 state equal the reference's bit for bit) on the SAME workload ...
+        try:
+            extras["exact_f64_value"] = side_measurement(args.workload, WORKLOADS[args.workload] if not (args.n_envs or args.n_steps) else dict(wl, mixed=mixed),
+                                                         env_dtype="f64", epochs=3)
+        except Exception as ex:
+            extras["exact_f64_value"] = {"error": repr(ex)}
+        # ... and every other single-GPU BASELINE configuration, each with its own ms_per_step and roofline fraction
+        others = {}
+        for name in ("target", "cfg1", "cfg2", "cfg4"):
+            if name == args.workload:
+                continue
+            try:
+                others[name] = side_measurement(name, WORKLOADS[name], env_dtype="f32", epochs=5)
+            except Exception as ex:
+                others[name] = {"error": repr(ex)}
+        extras["other_workloads"] = others
+
     if rank == 0:
         env_steps = cfg.n_envs * cfg.n_steps * args.steps * world
         nr = cfg.num_rays
-        per_step_bytes = ALGO_BYTES.get(nr, 4 * obs_dim + 84)     # algorithmic bytes per env step
-        per_step_flops = ALGO_FLOPS.get(nr, 0)
+        per_step_bytes = algo_bytes(obs_dim - 6)                           # algorithmic bytes per env step
+        per_step_flops = algo_flops(obs_dim - 6, wall_counts(track))       # ... and flops, for this batch's track(s)
         k1 = {"kernel": "env_step_kernel (K1), stand-alone", "launch_us": k1_us, "achieved": per_step_bytes * cfg.n_envs / (k1_us * 1e-6) / 1e9,
               "unit": "GB/s", "frac": per_step_bytes * cfg.n_envs / (k1_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
               "launch_us_method": f"{PROBE} back-to-back launches on an identical env batch between two HIP events on the launch stream, "
@@ -410,14 +553,14 @@ def main():
         mlp_flops = 2 * (2 * D * 256 + 256 * A + 256)                       # both MLPs, one env step (model.py:14-32)
         n_prod = {"fp16x2": 3, "bf16x3": 6, "fp32": 1}[args.policy_arith]
         track_name = "track.json + big_track.json (halves)" if mixed else "big_track.json"
-        roof = {"kernel": dom_name, "bound": "valu" if not mixed else "valu (mixed tracks: flops priced with big_track's 24 walls)",
+        roof = {"kernel": dom_name, "bound": "valu",
                 "achieved": per_step_flops * units / sec / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": per_step_flops * units / sec / 1e12 / VALU_PEAK_TFLOPS, "traffic": None,
                 "launch_us": dom_us, "launch_us_method": dom_method, "algorithmic_bytes_per_launch": algo_bytes,
                 "env_steps_per_launch": units,
                 "note": "the launch is bound by the SIMDs' vector issue port (fp32 ray geometry: 66 flop/B against a ridge of 20; PMC: "
                         "vector issue 85-89 % busy, DESIGN.md section 4.2): achieved / peak / frac price SURVEY 8(d)'s env-step flops "
-                        "(" + f"{per_step_flops}" + " per env step) against the fp32 vector peak -- most of the kernel's vector instructions are not "
+                        "(" + f"{per_step_flops:.0f}" + " per env step: 28 x (rays x walls + 4) + 2 x rays + 30, the mean over the batch's tracks) against the fp32 vector peak -- most of the kernel's vector instructions are not "
                         "FMAs, so the flop fraction understates the port's occupancy; `hbm` = SURVEY 8(d)'s algorithmic bytes against the "
                         "HBM peak (the figure the task prices), `traffic` = the PMC bytes per launch; `mfma` = the policy GEMMs",
                 "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None},
@@ -450,6 +593,7 @@ def main():
                        "backend": (dist.get_backend() if dist is not None else None),
                        "gradient_exchange": (("one-shot all-reduce over peer-mapped buffers (pc_xchg)" if args.exchange == "p2p" else "torch.distributed all_reduce")
                                              if world > 1 else None),
+                       "replicas_bit_identical": replicas_equal,      # (None on one rank)
                        "env_kernel": info, "policy_step": args.policy, "rollout": rollout_mode,
                        "policy_gemm_arithmetic": POLICY_ARITH, "hip_graphs": bool(cfg.use_graphs),
                        "fused_update": bool(cfg.fused_update), "custom_mlp_update": custom, "epoch_split": split,

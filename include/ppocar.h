@@ -79,8 +79,8 @@ int pc_ray_count(int num_rays_nominal);
  * reference allows a different track per env through reset(options=...) (car_env.py:621-628).
  * Replaces: CarEnv.__init__ (car_env.py:475-533) x N + AsyncVectorEnv construction.
  * F32 handles check what their float32 selector assumes of a track (car_env.py:155-184 puts no constraint on the walls): the
- * walls' bounding box must fit 2000 px and a track may have at most 8192 chain vertices (PC_ERR_UNSUPPORTED, pc_last_hip_error
- * says which: use PC_DTYPE_F64); walls that cross or touch without being chain neighbours, spikes sharper than ~13 degrees and
+ * walls' bounding box must fit 2000 px and a track may have at most 8192 chain vertices (PC_ERR_UNSUPPORTED; pc_last_hip_error
+ * names the track's index and which of the two limits it breaks: use PC_DTYPE_F64); walls that cross or touch without being chain neighbours, spikes sharper than ~13 degrees and
  * walls shorter than the corner margin are accepted and resolved exactly (every ray that selects one of them takes the float64
  * scan of the whole chain): slower on those rays, never different from the reference. */
 int pc_env_create(int device, int64_t n_envs, int num_rays_nominal, const pc_track* const* tracks, int n_tracks,
@@ -292,11 +292,14 @@ int pc_ppo_epoch_prepared(int device, const float* prepared, int n_mb, int B, in
  * waits for its own W flags and sums the W slots locally in rank order, so the reduced buckets are bit-identical on all
  * ranks.  One process per rank (ranks of one node; up to 8):
  *   pc_xchg_create(device, rank, world, n_floats)   allocates this rank's staging buffer (uncached device memory);
- *   pc_xchg_local_handle(x, out)                    PC_XCHG_HANDLE_BYTES bytes (a hipIpcMemHandle_t) for the other ranks -- the
- *                                                   caller carries them across (e.g. torch.distributed.all_gather_object);
- *   pc_xchg_connect(x, all)                         `all` = world x PC_XCHG_HANDLE_BYTES bytes in rank order: maps the peers and
- *                                                   verifies / enables peer access to each peer's device (PC_ERR_UNSUPPORTED with a
- *                                                   message in pc_last_hip_error when a peer is unreachable);
+ *   pc_xchg_local_handle(x, out)                    PC_XCHG_HANDLE_BYTES bytes for the other ranks: the hipIpcMemHandle_t of the
+ *                                                   staging buffer, then the PCI bus id of its device (text) -- the caller carries
+ *                                                   them across (e.g. torch.distributed.all_gather_object);
+ *   pc_xchg_connect(x, all)                         `all` = world x PC_XCHG_HANDLE_BYTES bytes in rank order: resolves every peer's
+ *                                                   PCI bus id to this process's device ordinal, verifies / enables peer access
+ *                                                   to it (PC_ERR_UNSUPPORTED with a message in pc_last_hip_error when the device
+ *                                                   is not visible to this process or not reachable), THEN maps the peers'
+ *                                                   buffers; a failed connect closes what it opened and leaves the handle as it was;
  *   pc_xchg_set_timeout(x, seconds)                 patience of a wait inside the exchange kernel (default 20 s);
  *   pc_xchg_allreduce(x, bucket, stream)            in place, asynchronous on `stream`, capturable into a HIP graph: bucket[0..n)
  *                                                   := sum over ranks (rank order) of their buckets.  Every rank must make the
@@ -306,7 +309,7 @@ int pc_ppo_epoch_prepared(int device, const float* prepared, int n_mb, int B, in
  *                                                   WRONG sum rather than hang the GPU, and later calls on the handle do not wait
  *                                                   again): the caller must check it wherever it synchronises and abort the job;
  *   pc_xchg_destroy(x)                              after every rank has finished using it (the caller synchronises the ranks). */
-#define PC_XCHG_HANDLE_BYTES 64
+#define PC_XCHG_HANDLE_BYTES 128
 int pc_xchg_create(int device, int rank, int world, int64_t n_floats, pc_xchg** out);
 int pc_xchg_local_handle(pc_xchg* x, void* handle_out);
 int pc_xchg_connect(pc_xchg* x, const void* all_handles);
@@ -326,6 +329,12 @@ int pc_build_ablate(void);
 /* Kernel-launch geometry of the last pc_env_step on this handle (lanes per env, rays per lane,
  * blocks, threads) -- for bench.py / DESIGN.md; any pointer may be NULL. */
 int pc_env_launch_info(const pc_env* e, int* lanes_per_env, int* rays_per_lane, int* blocks, int* threads);
+/* What pc_env_create made of track `track` of this handle: its wall count (car_env.py:653-670), the vertices of its wall chains,
+ * and -- F32 handles -- how many wall segments carry the "resolve by the float64 chain scan" mark (walls that cross or touch
+ * without being chain neighbours, spikes, walls shorter than the corner margin: exact, but every ray that selects one of them
+ * costs an O(n_walls) float64 scan).  A track where that is a large share of the walls runs correctly and SLOWLY in dtype f32: the
+ * Python host layer warns above 25 %.  0 for F64 handles.  Any pointer may be NULL. */
+int pc_env_track_info(const pc_env* e, int track, int* n_walls, int* n_chain_vertices, int* n_scan_segments);
 /* Override the lanes-per-env choice (power of two 1..64; 0 = automatic).  Tuning knob for bench.py. */
 int pc_env_set_lanes_per_env(pc_env* e, int lanes_per_env);
 

@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "libppocar.so")
 
 PC_OK = 0
 PC_ERR_INVALID_ARG, PC_ERR_IO, PC_ERR_PARSE, PC_ERR_HIP, PC_ERR_UNSUPPORTED, PC_ERR_NO_DEVICE, PC_ERR_TIMEOUT = -1, -2, -3, -4, -5, -6, -7
-PC_XCHG_HANDLE_BYTES = 64
+PC_XCHG_HANDLE_BYTES = 128
 PC_DTYPE_F32, PC_DTYPE_F64 = 0, 1
 PC_OPT_ROLLOUT_FORM, PC_OPT_ROLLOUT_EPW, PC_OPT_ROLLOUT_FAST = 1, 2, 3
 DTYPES = {"f32": PC_DTYPE_F32, "float32": PC_DTYPE_F32, "f64": PC_DTYPE_F64, "float64": PC_DTYPE_F64}
@@ -105,6 +105,7 @@ _sig = {
     "pc_last_hip_error": (C.c_char_p, []),
     "pc_env_launch_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "pc_env_set_lanes_per_env": (_i, [_vp, _i]),
+    "pc_env_track_info": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
 }
 for _name, (_res, _args) in _sig.items():
     _f = getattr(lib, _name)  # AttributeError here = the library does not export what ppocar.h declares

@@ -154,18 +154,18 @@ constexpr int FB_S = 8;  // samples per workgroup
 // clip_grad_norm_ + Adam for ONE element, shared by K12 (adam_kernel), K12m (clip_adam_mb_kernel) and K10's deferred form: the
 // same instruction sequence wherever a parameter is updated, so every path gives the same bits.  torch's update is
 //   g = grad * clip_coef;  m = m + (1 - b1)(g - m);  v = b2 v + (1 - b2) g g;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
-// (train.py:260-261, Adam(eps = 1e-5) train.py:146).  The square root and the two divisions are v_sqrt_f32 / v_rcp_f32 (one ulp
-// each) and a multiply by the exactly computed 1 / sqrt(bc2): the update term (<= lr ~ 3e-4) moves by 2.4e-7 of itself, 7e-11
-// absolute per step against the 2e-6 the parameters are held to against torch -- where the IEEE forms cost ~35 instructions
-// per element, which K10's deferred form would pay 58 times per thread at the head of its critical path.
-struct AdamCoef { float coef, step_size, inv_bc2_sqrt, beta1, beta2, eps; };
+// (train.py:260-261, Adam(eps = 1e-5) train.py:146), with torch's own operations: a correctly rounded square root and two
+// correctly rounded divisions (sqrtf, `/`: ~35 instructions per element, one element per thread in K12 -- nothing against the
+// launch; denormal second moments are honoured).  Round 4 had v_sqrt_f32 / v_rcp_f32 here for the sake of K10's deferred form
+// (off by default, measured slower): an approximation in the shipped update for a disabled feature -- gone.
+struct AdamCoef { float coef, step_size, bc2_sqrt, beta1, beta2, eps; };
 __device__ __forceinline__ AdamCoef adam_coef(const float norm_sq, const float step, const float lr, const float max_norm, const float beta1,
                                               const float beta2, const float eps) {
     AdamCoef c;
     c.coef = fminf(max_norm / (sqrtf(norm_sq) + 1e-6f), 1.0f);                 // clip_coef_clamped
     const float bc1 = 1.0f - powf(beta1, step), bc2 = 1.0f - powf(beta2, step);
     c.step_size = lr / bc1;
-    c.inv_bc2_sqrt = 1.0f / sqrtf(bc2);
+    c.bc2_sqrt = sqrtf(bc2);
     c.beta1 = beta1;
     c.beta2 = beta2;
     c.eps = eps;
@@ -175,8 +175,8 @@ __device__ __forceinline__ void adam_elem(const AdamCoef& c, const float g_raw, 
     const float g = g_raw * c.coef;
     m = m + (1.0f - c.beta1) * (g - m);                                        // exp_avg.lerp_(grad, 1 - beta1)
     v = c.beta2 * v + (1.0f - c.beta2) * g * g;                                // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
-    const float denom = __builtin_amdgcn_sqrtf(v) * c.inv_bc2_sqrt + c.eps;
-    p = p - c.step_size * (m * __builtin_amdgcn_rcpf(denom));                  // param.addcdiv_(exp_avg, denom, -step_size)
+    const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;                         // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+    p = p - c.step_size * (m / denom);                                         // param.addcdiv_(exp_avg, denom, -step_size)
 }
 // the squared gradient norm from K11's per-block partials, summed in index order (every thread, every workgroup: the same float)
 __device__ __forceinline__ float norm_sq_from_partials(const float* __restrict__ norm_partial, const int n_norm) {

@@ -254,12 +254,14 @@ const char* pc_strerror(int code) {
 const char* pc_last_hip_error(void) { return g_hip_err.c_str(); }
 
 int pc_ray_count(int n) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (n < 4 || n > 360) return PC_ERR_INVALID_ARG;
     const int step = 360 / n;
     return (360 + step - 1) / step;  // len(range(0, 360, 360 // n)), car_env.py:269
 }
 
 int pc_track_load_json(const char* path, pc_track** out) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!path || !out) return PC_ERR_INVALID_ARG;
     std::unique_ptr<pc_track> t(new (std::nothrow) pc_track);
     if (!t) return PC_ERR_INVALID_ARG;
@@ -271,6 +273,7 @@ int pc_track_load_json(const char* path, pc_track** out) {
 
 int pc_track_from_arrays(const double* walls, int n_walls, const double* gates, int n_gates, double start_x, double start_y,
                          double start_angle_deg, pc_track** out) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!walls || !gates || n_walls < 1 || n_gates < 1 || !out) return PC_ERR_INVALID_ARG;
     pc_track* t = new (std::nothrow) pc_track;
     if (!t) return PC_ERR_INVALID_ARG;
@@ -284,6 +287,7 @@ int pc_track_from_arrays(const double* walls, int n_walls, const double* gates, 
 }
 
 int pc_track_info(const pc_track* t, int* n_walls, int* n_gates, double* start) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!t) return PC_ERR_INVALID_ARG;
     if (n_walls) *n_walls = t->n_walls();
     if (n_gates) *n_gates = t->n_gates();
@@ -296,6 +300,7 @@ int pc_track_info(const pc_track* t, int* n_walls, int* n_gates, double* start) 
 }
 
 int pc_track_geometry(const pc_track* t, double* walls, double* gates) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!t) return PC_ERR_INVALID_ARG;
     if (walls) memcpy(walls, t->walls.data(), t->walls.size() * sizeof(double));
     if (gates) memcpy(gates, t->gates.data(), t->gates.size() * sizeof(double));
@@ -448,7 +453,8 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
             while ((1 << bits) < h.nV) ++bits;
             const double sel_res = 1001.0 * std::ldexp(1.0, -(23 - bits));
             const double margin = std::max(0.05, 4.6 * sel_res), near = std::max(0.05, 1.5 * sel_res);
-            for (int k = 0; k < n; ++k) {
+            // (F32 handles only: nV <= 8192 there, so prev / next fit their 15 bits beside PC_SEG_SCAN; the F64 kernels never read seg64)
+            for (int k = 0; k < n && !f64; ++k) {
                 if (is_start(k)) continue;     // chain starts / padding: no segment (h = -1: |t - 0.5| < h never holds)
                 int c0 = k;     // first vertex of this chain, and its last
                 while (!is_start(c0)) --c0;
@@ -457,7 +463,8 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
                 const bool closed = c1 > c0 && vpos[o + c0].x == vpos[o + c1].x && vpos[o + c0].y == vpos[o + c1].y;
                 const int prev = k - 1 > c0 ? k - 1 : (closed && c1 != k ? c1 : 0);       // shares this segment's first endpoint
                 const int next = k + 1 <= c1 ? k + 1 : (closed && c0 + 1 != k ? c0 + 1 : 0);   // shares its second endpoint
-                seg64[o + k].prev_next = prev | (next << 16);
+                static_assert(PC_SEG_SCAN == 0x8000, "prev in bits 0..14, PC_SEG_SCAN in bit 15, next in bits 16..30");
+                seg64[o + k].prev_next = prev | (next << 16);      // (prev, next < nV <= 8192)
                 const double len = std::hypot(seg64[o + k].ex, seg64[o + k].ey);
                 seg64[o + k].h = 0.5 - margin / len;
                 if (len < 2.0 * margin) seg64[o + k].prev_next |= PC_SEG_SCAN;
@@ -671,6 +678,7 @@ int pc_env_num_actions(const pc_env* e) { return e ? 9 : PC_ERR_INVALID_ARG; }  
 int64_t pc_env_num_envs(const pc_env* e) { return e ? e->N : PC_ERR_INVALID_ARG; }
 
 int pc_env_set_lanes_per_env(pc_env* e, int lanes) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!e || lanes < 0 || lanes > 64 || (lanes & (lanes - 1))) return PC_ERR_INVALID_ARG;
     const int prev = e->lanes_override;
     e->lanes_override = lanes;
@@ -682,7 +690,18 @@ int pc_env_set_lanes_per_env(pc_env* e, int lanes) {
     return rc;
 }
 
+int pc_env_track_info(const pc_env* e, int track, int* n_walls, int* n_chain_vertices, int* n_scan_segments) {
+    g_hip_err.clear();
+    if (!e || track < 0 || track >= e->n_tracks) return PC_ERR_INVALID_ARG;
+    const TrackHdr& h = e->hdr_host[track];
+    if (n_walls) *n_walls = h.S;
+    if (n_chain_vertices) *n_chain_vertices = h.n_chain;
+    if (n_scan_segments) *n_scan_segments = e->dtype == PC_DTYPE_F32 ? h.n_scan : 0;
+    return PC_OK;
+}
+
 int pc_env_launch_info(const pc_env* e, int* lanes_per_env, int* rays_per_lane, int* blocks, int* threads) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!e) return PC_ERR_INVALID_ARG;
     if (lanes_per_env) *lanes_per_env = 1 << e->lg;
     if (rays_per_lane) *rays_per_lane = e->rpl;
@@ -692,6 +711,7 @@ int pc_env_launch_info(const pc_env* e, int* lanes_per_env, int* rays_per_lane, 
 }
 
 int pc_env_reset(pc_env* e, float* obs, void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!e) return PC_ERR_INVALID_ARG;
     DeviceGuard guard(e->device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
@@ -707,6 +727,7 @@ int pc_env_reset(pc_env* e, float* obs, void* stream) {
 
 int pc_env_step(pc_env* e, const int64_t* actions, double reward_scale, float* obs, float* reward, float* terminated,
                 float* truncated, int32_t* gates_passed, float* final_obs, void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!e || !actions || !obs || !reward || !terminated || !truncated) return PC_ERR_INVALID_ARG;
     DeviceGuard guard(e->device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
@@ -736,6 +757,7 @@ int pc_env_step(pc_env* e, const int64_t* actions, double reward_scale, float* o
 }
 
 int pc_env_info(pc_env* e, int32_t* gates_passed, int32_t* time_passed, void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!e) return PC_ERR_INVALID_ARG;
     DeviceGuard guard(e->device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
@@ -754,6 +776,7 @@ int pc_build_ablate(void) { return PC_ABLATE; }
 #ifdef PC_STAMPS
 // developer build only (not declared in ppocar.h): copy the phase stamps of the last pc_rollout launch to the host
 int pc_debug_read_stamps(unsigned long long* out, int n) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     const int total = 8 * STAMP_NT * STAMP_NPH;
     if (n < total) return -1;
     if (hipDeviceSynchronize() != hipSuccess) return -2;
@@ -761,6 +784,7 @@ int pc_debug_read_stamps(unsigned long long* out, int n) {
     return total;
 }
 int pc_debug_read_stamps_u(unsigned long long* out) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (hipDeviceSynchronize() != hipSuccess) return -2;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_u), 16 * sizeof(unsigned long long)) != hipSuccess) return -3;
     return 16;
@@ -769,6 +793,7 @@ int pc_debug_read_stamps_u(unsigned long long* out) {
 
 int pc_env_get_state(pc_env* e, double* px, double* py, double* vx, double* vy, double* rot, int64_t* time_step,
                      int64_t* next_gate, int64_t* passed) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!e) return PC_ERR_INVALID_ARG;
     DeviceGuard guard(e->device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
@@ -798,6 +823,7 @@ int pc_env_get_state(pc_env* e, double* px, double* py, double* vx, double* vy, 
 
 int pc_env_set_state(pc_env* e, const double* px, const double* py, const double* vx, const double* vy, const double* rot,
                      const int64_t* time_step, const int64_t* next_gate, const int64_t* passed) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!e) return PC_ERR_INVALID_ARG;
     DeviceGuard guard(e->device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
@@ -832,6 +858,7 @@ int pc_env_set_state(pc_env* e, const double* px, const double* py, const double
 int pc_gae(int device, const float* rew, const float* val, const float* term, const float* trunc, const float* last_val,
            const float* last_term, const float* last_trunc, double gamma, double lam, int64_t T, int64_t N, float* adv,
            float* ret, void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!rew || !val || !term || !trunc || !last_val || !last_term || !last_trunc || !adv || !ret || T < 1 || N < 1)
         return PC_ERR_INVALID_ARG;
     int count = 0;
@@ -848,6 +875,7 @@ int pc_gae(int device, const float* rew, const float* val, const float* term, co
 
 int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, uint64_t offset, int64_t* actions,
               float* logprob, float* entropy, void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!logits || !actions || !logprob || N < 1 || A < 1) return PC_ERR_INVALID_ARG;
     if (A > 16) return PC_ERR_UNSUPPORTED;
     int count = 0;
@@ -883,6 +911,7 @@ struct pc_policy {
 extern "C" {
 
 int pc_policy_create(int device, int D, int H, int A, int precision, int split, pc_policy** out) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!out || precision < -1 || precision > 2 || split < -1 || split > 1) return PC_ERR_INVALID_ARG;
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;  // the caller falls back to its own GEMMs
     pc_policy* p = new (std::nothrow) pc_policy;
@@ -900,6 +929,7 @@ int pc_policy_create(int device, int D, int H, int A, int precision, int split, 
 void pc_policy_destroy(pc_policy* p) { delete p; }
 
 int pc_policy_get(const pc_policy* p, int* precision, int* split, int64_t* image_floats) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!p) return PC_ERR_INVALID_ARG;
     if (precision) *precision = p->precision;
     if (split) *split = p->split;
@@ -908,6 +938,7 @@ int pc_policy_get(const pc_policy* p, int* precision, int* split, int64_t* image
 }
 
 int pc_env_set_option(pc_env* e, int option, int value) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!e) return PC_ERR_INVALID_ARG;
     switch (option) {
         case PC_OPT_ROLLOUT_FORM:
@@ -929,6 +960,7 @@ int pc_env_set_option(pc_env* e, int option, int value) {
 }
 
 int pc_env_get_option(const pc_env* e, int option, int* value) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!e || !value) return PC_ERR_INVALID_ARG;
     switch (option) {
         case PC_OPT_ROLLOUT_FORM: *value = e->opt.form < 0 ? -1 : e->opt.form + (e->opt.rden ? 0 : 2); return PC_OK;
@@ -1019,6 +1051,7 @@ static int policy_act_impl(int device, int prec, int split_mode, const float* ob
 
 int pc_policy_pack(const pc_policy* p, const float* aW1, const float* ab1, const float* aW2, const float* ab2, const float* cW1,
                    const float* cb1, const float* cW2, const float* cb2, float* image, void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!p) return PC_ERR_INVALID_ARG;
     return policy_pack_impl(p->device, p->precision, p->D, p->H, p->A, aW1, ab1, aW2, ab2, cW1, cb1, cW2, cb2, image, stream);
 }
@@ -1026,6 +1059,7 @@ int pc_policy_pack(const pc_policy* p, const float* aW1, const float* ab1, const
 int pc_policy_act(const pc_policy* p, const float* obs, int64_t N, const float* image, uint64_t seed, uint64_t offset,
                   const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob, float* value, float* logits_out,
                   void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!p) return PC_ERR_INVALID_ARG;
     return policy_act_impl(p->device, p->precision, p->split, obs, N, p->D, p->H, p->A, image, seed, offset, offset_dev, action, action_f32,
                            logprob, value, logits_out, stream);
@@ -1034,6 +1068,7 @@ int pc_policy_act(const pc_policy* p, const float* obs, int64_t N, const float* 
 int pc_ppo_gather(int device, const int64_t* idx, int B, int D, const float* obs, const float* act, const float* logprob,
                   const float* adv, const float* ret, float* o_obs, float* o_act, float* o_logprob, float* o_adv, float* o_ret,
                   void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!idx || !obs || !act || !logprob || !adv || !ret || !o_obs || !o_act || !o_logprob || !o_adv || !o_ret || B < 1 || D < 1)
         return PC_ERR_INVALID_ARG;
     DeviceGuard guard(device);
@@ -1048,6 +1083,7 @@ int pc_ppo_gather(int device, const int64_t* idx, int B, int D, const float* obs
 int pc_ppo_loss(int device, const float* logits, const float* values, const float* act, const float* old_logprob,
                 const float* adv, const float* ret, int B, int A, double clip_ratio, double vf_coef, double ent_coef,
                 float* dlogits, float* dvalues, float* metrics, void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!logits || !values || !act || !old_logprob || !adv || !ret || !dlogits || !dvalues || !metrics) return PC_ERR_INVALID_ARG;
     if (B < 2 || B > 1024 || A < 1 || A > 16) return PC_ERR_UNSUPPORTED;
     DeviceGuard guard(device);
@@ -1061,6 +1097,7 @@ int pc_ppo_loss(int device, const float* logits, const float* values, const floa
 
 int pc_clip_adam(int device, float* param, float* grad, float* exp_avg, float* exp_avg_sq, float* step_count, const float* lr_dev,
                  int64_t n, double max_norm, double grad_scale, double beta1, double beta2, double eps, void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_count || !lr_dev || n < 1 || n > (1 << 26)) return PC_ERR_INVALID_ARG;
     DeviceGuard guard(device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
@@ -1073,6 +1110,7 @@ int pc_clip_adam(int device, float* param, float* grad, float* exp_avg, float* e
 int pc_clip_adam_advanced(int device, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* step_count,
                           const float* lr_dev, int64_t n, double max_norm, double grad_scale, double beta1, double beta2, double eps,
                           void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_count || !lr_dev || n < 1 || n > (1 << 26)) return PC_ERR_INVALID_ARG;
     DeviceGuard guard(device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
@@ -1223,6 +1261,7 @@ int pc_rollout(pc_env* e, const pc_policy* p, const float* image, int64_t T, dou
                const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
                float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, float* last_value,
                float* reward_sum, void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!e || !p) return PC_ERR_INVALID_ARG;
     if (p->D != e->D || p->device != e->device) return PC_ERR_INVALID_ARG;     // the policy was built for another observation width / device
     return rollout_impl(e, p->precision, image, p->A, T, reward_scale, seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf,
@@ -1230,6 +1269,7 @@ int pc_rollout(pc_env* e, const pc_policy* p, const float* image, int64_t T, dou
 }
 
 int64_t pc_ppo_workspace_floats(int B, int D, int H, int A) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40 || B < 2 || B > 1024) return PC_ERR_UNSUPPORTED;
     const int64_t n_param = 2 * ((int64_t)H * D + H) + (int64_t)A * H + A + H + 1;
     const int64_t n_part = (B + FB_S - 1) / FB_S;
@@ -1309,18 +1349,21 @@ int pc_ppo_minibatch(int device, const int64_t* idx, int B, int D, int H, int A,
                      float* exp_avg_sq, float* step_count, const float* lr_dev, double clip_ratio, double vf_coef, double ent_coef,
                      double max_norm, double beta1, double beta2, double eps, float* metrics, float* workspace, int apply,
                      void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     return ppo_minibatch_impl(device, idx, nullptr, B, D, H, A, obs, act, old_logprob, adv, ret, param, grad, exp_avg, exp_avg_sq,
                               step_count, lr_dev, clip_ratio, vf_coef, ent_coef, max_norm, beta1, beta2, eps, metrics, workspace, apply,
                               stream);
 }
 
 int64_t pc_ppo_prepared_floats(int B, int D) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (D < 1 || D > 40 || B < 2 || B > 1024) return PC_ERR_UNSUPPORTED;
     return (int64_t)B * (D + 4) + 4;
 }
 
 int pc_ppo_prepare(int device, const int64_t* idx, int64_t idx_ld, int n_mb, int B, int D, const float* obs, const float* act,
                    const float* old_logprob, const float* adv, const float* ret, float* prepared, void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!idx || !obs || !act || !old_logprob || !adv || !ret || !prepared || n_mb < 1 || idx_ld < B) return PC_ERR_INVALID_ARG;
     if (D < 1 || D > 40 || B < 2 || B > 1024) return PC_ERR_UNSUPPORTED;
     DeviceGuard guard(device);
@@ -1335,6 +1378,7 @@ int pc_ppo_minibatch_prepared(int device, const float* prepared_mb, int B, int D
                               float* exp_avg_sq, float* step_count, const float* lr_dev, double clip_ratio, double vf_coef,
                               double ent_coef, double max_norm, double beta1, double beta2, double eps, float* metrics,
                               float* workspace, int apply, void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!prepared_mb) return PC_ERR_INVALID_ARG;
     return ppo_minibatch_impl(device, nullptr, prepared_mb, B, D, H, A, nullptr, nullptr, nullptr, nullptr, nullptr, param, grad, exp_avg,
                               exp_avg_sq, step_count, lr_dev, clip_ratio, vf_coef, ent_coef, max_norm, beta1, beta2, eps, metrics,
@@ -1343,6 +1387,7 @@ int pc_ppo_minibatch_prepared(int device, const float* prepared_mb, int B, int D
 
 
 int64_t pc_ppo_epoch_state_floats(int D, int H, int A) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
     const int64_t n_param = 2 * ((int64_t)H * D + H) + (int64_t)A * H + A + H + 1;
     return 3 * ((n_param + 3) & ~(int64_t)3);
@@ -1352,6 +1397,7 @@ int pc_ppo_epoch_prepared(int device, const float* prepared, int n_mb, int B, in
                           float* exp_avg_sq, float* step_count, const float* lr_dev, double clip_ratio, double vf_coef, double ent_coef,
                           double max_norm, double beta1, double beta2, double eps, float* metrics, float* workspace, float* state2,
                           void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!prepared || !param || !grad || !exp_avg || !exp_avg_sq || !step_count || !lr_dev || !metrics || !workspace || !state2 || n_mb < 1)
         return PC_ERR_INVALID_ARG;
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40 || B < 2 || B > 1024) return PC_ERR_UNSUPPORTED;
@@ -1433,6 +1479,7 @@ struct pc_xchg {
 extern "C" {
 
 int pc_xchg_create(int device, int rank, int world, int64_t n_floats, pc_xchg** out) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!out || world < 1 || world > XCHG_MAX_RANKS || rank < 0 || rank >= world || n_floats < 1 || n_floats > (1 << 24)) return PC_ERR_INVALID_ARG;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1 || device < 0 || device >= count) return PC_ERR_NO_DEVICE;
@@ -1467,13 +1514,21 @@ int pc_xchg_create(int device, int rank, int world, int64_t n_floats, pc_xchg** 
     return PC_OK;
 }
 
+// The handle a rank publishes = the hipIpcMemHandle_t of its staging buffer (64 bytes) followed by the PCI bus id of the device the
+// buffer lives on (NUL-terminated text, hipDeviceGetPCIBusId): a peer resolves THAT to its own ordinal of the device -- the
+// pointer a peer gets from hipIpcOpenMemHandle says nothing reliable about the owning device (hipPointerGetAttributes on an IPC
+// mapping reports the opener's device or fails).
 int pc_xchg_local_handle(pc_xchg* x, void* handle_out) {
     if (!x || !handle_out) return PC_ERR_INVALID_ARG;
-    static_assert(sizeof(hipIpcMemHandle_t) == PC_XCHG_HANDLE_BYTES, "handle size");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64 && PC_XCHG_HANDLE_BYTES == 128, "handle layout");
+    g_hip_err.clear();
     DeviceGuard guard(x->device);
     hipIpcMemHandle_t h;
     HIPCHK(hipIpcGetMemHandle(&h, x->local));
-    memcpy(handle_out, &h, sizeof(h));
+    char* out = static_cast<char*>(handle_out);
+    memset(out, 0, PC_XCHG_HANDLE_BYTES);
+    memcpy(out, &h, sizeof(h));
+    HIPCHK(hipDeviceGetPCIBusId(out + sizeof(h), PC_XCHG_HANDLE_BYTES - (int)sizeof(h) - 1, x->device));
     return PC_OK;
 }
 
@@ -1482,42 +1537,64 @@ int pc_xchg_connect(pc_xchg* x, const void* all_handles) {
     DeviceGuard guard(x->device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
     g_hip_err.clear();
+    const char* all = static_cast<const char*>(all_handles);
+    // a failed connect leaves the handle as it was: the mappings opened by THIS call are closed again, and no HIP error stays
+    // behind for an unrelated later call to report
+    std::vector<int> opened;
+    auto fail = [&](int code, const std::string& why) {
+        for (int r : opened) { (void)hipIpcCloseMemHandle(x->peer[r]); x->peer[r] = nullptr; }
+        (void)hipGetLastError();
+        g_hip_err = why;
+        return code;
+    };
+    // 1. every peer's DEVICE must be reachable from ours before a kernel of ours writes into its memory: resolve the published
+    //    PCI bus id to this process's ordinal and verify / enable peer access -- a distinct error NOW, not a 20-second wait for a
+    //    flag that can never arrive
+    for (int r = 0; r < x->world; ++r) {
+        if (r == x->rank || x->peer[r]) continue;
+        char bus[PC_XCHG_HANDLE_BYTES - 64];
+        memcpy(bus, all + (size_t)r * PC_XCHG_HANDLE_BYTES + 64, sizeof(bus));
+        bus[sizeof(bus) - 1] = 0;
+        int pdev = -1;
+        const hipError_t be = bus[0] ? hipDeviceGetByPCIBusId(&pdev, bus) : hipErrorInvalidValue;
+        if (be != hipSuccess || pdev < 0)
+            return fail(PC_ERR_UNSUPPORTED, "pc_xchg_connect: rank " + std::to_string(r) + "'s device (PCI " + std::string(bus) +
+                        ") is not visible to this process (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES hide it, or the rank is on another node): "
+                        "peer-mapped exchange impossible, use PPOConfig.exchange = \"rccl\"");
+        if (pdev == x->device) continue;     // the same device (a one-GPU rehearsal): nothing to enable
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, x->device, pdev) != hipSuccess || !can)
+            return fail(PC_ERR_UNSUPPORTED, "pc_xchg_connect: device " + std::to_string(x->device) + " has no peer access to rank " + std::to_string(r) +
+                        "'s device " + std::to_string(pdev) + " (PCI " + std::string(bus) + "; xGMI / PCIe P2P unavailable): use PPOConfig.exchange = \"rccl\"");
+        const hipError_t pe = hipDeviceEnablePeerAccess(pdev, 0);
+        (void)hipGetLastError();     // (hipErrorPeerAccessAlreadyEnabled is sticky otherwise)
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+            return fail(PC_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe));
+    }
+    // 2. map the peers' staging buffers
     for (int r = 0; r < x->world; ++r) {
         if (r == x->rank || x->peer[r]) continue;
         hipIpcMemHandle_t h;
-        memcpy(&h, static_cast<const char*>(all_handles) + (size_t)r * sizeof(h), sizeof(h));
+        memcpy(&h, all + (size_t)r * PC_XCHG_HANDLE_BYTES, sizeof(h));
         void* q = nullptr;
-        HIPCHK(hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess));
+        const hipError_t oe = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
+        if (oe != hipSuccess || !q) return fail(PC_ERR_HIP, std::string("hipIpcOpenMemHandle(rank ") + std::to_string(r) + "): " + hipGetErrorString(oe));
         x->peer[r] = static_cast<char*>(q);
-        // The exchange kernel WRITES into this mapping from a running kernel: make sure the peer's device is reachable from ours
-        // NOW (a distinct error at connect time) rather than as a 20-second wait for a flag that can never arrive.
-        hipPointerAttribute_t attr;
-        if (hipPointerGetAttributes(&attr, q) == hipSuccess && attr.device != x->device && attr.device >= 0) {
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, x->device, attr.device) != hipSuccess || !can) {
-                g_hip_err = "pc_xchg_connect: device " + std::to_string(x->device) + " has no peer access to rank " + std::to_string(r) +
-                            "'s device " + std::to_string(attr.device) + " (xGMI / PCIe P2P unavailable): use PPOConfig.exchange = \"rccl\"";
-                return PC_ERR_UNSUPPORTED;
-            }
-            const hipError_t pe = hipDeviceEnablePeerAccess(attr.device, 0);
-            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
-                g_hip_err = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe);
-                return PC_ERR_HIP;
-            }
-            (void)hipGetLastError();     // (hipErrorPeerAccessAlreadyEnabled is sticky otherwise)
-        }
+        opened.push_back(r);
     }
     x->connected = true;
     return PC_OK;
 }
 
 int pc_xchg_set_timeout(pc_xchg* x, double seconds) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!x || !(seconds > 0.0) || seconds > 3600.0) return PC_ERR_INVALID_ARG;
     x->timeout_s = seconds;
     return PC_OK;
 }
 
 int pc_xchg_allreduce(pc_xchg* x, float* bucket, void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!x || !bucket) return PC_ERR_INVALID_ARG;
     if (!x->connected) return PC_ERR_INVALID_ARG;
     DeviceGuard guard(x->device);
@@ -1528,6 +1605,7 @@ int pc_xchg_allreduce(pc_xchg* x, float* bucket, void* stream) {
 }
 
 int pc_xchg_status(pc_xchg* x) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!x) return PC_ERR_INVALID_ARG;
     DeviceGuard guard(x->device);
     int err = 0;

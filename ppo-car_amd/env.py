@@ -52,14 +52,45 @@ def ray_count(num_rays):
 
 
 class _Space:
-    """The two attributes of gymnasium's spaces that train.py reads (train.py:141-142): `.shape` of the Box observation
-    space (car_env.py:522-524) and `.n` of Discrete(9) (car_env.py:525)."""
+    """gymnasium's two spaces as the reference declares and train.py reads them (train.py:141-142): the Box observation space
+    with its bound vectors (car_env.py:513-524: low = [0, 0, -1, -1, -1, -1, 0 ...], high = 1, float32) and Discrete(9)
+    (car_env.py:525).  `.shape` is the width CarEnv.step actually PRODUCES, 6 + R (R = 12 / 17 / 33 rays for num_rays 12 / 16 /
+    32, car_env.py:269); the reference declares 6 + num_rays (its Box for num_rays = 16 says (22,) while _get_obs returns 23
+    entries -- SURVEY quirk Q1): that declared shape is kept as `.declared_shape`."""
 
-    def __init__(self, shape=None, n=None, dtype=np.float32):
+    def __init__(self, shape=None, n=None, dtype=np.float32, low=None, high=None, declared_shape=None):
         self.shape, self.n, self.dtype = shape, n, dtype
+        self.low, self.high = low, high
+        self.declared_shape = declared_shape if declared_shape is not None else shape
+
+    @classmethod
+    def car_obs(cls, obs_dim, num_rays_nominal, batch=None):
+        """Box(low, high) of CarEnv.__init__ (car_env.py:514-524) for an observation of obs_dim entries; batch = n_envs gives the
+        vector env's batched space (gymnasium tiles the single space's bounds)."""
+        low = np.concatenate([np.array([0.0, 0.0, -1.0, -1.0, -1.0, -1.0], np.float32), np.zeros(obs_dim - 6, np.float32)])
+        high = np.ones(obs_dim, np.float32)
+        shape, decl = (obs_dim,), (6 + num_rays_nominal,)
+        if batch is not None:
+            low, high = np.broadcast_to(low, (batch, obs_dim)), np.broadcast_to(high, (batch, obs_dim))
+            shape, decl = (batch, obs_dim), (batch, 6 + num_rays_nominal)
+        return cls(shape=shape, low=low, high=high, declared_shape=decl)
+
+    def contains(self, x):
+        """gymnasium.spaces.Box.contains / Discrete.contains.  (The reference never clips the position to the track's frame, so a
+        car that leaves the 1280 x 720 window produces an observation outside its own declared Box: car_env.py:578-581.)"""
+        x = np.asarray(x)
+        if self.n is not None:
+            return bool(np.issubdtype(x.dtype, np.integer) and np.all((x >= 0) & (x < self.n)))
+        if self.low is None:
+            return tuple(x.shape) == tuple(self.shape)
+        return bool(tuple(x.shape) == tuple(self.shape) and np.all(x >= self.low) and np.all(x <= self.high))
 
     def __repr__(self):
-        return f"Discrete({self.n})" if self.n is not None else f"Box(-inf, inf, {self.shape}, float32)"
+        if self.n is not None:
+            return f"Discrete({self.n})"
+        if self.low is None:
+            return f"Box(-inf, inf, {self.shape}, float32)"
+        return f"Box({float(np.min(self.low))}, {float(np.max(self.high))}, {self.shape}, float32)"
 
 
 def _device_index(device):
@@ -112,10 +143,22 @@ class VecCarEnv:
         self._h, self._tracks = h, tr
         self.obs_dim = lib.pc_env_obs_dim(h)
         self.act_dim = lib.pc_env_num_actions(h)
+        # dtype f32: walls that float32 cannot order (crossing / touching non-neighbours, spikes, very short walls) are resolved by a
+        # float64 scan of the whole chain -- exact, and an O(n_walls) cost on every ray that selects one: say so when it is a large share
+        self.track_info = []
+        for k in range(len(tr)):
+            w, nv, ns = C.c_int(), C.c_int(), C.c_int()
+            check(lib.pc_env_track_info(h, k, C.byref(w), C.byref(nv), C.byref(ns)), "pc_env_track_info")
+            self.track_info.append({"n_walls": w.value, "n_chain_vertices": nv.value, "n_scan_segments": ns.value})
+            if self.dtype in ("f32", "float32") and ns.value * 4 > w.value:
+                import warnings
+                warnings.warn(f"track {k} ({getattr(tr[k], 'path', None)}): {ns.value} of {w.value} walls cross, touch or fold back on another wall; "
+                              "dtype='f32' resolves every ray that selects one of them by a float64 scan of all walls (exact, slow) -- "
+                              "consider dtype='f64' or cleaning the track (python -m ppo_car_amd.track_tool check)", RuntimeWarning, stacklevel=3)
         # what train.py:141-142 reads: envs.single_observation_space.shape, envs.single_action_space.n
-        self.single_observation_space = _Space(shape=(self.obs_dim,))
+        self.single_observation_space = _Space.car_obs(self.obs_dim, self.num_rays)
         self.single_action_space = _Space(n=self.act_dim, dtype=np.int64)
-        self.observation_space = _Space(shape=(self.num_envs, self.obs_dim))
+        self.observation_space = _Space.car_obs(self.obs_dim, self.num_rays, batch=self.num_envs)
         self.action_space = _Space(shape=(self.num_envs,), dtype=np.int64)
         self.single_observation_space_shape = (self.obs_dim,)     # (round-1 spellings, kept)
         self.single_action_space_n = self.act_dim

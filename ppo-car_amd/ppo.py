@@ -21,6 +21,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _capi
 from ._capi import check, lib
 from .buffer import Buffer
 from .env import VecCarEnv
@@ -144,16 +145,23 @@ class P2PExchange:
         self.device = torch.device(device)
         self._h = None
         self.failed = False
-        hosts = [None] * world_size
-        dist.all_gather_object(hosts, socket.gethostname())
-        if len(set(hosts)) != 1:       # hipIpc handles are meaningful inside one node only
-            raise ValueError(f"PPOConfig.exchange = 'p2p' needs all ranks on one node (got hosts {sorted(set(hosts))}): use exchange = 'rccl'")
+        # hipIpc handles are meaningful inside one node only.  The node's identity is the kernel's boot id, not the hostname: two
+        # containers on one node have different hostnames (and can exchange), two nodes may be given the same one.  Whether a
+        # peer's DEVICE is reachable is pc_xchg_connect's check (by PCI bus id), with its own error.
+        try:
+            node = open("/proc/sys/kernel/random/boot_id").read().strip()
+        except OSError:
+            node = socket.gethostname()
+        nodes = [None] * world_size
+        dist.all_gather_object(nodes, node)
+        if len(set(nodes)) != 1:
+            raise ValueError(f"PPOConfig.exchange = 'p2p' needs all ranks on one node (got {len(set(nodes))} different boot ids): use exchange = 'rccl'")
         di = self.device.index if self.device.index is not None else torch.cuda.current_device()
         h = C.c_void_p()
         check(lib.pc_xchg_create(di, rank, world_size, flat_grad.numel(), C.byref(h)), "pc_xchg_create")
         self._h = h
         check(lib.pc_xchg_set_timeout(h, float(timeout_s)), "pc_xchg_set_timeout")
-        mine = (C.c_char * 64)()
+        mine = (C.c_char * _capi.PC_XCHG_HANDLE_BYTES)()
         check(lib.pc_xchg_local_handle(h, mine), "pc_xchg_local_handle")
         handles = [None] * world_size
         dist.all_gather_object(handles, bytes(mine.raw))

@@ -18,6 +18,7 @@ reward_scaling) are restated in `run_group` below from the gymnasium 0.29.1 beha
 (requirements.txt:5) -- that part of the fixtures is "parity unpinned" by the reference.
 
 Run:  python tests/golden/make_golden.py          (≈ 3 min, writes tests/golden/*.npz)
+      python tests/golden/make_golden.py ppo      (seconds: tests/golden/ppo_minibatch.npz only -- lib/model.py's Agent)
 """
 import os
 import sys
@@ -238,8 +239,94 @@ def gae_cases():
     return out
 
 
+def ppo_cases():
+    """SURVEY 8(c) fixture 6: ONE seeded PPO minibatch through the reference's own `Agent` (lib/model.py:12-41, imported
+    unmodified; `layer_init` :6-9 runs inside its constructor) -> logits, log-probs, entropy, value, the three loss terms, the
+    total, every gradient, the pre-clip gradient norm, and the parameters after the one optimizer step of train.py:257-261.
+    train.py itself cannot be imported (tkinter / cv2 / tensorboardX / gymnasium at module level, a script body under
+    __main__): its minibatch expression train.py:233-261 is restated below LINE BY LINE with the reference's own names, on
+    the reference's Agent / torch.optim.Adam(lr=3e-4, eps=1e-5) (train.py:146).  The WEIGHTS are stored in the fixture, so the
+    consumer does not depend on this torch version's orthogonal_ RNG stream."""
+    import torch
+    import torch.nn as nn
+    from lib.model import Agent
+    out = {}
+    clip_ratio, vf_coef, ent_coef, max_grad_norm, lr = 0.2, 0.5, 0.001, 1.0, 3e-4      # train.py:84-89 defaults
+    # (track, nominal rays, minibatch size, seed, scale of the returns: case 1's gradient norm exceeds max_grad_norm, so the clip acts)
+    cases = [("big_track", 16, 512, 0, 1.0), ("big_track", 12, 512, 1, 20.0), ("track", 32, 64, 2, 1.0)]
+    for ci, (track, n, B, seed, ret_scale) in enumerate(cases):
+        torch.manual_seed(1234 + seed)
+        g = torch.Generator().manual_seed(seed)
+        rec = np.load(f"{OUT}/env_{track}_n{n}.npz")
+        pool = torch.from_numpy(rec["short_ret_obs"].reshape(-1, rec["short_ret_obs"].shape[-1]))   # observations the reference env produced
+        pool = pool[torch.randperm(pool.shape[0], generator=g)[:2048]].contiguous()
+        D = pool.shape[1]
+        agent = Agent(D, 9)                                         # train.py:145
+        # a few SGD-free perturbations so that the output layers are not the near-zero init (std 0.01) only
+        with torch.no_grad():
+            for p_ in agent.parameters():
+                p_.add_(0.05 * torch.randn(p_.shape, generator=g))
+        optimizer = torch.optim.Adam(agent.parameters(), lr=lr, eps=1e-5)   # train.py:146
+        weights = {k: v.detach().clone().numpy() for k, v in agent.state_dict().items()}
+        M = pool.shape[0]
+        batch_indices = torch.randperm(M, generator=g)[:B]
+        traj_obs = pool
+        traj_act = torch.randint(0, 9, (M,), generator=g).float()                  # actions are stored as float32 (buffer.py:13)
+        with torch.no_grad():
+            _, lp_now, _, _ = agent.get_action_and_value(traj_obs, traj_act)
+        traj_logprob = lp_now + 0.25 * torch.randn(M, generator=g)                # ratios on both sides of the clip range
+        traj_adv = torch.randn(M, generator=g) * 2.0 + 0.3
+        traj_ret = torch.randn(M, generator=g) * ret_scale
+        device = torch.device("cpu")
+        # ---- train.py:233-261, verbatim semantics
+        _, new_logprobs, entropies, new_values = agent.get_action_and_value(traj_obs[batch_indices], traj_act[batch_indices])
+        ratios = torch.exp(new_logprobs - traj_logprob[batch_indices])
+        batch_adv = traj_adv[batch_indices]
+        batch_adv = (batch_adv - batch_adv.mean()) / torch.max(batch_adv.std(), torch.tensor(1e-5, device=device))
+        policy_loss1 = -batch_adv * ratios
+        policy_loss2 = -batch_adv * torch.clamp(ratios, 1.0 - clip_ratio, 1.0 + clip_ratio)
+        policy_loss = torch.max(policy_loss1, policy_loss2).mean()
+        new_values = new_values.view(-1)
+        value_loss = 0.5 * ((new_values - traj_ret[batch_indices]) ** 2).mean()
+        entropy = entropies.mean()
+        loss = policy_loss + vf_coef * value_loss - ent_coef * entropy
+        optimizer.zero_grad()
+        loss.backward()
+        grads = {k: p_.grad.detach().clone().numpy() for k, p_ in agent.named_parameters()}
+        grad_norm = nn.utils.clip_grad_norm_(agent.parameters(), max_grad_norm)   # returns the norm BEFORE clipping
+        optimizer.step()
+        logits = agent.actor(traj_obs[batch_indices]).detach()
+        pre = f"c{ci}_"
+        out.update({pre + "w_" + k: v for k, v in weights.items()})
+        out.update({pre + "g_" + k: v for k, v in grads.items()})
+        out.update({pre + "p1_" + k: v.detach().numpy() for k, v in agent.state_dict().items()})
+        # NB `logits` above was taken AFTER the step; the pre-step logits are recomputed from the stored weights
+        ref = Agent(D, 9)
+        ref.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+        with torch.no_grad():
+            logits0 = ref.actor(traj_obs[batch_indices])
+        out.update({pre + "obs": traj_obs.numpy(), pre + "act": traj_act.numpy(), pre + "old_logprob": traj_logprob.numpy(),
+                    pre + "adv": traj_adv.numpy(), pre + "ret": traj_ret.numpy(), pre + "idx": batch_indices.numpy().astype(np.int64),
+                    pre + "logits": logits0.numpy(), pre + "new_logprob": new_logprobs.detach().numpy(),
+                    pre + "entropies": entropies.detach().numpy(), pre + "new_values": new_values.detach().numpy(),
+                    pre + "ratios": ratios.detach().numpy(), pre + "batch_adv_norm": batch_adv.detach().numpy(),
+                    pre + "policy_loss": np.float32(policy_loss.item()), pre + "value_loss": np.float32(value_loss.item()),
+                    pre + "entropy": np.float32(entropy.item()), pre + "loss": np.float32(loss.item()),
+                    pre + "grad_norm": np.float32(float(grad_norm)), pre + "num_rays_nominal": np.int64(n)})
+        print(f"ppo case {ci}: D={D} B={B} loss {loss.item():.6f} = {policy_loss.item():.6f} + {vf_coef}*{value_loss.item():.6f} - "
+              f"{ent_coef}*{entropy.item():.6f}; grad norm {float(grad_norm):.4f}; clipped share "
+              f"{float(((ratios < 0.8) | (ratios > 1.2)).float().mean()):.2f}", flush=True)
+    out.update({"n_cases": np.int64(len(cases)), "clip_ratio": np.float64(clip_ratio), "vf_coef": np.float64(vf_coef),
+                "ent_coef": np.float64(ent_coef), "max_grad_norm": np.float64(max_grad_norm), "lr": np.float64(lr),
+                "adam_eps": np.float64(1e-5), "torch_version": np.array(torch.__version__)})
+    return out
+
+
 def main():
     os.chdir(REF)  # the reference loads "lib/assets/car.png" relative to cwd (stubbed, but keep the cwd it expects)
+    if sys.argv[1:] == ["ppo"]:               # `make_golden.py ppo`: only the PPO-minibatch fixture (reads the env fixtures for its observations)
+        np.savez_compressed(f"{OUT}/ppo_minibatch.npz", **ppo_cases())
+        return
     if not sys.argv[1:]:
         np.savez_compressed(f"{OUT}/ray_cases.npz", **ray_unit_cases())
         np.savez_compressed(f"{OUT}/gae_cases.npz", **gae_cases())

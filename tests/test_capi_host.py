@@ -130,11 +130,46 @@ def test_product_never_touches_the_oracle():
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not re.search(r"^\s*(import|from)\s+oracle", src, flags=re.M), f
                 assert "liboracle" not in src and "carenv_oracle" not in src, f
-    for f in ("train.py",):
-        p = os.path.join(ROOT, f)
-        if os.path.exists(p):
-            src = open(p).read()
-            assert not re.search(r"^\s*(import|from)\s+oracle", src, flags=re.M), f
+    # every top-level script and example of the product, the import shim, the C header
+    scripts = ["train.py", "evaluate.py", os.path.join("ppo_car_amd", "__init__.py")]
+    scripts += [os.path.join("examples", f) for f in sorted(os.listdir(os.path.join(ROOT, "examples"))) if f.endswith(".py")]
+    scripts += [os.path.join("include", f) for f in sorted(os.listdir(os.path.join(ROOT, "include")))]
+    assert "evaluate.py" in scripts and any(s.startswith("examples") for s in scripts)
+    for f in scripts:
+        src = open(os.path.join(ROOT, f)).read()
+        assert not re.search(r"^\s*(import|from)\s+oracle", src, flags=re.M), f
+        assert "liboracle" not in src and "carenv_oracle" not in src, f
+
+
+def test_bench_uses_the_oracle_only_as_checker_and_cpu_baseline():
+    """bench.py may touch oracle/ in exactly two places: the `cpu_baseline` leg and the `parity_check` leg (both run AFTER the
+    timed region, on rank 0).  Nothing else in the file -- the timed region in main() least of all -- names it."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    allowed = {"cpu_baseline", "parity_check"}
+    users = set()
+
+    def walk(node, fn):
+        for ch in ast.iter_child_nodes(node):
+            name = ch.name if (isinstance(ch, (ast.FunctionDef, ast.AsyncFunctionDef)) and fn == "<module>") else fn   # the TOP-LEVEL function
+            if isinstance(ch, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in ch.names):
+                users.add(fn)
+            if isinstance(ch, ast.ImportFrom) and (ch.module or "").split(".")[0] == "oracle":
+                users.add(fn)
+            if isinstance(ch, ast.Name) and ch.id == "oracle":
+                users.add(fn)
+            walk(ch, name)
+
+    walk(tree, "<module>")
+    assert users and users <= allowed, users
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    assert "oracle" not in {n.id for n in ast.walk(main) if isinstance(n, ast.Name)}
+    # ... and main() calls the two legs only after the timed region (`dt = timed(tr, args.steps)`)
+    timed_line = next(n.lineno for n in ast.walk(main) if isinstance(n, ast.Call) and getattr(n.func, "id", "") == "timed")
+    for n in ast.walk(main):
+        if isinstance(n, ast.Call) and getattr(n.func, "id", "") in allowed:
+            assert n.lineno > timed_line, (n.func.id, n.lineno)
 
 
 def test_buffer_store_get_semantics_cpu_storage():

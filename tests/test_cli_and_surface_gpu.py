@@ -105,8 +105,16 @@ def test_spaces_and_info_keys():
     env = pc.VecCarEnv(64, TRACKS["big_track"], num_rays=16, reward_scaling=0.1)
     assert env.single_observation_space.shape == (23,) and env.single_action_space.n == 9      # train.py:141-142
     assert env.observation_space.shape == (64, 23) and env.num_envs == 64
+    # the Box bounds CarEnv.__init__ declares (car_env.py:514-524): low = [0, 0, -1, -1, -1, -1, 0 ...], high = 1, float32; the
+    # reference's own declared width is 6 + num_rays = 22 while it produces 23 entries (quirk Q1)
+    sp = env.single_observation_space
+    assert sp.low.dtype == np.float32 and sp.high.dtype == np.float32 and sp.low.shape == (23,) == sp.high.shape
+    assert sp.low.tolist() == [0.0, 0.0, -1.0, -1.0, -1.0, -1.0] + [0.0] * 17 and sp.high.tolist() == [1.0] * 23
+    assert sp.declared_shape == (22,) and env.observation_space.low.shape == (64, 23)
+    assert env.single_action_space.contains(np.int64(8)) and not env.single_action_space.contains(np.int64(9))
     obs, info = env.reset()
     assert info == {} and obs.shape == (64, 23)
+    assert sp.contains(obs[0].cpu().numpy()) and env.observation_space.contains(obs.cpu().numpy())
     ora = oracle.OracleVecEnv(oracle.Track(TRACKS["big_track"]), 64, num_rays=16, reward_scaling=0.1)
     ora.reset()
     rng = np.random.default_rng(0)
@@ -253,3 +261,37 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["config"]["n_envs_total"] == 8192
     assert d["config"]["backend"] == "gloo" and d["config"]["rccl_ranks"] == 0      # the line names the transport that really ran
     assert d["value"] > 0 and d["scaling"] == "weak"
+
+
+# ------------------------------------------------------------------------------------------------
+# the driver's multi-GPU invocation, rehearsed end to end on one device
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("exchange,capture", [("p2p", True), ("rccl", False)])
+def test_bench_self_spawned_two_ranks_on_one_device(exchange, capture):
+    """`python bench.py --gpus 2` the way the driver's N > 1 run enters it when no launcher is around: the parent (which never
+    touches the GPU) starts `python -m torch.distributed.run` as a CHILD, two ranks come up, train, and rank 0 prints exactly one
+    JSON line.  Rehearsal form: both ranks on cuda:0, gloo for the rendezvous; the gradient exchange per minibatch is the
+    library's one-shot all-reduce over hipIpc-mapped buffers captured into the epoch graph (p2p), or torch.distributed's
+    all_reduce enqueued eagerly (what `nccl` = RCCL takes on real multi-GPU nodes).  Checked: exit code 0, one line, two ranks,
+    no RCCL communicator claimed, the exchange named, the replicas bit-identical after the timed epochs (train.py:259-261)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo", "--exchange", exchange,
+           "--workload", "cfg1", "--n-envs", "1024", "--n-steps", "64", "--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--no-extras"]
+    if capture:
+        cmd.append("--capture-collectives")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]                       # ONE JSON line on stdout, nothing else (RCCL banners, warnings: stderr)
+    out = json.loads(lines[0])
+    c = out["config"]
+    assert out["n_gpus"] == 2 and c["ranks"] == 2 and c["n_envs_total"] == 2048 and out["scaling"] == "weak"
+    assert c["rccl_ranks"] == 0 and c["backend"] == "gloo"          # no RCCL communicator exists in this rehearsal, and none is claimed
+    assert ("one-shot" in c["gradient_exchange"]) == (exchange == "p2p")
+    assert ("captured" in c["update_path"]) == capture and "multi-rank" in c["update_path"]
+    assert c["replicas_bit_identical"] is True
+    assert out["value"] > 0 and c["rollout"] == "mega"

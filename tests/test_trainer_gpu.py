@@ -417,11 +417,25 @@ def _xchg_worker(rank, world, port, out_dir, n, epochs):
     check(lib.pc_xchg_create(0, rank, world, n, C.byref(h)), "pc_xchg_create")
     check(lib.pc_xchg_set_timeout(h, 60.0), "pc_xchg_set_timeout")
     assert lib.pc_xchg_set_timeout(h, -1.0) != 0
-    mine = (C.c_char * 64)()
+    from ppo_car_amd._capi import PC_XCHG_HANDLE_BYTES as HB
+    mine = (C.c_char * HB)()
     check(lib.pc_xchg_local_handle(h, mine), "pc_xchg_local_handle")
+    assert HB == 128 and b":" in bytes(mine.raw)[64:]          # the IPC handle, then the PCI bus id of the buffer's device (text)
     handles = [None] * world
     dist.all_gather_object(handles, bytes(mine.raw))
+    if world > 1:
+        # a peer whose device this process cannot resolve (here: a PCI bus id no device has) is refused AT CONNECT TIME with its own
+        # message, nothing stays mapped, no HIP error stays behind -- and the handle then connects normally
+        bogus = list(handles)
+        peer = 1 - rank
+        bogus[peer] = bogus[peer][:64] + b"ffff:ff:1f.7".ljust(HB - 64, b"\0")
+        assert lib.pc_xchg_connect(h, C.c_char_p(b"".join(bogus))) == -5          # PC_ERR_UNSUPPORTED
+        msg = lib.pc_last_hip_error().decode()
+        assert "not visible" in msg and "ffff:ff:1f.7" in msg and "rccl" in msg, msg
+        assert lib.pc_xchg_allreduce(h, torch.zeros(n, device="cuda").data_ptr(), None) == -1   # still unconnected: refused, not launched
+        torch.zeros(4, device="cuda").sum().item()                                  # (a HIP call after the failure: no stale error)
     check(lib.pc_xchg_connect(h, C.c_char_p(b"".join(handles))), "pc_xchg_connect")
+    assert lib.pc_last_hip_error().decode() == ""
     dist.barrier()
     idx = torch.arange(n, device="cuda", dtype=torch.float32)
     gen = lambda r, ep: torch.sin(idx * (0.37 + r) + ep * 1.7) * (1.0 + 1000.0 * (ep % 3)) + r       # irregular magnitudes
