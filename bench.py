@@ -62,11 +62,11 @@ WORKLOADS = {
 # = 156 / 176 / 240 B at 12 / 17 / 33 actual rays; 28 flop per ray-segment test x (R S + 4 gate tests) + R sincos pairs + ~30 physics
 # = 8.2 / 11.6 / 22.4 kflop on big_track (S = 24 walls).  As FORMULAS of the actual ray count R and the track's wall count S, so
 # that every ray count and every track prices its launch (a mixed batch: the mean over its envs' tracks).
-def algo_bytes(R):
+def step_bytes(R):
     return 4 * (6 + R) + 84
 
 
-def algo_flops(R, walls):
+def step_flops(R, walls):
     """walls: the wall count of every track of the batch, weighted equally (ppo.Trainer deals the envs to the tracks in equal blocks)"""
     return sum(28 * (R * S + 4) + 2 * R + 30 for S in walls) / len(walls)
 
@@ -366,7 +366,7 @@ def main():
             d_ = timed(t_, epochs)
             torch.cuda.synchronize()
             R_ = t_.obs_dim[0] - 6
-            fl, by = algo_flops(R_, wall_counts(trk)), algo_bytes(R_)
+            fl, by = step_flops(R_, wall_counts(trk)), step_bytes(R_)
             units_ = c_.n_envs * c_.n_steps
             r_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in t_.phase_events]))
             mega = float(np.mean([a.elapsed_time(b) for a, b in t_.mega_events]) * 1e3) if t_.mega_events else None
@@ -531,8 +531,8 @@ def main():
     if rank == 0:
         env_steps = cfg.n_envs * cfg.n_steps * args.steps * world
         nr = cfg.num_rays
-        per_step_bytes = algo_bytes(obs_dim - 6)                           # algorithmic bytes per env step
-        per_step_flops = algo_flops(obs_dim - 6, wall_counts(track))       # ... and flops, for this batch's track(s)
+        per_step_bytes = step_bytes(obs_dim - 6)                           # algorithmic bytes per env step
+        per_step_flops = step_flops(obs_dim - 6, wall_counts(track))       # ... and flops, for this batch's track(s)
         k1 = {"kernel": "env_step_kernel (K1), stand-alone", "launch_us": k1_us, "achieved": per_step_bytes * cfg.n_envs / (k1_us * 1e-6) / 1e9,
               "unit": "GB/s", "frac": per_step_bytes * cfg.n_envs / (k1_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
               "launch_us_method": f"{PROBE} back-to-back launches on an identical env batch between two HIP events on the launch stream, "

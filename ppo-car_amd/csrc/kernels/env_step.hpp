@@ -362,12 +362,23 @@ __device__ __forceinline__ void wall_sweep_loops(const VtxP* vp, const float pxr
     }
     // side values of position i of both chains: a = p - pos, c[s] = cross(a, dir_s), and the smallest |c| per slot
     auto side = [&](const VtxP& v, f32x2& ax, f32x2& ay, f32x2(&c)[RPL]) {
+#ifdef PC_AB_UNPACK   // developer A/B (tools/ab_run.sh build unpack "-DPC_AB_UNPACK -fno-slp-vectorize"): the same arithmetic as plain
+                      // v_sub / v_mul / v_fma_f32 per component instead of v_pk_* (same bits: every operation is the same IEEE operation)
+        ax.x = v.xr.x - pxr; ax.y = v.xr.y - pxr;
+        ay.x = v.yr.x - pyr; ay.y = v.yr.y - pyr;
+#else
         ax = v.xr - px2;
         ay = v.yr - py2;
+#endif
 #pragma unroll
         for (int s = 0; s < RPL; ++s) {
             const f32x2 dxs = {dx[s], dx[s]}, dys = {dy[s], dy[s]};
+#ifdef PC_AB_UNPACK
+            c[s].x = __builtin_fmaf(ay.x, dx[s], -(ax.x * dy[s]));
+            c[s].y = __builtin_fmaf(ay.y, dx[s], -(ax.y * dy[s]));
+#else
             c[s] = __builtin_elementwise_fma(ay, dxs, -(ax * dys));
+#endif
             if constexpr (!(PC_ABLATE & 32)) cm[s] = __builtin_fminf(__builtin_fminf(cm[s], __builtin_fabsf(c[s].x)), __builtin_fabsf(c[s].y));   // v_min3_f32 |.|
         }
     };
@@ -375,11 +386,23 @@ __device__ __forceinline__ void wall_sweep_loops(const VtxP* vp, const float pxr
     auto cand = [&](auto IC, const VtxP& v, const f32x2 axp, const f32x2 ayp, const f32x2(&cp)[RPL], const f32x2(&c)[RPL],
                     const f32x4(&rd)[RPL]) {
         constexpr int I = decltype(IC)::value;
+#ifdef PC_AB_UNPACK
+        f32x2 un;
+        un.x = __builtin_fmaf(v.eys.x, axp.x, -(v.exs.x * ayp.x));
+        un.y = __builtin_fmaf(v.eys.y, axp.y, -(v.exs.y * ayp.y));
+#else
         const f32x2 un = __builtin_elementwise_fma(v.eys, axp, -(v.exs * ayp));
+#endif
         um = __builtin_fminf(__builtin_fminf(um, __builtin_fabsf(un.x)), __builtin_fabsf(un.y));
 #pragma unroll
         for (int s = 0; s < RPL; ++s) {
+#ifdef PC_AB_UNPACK
+            f32x2 P;
+            asm("v_mul_f32 %0, %1, %2 clamp" : "=v"(P.x) : "v"(cp[s].x), "v"(c[s].x));
+            asm("v_mul_f32 %0, %1, %2 clamp" : "=v"(P.y) : "v"(cp[s].y), "v"(c[s].y));
+#else
             const f32x2 P = pk_mul_clamp(cp[s], c[s]);
+#endif
             f32x2 r;
             if constexpr (TAB) {
                 r = (I & 1) ? (f32x2){rd[s][2], rd[s][3]} : (f32x2){rd[s][0], rd[s][1]};
@@ -388,7 +411,13 @@ __device__ __forceinline__ void wall_sweep_loops(const VtxP* vp, const float pxr
                 const f32x2 den = __builtin_elementwise_fma(v.ey, dxs, -(v.ex * dys));   // = rden_build_kernel's
                 r = (f32x2){__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
             }
+#ifdef PC_AB_UNPACK
+            f32x2 u;
+            u.x = __builtin_fmaf(un.x, r.x, P.x);
+            u.y = __builtin_fmaf(un.y, r.y, P.y);
+#else
             const f32x2 u = __builtin_elementwise_fma(un, r, P);
+#endif
             bb[s] = min(min(bb[s], and_or_k<I>(__float_as_uint(u.x), keep)), and_or_k<L + I>(__float_as_uint(u.y), keep));   // v_min3_u32
         }
     };
@@ -624,15 +653,58 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
             }
         }
     } else {
+        // F64: Ray.get_distance (:186-213) over all walls, the reference's own arithmetic -- in two passes per block of 32 walls.
+        //   Pass 1 FILTERS: Ray.cast's numerators and denominator formed exactly as cast_ref forms them (the rounded differences
+        //   x3 - x4, y3 - y4 included, :166-176) and the hit test `0 < t < 1 and u > 0` (:178) decided on them WITHOUT a division --
+        //   with IEEE division 0 < fl(n / d) <=> n, d of equal sign, fl(n / d) < 1 <=> |n| < |d| (see cast_exact) -- in its
+        //   NON-strict form (signs by the sign bits, |tn| <= |den|): a superset of the hits, never a miss of one.  ~16 instructions
+        //   per ray and wall where the two float64 divisions and the square root of the literal form cost ~70.
+        //   Pass 2 runs the LITERAL cast_ref on the filtered (ray, wall) pairs only -- a ray crosses 1-3 of a track's walls -- and it
+        //   alone decides and measures: a pair that is no hit after all returns 1000.0 as it always did.  Same bits as the loop
+        //   over all pairs (min is order-independent), by construction.
         const Seg* walls = p.segs + h.wall_off;
-        Seg nxt = cload(walls);
-        for (int w = 0; w < h.S; ++w) {
-            const Seg sg = nxt;  // wave-uniform -> s_load_dwordx8
-            nxt = cload(walls + (w + 1 < h.S ? w + 1 : w));
+        double mx[RPL], my[RPL];
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const double x4 = npx + dx[s], y4 = npy + dy[s];     // :169
+            mx[s] = npx - x4;                                     // (x3 - x4)
+            my[s] = npy - y4;                                     // (y3 - y4)
+        }
+        for (int w0 = 0; w0 < h.S; w0 += 32) {
+            const int wn = h.S - w0 < 32 ? h.S - w0 : 32;
+            unsigned hm[RPL];
+#pragma unroll
+            for (int s = 0; s < RPL; ++s) hm[s] = 0u;
+            Seg nxt = cload(walls + w0);
+            for (int j = 0; j < wn; ++j) {
+                const Seg sg = nxt;  // wave-uniform -> s_load_dwordx8
+                nxt = cload(walls + w0 + (j + 1 < wn ? j + 1 : j));
+                const double ex = sg.x1 - sg.x2, ey = sg.y1 - sg.y2;      // (x1 - x2), (y1 - y2)
+                const double ax = sg.x1 - npx, ay = sg.y1 - npy;          // (x1 - x3), (y1 - y3)
+                const double unn = ex * ay - ey * ax;                     // u = -unn / den (:176)
+                const int un_hi = __double2hiint(unn);
+                const unsigned bit = 1u << j;
+#pragma unroll
+                for (int s = 0; s < RPL; ++s) {
+                    const double den = ex * my[s] - ey * mx[s];           // :171
+                    const double tn = ax * my[s] - ay * mx[s];            // :175 numerator
+                    const int den_hi = __double2hiint(den);
+                    // 0 <= t: equal sign bits; t <= 1: |tn| <= |den|; u >= 0: -unn and den of equal sign bits, i.e. unn and den of different ones
+                    const bool maybe = ((__double2hiint(tn) ^ den_hi) >= 0) & (__builtin_fabs(tn) <= __builtin_fabs(den)) & ((un_hi ^ den_hi) < 0);
+                    hm[s] |= maybe ? bit : 0u;
+                }
+            }
 #pragma unroll
             for (int s = 0; s < RPL; ++s) {
-                const double d = cast_ref(sg.x1, sg.y1, sg.x2, sg.y2, npx, npy, dx[s], dy[s]);
-                if (d < best[s]) best[s] = d;  // :203-207
+                while (__builtin_amdgcn_ballot_w64(hm[s] != 0u) != 0) {
+                    if (hm[s] != 0u) {
+                        const int j = __builtin_ctz(hm[s]);
+                        hm[s] &= hm[s] - 1u;
+                        const Seg sg = walls[w0 + j];       // (per-lane wall: a vector load of the 32-byte record)
+                        const double d = cast_ref(sg.x1, sg.y1, sg.x2, sg.y2, npx, npy, dx[s], dy[s]);
+                        if (d < best[s]) best[s] = d;  // :203-207
+                    }
+                }
             }
         }
     }

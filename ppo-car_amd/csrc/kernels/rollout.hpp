@@ -271,11 +271,14 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
 
     // ---- ray directions at the new heading: lattice entry 5 k + step_deg * ray (< 720: the table goes twice around), read as
     // (cos, sin, LDS address of the direction's 1/den row) through a byte address that costs one add per slot
-    float dx[RPL], dy[RPL];
-    int didx[RPL];    // TAB: the LDS byte address of the slot's 1/den row
+    // (more than 12 slots per lane -- 33 rays -- are swept in passes: each pass reads its own slots' entries, so that no more
+    // than one pass's directions are alive at a time)
+    constexpr bool DIR_PER_PASS = RPL > 12;
+    float dx[DIR_PER_PASS ? 1 : RPL], dy[DIR_PER_PASS ? 1 : RPL];
+    int didx[DIR_PER_PASS ? 1 : RPL];    // TAB: the LDS byte address of the slot's 1/den row
     const int k80n = 80 * k72n;                                         // 16 bytes x 5 entries per turn step
     const int m0 = k80n + fl.rs0, m_last = k80n + fl.rs_last;
-    {
+    if constexpr (!DIR_PER_PASS) {
         int m = m0;
 #pragma unroll
         for (int s = 0; s < RPL; ++s) {
@@ -304,7 +307,11 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     // the vertex chain, 9 + 8 slots: one pass would need ~40 more registers than the 256 a wave has at two waves per SIMD (it
     // spilled 67 of them to scratch); the second pass repeats only the per-vertex position arithmetic (4 of ~50 instructions per
     // vertex and pass).
-    constexpr int R1 = RPL > 12 ? (RPL + 1) / 2 : RPL, R2 = RPL - R1;
+    // (33 rays, 17 slots per lane: two passes, 9 + 8.  The chain-packed sweep at 33 rays -- three passes of 6 + 6 + 5 slots fit the
+    // registers but for 9 of them -- was built in round 5: 3-4 % faster per launch, and ONE observation entry in 3e8 differed from
+    // the per-step kernels in one run of two: not shipped, profiles/r5_ab_experiments.txt)
+    constexpr int NPASS = RPL > 12 ? 2 : 1;
+    constexpr int R1 = (RPL + NPASS - 1) / NPASS;
     unsigned bb[RPL + 2];
     const float tau = flag_threshold(h, npx, npy);
     const float pxr = (float)(npx - h.ax0), pyr = (float)(npy - h.ay0);   // the car relative to the track's anchor (see Vtx)
@@ -312,47 +319,51 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     if constexpr (PC_ABLATE & 64) {
 #pragma unroll
         for (int s = 0; s < RPL; ++s) bb[s] = 1u + (unsigned)s;
-    } else
-    {
-        const float(&dxa)[R1] = *reinterpret_cast<const float(*)[R1]>(&dx[0]);
-        const float(&dya)[R1] = *reinterpret_cast<const float(*)[R1]>(&dy[0]);
-        const int(&dia)[R1] = *reinterpret_cast<const int(*)[R1]>(&didx[0]);
-        unsigned ba[2 * ((R1 + 1) / 2)];
-        if (PARTS > 1)                  // small form: latency-oriented sweep over the LDS copy of the chain
-            wall_sweep_lds<R1, PARTS, TAB, true>(ft.vtx, h.nV, part, pxr, pyr, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
-        else if constexpr (SWP == 7)       // the host guarantees big_track's layout (two loops of 13 vertices, packed: TrackHdr::vtxp_off)
-            wall_sweep_loops<R1, TAB, 13, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);
-        else if constexpr (SWP == 5) {     // ... or two loops of 13 or of 9 vertices per track (track.json: 8 walls each): a mixed batch, workgroup-uniform
-            if (h.brk2 == 13) wall_sweep_loops<R1, TAB, 13, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);
-            else wall_sweep_loops<R1, TAB, 9, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);
-        }
-        else if (h.nV == 28)               // (wave-uniform) a chain of 28: the unrolled sweep
-            wall_sweep_unrolled<R1, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);   // chain length
-        else if constexpr (SWP == 0)       // and the generic loop is not even compiled in (1 % from the shorter kernel alone)
-            wall_sweep_f32<R1, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, pxr, pyr, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
+    } else {
+        // one pass over the chain for the slots [S0, S0 + RN)
+        auto sweep_pass = [&](auto S0C, auto RNC) {
+            constexpr int S0 = decltype(S0C)::value, RN = decltype(RNC)::value;
+            float dxp[RN], dyp[RN];
+            int dip[RN];
+            if constexpr (DIR_PER_PASS) {
 #pragma unroll
-        for (int s = 0; s < R1; ++s) bb[s] = ba[s];
-    }
-    if constexpr (R2 > 0) {
-        __builtin_amdgcn_sched_barrier(0);   // the passes one after the other
-        const float(&dxb)[R2] = *reinterpret_cast<const float(*)[R2]>(&dx[R1]);
-        const float(&dyb)[R2] = *reinterpret_cast<const float(*)[R2]>(&dy[R1]);
-        const int(&dib)[R2] = *reinterpret_cast<const int(*)[R2]>(&didx[R1]);
-        unsigned bc[2 * ((R2 + 1) / 2)];
-        if (PARTS > 1)
-            wall_sweep_lds<R2, PARTS, TAB, true>(ft.vtx, h.nV, part, pxr, pyr, dxb, dyb, dib, ft.rden, tau, h.idx_mask, bc);
-        else if constexpr (SWP == 7)
-            wall_sweep_loops<R2, TAB, 13, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxb, dyb, dib, ft.rden, tau, bc);
-        else if constexpr (SWP == 5) {
-            if (h.brk2 == 13) wall_sweep_loops<R2, TAB, 13, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxb, dyb, dib, ft.rden, tau, bc);
-            else wall_sweep_loops<R2, TAB, 9, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxb, dyb, dib, ft.rden, tau, bc);
-        }
-        else if (h.nV == 28)
-            wall_sweep_unrolled<R2, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, pxr, pyr, dxb, dyb, dib, ft.rden, tau, bc);
-        else if constexpr (SWP == 0)
-            wall_sweep_f32<R2, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, pxr, pyr, dxb, dyb, dib, ft.rden, tau, h.idx_mask, bc);
+                for (int s = 0; s < RN; ++s) {
+                    const int m = m0 + (S0 + s) * fl.rstep;
+                    const f32x4 cs = *(lds_f4c)(size_t)(unsigned)(S0 + s + 1 < RPL ? m : min(m, m_last));
+                    dxp[s] = cs.x;
+                    dyp[s] = cs.y;
+                    dip[s] = (int)__float_as_uint(cs.z);
+                }
+            }
+            const float(&dxa)[RN] = DIR_PER_PASS ? dxp : *reinterpret_cast<const float(*)[RN]>(&dx[DIR_PER_PASS ? 0 : S0]);
+            const float(&dya)[RN] = DIR_PER_PASS ? dyp : *reinterpret_cast<const float(*)[RN]>(&dy[DIR_PER_PASS ? 0 : S0]);
+            const int(&dia)[RN] = DIR_PER_PASS ? dip : *reinterpret_cast<const int(*)[RN]>(&didx[DIR_PER_PASS ? 0 : S0]);
+            unsigned ba[2 * ((RN + 1) / 2)];
+            if (PARTS > 1)                  // small form: latency-oriented sweep over the LDS copy of the chain
+                wall_sweep_lds<RN, PARTS, TAB, true>(ft.vtx, h.nV, part, pxr, pyr, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
+            else if constexpr (SWP == 7)       // the host guarantees big_track's layout (two loops of 13 vertices, packed: TrackHdr::vtxp_off)
+                wall_sweep_loops<RN, TAB, 13, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);
+            else if constexpr (SWP == 5) {     // ... or two loops of 13 or of 9 vertices per track (track.json: 8 walls each): a mixed batch, workgroup-uniform
+                if (h.brk2 == 13) wall_sweep_loops<RN, TAB, 13, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);
+                else wall_sweep_loops<RN, TAB, 9, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);
+            }
+            else if (h.nV == 28)               // (wave-uniform) a chain of 28: the unrolled sweep
+                wall_sweep_unrolled<RN, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);   // chain length
+            else if constexpr (SWP == 0)       // and the generic loop is not even compiled in (1 % from the shorter kernel alone)
+                wall_sweep_f32<RN, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, pxr, pyr, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
 #pragma unroll
-        for (int s = 0; s < R2; ++s) bb[R1 + s] = bc[s];
+            for (int s = 0; s < RN; ++s) bb[S0 + s] = ba[s];
+        };
+        sweep_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, R1>{});
+        if constexpr (NPASS >= 2) {
+            __builtin_amdgcn_sched_barrier(0);   // the passes one after the other
+            constexpr int RB = NPASS == 2 ? RPL - R1 : R1;
+            sweep_pass(std::integral_constant<int, R1>{}, std::integral_constant<int, RB>{});
+        }
+        if constexpr (NPASS >= 3) {
+            __builtin_amdgcn_sched_barrier(0);
+            sweep_pass(std::integral_constant<int, 2 * R1>{}, std::integral_constant<int, RPL - 2 * R1>{});
+        }
     }
     if constexpr (PARTS > 1) {   // the parts' selections meet in LDS (min is exact: the same bits as one wave sweeping everything)
         unsigned* ex = reinterpret_cast<unsigned*>(exch);

@@ -19,7 +19,7 @@ if [ "$1" = "build" ]; then
 fi
 N=${2:-65536}; T=${3:-1024}; R=${4:-16}
 for round in $(seq 1 ${AB_ROUNDS:-4}); do
-  for P in $ROOT/build/ab_*_pkg; do
+  for P in $ROOT/build/${AB_GLOB:-ab_*_pkg}; do
     python3 - $P $N $T $R <<'PY'
 import sys, os
 pkg, N, T, R = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
