@@ -189,7 +189,7 @@ int pc_policy_act(const pc_policy* p, const float* obs, int64_t N, const float* 
  *   (action, logprob, value) = Agent.get_action_and_value(obs_t)      [pc_policy_act's arithmetic and RNG, offset + t]
  *   obs_{t+1}, reward, terminated, truncated = envs.step(action)      [pc_env_step's arithmetic]
  *   Buffer.store(...)                                                 [rows written in place]
- * Inputs: the env handle (F32; single track, or mixed tracks with every aligned block of 32 envs on one track -- when the
+ * Inputs: the env handle (single track, or mixed tracks with every aligned block of 32 envs on one track -- when the
  * blocks are as large as the launch's workgroups, 128 / 256 envs in the large form and 16 / 32 in the small one, each
  * workgroup stages its track's tables in LDS as for a single track, else every wave reads them from global memory), the
  * policy handle and the weight image it packed, and next_obs / next_term / next_trunc [N] = observation and flags the rollout
@@ -202,7 +202,10 @@ int pc_policy_act(const pc_policy* p, const float* obs, int64_t N, const float* 
  *                pass inside the launch (the fused policy step's arithmetic, i.e. what val_buf's rows hold for the other steps);
  *   reward_sum : the sum over the T steps of the env's (scaled) rewards, accumulated in float32 in step order -- the numerator
  *                of train.py:272's average reward without re-reading rew_buf.
- * PC_ERR_UNSUPPORTED for F64 handles, mixed-track handles whose track ids change inside an aligned block of 32 envs, ray
+ * F64 handles (PC_DTYPE_F64) take the same call: the launch then steps the env in the reference's own float64 (the per-step
+ * kernel's env_step arithmetic, bit for bit: observations, rewards, events and the float64 state equal the reference's) -- Discrete(9),
+ * the split-operand policy forms, 12 or 16 nominal rays; other shapes are PC_ERR_UNSUPPORTED (the caller's per-step kernels run them).
+ * PC_ERR_UNSUPPORTED for mixed-track handles whose track ids change inside an aligned block of 32 envs, ray
  * counts whose slots per lane are not on the kernel menu (12 / 16 / 32 run the table-driven fast mode; 17 and 18 share the
  * slots of 16 and run the generic mode), shapes whose LDS footprint exceeds 160 KB (33 rays with the fp32 or bf16x3 weight
  * image in the large form), and 33 rays in the GENERIC mode with split operands (a mixed-track batch whose workgroups

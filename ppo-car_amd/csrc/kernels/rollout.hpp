@@ -1051,6 +1051,149 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     }
 }
 
+// K9d: the persistent rollout of the BIT-EXACT dtype (PC_DTYPE_F64: float64 throughout in the reference's operation order, glibc's
+// cos / sin by lookup -- env_step_core<double>, the very function env_step_kernel<double> runs).  K9's generic decomposition: a
+// workgroup = 8 independent waves of 32 envs, 2 lanes per env, the policy pass in the split-operand arithmetic PREC on the matrix
+// cores, the pair draw, then CarEnv.step for the wave's own envs with the observation row written straight into the rollout buffer and
+// into the wave's LDS rows (the next policy pass reads it there); no barrier after staging.  Nothing of the track is staged: the
+// float64 wall records come through scalar loads, the direction hash table through the vector cache (both L2-resident).
+// Bit-identical to T x (policy_kernel<KS, false, PREC>; env_step_kernel<double>): same arithmetic, same Philox counters.
+// (train.py:173-195 with the env of car_env.py:693-760 in its own float64)
+template <int KS, int RPL, int PREC>
+__global__ __launch_bounds__(512) void rollout_f64_kernel(const EnvParams<double> p, const float* __restrict__ image, const int A,
+                                                          const int T, const double reward_scale, const uint64_t seed,
+                                                          const uint64_t offset, const uint64_t* __restrict__ offset_dev,
+                                                          float* __restrict__ obs_buf, float* __restrict__ act_buf,
+                                                          float* __restrict__ rew_buf, float* __restrict__ val_buf,
+                                                          float* __restrict__ term_buf, float* __restrict__ trunc_buf,
+                                                          float* __restrict__ logprob_buf, float* __restrict__ next_obs,
+                                                          float* __restrict__ next_term, float* __restrict__ next_trunc,
+                                                          const int epw, float* __restrict__ last_val, float* __restrict__ rew_sum) {
+    static_assert(PREC != 0, "split-operand policy forms");
+    constexpr int HID = 256, NT = 2 * HID / 16, ET = 2, LDO = 20;
+    constexpr int NG = pol_ng(KS), KB = pol_kb(KS);
+    constexpr int IMG = polx_image_dwords(PREC, NG);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sB1 = lds + polx_w1_dwords(PREC, NG) + polx_w2_dwords(PREC);
+    float* sB2 = sB1 + 512;
+    const unsigned* sW1p = reinterpret_cast<const unsigned*>(lds);
+    const unsigned* sW2p = sW1p + polx_w1_dwords(PREC, NG);
+    const float* sW2c = sB2 + 16;
+    const int64_t N = p.N;
+    const int D = p.D;
+    constexpr int LDX = 4 * KS + 1;                 // observation of the step in flight, [256 envs][LDX]
+    float* sObs = lds + IMG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, lk = lane >> 4;
+    policy_stage_image<IMG>(image, lds, tid);
+    const int pbase = wave * 32;
+    const int el = pbase + (lane >> 1), g = lane & 1;
+    const int64_t e_wave = (int64_t)blockIdx.x * epw + pbase;
+    const int64_t e_env = e_wave + (lane >> 1);
+    const bool e_valid = e_env < N;
+    EnvRegs st = {};
+    if (e_valid) st = env_load<double>(p, e_env);
+    const int trk = p.track_id ? (int)p.track_id[e_valid ? e_env : N - 1] : 0;     // (every aligned block of 32 envs shares a track: host check)
+    for (int f = g; f < 4 * KS; f += 2) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
+    static_assert(4 * KS + 1 >= 20, "the output tile must fit the wave's observation rows");
+    float* myOut = sObs + wave * 32 * LDX;          // the wave's output tile lives in its own observation rows (see rollout_kernel)
+    const uint64_t off0 = offset + (offset_dev ? *offset_dev : 0);
+    PhiloxBlock rnd = {};
+    __syncthreads();  // the weight image is in place; from here on the waves never synchronise again
+    if (pbase >= epw) return;
+    asm volatile("" : "+v"(st.px), "+v"(st.py), "+v"(st.vx), "+v"(st.vy), "+v"(st.rot), "+v"(st.time), "+v"(st.next), "+v"(st.passed));
+    const int TT = last_val ? T + 1 : T;   // tail iteration t == T: the final observation's value only (see rollout_kernel)
+    float rsum = 0.0f;
+    int act_reg = 8;
+#pragma unroll 1
+    for (int t = 0; t < TT; ++t) {
+        const bool tail = t == T;      // (uniform)
+        {
+            // ---------------- P(t): Agent.get_action_and_value (model.py:34-41)
+            f32x4 out[ET];
+#pragma unroll
+            for (int et = 0; et < ET; ++et) out[et] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            Pieces<PREC> x[ET][KB];
+#pragma unroll
+            for (int et = 0; et < ET; ++et) {
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int f = 8 * (4 * kb + lk) + j;
+                        const float raw = sObs[(pbase + 16 * et + lc) * LDX + (f < LDX ? f : 0)];
+                        v[j] = f < D ? raw : 0.0f;
+                        if constexpr (PREC == 2) v[j] = clamp_h(v[j] * PolScale<PREC>::sx);
+                    }
+                    x[et][kb] = split8<PREC>(v);
+                }
+            }
+            float val[ET] = {0.0f, 0.0f};
+            policy_pass16<PREC, KB>(sW1p, sW2p, sB1, sW2c, 0, NT / 2, x, out, val, lc, lk);
+#pragma unroll
+            for (int et = 0; et < ET; ++et) {
+                float tv = val[et];
+                tv += __shfl_xor(tv, 16, 64);
+                tv += __shfl_xor(tv, 32, 64);
+                if (A >> 2 == lk) out[et][A & 3] += tv;
+            }
+#pragma unroll
+            for (int et = 0; et < ET; ++et) *reinterpret_cast<f32x4*>(myOut + (16 * et + lc) * LDO + 4 * lk) = out[et];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint64_t o = off0 + (uint64_t)t;
+            if (e_valid) {      // Discrete(9): the env's two lanes draw together (policy_tail_pair, as policy_kernel does for A == 9)
+                float w[5];
+                pair_outputs<LDO>(myOut, lane >> 1, g, PolScale<PREC>::so_inv, sB2, w);
+                float lp, vv;
+                if (t == 0 || (o & 3) == 0) {
+                    uint64_t ctr = (uint64_t)e_env;
+                    asm volatile("" : "+v"(ctr));
+                    rnd = philox_block(seed, o >> 2, ctr);
+                }
+                policy_tail_pair(w, g, philox_word_uniform(rnd, (unsigned)(o & 3)), act_reg, lp, vv);
+                if (g == 0) {
+                    if (tail) {
+                        last_val[e_env] = vv;
+                    } else {
+                        const int64_t row = (int64_t)t * N + e_env;
+                        act_buf[row] = (float)act_reg;     // stored as float32 like the reference (buffer.py:13)
+                        logprob_buf[row] = lp;
+                        val_buf[row] = vv;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (tail) break;
+        const bool last = t + 1 == T;
+        if (e_valid) {
+            // ---------------- E(t): envs.step (train.py:185) in the reference's float64
+            float* orow = last ? next_obs + e_env * D : obs_buf + ((int64_t)(t + 1) * N + e_env) * D;
+            float rw;
+            bool term, trunc;
+            int passed;
+            env_step_core<double, RPL>(p, trk, g, 1, st, (int64_t)act_reg, reward_scale, orow, nullptr, sObs + el * LDX, rw, term, trunc, passed);
+            rsum += rw;
+            if (g == 0) {
+                rew_buf[(int64_t)t * N + e_env] = rw;
+                float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;    // flags that precede obs t+1 (train.py:176-177,195)
+                float* tc = last ? next_trunc : trunc_buf + (int64_t)(t + 1) * N;
+                tr[e_env] = term ? 1.0f : 0.0f;
+                tc[e_env] = trunc ? 1.0f : 0.0f;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // obs rows in LDS are this wave's own
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (e_valid && g == 0) {
+        env_store<double>(p, e_env, st);
+        if (rew_sum) rew_sum[e_env] = rsum;
+    }
+}
+
 // K9s: the same persistent rollout for SMALL batches (n_envs < ~32 k): a workgroup owns only 32 envs, so that
 // n_envs / 32 workgroups fill the chip.  Per step: the 8 waves split the policy's hidden tiles exactly as
 // policy_kernel<SPLIT> does (partial output tiles summed through LDS, same order: bit-identical), wave 0 draws the

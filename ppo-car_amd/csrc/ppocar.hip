@@ -1120,6 +1120,46 @@ int pc_clip_adam_advanced(int device, float* param, const float* grad, float* ex
     return PC_OK;
 }
 
+// pc_rollout for PC_DTYPE_F64 handles: K9d, rollout_f64_kernel (the bit-exact env inside the persistent launch).  Discrete(9), the
+// split-operand policy forms, 12 or 16 nominal rays (6 / 9 ray slots per lane); anything else is
+// PC_ERR_UNSUPPORTED and runs through the per-step kernels, which fill the same buffers bit for bit.
+static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
+                            const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
+                            float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, float* last_value,
+                            float* reward_sum, void* stream) {
+    if ((e->track_id && !e->track_blocks32) || A != 9) return PC_ERR_UNSUPPORTED;
+    const int KS = policy_ks(e->D);
+    const int prec = policy_prec(prec_request, e->D, A);
+    if (prec == 0) return PC_ERR_UNSUPPORTED;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    const int rpl = (e->R + 1) / 2;
+    const int epw = e->opt.epw_override >= 128 ? e->opt.epw_override : (e->N <= g_rollout_epw128_max ? 128 : 256);
+    const int blocks = (int)((e->N + epw - 1) / epw);
+    const size_t lds = (size_t)(polx_image_dwords(prec, pol_ng(KS)) + 256 * (4 * KS + 1)) * sizeof(float);
+    if (lds > 160 * 1024) return PC_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const EnvParams<double> prm = [&] { EnvParams<double> q = e->params<double>(); q.lg = 1; return q; }();
+#define PC_ROLLD(KSV, RPLV, PRC)                                                                                         \
+    do {                                                                                                                 \
+        static bool attr_set[64] = {false};                                                                              \
+        if (e->device >= 64 || !attr_set[e->device]) {                                                                    \
+            HIPCHK(hipFuncSetAttribute((const void*)rollout_f64_kernel<KSV, RPLV, PRC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            if (e->device < 64) attr_set[e->device] = true;                                                                \
+        }                                                                                                                \
+        hipLaunchKernelGGL((rollout_f64_kernel<KSV, RPLV, PRC>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, seed, \
+                           offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs,  \
+                           next_term, next_trunc, epw, last_value, reward_sum);                                          \
+    } while (0)
+    if (KS == 5 && rpl == 6) { PC_FULL(if (prec == 2) PC_ROLLD(5, 6, 2); else PC_ROLLD(5, 6, 1)); }              // 12 rays, D = 18
+    else if (KS == 6 && rpl == 9) { if (prec == 2) PC_DEV(3, PC_ROLLD(6, 9, 2)); else PC_FULL(PC_ROLLD(6, 9, 1)); }   // 16 -> 17 rays, D = 23
+    else return PC_ERR_UNSUPPORTED;     // (32 -> 33 rays: 17 float64 ray slots per lane beside the policy state spill 96 registers -- not built;
+                                        //  the per-step kernels run that shape)
+#undef PC_ROLLD
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
+
 static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, int64_t T, double reward_scale, uint64_t seed, uint64_t offset,
                         const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
                         float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, float* last_value,
@@ -1128,6 +1168,9 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
         !next_term || !next_trunc || T < 1 || T > (1 << 24))
         return PC_ERR_INVALID_ARG;
     // mixed tracks: a wave (big form) / a workgroup (small form) steps 32 consecutive envs, which must share one track
+    if (e->dtype == PC_DTYPE_F64)
+        return rollout_f64_impl(e, prec_request, image, A, T, reward_scale, seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf,
+                                trunc_buf, logprob_buf, next_obs, next_term, next_trunc, last_value, reward_sum, stream);
     if (e->dtype != PC_DTYPE_F32 || (e->track_id && !e->track_blocks32) || A < 1 || A > 15) return PC_ERR_UNSUPPORTED;
     const int KS = policy_ks(e->D);
     DeviceGuard guard(e->device);

@@ -1,0 +1,119 @@
+"""K9d: pc_rollout on PC_DTYPE_F64 handles -- the whole rollout (train.py:173-195) as one persistent launch with the env in the
+reference's own float64 (car_env.py:693-760 literally: env_step_core<double>).  Two bars:
+  (i)  every buffer and the final env state equal the per-step kernels' (policy_kernel; env_step_kernel<double>) bit for bit;
+  (ii) the stored actions replayed through the CPU oracle reproduce EVERY observation, reward and flag of EVERY env bit for bit
+       (this dtype has no tolerance: it is the configuration whose index / event exactness holds by construction)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from ppo_car_amd.ppo import PPOConfig, Trainer
+from conftest import TRACKS
+
+pytestmark = pytest.mark.gpu
+
+
+def _snap(tr):
+    b = tr.buffer
+    return [t.clone() for t in (b.obs_buf, b.act_buf, b.rew_buf, b.val_buf, b.logprob_buf, b.term_buf, b.trunc_buf,
+                                tr.next_obs, tr.next_term, tr.next_trunc, tr._boot_val if tr._boot_val is not None else tr.next_term)]
+
+
+def _oracle_exact(cfg, snap, first, track, sel):
+    """all T steps of the envs `sel` through the oracle, teacher-forced by the stored actions: bit equality, no exceptions"""
+    obs, act, rew, _, _, term, trunc, nobs, nterm, ntrunc = [t.cpu().numpy() for t in snap[:10]]
+    T = cfg.n_steps
+    ora = oracle.OracleVecEnv(oracle.Track(track), len(sel), num_rays=cfg.num_rays, reward_scaling=cfg.reward_scaling, threads=4)
+    o = ora.reset()
+    assert np.array_equal(first.cpu().numpy()[sel], o) and np.array_equal(obs[0][:, :][sel], o)
+    done = 0
+    for t in range(T):
+        o, r, te, trn = ora.step(act[t][sel].astype(np.int64))
+        nxt_o = obs[t + 1][sel] if t + 1 < T else nobs[sel]
+        nxt_te = term[t + 1][sel] if t + 1 < T else nterm[sel]
+        nxt_tr = trunc[t + 1][sel] if t + 1 < T else ntrunc[sel]
+        assert np.array_equal(nxt_o, o), t
+        assert np.array_equal(rew[t][sel], r.astype(np.float32)), t
+        assert np.array_equal(nxt_te != 0, te) and np.array_equal(nxt_tr != 0, trn), t
+        done += int((te | trn).sum())
+    return done
+
+
+@pytest.mark.parametrize("precision", [2, 1])
+@pytest.mark.parametrize("num_rays,n_envs,n_steps", [(16, 1000, 80), (12, 512, 80), (16, 20000, 200), (12, 40000, 64)])
+def test_f64_persistent_rollout_is_bitwise_the_per_step_kernels_and_the_oracle(num_rays, n_envs, n_steps, precision):
+    res, first = {}, None
+    for mode in ("mega", "steps"):
+        cfg = PPOConfig(n_envs=n_envs, n_steps=n_steps, num_rays=num_rays, track=TRACKS["big_track"], rollout_kernel=mode, env_dtype="f64",
+                        use_graphs=False, seed=21, policy_precision=precision, policy_split=0)
+        tr = Trainer(cfg, device="cuda")
+        if first is None:
+            first = tr.next_obs.clone()
+        for ep in range(2):                      # two rollouts: the second starts from mid-episode states and fresh Philox counters
+            tr.rollout()
+            torch.cuda.synchronize()
+            assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager"), tr.rollout_mode
+            res[(mode, ep)] = _snap(tr)
+            tr.buffer.ptr = 0
+        res[mode + "_state"] = tr.envs.get_state()
+        tr.close()
+    for ep in range(2):
+        for i, (a, b) in enumerate(zip(res[("mega", ep)][:10], res[("steps", ep)][:10])):
+            assert torch.equal(a, b), f"rollout {ep}: buffer {i} differs between the persistent float64 launch and the per-step kernels"
+    for k in res["mega_state"]:
+        assert np.array_equal(res["mega_state"][k], res["steps_state"][k]), k       # the float64 state itself, heading included
+    sel = np.arange(0, n_envs, max(1, n_envs // 256))[:256]
+    done = _oracle_exact(cfg, res[("mega", 0)], first, TRACKS["big_track"], sel)
+    assert done > 0      # episodes ended inside the replay: auto-reset rows were compared too
+
+
+def test_f64_persistent_rollout_at_the_target_shape_against_the_oracle():
+    """65536 envs x 17 rays (the size BASELINE's target is quoted on), 96 steps, default dispatch: one env of every 32-env wave --
+    2048 envs -- replayed through the oracle, everything bit-equal.  (bench.py reports this configuration as exact_f64_value.)"""
+    cfg = PPOConfig(n_envs=65536, n_steps=96, num_rays=16, track=TRACKS["big_track"], env_dtype="f64", use_graphs=False, seed=4)
+    tr = Trainer(cfg, device="cuda")
+    first = tr.next_obs.clone()
+    tr.rollout()
+    torch.cuda.synchronize()
+    assert tr.rollout_mode == "mega"
+    snap = _snap(tr)
+    tr.close()
+    sel = np.arange(0, 65536, 32) + (np.arange(2048) % 32)
+    assert _oracle_exact(cfg, snap, first, TRACKS["big_track"], sel) > 0
+
+
+def test_f64_persistent_rollout_mixed_tracks_and_whole_epochs():
+    """track.json + big_track.json in blocks (BASELINE configs[4]'s layout) through K9d: bitwise the per-step kernels; then whole
+    epochs (rollout + GAE + update, bootstrap value from the launch's own critic pass) run and stay finite."""
+    tracks = [TRACKS["track"], TRACKS["big_track"]]
+    res = {}
+    for mode in ("mega", "steps"):
+        tr = Trainer(PPOConfig(n_envs=2048, n_steps=64, num_rays=16, track=tracks, rollout_kernel=mode, env_dtype="f64", use_graphs=False, seed=9,
+                               policy_split=0), device="cuda")
+        tr.rollout()
+        torch.cuda.synchronize()
+        assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
+        res[mode] = _snap(tr)
+        tr.close()
+    for i, (a, b) in enumerate(zip(res["mega"][:10], res["steps"][:10])):
+        assert torch.equal(a, b), i
+    tr = Trainer(PPOConfig(n_envs=1024, n_steps=64, batch_size=64, train_iters=2, num_rays=16, track=TRACKS["big_track"], env_dtype="f64"), device="cuda")
+    for _ in range(3):
+        s = tr.run_epoch()
+        assert tr.rollout_mode == "mega" and np.isfinite(s["losses/total_loss"])
+    tr.close()
+
+
+def test_f64_shapes_outside_the_persistent_menu_fall_back_to_the_per_step_kernels():
+    """33 rays in float64 (17 ray slots per lane beside the policy state: not built) -> pc_rollout answers PC_ERR_UNSUPPORTED and the
+    trainer runs the per-step kernels: the rollout still happens, bit-exact against the oracle."""
+    cfg = PPOConfig(n_envs=512, n_steps=48, num_rays=32, track=TRACKS["big_track"], env_dtype="f64", use_graphs=False, seed=2)
+    tr = Trainer(cfg, device="cuda")
+    first = tr.next_obs.clone()
+    tr.rollout()
+    torch.cuda.synchronize()
+    assert tr.rollout_mode == "steps-eager"
+    snap = _snap(tr)
+    tr.close()
+    _oracle_exact(cfg, snap, first, TRACKS["big_track"], np.arange(0, 512, 4))

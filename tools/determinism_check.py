@@ -2,7 +2,7 @@
 """Developer probe: is pc_rollout deterministic launch to launch?  For each shape the same rollout (same env state, same Philox
 counters, same weights) is launched REPS times; every launch's buffers must be bit-identical to the first's.  A run-to-run
 difference is a race or a hazard in the kernel (round 5: a 33-ray chain-packed variant differed in ONE of 3e8 observation entries in
-one run of two and was not shipped).   usage: python tools/determinism_check.py [reps] [shape ...]   shapes: target cfg1 cfg2 cfg4"""
+one run of two and was not shipped).   usage: python tools/determinism_check.py [reps] [shape ...]   shapes: target cfg1 cfg2 cfg4 f64"""
 import json
 import os
 import sys
@@ -14,7 +14,8 @@ sys.path.insert(0, ROOT)
 from ppo_car_amd.ppo import PPOConfig, Trainer  # noqa: E402
 
 SHAPES = {"target": dict(n_envs=65536, n_steps=1024, num_rays=16), "cfg1": dict(n_envs=4096, n_steps=1024, num_rays=16),
-          "cfg2": dict(n_envs=65536, n_steps=128, num_rays=32), "cfg4": dict(n_envs=32768, n_steps=1024, num_rays=16, mixed=True)}
+          "cfg2": dict(n_envs=65536, n_steps=128, num_rays=32), "cfg4": dict(n_envs=32768, n_steps=1024, num_rays=16, mixed=True),
+          "f64": dict(n_envs=65536, n_steps=128, num_rays=16, env_dtype="f64")}
 
 
 def main():
