@@ -221,3 +221,20 @@ def test_shape_menus_are_reported_without_a_gpu():
     assert n_param == 14858 and n == 64 * n_pad + 64 * 4 + (n_param + 255) // 256
     assert lib.pc_ppo_workspace_floats(2048, 23, 256, 9) == _capi.PC_ERR_UNSUPPORTED    # batch above 1024
     assert lib.pc_ppo_workspace_floats(512, 23, 64, 9) == _capi.PC_ERR_UNSUPPORTED
+
+
+def test_bench_algorithmic_counts_are_surveys_figures_for_every_ray_count_and_track():
+    """bench.py prices a launch with SURVEY 8(d)'s expressions evaluated for the ACTUAL ray count and each track's wall count: they
+    reproduce the survey's table (156 / 176 / 240 B; 8.2 / 11.6 / 22.4 kflop on big_track's 24 walls; 5.6 / 7.8 / 15.0 kflop on
+    track.json's 16) and never fall back to zero flops for another ray count; a mixed batch is the mean over its tracks."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert [b.step_bytes(R) for R in (12, 17, 33)] == [156, 176, 240]
+    for R, S, kflop in ((12, 24, 8.2), (17, 24, 11.6), (33, 24, 22.4), (12, 16, 5.6), (17, 16, 7.8), (33, 16, 15.0)):
+        assert abs(b.step_flops(R, [S]) / 1e3 - kflop) < 0.06, (R, S)
+    assert b.step_flops(19, [24]) > b.step_flops(17, [24]) > 0                      # (18 -> 19 rays: priced, not zero)
+    assert b.step_flops(17, [16, 24]) == (b.step_flops(17, [16]) + b.step_flops(17, [24])) / 2
+    host, usable, quota = b.usable_cpus()
+    assert 1 <= usable <= host and (quota is None or quota > 0)

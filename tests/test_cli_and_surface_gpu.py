@@ -295,3 +295,37 @@ def test_bench_self_spawned_two_ranks_on_one_device(exchange, capture):
     assert ("captured" in c["update_path"]) == capture and "multi-rank" in c["update_path"]
     assert c["replicas_bit_identical"] is True
     assert out["value"] > 0 and c["rollout"] == "mega"
+
+
+def test_bench_default_line_carries_every_baseline_config_and_the_exact_dtype():
+    """`python bench.py` as the driver runs it (shortened: 2 timed epochs): ONE JSON line whose headline is the target workload and
+    which also holds the bit-exact dtype's value on the same workload, every other single-GPU BASELINE config with its own
+    ms_per_step / launch duration / roofline fraction, the all-usable-cores CPU baseline with its core counts, and the live
+    parity check -- measured, finite, from the kernels the headline claims (persistent launches, K9d for f64)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "2"], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("env steps/sec") and d["n_gpus"] == 1 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["config"]["rollout"] == "mega" and d["value"] > 1e9
+    rf = d["roofline"]
+    assert rf["bound"] == "valu" and 0.1 < rf["frac"] < 1.0 and rf["launch_us"] > 0 and rf["traffic"] is not None
+    assert d["parity_check"]["ok"] is True
+    e = d["exact_f64_value"]
+    assert e["dtype"] == "f64" and e["rollout"] == "mega" and e["value"] > 3e8 and 0 < e["roofline"]["frac"] < rf["frac"]
+    ow = d["other_workloads"]
+    assert set(ow) == {"cfg1", "cfg2", "cfg4"}
+    for k, v in ow.items():
+        assert "error" not in v, (k, v)
+        assert v["rollout"] == "mega" and v["value"] > 1e8 and v["ms_per_step"] > 0 and 0 < v["roofline"]["frac"] < 1 and v["roofline"]["flops_per_env_step"] > 0
+    assert "33 actual" in ow["cfg2"]["workload"] and "track.json + big_track.json" in ow["cfg4"]["workload"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["threads"] == c["cores"] == c["usable_cores"] <= c["host_cores"]
+    assert c["env_only_value"] > c["env_only_one_thread_value"] > 0 and c["value"] > 0
+    assert d["strict_fp32_value"]["value"] > 0 and d["fp32_grade_bf16x3_value"]["value"] > 0
