@@ -663,57 +663,63 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
         //   alone decides and measures: a pair that is no hit after all returns 1000.0 as it always did.  Same bits as the loop
         //   over all pairs (min is order-independent), by construction.
         const Seg* walls = p.segs + h.wall_off;
-        double mx[RPL], my[RPL];
+        // (the ray slots in groups of at most five: a group's rounded differences and hit masks are alive together, not all RPL of
+        // them -- 9 or 17 float64 slots per lane beside a persistent kernel's other state do not fit the register file)
+        constexpr int SG = RPL <= 6 ? RPL : (RPL <= 10 ? (RPL + 1) / 2 : 5);
 #pragma unroll
-        for (int s = 0; s < RPL; ++s) {
-            const double x4 = npx + dx[s], y4 = npy + dy[s];     // :169
-            mx[s] = npx - x4;                                     // (x3 - x4)
-            my[s] = npy - y4;                                     // (y3 - y4)
-        }
-        for (int w0 = 0; w0 < h.S; w0 += 32) {
-            const int wn = h.S - w0 < 32 ? h.S - w0 : 32;
-            unsigned hm[RPL];
+        for (int g0 = 0; g0 < RPL; g0 += SG) {
+            constexpr int SGN = SG;
+            double mx[SGN], my[SGN];
 #pragma unroll
-            for (int s = 0; s < RPL; ++s) hm[s] = 0u;
-            Seg nxt = cload(walls + w0);
-            for (int j = 0; j < wn; ++j) {
-                const Seg sg = nxt;  // wave-uniform -> s_load_dwordx8
-                nxt = cload(walls + w0 + (j + 1 < wn ? j + 1 : j));
-                const double ex = sg.x1 - sg.x2, ey = sg.y1 - sg.y2;      // (x1 - x2), (y1 - y2)
-                const double ax = sg.x1 - npx, ay = sg.y1 - npy;          // (x1 - x3), (y1 - y3)
-                const double unn = ex * ay - ey * ax;                     // u = -unn / den (:176)
-                const int un_hi = __double2hiint(unn);
-                const unsigned bit = 1u << j;
-#pragma unroll
-                for (int s = 0; s < RPL; ++s) {
-                    const double den = ex * my[s] - ey * mx[s];           // :171
-                    const double tn = ax * my[s] - ay * mx[s];            // :175 numerator
-                    const int den_hi = __double2hiint(den);
-                    // 0 <= t: equal sign bits; t <= 1: |tn| <= |den|; u >= 0: -unn and den of equal sign bits, i.e. unn and den of different ones
-                    const bool maybe = ((__double2hiint(tn) ^ den_hi) >= 0) & (__builtin_fabs(tn) <= __builtin_fabs(den)) & ((un_hi ^ den_hi) < 0);
-                    hm[s] |= maybe ? bit : 0u;
-                }
+            for (int q = 0; q < SGN; ++q) {
+                const int s = g0 + q < RPL ? g0 + q : RPL - 1;
+                const double x4 = npx + dx[s], y4 = npy + dy[s];     // :169
+                mx[q] = npx - x4;                                     // (x3 - x4)
+                my[q] = npy - y4;                                     // (y3 - y4)
             }
-            // (slot by slot; the NEXT filtered pair's wall record -- a per-lane vector load of 32 bytes -- is requested before the
-            // current pair is measured, so that the memory round trip runs under cast_ref's ~70 instructions.  Rounds of three slots
-            // with their loads in flight together were built and measured SLOWER, 69 against 58 ms per 65536 x 1024 rollout: every
-            // round then measures three pairs whether or not a lane has them)
+            for (int w0 = 0; w0 < h.S; w0 += 32) {
+                const int wn = h.S - w0 < 32 ? h.S - w0 : 32;
+                unsigned hm[SGN];
 #pragma unroll
-            for (int s = 0; s < RPL; ++s) {
-                unsigned m = hm[s];
-                Seg nx = walls[w0 + (m != 0u ? __builtin_ctz(m) : 0)];
-                while (__builtin_amdgcn_ballot_w64(m != 0u) != 0) {
-                    const Seg sg = nx;
-                    const bool has = m != 0u;
-                    m &= m - 1u;
-#ifndef PC_AB_F64_NOPREFETCH     // (developer A/B: the same loop without the prefetch)
-                    nx = walls[w0 + (m != 0u ? __builtin_ctz(m) : 0)];
-#endif
-                    const double d = cast_ref(sg.x1, sg.y1, sg.x2, sg.y2, npx, npy, dx[s], dy[s]);
-#ifdef PC_AB_F64_NOPREFETCH
-                    nx = walls[w0 + (m != 0u ? __builtin_ctz(m) : 0)];
-#endif
-                    if (has && d < best[s]) best[s] = d;  // :203-207
+                for (int q = 0; q < SGN; ++q) hm[q] = 0u;
+                Seg nxt = cload(walls + w0);
+                for (int j = 0; j < wn; ++j) {
+                    const Seg sg = nxt;  // wave-uniform -> s_load_dwordx8
+                    nxt = cload(walls + w0 + (j + 1 < wn ? j + 1 : j));
+                    const double ex = sg.x1 - sg.x2, ey = sg.y1 - sg.y2;      // (x1 - x2), (y1 - y2)
+                    const double ax = sg.x1 - npx, ay = sg.y1 - npy;          // (x1 - x3), (y1 - y3)
+                    const double unn = ex * ay - ey * ax;                     // u = -unn / den (:176)
+                    const int un_hi = __double2hiint(unn);
+                    const unsigned bit = 1u << j;
+#pragma unroll
+                    for (int q = 0; q < SGN; ++q) {
+                        const double den = ex * my[q] - ey * mx[q];           // :171
+                        const double tn = ax * my[q] - ay * mx[q];            // :175 numerator
+                        const int den_hi = __double2hiint(den);
+                        // 0 <= t: equal sign bits; t <= 1: |tn| <= |den|; u >= 0: -unn and den of equal sign bits, i.e. unn and den of different ones
+                        const bool maybe = ((__double2hiint(tn) ^ den_hi) >= 0) & (__builtin_fabs(tn) <= __builtin_fabs(den)) & ((un_hi ^ den_hi) < 0);
+                        hm[q] |= maybe ? bit : 0u;
+                    }
+                }
+                // (slot by slot; the NEXT filtered pair's wall record -- a per-lane vector load of 32 bytes -- is requested before the
+                // current pair is measured, so that the memory round trip runs under cast_ref's ~70 instructions.  Rounds of three slots
+                // with their loads in flight together were built and measured SLOWER, 69 against 58 ms per 65536 x 1024 rollout: every
+                // round then measures three pairs whether or not a lane has them)
+#pragma unroll
+                for (int q = 0; q < SGN; ++q) {
+                    if (g0 + q < RPL) {
+                        const int s = g0 + q;
+                        unsigned m = hm[q];
+                        Seg nx = walls[w0 + (m != 0u ? __builtin_ctz(m) : 0)];
+                        while (__builtin_amdgcn_ballot_w64(m != 0u) != 0) {
+                            const Seg sg = nx;
+                            const bool has = m != 0u;
+                            m &= m - 1u;
+                            nx = walls[w0 + (m != 0u ? __builtin_ctz(m) : 0)];
+                            const double d = cast_ref(sg.x1, sg.y1, sg.x2, sg.y2, npx, npy, dx[s], dy[s]);
+                            if (has && d < best[s]) best[s] = d;  // :203-207
+                        }
+                    }
                 }
             }
         }

@@ -870,6 +870,24 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 __builtin_amdgcn_s_setprio(0);
                 if (!(dbg & 1)) policy_pass<KS>(sW1, sB1, sW2, 0, NT, x, out, lc, lk, lane);  // dbg: timing ablations only
                 __builtin_amdgcn_s_setprio(3);
+            } else if constexpr (pol_wide(PREC)) {
+                // fp16 x 2: the wave's 32 envs as ONE column tile of v_mfma_f32_32x32x16_f16 (policy_pass32).  Observation loads are
+                // unconditional (K padding reads a few floats into the next row / the tables behind: inside the workgroup's LDS)
+                constexpr int KSTEPS = pol_ksteps(KB);
+                const float* xrow = sObs + (pbase + (lane & 31)) * LDX;
+                Pieces<2> xs[KSTEPS];
+#pragma unroll
+                for (int st = 0; st < KSTEPS; ++st) xs[st] = obs_pieces32([&](const int f) { return xrow[f]; }, st, lane >> 5, D);
+                f32x16 o32;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o32[i] = 0.0f;
+                float v32 = 0.0f;
+                __builtin_amdgcn_s_setprio(0);
+                PC_STAMP(1)
+                if (!(dbg & 1)) policy_pass32<KSTEPS, NG>(sW1p, sW2p, sB1, sW2c, xs, o32, v32, lane);
+                PC_STAMP(2)
+                __builtin_amdgcn_s_setprio(3);
+                store_out32<LDO>(myOut, o32, v32, A, lane);
             } else {
                 Pieces<PREC> x[ET][KB];
 #pragma unroll
@@ -905,8 +923,10 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                     if (A >> 2 == lk) out[et][A & 3] += tv;
                 }
             }
+            if constexpr (!(PREC != 0 && pol_wide(PREC))) {
 #pragma unroll
-            for (int et = 0; et < ET; ++et) *reinterpret_cast<f32x4*>(myOut + (16 * et + lc) * LDO + 4 * lk) = out[et];
+                for (int et = 0; et < ET; ++et) *reinterpret_cast<f32x4*>(myOut + (16 * et + lc) * LDO + 4 * lk) = out[et];
+            }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the tile is written and read by this wave only
             __builtin_amdgcn_wave_barrier();
             const uint64_t o = off0 + (uint64_t)t;
@@ -1110,36 +1130,50 @@ __global__ __launch_bounds__(512) void rollout_f64_kernel(const EnvParams<double
         const bool tail = t == T;      // (uniform)
         {
             // ---------------- P(t): Agent.get_action_and_value (model.py:34-41)
-            f32x4 out[ET];
+            if constexpr (pol_wide(PREC)) {      // fp16 x 2: one 32-env column tile of the 32x32x16 instruction, as policy_kernel does
+                constexpr int KSTEPS = pol_ksteps(KB);
+                const float* xrow = sObs + (pbase + (lane & 31)) * LDX;
+                Pieces<2> xs[KSTEPS];
 #pragma unroll
-            for (int et = 0; et < ET; ++et) out[et] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            Pieces<PREC> x[ET][KB];
+                for (int st = 0; st < KSTEPS; ++st) xs[st] = obs_pieces32([&](const int f) { return xrow[f < LDX ? f : 0]; }, st, lane >> 5, D);
+                f32x16 o32;
 #pragma unroll
-            for (int et = 0; et < ET; ++et) {
+                for (int i = 0; i < 16; ++i) o32[i] = 0.0f;
+                float v32 = 0.0f;
+                policy_pass32<KSTEPS, NG>(sW1p, sW2p, sB1, sW2c, xs, o32, v32, lane);
+                store_out32<LDO>(myOut, o32, v32, A, lane);
+            } else {
+                f32x4 out[ET];
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) {
-                    float v[8];
+                for (int et = 0; et < ET; ++et) out[et] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                Pieces<PREC> x[ET][KB];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int f = 8 * (4 * kb + lk) + j;
-                        const float raw = sObs[(pbase + 16 * et + lc) * LDX + (f < LDX ? f : 0)];
-                        v[j] = f < D ? raw : 0.0f;
-                        if constexpr (PREC == 2) v[j] = clamp_h(v[j] * PolScale<PREC>::sx);
+                for (int et = 0; et < ET; ++et) {
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) {
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int f = 8 * (4 * kb + lk) + j;
+                            const float raw = sObs[(pbase + 16 * et + lc) * LDX + (f < LDX ? f : 0)];
+                            v[j] = f < D ? raw : 0.0f;
+                            if constexpr (PREC == 2) v[j] = clamp_h(v[j] * PolScale<PREC>::sx);
+                        }
+                        x[et][kb] = split8<PREC>(v);
                     }
-                    x[et][kb] = split8<PREC>(v);
                 }
-            }
-            float val[ET] = {0.0f, 0.0f};
-            policy_pass16<PREC, KB>(sW1p, sW2p, sB1, sW2c, 0, NT / 2, x, out, val, lc, lk);
+                float val[ET] = {0.0f, 0.0f};
+                policy_pass16<PREC, KB>(sW1p, sW2p, sB1, sW2c, 0, NT / 2, x, out, val, lc, lk);
 #pragma unroll
-            for (int et = 0; et < ET; ++et) {
-                float tv = val[et];
-                tv += __shfl_xor(tv, 16, 64);
-                tv += __shfl_xor(tv, 32, 64);
-                if (A >> 2 == lk) out[et][A & 3] += tv;
-            }
+                for (int et = 0; et < ET; ++et) {
+                    float tv = val[et];
+                    tv += __shfl_xor(tv, 16, 64);
+                    tv += __shfl_xor(tv, 32, 64);
+                    if (A >> 2 == lk) out[et][A & 3] += tv;
+                }
 #pragma unroll
-            for (int et = 0; et < ET; ++et) *reinterpret_cast<f32x4*>(myOut + (16 * et + lc) * LDO + 4 * lk) = out[et];
+                for (int et = 0; et < ET; ++et) *reinterpret_cast<f32x4*>(myOut + (16 * et + lc) * LDO + 4 * lk) = out[et];
+            }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const uint64_t o = off0 + (uint64_t)t;

@@ -23,6 +23,66 @@ template <int KIND> __device__ __forceinline__ void filler(float& a, float& b, f
     if constexpr (KIND == 5) asm volatile("v_rcp_f32 %0, %1" : "=v"(a) : "v"(b));
 }
 
+// Round 5, second question: the same matrix work as ONE v_mfma_f32_32x32x16_f16 instead of TWO v_mfma_f32_16x16x32_f16 (16 Kflop
+// either way): cycles per unit with K fillers per unit.  If an MFMA holds the issue port for ~8 cycles whatever its shape, the wide
+// form leaves more of the port to the fillers.
+typedef float f16v __attribute__((ext_vector_type(16)));
+template <int WIDE, int K> __global__ void kern_shape(unsigned long long* out, float* sink, const float* src) {
+    const int wave = threadIdx.x >> 6;
+    float a[4], b = src[threadIdx.x] + 1.0f;
+    for (int i = 0; i < 4; ++i) a[i] = src[threadIdx.x] + i;
+    f4 c[4];
+    f16v cw[2];
+    for (int i = 0; i < 4; ++i) c[i] = (f4){0, 0, 0, 0};
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 16; ++j) cw[i][j] = 0.0f;
+    h8 ha, hb;
+    for (int i = 0; i < 8; ++i) { ha[i] = (_Float16)(0.001f * b); hb[i] = (_Float16)(0.002f * b); }
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int r = 0; r < REP; ++r) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {     // two units per iteration
+            if constexpr (WIDE) {
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(cw[m]) : "v"(ha), "v"(hb));
+            } else {
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c[2 * m]) : "v"(ha), "v"(hb));
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c[2 * m + 1]) : "v"(ha), "v"(hb));
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) asm volatile("v_fma_f32 %0, %1, %1, %0" : "+v"(a[j & 3]) : "v"(b));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 8 + wave] = t1 - t0;
+    float s = 0;
+    for (int i = 0; i < 4; ++i) s += a[i] + c[i][0];
+    s += cw[0][0] + cw[1][3];
+    if (s == 12345.678f) sink[threadIdx.x] = s;
+}
+template <int WIDE, int K> double run_shape(int threads, unsigned long long* d_out, float* d_sink, float* d_src) {
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((kern_shape<WIDE, K>), dim3(256), dim3(threads), 0, 0, d_out, d_sink, d_src);
+    hipDeviceSynchronize();
+    const int nw = threads / 64;
+    std::vector<unsigned long long> h(256 * 8);
+    hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<unsigned long long> v;
+    for (int bk = 0; bk < 256; ++bk) for (int w = 0; w < nw; ++w) v.push_back(h[bk * 8 + w]);
+    std::sort(v.begin(), v.end());
+    return (double)v[v.size() / 2] / (REP * 2.0);
+}
+template <int WIDE> void sweep_shape(const char* name, unsigned long long* d_out, float* d_sink, float* d_src) {
+    for (int threads : {256, 512}) {
+        double r[7];
+        r[0] = run_shape<WIDE, 0>(threads, d_out, d_sink, d_src); r[1] = run_shape<WIDE, 2>(threads, d_out, d_sink, d_src);
+        r[2] = run_shape<WIDE, 4>(threads, d_out, d_sink, d_src); r[3] = run_shape<WIDE, 6>(threads, d_out, d_sink, d_src);
+        r[4] = run_shape<WIDE, 8>(threads, d_out, d_sink, d_src); r[5] = run_shape<WIDE, 12>(threads, d_out, d_sink, d_src);
+        r[6] = run_shape<WIDE, 16>(threads, d_out, d_sink, d_src);
+        printf("{\"shape\": \"%s\", \"waves_per_simd\": %d, \"cycles_per_16Kflop_unit_with_K_v_fma_f32\": {\"0\": %.1f, \"2\": %.1f, \"4\": %.1f, \"6\": %.1f, \"8\": %.1f, \"12\": %.1f, \"16\": %.1f}}\n",
+               name, threads / 256, r[0], r[1], r[2], r[3], r[4], r[5], r[6]);
+    }
+}
+
 // K fillers after each MFMA; the fillers rotate over 4 independent destination registers so that they do not wait for each other
 template <int KIND, int K> __global__ void kern(unsigned long long* out, float* sink, const float* src) {
     const int wave = threadIdx.x >> 6;
@@ -86,6 +146,8 @@ int main() {
     hipMalloc(&d_out, 1 << 20); hipMalloc(&d_sink, 1 << 16); hipMalloc(&d_src, 1 << 16);
     std::vector<float> src(4096); for (int i = 0; i < 4096; ++i) src[i] = 0.5f + 0.001f * i;
     hipMemcpy(d_src, src.data(), 4096 * 4, hipMemcpyHostToDevice);
+    sweep_shape<0>("2 x v_mfma_f32_16x16x32_f16", d_out, d_sink, d_src);
+    sweep_shape<1>("1 x v_mfma_f32_32x32x16_f16", d_out, d_sink, d_src);
     sweep<0>("v_fma_f32", d_out, d_sink, d_src);
     sweep<1>("v_pk_fma_f32", d_out, d_sink, d_src);
     sweep<2>("v_fma_f64", d_out, d_sink, d_src);
