@@ -1,4 +1,5 @@
-"""Run only the persistent rollout kernel (for rocprofv3): N envs, 16 rays, T steps, a few launches."""
+"""Run only the persistent rollout kernel (for rocprofv3): N envs, 16 rays, T steps, a few launches.
+   python tools/mega_only.py [N] [T] [mega|steps] [f32|f64]"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -6,7 +7,8 @@ from ppo_car_amd.ppo import PPOConfig, Trainer
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 mode = sys.argv[3] if len(sys.argv) > 3 else "mega"
-cfg = PPOConfig(n_envs=N, n_steps=T, num_rays=16, track=f"{ROOT}/tracks/big_track.json", rollout_kernel=mode, use_graphs=False)
+dtype = sys.argv[4] if len(sys.argv) > 4 else "f32"      # "f64": the bit-exact dtype's persistent kernel (K9d)
+cfg = PPOConfig(n_envs=N, n_steps=T, num_rays=16, track=f"{ROOT}/tracks/big_track.json", rollout_kernel=mode, use_graphs=False, env_dtype=dtype)
 tr = Trainer(cfg, device="cuda")
 for _ in range(3):
     tr.rollout(); tr.buffer.ptr = 0
