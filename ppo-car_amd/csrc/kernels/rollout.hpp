@@ -410,6 +410,43 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     // Slots in batches: every LDS read of a batch -- the selected segments' records, the slots' float64 directions -- is issued
     // before the first float64 instruction, so that the wave pays the LDS round trip once per batch, not once per slot.
     constexpr int NB = RPL <= 5 ? RPL : (RPL <= 9 ? (RPL + 1) / 2 : (RPL + 3) / 4);   // (14 registers per slot in flight: all nine of the 17-ray kernel at once spill)
+    if constexpr ((PC_ABLATE & 512) != 0 && PARTS == 1) {
+        // DEVELOPER COST MODEL of an "f32n" tier (never in the product): the observation from the selector's own
+        // float32 distance, the float64 refinement only for the ill-conditioned slots -- modelled as a pseudo-random 1/16 of the
+        // slots (bits of the candidate) plus the flagged ones -- through a per-slot fallback loop.  Results are NOT the product's.
+        unsigned ill_mask = 0;
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const unsigned b = bb[s];
+            const bool ill = (((b >> 5) & 15u) == 0u) | ((b & h.idx_mask) == 0u);
+            const float uf = __uint_as_float((b & ~h.idx_mask) | 16u) * 0x1p40f;
+            const float o = __builtin_fminf(uf, 1000.0f) * 0.001f;
+            uint64_t col_lanes = 0;
+#pragma unroll
+            for (int gg = 0; gg < G; ++gg) col_lanes |= ((colm_g[gg] >> s) & 1) ? LANES_G0 << gg : 0ull;
+            hit_mask |= __builtin_amdgcn_ballot_w64(!ill & (uf < 10.0f)) & col_lanes;
+            if (s + 1 < RPL) fl.lray[G * s] = o;
+            else fl.llast[0] = o;
+            ill_mask |= ill ? 1u << s : 0u;
+        }
+        while (__builtin_amdgcn_ballot_w64(ill_mask != 0) != 0) {
+            const int s1 = ill_mask ? __builtin_ctz(ill_mask) : -1;
+            unsigned sel = 0;
+#pragma unroll
+            for (int s = 0; s < RPL; ++s) sel = s == s1 ? bb[s] : sel;
+            if (s1 >= 0) {
+                const int ms = m0 + s1 * fl.rstep;
+                const f64x2 d64 = dir64_at(s1 + 1 < RPL ? ms : min(ms, m_last));
+                bool ok;
+                const double d = refine_fast(segs((int)(sel & h.idx_mask)), npx, npy, d64.x, d64.y, ok);
+                todo |= ok ? 0u : 1u << s1;
+                wall_hit |= (bool)((fl.colmask >> s1) & 1) & ok & (d < 10.0);
+                const lds_fp dst = s1 + 1 < RPL ? fl.lray + G * s1 : fl.llast;
+                dst[0] = obs_dist(d);
+                ill_mask &= ill_mask - 1;
+            }
+        }
+    } else
 #pragma unroll
     for (int s0 = 0; s0 < RPL; s0 += NB) {
         SegD sg[NB];
@@ -444,7 +481,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
             }
         }
     }
-    wall_hit = __builtin_amdgcn_inverse_ballot_w64(hit_mask);
+    wall_hit |= __builtin_amdgcn_inverse_ballot_w64(hit_mask);
     PC_STAMP_E(8)
     // the rare rest, one slot of one lane at a time through ONE copy of the careful code (a select chain picks the slot's selection)
     while (__builtin_expect(__builtin_amdgcn_ballot_w64(todo != 0) != 0, 0)) {
@@ -676,7 +713,8 @@ __device__ __forceinline__ bool env_step_wave(const EnvParams<float>& p, const T
 
 // Developer-only timing ablation of the persistent rollout kernels: a SEPARATE build (make ABLATE=n -> libppocar_ablate.so,
 // never loaded by the product or the tests) compiled with -DPC_ABLATE=n skips the policy MFMAs (1), the env step (2), the draw
-// (4), the gate casts (8), the float64 refinement (16), the sweep's flag minima (32), the whole sweep (64) or the copy-out (256).
+// (4), the gate casts (8), the float64 refinement (16), the sweep's flag minima (32), the whole sweep (64) or the copy-out (256); 512 = the
+// cost model of a float32-observation tier (refinement only for a pseudo-random 1/16 of the slots and the flagged ones).
 // The shipped library is built with PC_ABLATE = 0 (env_math.hpp): there is no run-time switch that makes a kernel do less.
 // K9: the whole rollout (train.py:173-195) as ONE persistent launch.
 // A workgroup (8 waves) owns 256 envs for all T steps: the policy weights stay in LDS, the env state in
