@@ -680,8 +680,17 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
             for (int w0 = 0; w0 < h.S; w0 += 32) {
                 const int wn = h.S - w0 < 32 ? h.S - w0 : 32;
                 unsigned hm[SGN];
+                // Beside the filter: a float32 ESTIMATE of every filtered pair's distance, u = |unn| / |den| (the reference's own
+                // quotient, car_env.py:176, good to ~3e-7 here), wall index in the five low mantissa bits, and per slot the smallest
+                // and the second smallest of them (unsigned order = value order for non-negative floats).  Pass 2 then measures the
+                // estimated-nearest pair with the literal cast_ref -- ONE pair per slot instead of every filtered one, of which a
+                // wave's 64 lanes held up to seven -- and falls back to all of the slot's pairs only where the runner-up's estimate is
+                // not clearly (1e-4 relative: 300 x the estimate's error, 1e11 x the literal arithmetic's) beyond the measured
+                // distance: two walls hit at the same place, i.e. a corner.  The minimum of the literal distances is unchanged.
+                unsigned e1[SGN], e2[SGN];
+                constexpr unsigned EST_NONE = 0x7f800000u;      // +inf: no filtered pair
 #pragma unroll
-                for (int q = 0; q < SGN; ++q) hm[q] = 0u;
+                for (int q = 0; q < SGN; ++q) { hm[q] = 0u; e1[q] = EST_NONE; e2[q] = EST_NONE; }
                 Seg nxt = cload(walls + w0);
                 for (int j = 0; j < wn; ++j) {
                     const Seg sg = nxt;  // wave-uniform -> s_load_dwordx8
@@ -690,7 +699,10 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
                     const double ax = sg.x1 - npx, ay = sg.y1 - npy;          // (x1 - x3), (y1 - y3)
                     const double unn = ex * ay - ey * ax;                     // u = -unn / den (:176)
                     const int un_hi = __double2hiint(unn);
+                    const float unf = __builtin_fabsf((float)unn);
                     const unsigned bit = 1u << j;
+                    unsigned jv;
+                    asm("v_mov_b32 %0, %1" : "=v"(jv) : "s"(j));
 #pragma unroll
                     for (int q = 0; q < SGN; ++q) {
                         const double den = ex * my[q] - ey * mx[q];           // :171
@@ -699,25 +711,36 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
                         // 0 <= t: equal sign bits; t <= 1: |tn| <= |den|; u >= 0: -unn and den of equal sign bits, i.e. unn and den of different ones
                         const bool maybe = ((__double2hiint(tn) ^ den_hi) >= 0) & (__builtin_fabs(tn) <= __builtin_fabs(den)) & ((un_hi ^ den_hi) < 0);
                         hm[q] |= maybe ? bit : 0u;
+                        // (an estimate that overflowed or is not a number -- a denominator below float32's range -- becomes 3e38: beyond every
+                        // distance that matters, Ray.get_distance caps at 1000 px, car_env.py:198)
+                        const float est = __builtin_fminf(unf * __builtin_amdgcn_rcpf(__builtin_fabsf((float)den)), 3.0e38f);
+                        const unsigned cand = maybe ? ((__float_as_uint(est) & ~31u) | jv) : EST_NONE;
+                        e2[q] = min(e2[q], max(e1[q], cand));
+                        e1[q] = min(e1[q], cand);
                     }
                 }
-                // (slot by slot; the NEXT filtered pair's wall record -- a per-lane vector load of 32 bytes -- is requested before the
-                // current pair is measured, so that the memory round trip runs under cast_ref's ~70 instructions.  Rounds of three slots
-                // with their loads in flight together were built and measured SLOWER, 69 against 58 ms per 65536 x 1024 rollout: every
-                // round then measures three pairs whether or not a lane has them)
 #pragma unroll
                 for (int q = 0; q < SGN; ++q) {
                     if (g0 + q < RPL) {
                         const int s = g0 + q;
-                        unsigned m = hm[q];
-                        Seg nx = walls[w0 + (m != 0u ? __builtin_ctz(m) : 0)];
-                        while (__builtin_amdgcn_ballot_w64(m != 0u) != 0) {
-                            const Seg sg = nx;
-                            const bool has = m != 0u;
-                            m &= m - 1u;
-                            nx = walls[w0 + (m != 0u ? __builtin_ctz(m) : 0)];
+                        // the estimated-nearest pair, unless even it lies clearly beyond what an earlier block of walls gave
+                        const bool need1 = e1[q] < EST_NONE && __uint_as_float(e1[q] & ~31u) <= (float)best[s] * 1.0001f;
+                        if (__builtin_amdgcn_ballot_w64(need1) != 0) {
+                            const Seg sg = walls[w0 + (int)(e1[q] & 31u)];       // (per-lane wall: a vector load of the 32-byte record)
                             const double d = cast_ref(sg.x1, sg.y1, sg.x2, sg.y2, npx, npy, dx[s], dy[s]);
-                            if (has && d < best[s]) best[s] = d;  // :203-207
+                            if (need1 && d < best[s]) best[s] = d;  // :203-207
+                        }
+                        // the runner-up within 1e-4 of the measured minimum (or an estimate that is not a number): every filtered pair of the slot
+                        const bool need_all = e2[q] != EST_NONE && !(__uint_as_float(e2[q] & ~31u) > (float)best[s] * 1.0001f);
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(need_all) != 0, 0)) {
+                            unsigned m = need_all ? hm[q] : 0u;
+                            while (__builtin_amdgcn_ballot_w64(m != 0u) != 0) {
+                                const bool has = m != 0u;
+                                const Seg sg = walls[w0 + (has ? __builtin_ctz(m) : 0)];
+                                m &= m - 1u;
+                                const double d = cast_ref(sg.x1, sg.y1, sg.x2, sg.y2, npx, npy, dx[s], dy[s]);
+                                if (has && d < best[s]) best[s] = d;
+                            }
                         }
                     }
                 }
