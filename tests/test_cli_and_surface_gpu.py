@@ -327,5 +327,5 @@ def test_bench_default_line_carries_every_baseline_config_and_the_exact_dtype():
     assert "33 actual" in ow["cfg2"]["workload"] and "track.json + big_track.json" in ow["cfg4"]["workload"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["threads"] == c["cores"] == c["usable_cores"] <= c["host_cores"]
-    assert c["env_only_value"] > c["env_only_one_thread_value"] > 0 and c["value"] > 0
+    assert c["env_only_value"] > 0 and c["env_only_one_thread_value"] > 0 and c["value"] > 0      # (how they compare is the host's business)
     assert d["strict_fp32_value"]["value"] > 0 and d["fp32_grade_bf16x3_value"]["value"] > 0
