@@ -29,6 +29,7 @@ struct TrackHdr {        // one per track, read with scalar loads
     int brk2;                   // F32: index of the chain's SECOND chain-start vertex when the walls are exactly two chains (-1 otherwise)
     int vtxp_off;               // F32: those two chains have the same length (n_chain = 2 brk2): their vertices again, packed by
                                 //      position in the chain, vtxp[vtxp_off .. vtxp_off + brk2) (-1 otherwise)
+    int rot_off, n_rot;         // F64: the track's ROTATION TABLE in dirtab64 (Math<double>): n_rot rows of R + 1 entries; -1 = none
 };
 
 // One wall / gate segment as the reference holds it (Boundary.get_points, car_env.py:74): 32 bytes.
@@ -270,16 +271,44 @@ template <> struct Math<double> {
         s = es;
         return true;
     }
+    // Round 5: the ROTATION TABLE.  An env's heading is start_rot after a sequence of +-5.0 (car_env.py:440-442), one of the n_rot
+    // float64 values the host enumerated (breadth first, rotation 0 = start_rot: what reset gives).  The env state carries that
+    // rotation's INDEX k beside the value (iv.x; -1 = a rotation set_state gave that no episode reaches): row k of the table holds
+    // the R rays' (cos, sin) -- glibc's, of the very angles rot + ray * step -- and, as entry R, the indices of rot - 5.0 and rot +
+    // 5.0 ((double) left, (double) right; -1 beyond the 1000 turns an episode can make).  One 16-byte load per direction where the
+    // hash lookup below takes eight probes and the entry; the hash stays for k = -1.  Same values either way.
+    static __device__ __forceinline__ bool indexed(const TrackHdr& h, const int k) { return (k >= 0) & (h.rot_off >= 0); }
+    static __device__ __forceinline__ double2 rot_entry(const EnvParams<double>& p, const TrackHdr& h, const int k, const int col) {
+        return p.dirtab64[h.rot_off + k * (p.R + 1) + col];
+    }
+    // the index of rot -+ 5.0 (left: -5.0, car_env.py:440; right: +5.0, :442)
+    static __device__ __forceinline__ int turn(const EnvParams<double>& p, const TrackHdr& h, const int k, const bool left) {
+        if (!indexed(h, k)) return -1;
+        const double2 t = rot_entry(p, h, k, p.R);
+        return (int)(left ? t.x : t.y);
+    }
     // heading (cos, sin) of the float64 heading, as the reference forms it (:426-427, :584)
-    static __device__ __forceinline__ void heading(const EnvParams<double>& p, const TrackHdr& h, int, double rot, double& c,
+    static __device__ __forceinline__ void heading(const EnvParams<double>& p, const TrackHdr& h, int k, double rot, double& c,
                                                    double& s) {
+        if (indexed(h, k)) {
+            const double2 e = rot_entry(p, h, k, 0);      // (rot + 0 * step is rot itself)
+            c = e.x;
+            s = e.y;
+            return;
+        }
         if (lookup(p, h, rot, c, s)) return;
         const double a = d_radians(rot);
         c = cos(a);
         s = sin(a);
     }
-    static __device__ __forceinline__ void ray_dir(const EnvParams<double>& p, const TrackHdr& h, int ray, int, double rot,
+    static __device__ __forceinline__ void ray_dir(const EnvParams<double>& p, const TrackHdr& h, int ray, int k, double rot,
                                                    double& dx, double& dy) {
+        if (indexed(h, k)) {
+            const double2 e = rot_entry(p, h, k, ray);
+            dx = e.x;
+            dy = e.y;
+            return;
+        }
         const double deg = rot + (double)(ray * p.step_deg);   // Ray.update(x, y, rot + a) :463-466, :153
         if (lookup(p, h, deg, dx, dy)) return;
         const double a = d_radians(deg);

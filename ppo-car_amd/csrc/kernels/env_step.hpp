@@ -493,6 +493,10 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
         k_new += 1;
     }
     const bool turned = left | right;
+    if constexpr (sizeof(T) == 8) {      // F64: k indexes the track's rotation table (Math<double>): follow its transition entry
+        k_new = st.k;
+        if (turned) k_new = Math<double>::turn(p, h, st.k, left);
+    }
     double ch1 = ch0, sh1 = sh0;  // heading after the turn
     if (turned) Math<T>::heading(p, h, k_new, rot_new, ch1, sh1);
 

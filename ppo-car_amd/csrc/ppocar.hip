@@ -55,6 +55,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <unordered_set>
 #include <utility>
 #include <vector>
@@ -159,6 +160,7 @@ struct pc_env {
     double2* dirtab64 = nullptr;
     SegD* seg64 = nullptr;
     F64Dir* dirhash = nullptr;
+    std::vector<std::unordered_map<uint64_t, int>> rot_ids;   // F64, host only: per track, rotation bits -> row of the rotation table (pc_env_set_state)
     float* reset_obs = nullptr;
 
     template <typename T> EnvParams<T> params() const {
@@ -350,12 +352,15 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
     std::vector<double2> vpos;      // host only: the chain vertices' exact positions (indexed like vtx)
     size_t rden_floats = 0;
     e->hdr_host.resize(e->n_tracks);
+    e->rot_ids.assign(e->n_tracks, {});
     for (int k = 0; k < e->n_tracks; ++k) {
         const pc_track* t = tracks[k];
         TrackHdr& h = e->hdr_host[k];
         h.S = t->n_walls();
         h.G = t->n_gates();
         h.n_scan = 0;
+        h.rot_off = -1;     // (F64 handles: set below)
+        h.n_rot = 0;
         h.wall_off = (int)segs.size();
         for (size_t i = 0; i < t->walls.size(); i += 4) segs.push_back(Seg{t->walls[i], t->walls[i + 1], t->walls[i + 2], t->walls[i + 3]});
         h.gate_off = (int)segs.size();
@@ -515,18 +520,42 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
             // F64 mode: every angle an episode can reach (see Math<double>), glibc's cos / sin of it, hashed by the angle's bits
             h.dir_off = -1;
             h.head_off = 0;
+            h.rot_off = -1;
+            h.n_rot = 0;
             if (e->n_tracks <= 16) {
                 std::unordered_set<uint64_t> rots, frontier, keys;
                 const auto bits = [](double v) { uint64_t b; std::memcpy(&b, &v, 8); return b; };
                 const auto val = [](uint64_t b) { double v; std::memcpy(&v, &b, 8); return v; };
-                rots.insert(bits(t->start_rot));
+                std::vector<uint64_t> rot_list;                       // index -> rotation (breadth first; index 0 = start_rot: what reset gives)
+                std::unordered_map<uint64_t, int>& rid = e->rot_ids[k];
+                rid.clear();
+                const auto add_rot = [&](uint64_t b) {
+                    if (!rots.insert(b).second) return false;
+                    rid[b] = (int)rot_list.size();
+                    rot_list.push_back(b);
+                    return true;
+                };
+                add_rot(bits(t->start_rot));
                 frontier = rots;
                 for (int turn = 0; turn < 1000 && !frontier.empty(); ++turn) {      // CarEnv truncates at 1000 steps (car_env.py:749)
                     std::unordered_set<uint64_t> next;
                     for (const uint64_t b : frontier)
                         for (const double w : {val(b) + 5.0, val(b) - 5.0})            // :440-442
-                            if (rots.insert(bits(w)).second) next.insert(bits(w));
+                            if (add_rot(bits(w))) next.insert(bits(w));
                     frontier.swap(next);
+                }
+                {   // the rotation table (Math<double>): row i = the R rays' (cos, sin) at rotation i, then (index of rot - 5.0, index of rot + 5.0)
+                    const int step_deg_ = 360 / e->n_nominal;
+                    h.rot_off = (int)dirtab64.size();
+                    h.n_rot = (int)rot_list.size();
+                    for (const uint64_t b : rot_list) {
+                        for (int ray = 0; ray < e->R; ++ray) {
+                            const double a = (val(b) + (double)(ray * step_deg_)) * (PC_PI / 180.0);   // np.radians(rot + a), :269, :465
+                            dirtab64.push_back(make_double2(libm_cos(a), libm_sin(a)));
+                        }
+                        const auto lk = rid.find(bits(val(b) - 5.0)), rk = rid.find(bits(val(b) + 5.0));
+                        dirtab64.push_back(make_double2(lk == rid.end() ? -1.0 : (double)lk->second, rk == rid.end() ? -1.0 : (double)rk->second));
+                    }
                 }
                 const int step_deg = 360 / e->n_nominal;
                 for (const uint64_t b : rots)
@@ -842,6 +871,13 @@ int pc_env_set_state(pc_env* e, const double* px, const double* py, const double
         if (vx) pv[4 * i + 2] = vx[i];
         if (vy) pv[4 * i + 3] = vy[i];
         if (rot && !f64) iv[i].x = (int)std::llround((rot[i] - e->hdr_host[tid[i]].start_rot) / 5.0);
+        if (rot && f64) {      // the rotation's row of the track's rotation table, or -1: a value no episode reaches (the kernels then hash / evaluate it)
+            uint64_t b;
+            std::memcpy(&b, &rot[i], 8);
+            const auto& ids = e->rot_ids[tid[i]];
+            const auto it = ids.find(b);
+            iv[i].x = it == ids.end() ? -1 : it->second;
+        }
         if (time_step) iv[i].y = (int)time_step[i];
         if (next_gate) {
             if (next_gate[i] < 0 || next_gate[i] >= e->hdr_host[tid[i]].G) return PC_ERR_INVALID_ARG;
@@ -1152,7 +1188,7 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
                            next_term, next_trunc, epw, last_value, reward_sum);                                          \
     } while (0)
     if (KS == 5 && rpl == 6) { PC_FULL(if (prec == 2) PC_ROLLD(5, 6, 2); else PC_ROLLD(5, 6, 1)); }              // 12 rays, D = 18
-    else if (KS == 6 && rpl == 9) { if (prec == 2) PC_DEV(3, PC_ROLLD(6, 9, 2)); else PC_FULL(PC_ROLLD(6, 9, 1)); }   // 16 -> 17 rays, D = 23
+    else if (KS == 6 && rpl == 9) { if (prec == 2) PC_DEV(3, PC_ROLLD(6, 9, 2)); else return PC_ERR_UNSUPPORTED; }   // 16 -> 17 rays, D = 23 (bf16 x 3 there spills 3 registers: not built)
     else return PC_ERR_UNSUPPORTED;     // (32 -> 33 rays: 17 float64 ray slots per lane beside the policy state spill 96 registers -- not built;
                                         //  the per-step kernels run that shape)
 #undef PC_ROLLD

@@ -43,6 +43,8 @@ def _oracle_exact(cfg, snap, first, track, sel):
 @pytest.mark.parametrize("precision", [2, 1])
 @pytest.mark.parametrize("num_rays,n_envs,n_steps", [(16, 1000, 80), (12, 512, 80), (16, 20000, 200), (12, 40000, 64)])
 def test_f64_persistent_rollout_is_bitwise_the_per_step_kernels_and_the_oracle(num_rays, n_envs, n_steps, precision):
+    if precision == 1 and num_rays != 12:
+        pytest.skip("bf16x3 beside nine float64 ray slots per lane is not on the persistent float64 kernel's menu (the per-step kernels run it)")
     res, first = {}, None
     for mode in ("mega", "steps"):
         cfg = PPOConfig(n_envs=n_envs, n_steps=n_steps, num_rays=num_rays, track=TRACKS["big_track"], rollout_kernel=mode, env_dtype="f64",
