@@ -30,6 +30,8 @@ struct TrackHdr {        // one per track, read with scalar loads
     int vtxp_off;               // F32: those two chains have the same length (n_chain = 2 brk2): their vertices again, packed by
                                 //      position in the chain, vtxp[vtxp_off .. vtxp_off + brk2) (-1 otherwise)
     int rot_off, n_rot;         // F64: the track's ROTATION TABLE in dirtab64 (Math<double>): n_rot rows of R + 1 entries; -1 = none
+    int lat_off;                // the track's float32 direction lattice [361] in dirtab (F32: = dir_off; F64: the selector's directions, -1 = none)
+    int sel_ok;                 // F64: the float32 selector may run on this track (chain tables built, <= 8192 vertices, fits 2000 px)
 };
 
 // One wall / gate segment as the reference holds it (Boundary.get_points, car_env.py:74): 32 bytes.
@@ -116,6 +118,26 @@ __device__ __forceinline__ double cast_ref(double x1, double y1, double x2, doub
         return sqrt(fma(d1, d1, d0 * d0));  // np.linalg.norm -> cblas_ddot with a fused tail (see oracle)
     }
     return 1000.0;
+}
+
+// The same arithmetic, also returning t (car_env.py:175): where along the wall the hit lies (the selector kernels' end-margin test)
+struct LitR { double d, t; bool hit; };
+__device__ __forceinline__ LitR cast_ref_t(double x1, double y1, double x2, double y2, double x3, double y3, double dx, double dy) {
+    // (straight-line: a zero denominator makes t infinite or NaN and the test below false -- :172's None --, and the distance is
+    // formed whether or not the test holds and selected afterwards: nine of these in a row with a branch each cost the persistent
+    // kernel 200 spilled registers)
+    const double x4 = x3 + dx, y4 = y3 + dy;                                  // :169
+    const double den = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4);         // :171
+    const double t = ((x1 - x3) * (y3 - y4) - (y1 - y3) * (x3 - x4)) / den;   // :175
+    const double u = -((x1 - x2) * (y1 - y3) - (y1 - y2) * (x1 - x3)) / den;  // :176
+    const double ptx = x1 + t * (x2 - x1), pty = y1 + t * (y2 - y1);          // :180-181
+    const double d0 = x3 - ptx, d1 = y3 - pty;
+    const double d = sqrt(fma(d1, d1, d0 * d0));
+    LitR r;
+    r.hit = (0 < t) & (t < 1) & (u > 0) & (den != 0);                         // :172, :178
+    r.t = t;
+    r.d = r.hit ? d : 1000.0;
+    return r;
 }
 
 // ---- F32 mode = float32 SELECTOR + float64 REFINEMENT ---------------------------------------------------------
@@ -224,6 +246,48 @@ __device__ __forceinline__ double refine_careful(const int k, const LoadSeg& seg
     if (!any) d = scan_chain_d(segs, nV, px, py, dx, dy);
     return d;
 }
+// ---- PC_DTYPE_F64 handles inside the persistent kernel (rollout_kernel<..., LIT>): the float32 sweep SELECTS exactly as above, and
+// what is then evaluated for the selected wall is the reference's own LITERAL arithmetic (cast_ref) on the float64 car position,
+// glibc's direction (the rotation table) and the wall's endpoints as the track file gives them: SegD records whose (ex, ey) fields
+// carry (x2, y2) on such handles.  The argument is the one above, with "exact" replaced by "literal": the sweep flags every ray
+// within tau ~ 2e-3 px of a vertex and every car within tau of a wall line, and the literal arithmetic differs from the exact one by
+// ~1e-10 px at most (rounded x3 - x4: see cast_exact) -- so for an unflagged ray the literal hit set IS the candidate set, the
+// selected wall is a literal hit, and a nearer literal hit can only lie within float32's resolution of it: around the corner next
+// to the hit (lit_careful's neighbours) or on a wall the host marked PC_SEG_SCAN (the literal loop over all walls).  Ray.get_distance
+// (car_env.py:186-213) is the minimum of the literal distances, and that is what comes out, bit for bit.
+//   lit_fast     the selected wall's literal cast; ok iff it is a hit at least the end margin inside both ends (|t - 0.5| < h)
+//   lit_careful  the rest: corner neighbours, or (nothing certified / the selection is no literal hit / PC_SEG_SCAN) every wall
+__device__ __forceinline__ double lit_fast(const SegD& sg, const double px, const double py, const double dx, const double dy, bool& ok) {
+    const LitR c = cast_ref_t(sg.x1, sg.y1, sg.ex, sg.ey, px, py, dx, dy);
+    ok = c.hit & (__builtin_fabs(c.t - 0.5) < sg.h);
+    return c.d;
+}
+template <typename LoadSeg>
+__device__ __forceinline__ double lit_careful(const int k, const LoadSeg& segs, const Seg* walls, const int S, const double px, const double py,
+                                              const double dx, const double dy) {
+    double d = 1000.0;                                             // :198
+    bool any = false;
+    if (k != 0) {
+        const SegD sg = segs(k);
+        const LitR c = cast_ref_t(sg.x1, sg.y1, sg.ex, sg.ey, px, py, dx, dy);
+        if (c.hit && !(sg.prev_next & PC_SEG_SCAN)) {
+            any = true;
+            const SegD a = segs(sg.prev_next & 0x7fff), b = segs((int)(((unsigned)sg.prev_next >> 16) & 0x7fff));   // (index 0: a chain start, x2 = x1: den == 0, never a hit)
+            const double da = cast_ref(a.x1, a.y1, a.ex, a.ey, px, py, dx, dy), db = cast_ref(b.x1, b.y1, b.ex, b.ey, px, py, dx, dy);
+            d = c.d;
+            d = da < d ? da : d;                                   // :203-207
+            d = db < d ? db : d;
+        }
+    }
+    if (!any) {
+        for (int w = 0; w < S; ++w) {
+            const Seg sg = walls[w];
+            const double dd = cast_ref(sg.x1, sg.y1, sg.x2, sg.y2, px, py, dx, dy);
+            d = dd < d ? dd : d;
+        }
+    }
+    return d;
+}
 // min(1000, d) / 1000 as the observation holds it (Ray.get_distance :198,:210-211; car_env.py:593,:595)
 __device__ __forceinline__ float obs_dist(const double d) { return (float)(__builtin_fmin(d, 1000.0) * 0.001); }
 // one ray against one segment (the reward gates: Car.check_collision(gate), car_env.py:387-390), float64, the reference's verdict
@@ -276,10 +340,11 @@ template <> struct Math<double> {
     // rotation's INDEX k beside the value (iv.x; -1 = a rotation set_state gave that no episode reaches): row k of the table holds
     // the R rays' (cos, sin) -- glibc's, of the very angles rot + ray * step -- and, as entry R, the indices of rot - 5.0 and rot +
     // 5.0 ((double) left, (double) right; -1 beyond the 1000 turns an episode can make).  One 16-byte load per direction where the
-    // hash lookup below takes eight probes and the entry; the hash stays for k = -1.  Same values either way.
+    // hash lookup below takes eight probes and the entry; the hash stays for k = -1.  Same values either way.  Entry R + 1 = (the
+    // rotation itself, -): the selector kernel keeps only the row in registers and stores the value from here.
     static __device__ __forceinline__ bool indexed(const TrackHdr& h, const int k) { return (k >= 0) & (h.rot_off >= 0); }
     static __device__ __forceinline__ double2 rot_entry(const EnvParams<double>& p, const TrackHdr& h, const int k, const int col) {
-        return p.dirtab64[h.rot_off + k * (p.R + 1) + col];
+        return p.dirtab64[h.rot_off + k * (p.R + 2) + col];
     }
     // the index of rot -+ 5.0 (left: -5.0, car_env.py:440; right: +5.0, :442)
     static __device__ __forceinline__ int turn(const EnvParams<double>& p, const TrackHdr& h, const int k, const bool left) {

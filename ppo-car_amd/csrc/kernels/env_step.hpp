@@ -670,31 +670,28 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
         // (the ray slots in groups of at most five: a group's rounded differences and hit masks are alive together, not all RPL of
         // them -- 9 or 17 float64 slots per lane beside a persistent kernel's other state do not fit the register file)
         constexpr int SG = RPL <= 6 ? RPL : (RPL <= 10 ? (RPL + 1) / 2 : 5);
-#pragma unroll
-        for (int g0 = 0; g0 < RPL; g0 += SG) {
-            constexpr int SGN = SG;
+        constexpr unsigned EST_NONE = 0x7f800000u;      // +inf: no filtered pair
+        auto slot_group = [&](auto G0C, auto CNTC) {
+            constexpr int g0 = decltype(G0C)::value, SGN = decltype(CNTC)::value;     // slots g0 .. g0 + SGN - 1
             double mx[SGN], my[SGN];
 #pragma unroll
             for (int q = 0; q < SGN; ++q) {
-                const int s = g0 + q < RPL ? g0 + q : RPL - 1;
-                const double x4 = npx + dx[s], y4 = npy + dy[s];     // :169
-                mx[q] = npx - x4;                                     // (x3 - x4)
-                my[q] = npy - y4;                                     // (y3 - y4)
+                const double x4 = npx + dx[g0 + q], y4 = npy + dy[g0 + q];     // :169
+                mx[q] = npx - x4;                                               // (x3 - x4)
+                my[q] = npy - y4;                                               // (y3 - y4)
             }
             for (int w0 = 0; w0 < h.S; w0 += 32) {
                 const int wn = h.S - w0 < 32 ? h.S - w0 : 32;
-                unsigned hm[SGN];
                 // Beside the filter: a float32 ESTIMATE of every filtered pair's distance, u = |unn| / |den| (the reference's own
                 // quotient, car_env.py:176, good to ~3e-7 here), wall index in the five low mantissa bits, and per slot the smallest
                 // and the second smallest of them (unsigned order = value order for non-negative floats).  Pass 2 then measures the
                 // estimated-nearest pair with the literal cast_ref -- ONE pair per slot instead of every filtered one, of which a
-                // wave's 64 lanes held up to seven -- and falls back to all of the slot's pairs only where the runner-up's estimate is
+                // wave's 64 lanes held up to seven -- and falls back to EVERY wall of the block only where the runner-up's estimate is
                 // not clearly (1e-4 relative: 300 x the estimate's error, 1e11 x the literal arithmetic's) beyond the measured
                 // distance: two walls hit at the same place, i.e. a corner.  The minimum of the literal distances is unchanged.
                 unsigned e1[SGN], e2[SGN];
-                constexpr unsigned EST_NONE = 0x7f800000u;      // +inf: no filtered pair
 #pragma unroll
-                for (int q = 0; q < SGN; ++q) { hm[q] = 0u; e1[q] = EST_NONE; e2[q] = EST_NONE; }
+                for (int q = 0; q < SGN; ++q) { e1[q] = EST_NONE; e2[q] = EST_NONE; }
                 Seg nxt = cload(walls + w0);
                 for (int j = 0; j < wn; ++j) {
                     const Seg sg = nxt;  // wave-uniform -> s_load_dwordx8
@@ -704,7 +701,6 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
                     const double unn = ex * ay - ey * ax;                     // u = -unn / den (:176)
                     const int un_hi = __double2hiint(unn);
                     const float unf = __builtin_fabsf((float)unn);
-                    const unsigned bit = 1u << j;
                     unsigned jv;
                     asm("v_mov_b32 %0, %1" : "=v"(jv) : "s"(j));
 #pragma unroll
@@ -714,7 +710,6 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
                         const int den_hi = __double2hiint(den);
                         // 0 <= t: equal sign bits; t <= 1: |tn| <= |den|; u >= 0: -unn and den of equal sign bits, i.e. unn and den of different ones
                         const bool maybe = ((__double2hiint(tn) ^ den_hi) >= 0) & (__builtin_fabs(tn) <= __builtin_fabs(den)) & ((un_hi ^ den_hi) < 0);
-                        hm[q] |= maybe ? bit : 0u;
                         // (an estimate that overflowed or is not a number -- a denominator below float32's range -- becomes 3e38: beyond every
                         // distance that matters, Ray.get_distance caps at 1000 px, car_env.py:198)
                         const float est = __builtin_fminf(unf * __builtin_amdgcn_rcpf(__builtin_fabsf((float)den)), 3.0e38f);
@@ -725,31 +720,31 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
                 }
 #pragma unroll
                 for (int q = 0; q < SGN; ++q) {
-                    if (g0 + q < RPL) {
-                        const int s = g0 + q;
-                        // the estimated-nearest pair, unless even it lies clearly beyond what an earlier block of walls gave
-                        const bool need1 = e1[q] < EST_NONE && __uint_as_float(e1[q] & ~31u) <= (float)best[s] * 1.0001f;
-                        if (__builtin_amdgcn_ballot_w64(need1) != 0) {
-                            const Seg sg = walls[w0 + (int)(e1[q] & 31u)];       // (per-lane wall: a vector load of the 32-byte record)
+                    const int s = g0 + q;
+                    // the estimated-nearest pair, unless even it lies clearly beyond what an earlier block of walls gave
+                    const bool need1 = e1[q] < EST_NONE && __uint_as_float(e1[q] & ~31u) <= (float)best[s] * 1.0001f;
+                    if (__builtin_amdgcn_ballot_w64(need1) != 0) {
+                        const Seg sg = walls[w0 + (int)(e1[q] & 31u)];       // (per-lane wall: a vector load of the 32-byte record)
+                        const double d = cast_ref(sg.x1, sg.y1, sg.x2, sg.y2, npx, npy, dx[s], dy[s]);
+                        if (need1 && d < best[s]) best[s] = d;  // :203-207
+                    }
+                    // the runner-up within 1e-4 of the measured minimum: the literal loop over every wall of the block for those lanes
+                    const bool need_all = e2[q] != EST_NONE && !(__uint_as_float(e2[q] & ~31u) > (float)best[s] * 1.0001f);
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(need_all) != 0, 0)) {
+                        for (int j = 0; j < wn; ++j) {
+                            const Seg sg = cload(walls + w0 + j);
                             const double d = cast_ref(sg.x1, sg.y1, sg.x2, sg.y2, npx, npy, dx[s], dy[s]);
-                            if (need1 && d < best[s]) best[s] = d;  // :203-207
-                        }
-                        // the runner-up within 1e-4 of the measured minimum (or an estimate that is not a number): every filtered pair of the slot
-                        const bool need_all = e2[q] != EST_NONE && !(__uint_as_float(e2[q] & ~31u) > (float)best[s] * 1.0001f);
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(need_all) != 0, 0)) {
-                            unsigned m = need_all ? hm[q] : 0u;
-                            while (__builtin_amdgcn_ballot_w64(m != 0u) != 0) {
-                                const bool has = m != 0u;
-                                const Seg sg = walls[w0 + (has ? __builtin_ctz(m) : 0)];
-                                m &= m - 1u;
-                                const double d = cast_ref(sg.x1, sg.y1, sg.x2, sg.y2, npx, npy, dx[s], dy[s]);
-                                if (has && d < best[s]) best[s] = d;
-                            }
+                            if (need_all && d < best[s]) best[s] = d;
                         }
                     }
                 }
             }
-        }
+        };
+        // (the ray slots in groups of at most five: a group's rounded differences and estimates are alive together, not all RPL of
+        // them -- 9 or 17 float64 slots per lane beside a persistent kernel's other state do not fit the register file)
+        [&]<int... Is>(std::integer_sequence<int, Is...>) {
+            (slot_group(std::integral_constant<int, Is * SG>{}, std::integral_constant<int, (Is * SG + SG <= RPL ? SG : RPL - Is * SG)>{}), ...);
+        }(std::make_integer_sequence<int, (RPL + SG - 1) / SG>{});
     }
     const bool store = PARTS == 1 || part == 0;
     bool wall_hit = false;
@@ -898,7 +893,7 @@ __global__ void rden_build_kernel(const EnvParams<float> p, const int n_tracks, 
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
             const int idx = i / h.nV, k = i - idx * h.nV;
             const Vtx v = p.vtx[h.vtx_off + k];
-            const float2 d = p.dirtab[h.dir_off + idx];
+            const float2 d = p.dirtab[h.lat_off + idx];
             const float den = __builtin_fmaf(v.ey, d.x, -(v.ex * d.y));
             rden[h.rden_off + i] = idx == 360 ? __builtin_inff() : __builtin_amdgcn_rcpf(den);
         }

@@ -82,12 +82,17 @@ __host__ __device__ constexpr int ft_floats(bool small, bool twice) { return ft_
 static_assert(FT_ACT % 4 == 0 && FT_GATES % 4 == 0 && FT_DIR % 4 == 0 && FT_VTX % 4 == 0 && FT_DIR64 % 4 == 0,
               "16-byte aligned records");
 
-template <bool SMALL, bool TWICE>
+// LIT (PC_DTYPE_F64 handles): the float64 heading table and direction lattice are not staged -- those kernels take headings and
+// directions from the track's rotation table (glibc's values of the very angles, Math<double>) -- and the chain records carry the
+// walls' second endpoints (lit_fast).
+template <bool SMALL, bool TWICE, bool LIT = false>
 __device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p, const TrackHdr& h0, const int trk, float* sTab,
                                                       const int tid, const int nthreads) {
     int* dst = reinterpret_cast<int*>(sTab);
-    const int* head = reinterpret_cast<const int*>(p.headtab + h0.head_off);
-    for (int i = tid; i < 72 * 4; i += nthreads) dst[FT_HEAD + i] = head[i];
+    if constexpr (!LIT) {
+        const int* head = reinterpret_cast<const int*>(p.headtab + h0.head_off);
+        for (int i = tid; i < 72 * 4; i += nthreads) dst[FT_HEAD + i] = head[i];
+    }
     for (int i = tid; i < 74; i += nthreads) dst[FT_WRAP + i] = i == 0 ? 71 : (i == 73 ? 0 : i - 1);
     if (tid < 16) {
         const int a = tid;
@@ -106,15 +111,17 @@ __device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p,
     // The direction lattice twice around (a ray's index 5 k + step_deg * ray < 720 needs no reduction mod 360), each entry
     // with the LDS byte address of its row of the 1/den table: one 16-byte read per ray slot replaces the index arithmetic.
     constexpr int FT_SEG = SMALL ? ft_seg_small(TWICE) : FT_VTX;
-    const float2* dir = p.dirtab + h0.dir_off;
+    const float2* dir = p.dirtab + h0.lat_off;
     const unsigned rden_base = (unsigned)(size_t)(lds_cfp)(sTab + ft_floats(SMALL, TWICE));
     for (int i = tid; i < 720; i += nthreads) {
         const int j = i < 360 ? i : i - 360;
         const float2 cs = dir[j];
         *reinterpret_cast<f32x4*>(sTab + FT_DIR + 4 * i) = (f32x4){cs.x, cs.y, __uint_as_float(rden_base + (unsigned)(j * h0.nV) * 4u), 0.0f};
     }
-    const int* d64 = reinterpret_cast<const int*>(p.dirtab64 + h0.dir_off);
-    for (int i = tid; i < (TWICE ? 720 : 360) * 4; i += nthreads) dst[FT_DIR64 + i] = d64[i < 360 * 4 ? i : i - 360 * 4];
+    if constexpr (!LIT) {
+        const int* d64 = reinterpret_cast<const int*>(p.dirtab64 + h0.dir_off);
+        for (int i = tid; i < (TWICE ? 720 : 360) * 4; i += nthreads) dst[FT_DIR64 + i] = d64[i < 360 * 4 ? i : i - 360 * 4];
+    }
     const int* ro = reinterpret_cast<const int*>(p.reset_obs + (size_t)trk * p.D);
     for (int i = tid; i < p.D; i += nthreads) dst[FT_RESET + i] = ro[i];
     if (h0.nV <= FT_VTX_MAX) {
@@ -238,14 +245,23 @@ __device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const i
 // part s % PARTS, which also writes that ray's column of the observation row), the parts' collision verdicts meet in LDS (`hitw`:
 // the env's [PARTS] words) across a second barrier (every thread of the workgroup must make the call), and all waves finish
 // the step on identical values; only `write_row` waves store the observation row.
-template <int RPL, bool TAB, int LG = 1, int PARTS = 1, int SWP = 0, bool TWICE = true>
+// LIT (PC_DTYPE_F64 handles, big form only): the same step with the reference's LITERAL float64 arithmetic wherever a value is
+// produced -- headings and ray directions are glibc's, read from the track's rotation table by the rotation's row st.k
+// (Math<double>; *hcar carries the heading of the current rotation from step to step), the gate casts and the selected walls'
+// distances are cast_ref's (lit_fast / lit_careful), the observation is normalised by division (Math<double>::norm) -- while
+// the float32 sweep only SELECTS, on the float32 lattice directions, exactly as for F32 handles.  Bit for bit what
+// env_step_core<double> computes (tests/test_rollout_f64_gpu.py).
+template <int RPL, bool TAB, int LG = 1, int PARTS = 1, int SWP = 0, bool TWICE = true, bool LIT = false>
 __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const TrackHdr& h, const FastTabs& ft, const FastLane& fl,
                                               const int (&gq)[2], const int g,
                                               EnvRegs& st, int& k72, const int a, const double reward_scale, lds_fp lrow,
                                               float& reward_f, float& term_f, float& trunc_f, const int t = 0, const int lane = 0,
                                               const int wave = 0, const int part = 0, float* exch = nullptr, const bool write_row = true,
-                                              int* hitw = nullptr) {
+                                              int* hitw = nullptr, f64x2* hcar = nullptr) {
     constexpr int G = 1 << LG;
+    static_assert(!LIT || (LG == 1 && PARTS == 1), "the literal form exists for the big form only");
+    const double2* rot_tab = p.dirtab64 + h.rot_off;      // LIT: row k = the R rays' (cos, sin) at rotation k, then (row of rot - 5, row of rot + 5), (rot, -)
+    const int rot_ld = p.R + 2;
     // the float64 twin of the lattice entry at LDS byte address m (see FT_D64_BYTES)
     const unsigned dir_b = (unsigned)(size_t)ft.dir;
     const auto dir64_at = [&](const int m) {
@@ -259,9 +275,25 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     const f64x2 Lf = ft.act[2 * a];                                     // (thrust, fric)
     const i32x2 Li = *(lds_ci2)(ft.act + 2 * a + 1);                    // (dk, fwd)
     struct { double thrust, fric; int dk, fwd; } L = {Lf.x, Lf.y, Li.x, Li.y};
-    const f64x2 cs0 = ft.head[k72];
     const int k72n = ft.wrap[k72 + L.dk + 1];
-    const f64x2 cs1 = ft.head[k72n];
+    f64x2 cs0, cs1;
+    int kid_new = st.k;           // LIT: the rotation table's row after the turn (the only thing of it that stays in registers across the sweep)
+    f64x2 gdir[LIT ? 4 / G : 1];  // LIT: the gate rays' directions at the PREVIOUS pose
+    if constexpr (LIT) {
+        cs0 = *hcar;
+        const double2* row = rot_tab + st.k * rot_ld;
+        const double2 lr = row[p.R];
+#pragma unroll
+        for (int jj = 0; jj < 4 / G; ++jj) {
+            const double2 e = row[(g + G * jj) * p.q];          // Car.check_collision's rays j * (n // 4), dealt over the env's lanes
+            gdir[jj] = (f64x2){e.x, e.y};
+        }
+        if (L.dk < 0) kid_new = (int)lr.x;      // rot - 5.0, :440
+        if (L.dk > 0) kid_new = (int)lr.y;      // rot + 5.0, :442
+    } else {
+        cs0 = ft.head[k72];
+        cs1 = ft.head[k72n];
+    }
     // ---- Car.update physics (car_env.py:452-461), float64: thrust with the PRE-turn heading, friction without thrust, clip
     double nvx = (st.vx + cs0.x * L.thrust) * L.fric, nvy = (st.vy + cs0.y * L.thrust) * L.fric;
     nvx = fmin(fmax(nvx, -10.0), 10.0);      // np.clip per component (:457); the velocity is never NaN
@@ -299,8 +331,16 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     if constexpr (!(PC_ABLATE & 8)) {
 #pragma unroll
         for (int jj = 0; jj < 4 / G; ++jj) {
-            const f64x2 cs = dir64_at(k80o + gq[jj]);
-            gate_hit |= cast_d(gate, opx, opy, cs.x, cs.y) < 10.0;  // :387,:390
+            if constexpr (LIT) {
+#ifdef PC_EXP1
+                gate_hit |= cast_d(gate, opx, opy, gdir[jj].x, gdir[jj].y) < 10.0;
+#else
+                gate_hit |= cast_ref(gate.x1, gate.y1, gate.x2, gate.y2, opx, opy, gdir[jj].x, gdir[jj].y) < 10.0;  // :387,:390
+#endif
+            } else {
+                const f64x2 cs = dir64_at(k80o + gq[jj]);
+                gate_hit |= cast_d(gate, opx, opy, cs.x, cs.y) < 10.0;  // :387,:390
+            }
         }
     }
     // ---- wall sweep (float32 selector, env_step.hpp).  More than 12 ray slots per lane (33 rays: 17) are swept in TWO passes over
@@ -398,6 +438,8 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         const f64x2 a = sgl[3 * k], b = sgl[3 * k + 1], c = sgl[3 * k + 2];
         return SegD{a.x, a.y, b.x, b.y, c.x, (int)(unsigned)__double_as_longlong(c.y), 0};
     };
+    const double2* rot_row_new = rot_tab + kid_new * rot_ld;
+    const auto ray_of = [&](const int s) { return min(g + G * s, p.R - 1); };
     bool wall_hit = false;
     unsigned todo = 0;   // bit s: slot s needs the careful path
     // Car.check_collision's slots as WAVE masks built on the scalar unit: the lanes g, g + G, ... of the wave share one colmask
@@ -409,7 +451,9 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     uint64_t hit_mask = 0;
     // Slots in batches: every LDS read of a batch -- the selected segments' records, the slots' float64 directions -- is issued
     // before the first float64 instruction, so that the wave pays the LDS round trip once per batch, not once per slot.
-    constexpr int NB = RPL <= 5 ? RPL : (RPL <= 9 ? (RPL + 1) / 2 : (RPL + 3) / 4);   // (14 registers per slot in flight: all nine of the 17-ray kernel at once spill)
+    // (LIT: three slots per batch, and one slot's literal cast -- two float64 divisions and a square root -- at a time: interleaved,
+    // five of them held 165 registers more than the wave has)
+    constexpr int NB = LIT ? 3 : (RPL <= 5 ? RPL : (RPL <= 9 ? (RPL + 1) / 2 : (RPL + 3) / 4));   // (14 registers per slot in flight: all nine of the 17-ray kernel at once spill)
     if constexpr ((PC_ABLATE & 512) != 0 && PARTS == 1) {
         // DEVELOPER COST MODEL of an "f32n" tier (never in the product): the observation from the selector's own
         // float32 distance, the float64 refinement only for the ill-conditioned slots -- modelled as a pseudo-random 1/16 of the
@@ -457,7 +501,12 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
             if (s < RPL && (PARTS == 1 || s % PARTS == part)) {
                 const int m = m0 + s * fl.rstep;
                 sg[j] = segs((int)(bb[s] & h.idx_mask));
-                d64[j] = dir64_at(s + 1 < RPL ? m : min(m, m_last));
+                if constexpr (LIT) {
+                    const double2 e = rot_row_new[ray_of(s)];
+                    d64[j] = (f64x2){e.x, e.y};
+                } else {
+                    d64[j] = dir64_at(s + 1 < RPL ? m : min(m, m_last));
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -467,17 +516,23 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
             if (s < RPL && (PARTS == 1 || s % PARTS == part)) {
                 bool ok = true;
                 double d = 500.0 + sg[j].x1 * 1e-9 + d64[j].x * 1e-9;
-                if constexpr (!(PC_ABLATE & 16)) d = refine_fast(sg[j], npx, npy, d64[j].x, d64[j].y, ok);
+#ifdef PC_EXP2
+                if constexpr (LIT) d = refine_fast(sg[j], npx, npy, d64[j].x, d64[j].y, ok);
+#else
+                if constexpr (LIT) d = lit_fast(sg[j], npx, npy, d64[j].x, d64[j].y, ok);
+#endif
+                else if constexpr (!(PC_ABLATE & 16)) d = refine_fast(sg[j], npx, npy, d64[j].x, d64[j].y, ok);
                 todo |= ok ? 0u : 1u << s;
                 uint64_t col_lanes = 0;
 #pragma unroll
                 for (int gg = 0; gg < G; ++gg) col_lanes |= ((colm_g[gg] >> s) & 1) ? LANES_G0 << gg : 0ull;
                 hit_mask |= __builtin_amdgcn_ballot_w64(ok & (d < 10.0)) & col_lanes;           // :387-390 on Car.check_collision's rays
-                const float o = obs_dist(d);                                                    // :593
+                const float o = LIT ? Math<double>::norm_dist(d < 1000.0 ? d : 1000.0) : obs_dist(d);    // :198, :593
                 if (write_row || PARTS > 1) {   // ray slot s -> column 6 + ray(s): G floats apart from the lane's first; the clamped last slot apart
                     if (s + 1 < RPL) fl.lray[G * s] = o;
                     else fl.llast[0] = o;
                 }
+                if constexpr (LIT) __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -491,12 +546,22 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         for (int s = 0; s < RPL; ++s) sel = s == s0 ? bb[s] : sel;
         if (s0 >= 0) {
             const int ms = m0 + s0 * fl.rstep;
-            const f64x2 d64 = dir64_at(s0 + 1 < RPL ? ms : min(ms, m_last));
-            const double d = refine_careful((int)(sel & h.idx_mask), segs, h.nV, npx, npy, d64.x, d64.y);
+            double d;
+            if constexpr (LIT) {
+                const double2 e = rot_row_new[ray_of(s0)];
+#ifdef PC_EXP3
+                d = refine_careful((int)(sel & h.idx_mask), segs, h.nV, npx, npy, e.x, e.y);
+#else
+                d = lit_careful((int)(sel & h.idx_mask), segs, p.segs + h.wall_off, h.S, npx, npy, e.x, e.y);
+#endif
+            } else {
+                const f64x2 d64 = dir64_at(s0 + 1 < RPL ? ms : min(ms, m_last));
+                d = refine_careful((int)(sel & h.idx_mask), segs, h.nV, npx, npy, d64.x, d64.y);
+            }
             wall_hit |= (bool)((fl.colmask >> s0) & 1) & (d < 10.0);
             if (write_row || PARTS > 1) {
                 const lds_fp dst = s0 + 1 < RPL ? fl.lray + G * s0 : fl.llast;
-                dst[0] = obs_dist(d);
+                dst[0] = LIT ? Math<double>::norm_dist(d < 1000.0 ? d : 1000.0) : obs_dist(d);
             }
             todo &= todo - 1;
         }
@@ -544,11 +609,16 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     trunc_f = trunc ? 1.0f : 0.0f;
     // ---- observation row -> LDS: the ray columns were written by the refinement loop (the reset observation of a finished env is
     // written by the caller's fix-up)
+    if constexpr (LIT) {      // the heading after the turn (rot + 0 * step is rot itself), read only now: nothing of it lives across the sweep
+        const double2 e1 = rot_tab[kid_new * rot_ld];
+        cs1 = (f64x2){e1.x, e1.y};
+    }
     if (!MERGED && g == 0 && write_row) {
-        lrow[0] = Math<float>::norm(npx, 1280.0);  // :578-581
-        lrow[1] = Math<float>::norm(npy, 720.0);
-        lrow[2] = Math<float>::norm(nvx, 10.0);
-        lrow[3] = Math<float>::norm(nvy, 10.0);
+        using M = Math<std::conditional_t<LIT, double, float>>;
+        lrow[0] = M::norm(npx, 1280.0);  // :578-581
+        lrow[1] = M::norm(npy, 720.0);
+        lrow[2] = M::norm(nvx, 10.0);
+        lrow[3] = M::norm(nvy, 10.0);
         lrow[4] = (float)cs1.x;                    // :584-588
         lrow[5] = (float)cs1.y;
     }
@@ -557,7 +627,12 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     st.py = npy;
     st.vx = nvx;
     st.vy = nvy;
-    st.k += L.dk;
+    if constexpr (LIT) {
+        st.k = kid_new;
+        *hcar = cs1;
+    } else {
+        st.k += L.dk;
+    }
     k72 = k72n;
     st.time = time;
     st.next = next;
@@ -565,9 +640,9 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     return done;
 }
 
-// CarEnv.reset (car_env.py:677-686) of a finished env's registers
+// CarEnv.reset (car_env.py:677-686) of a finished env's registers (F64 handles: row 0 of the rotation table is start_rot)
 __device__ __forceinline__ void env_reset_fast(const TrackHdr& h, EnvRegs& st, int& k72) {
-    st.px = h.start_x; st.py = h.start_y; st.vx = 0.0; st.vy = 0.0;
+    st.px = h.start_x; st.py = h.start_y; st.vx = 0.0; st.vy = 0.0; st.rot = h.start_rot;
     st.k = 0; st.time = 0; st.next = 0; st.passed = 0;
     k72 = 0;
 }
@@ -768,7 +843,9 @@ __device__ __forceinline__ EnvParams<float> stage_tables(const EnvParams<float>&
 //         kernel schedules worse without the generic branch -- it spills -- and keeps it).
 //         MODE 5 = 2 for batches whose tracks are all two equal chains of 13 OR of 9 vertices (big_track.json and track.json
 //         mixed: BASELINE configs[4]): the chain-packed sweep for both lengths, chosen per workgroup.
-template <int KS, int RPL, int PREC, int MODE>
+//         LIT (modes 3 and 5): the handle is PC_DTYPE_F64 -- env_step_fast's literal form; state with the float64 rotation and
+//         its row of the rotation table (env_load<double>).
+template <int KS, int RPL, int PREC, int MODE, bool LIT = false>
 __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, const float* __restrict__ image, const int A,
                                                       const int T, const double reward_scale, const uint64_t seed,
                                                       const uint64_t offset, const uint64_t* __restrict__ offset_dev,
@@ -813,7 +890,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const TrackHdr h0 = cload(p.hdr + trk_wg);
     EnvParams<float> q = p;
     FastTabs ft = {};
-    if constexpr (FAST) ft = stage_fast_tables<false, RPL != 17>(p, h0, trk_wg, sTab, tid, 512);
+    static_assert(!LIT || MODE == 3 || MODE == 5, "the literal form: fast modes with the 1/den table");
+    if constexpr (FAST) ft = stage_fast_tables<false, RPL != 17, LIT>(p, h0, trk_wg, sTab, tid, 512);
     else q = stage_tables(p, sTab, tid, 512);
     // the track's 1/den table, when the host found room for it (rden_lds != 0; sized for the batch's largest track)
     float* sRden = sTab + (FAST ? ft_floats(false, RPL != 17) : TAB_FLOATS);
@@ -844,8 +922,10 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const int64_t e_wave = (int64_t)blockIdx.x * epw + pbase;      // first env of this wave
     const int64_t e_env = e_wave + (lane >> 1);
     const bool e_valid = e_env < N;
+    using StateT = std::conditional_t<LIT, double, float>;
+    const EnvParams<StateT>& ps = reinterpret_cast<const EnvParams<StateT>&>(p);     // (one layout: EnvParams does not depend on its parameter)
     EnvRegs st = {};
-    if (e_valid) st = env_load<float>(p, e_env);
+    if (e_valid) st = env_load<StateT>(ps, e_env);
     // mixed-track batch: this wave's envs share one track (the host checked every aligned block of 32 envs)
     const int trk = p.track_id ? (int)p.track_id[e_valid ? e_env : N - 1] : 0;
     for (int f = g; f < (FAST ? D : 4 * KS); f += 2) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
@@ -865,6 +945,16 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
         gq[1] = (int)(size_t)ft.dir + 16 * (g + 2) * p.q * p.step_deg;      // as byte addresses into the direction table
         k72 = Math<float>::mod72(st.k);
     }
+    f64x2 hcar = {1.0, 0.0};      // LIT: (cos, sin) of the env's current rotation (row st.k of the rotation table)
+    if constexpr (LIT) {
+        // the lattice index of the heading: rot = start_rot after k turns of +-5.0 (each sum rounded; the quotient is within 1e-10 of k)
+        k72 = Math<float>::mod72((int)__builtin_rint((st.rot - h0.start_rot) / 5.0));
+        if (e_valid) {
+            const double2 e0 = p.dirtab64[h0.rot_off + st.k * (p.R + 2)];
+            hcar = (f64x2){e0.x, e0.y};
+        }
+        st.rot = 0.0;     // (not kept: the rotation is the row's last entry, read again when the state is stored)
+    }
     const lds_fp lrow = (lds_fp)(sObs + el * LDX);
     __syncthreads();  // the weight image is in place; from here on the waves never synchronise again
     if (pbase >= epw) return;
@@ -874,6 +964,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     // insertion, a fresh register value: waited for HERE, once -- otherwise the first use inside the loop carries a
     // conservative `s_waitcnt vmcnt(1)` on every iteration, i.e. a wait for the wave's own global stores of the step before.
     asm volatile("" : "+v"(st.px), "+v"(st.py), "+v"(st.vx), "+v"(st.vy), "+v"(st.k), "+v"(st.time), "+v"(st.next), "+v"(st.passed), "+v"(k72));
+    if constexpr (LIT) asm volatile("" : "+v"(hcar));
 
     // pc_rollout_ex: one more policy pass after the last env step gives the critic's value of the FINAL observation (the
     // bootstrap value of Buffer.calculate_advantages, train.py:200) -- tail iteration t == T: no draw stored, no env step --,
@@ -1027,7 +1118,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 // ---------------- E(t)
                 float rw, tf, cf;
                 const int a = e_valid ? act_reg : 8;
-                const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3 || MODE == 5, 1, 1, (MODE == 5 ? 5 : (MODE >= 3 ? 7 : 0)), RPL != 17>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave);
+                const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3 || MODE == 5, 1, 1, (MODE == 5 ? 5 : (MODE >= 3 ? 7 : 0)), RPL != 17, LIT>(
+                    p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, 0, nullptr, true, nullptr, &hcar);
                 rsum += rw;
                 PC_STAMP(6)
                 // gymnasium 0.29.1 same-step auto-reset: a finished env returns its reset observation
@@ -1043,6 +1135,10 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                         for (int j = 0; j < (DC + 1) / 2; ++j)
                             if (g + 2 * j < DC) lrow[g + 2 * j] = ro[j];
                         env_reset_fast(h0, st, k72);
+                        if constexpr (LIT) {
+                            const double2 e0 = p.dirtab64[h0.rot_off];      // row 0 = start_rot
+                            hcar = (f64x2){e0.x, e0.y};
+                        }
                     }
                 }
                 if (g == 0 && e_valid) {
@@ -1104,7 +1200,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
         __builtin_amdgcn_wave_barrier();
     }
     if (e_valid && g == 0) {
-        env_store<float>(p, e_env, st);
+        if constexpr (LIT) st.rot = p.dirtab64[h0.rot_off + st.k * (p.R + 2) + p.R + 1].x;
+        env_store<StateT>(ps, e_env, st);
         if (rew_sum) rew_sum[e_env] = rsum;
     }
 }

@@ -161,6 +161,9 @@ struct pc_env {
     SegD* seg64 = nullptr;
     F64Dir* dirhash = nullptr;
     std::vector<std::unordered_map<uint64_t, int>> rot_ids;   // F64, host only: per track, rotation bits -> row of the rotation table (pc_env_set_state)
+    std::vector<std::vector<int>> rot_depth;                  // F64, host only: per track and row, how many turns from start_rot reach it
+    bool f64_offgrid = false;      // F64: pc_env_set_state left an env whose episode can leave the rotation table (a rotation that is not a
+                                   // row, or a row more turns from start_rot than the env's time step): the selector kernel needs rows
     float* reset_obs = nullptr;
 
     template <typename T> EnvParams<T> params() const {
@@ -353,6 +356,7 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
     size_t rden_floats = 0;
     e->hdr_host.resize(e->n_tracks);
     e->rot_ids.assign(e->n_tracks, {});
+    e->rot_depth.assign(e->n_tracks, {});
     for (int k = 0; k < e->n_tracks; ++k) {
         const pc_track* t = tracks[k];
         TrackHdr& h = e->hdr_host[k];
@@ -361,6 +365,8 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
         h.n_scan = 0;
         h.rot_off = -1;     // (F64 handles: set below)
         h.n_rot = 0;
+        h.lat_off = -1;
+        h.sel_ok = 1;
         h.wall_off = (int)segs.size();
         for (size_t i = 0; i < t->walls.size(); i += 4) segs.push_back(Seg{t->walls[i], t->walls[i + 1], t->walls[i + 2], t->walls[i + 3]});
         h.gate_off = (int)segs.size();
@@ -420,6 +426,10 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
             g_hip_err = "track " + std::to_string(k) + ": the walls' bounding box exceeds 2000 px; dtype f32 is priced for tracks that fit (use dtype f64)";
             return PC_ERR_UNSUPPORTED;
         }
+        // F64 handles: the float32 SELECTOR (the persistent kernel's literal form, env_step_fast<..., LIT>) runs on a track within
+        // those same limits; any other track takes the filter form (env_step_core<double>), which has none.
+        const bool sel = !f64 || (h.nV <= 8192 && h.bx1 - h.bx0 <= 2000.0f && h.by1 - h.by0 <= 2000.0f);
+        h.sel_ok = sel ? 1 : 0;
         {   // low bits of a sweep candidate that carry the vertex index (at least 5: the unrolled 28-vertex sweep's constant)
             int b = 5;
             while ((1 << b) < h.nV) ++b;
@@ -458,8 +468,8 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
             while ((1 << bits) < h.nV) ++bits;
             const double sel_res = 1001.0 * std::ldexp(1.0, -(23 - bits));
             const double margin = std::max(0.05, 4.6 * sel_res), near = std::max(0.05, 1.5 * sel_res);
-            // (F32 handles only: nV <= 8192 there, so prev / next fit their 15 bits beside PC_SEG_SCAN; the F64 kernels never read seg64)
-            for (int k = 0; k < n && !f64; ++k) {
+            // (where the selector runs: nV <= 8192 there, so prev / next fit their 15 bits beside PC_SEG_SCAN; the F64 filter form never reads seg64)
+            for (int k = 0; k < n && sel; ++k) {
                 if (is_start(k)) continue;     // chain starts / padding: no segment (h = -1: |t - 0.5| < h never holds)
                 int c0 = k;     // first vertex of this chain, and its last
                 while (!is_start(c0)) --c0;
@@ -474,7 +484,7 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
                 seg64[o + k].h = 0.5 - margin / len;
                 if (len < 2.0 * margin) seg64[o + k].prev_next |= PC_SEG_SCAN;
             }
-            if (!f64) {
+            if (sel) {
                 const auto seg_of = [&](int w) { return segs[h.wall_off + w]; };
                 const auto pt_seg = [](double px, double py, const Seg& s) {     // distance of a point from a segment
                     const double ex = s.x2 - s.x1, ey = s.y2 - s.y1, l2 = ex * ex + ey * ey;
@@ -515,6 +525,17 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
                 for (int k = 0; k < n; ++k)
                     if (seg64[o + k].prev_next & PC_SEG_SCAN) { seg64[o + k].h = -1.0; ++h.n_scan; }
             }
+            // F64 handles: the literal arithmetic wants the wall's SECOND ENDPOINT as the track file gives it (x1 - ex need not be
+            // x2 to the last bit): the records' (ex, ey) fields carry (x2, y2) from here on (lit_fast); a chain start or padding
+            // record gets x2 = x1: den == 0, never a hit
+            if (f64 && sel) {
+                for (int k = 0; k < n; ++k) {
+                    SegD& r = seg64[o + k];
+                    const bool start = is_start(k);
+                    r.ex = start ? r.x1 : vpos[o + k].x;
+                    r.ey = start ? r.y1 : vpos[o + k].y;
+                }
+            }
         }
         if (f64) {
             // F64 mode: every angle an episode can reach (see Math<double>), glibc's cos / sin of it, hashed by the angle's bits
@@ -529,22 +550,26 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
                 std::vector<uint64_t> rot_list;                       // index -> rotation (breadth first; index 0 = start_rot: what reset gives)
                 std::unordered_map<uint64_t, int>& rid = e->rot_ids[k];
                 rid.clear();
+                std::vector<int>& depth = e->rot_depth[k];
+                int cur_depth = 0;
                 const auto add_rot = [&](uint64_t b) {
                     if (!rots.insert(b).second) return false;
                     rid[b] = (int)rot_list.size();
                     rot_list.push_back(b);
+                    depth.push_back(cur_depth);
                     return true;
                 };
                 add_rot(bits(t->start_rot));
                 frontier = rots;
                 for (int turn = 0; turn < 1000 && !frontier.empty(); ++turn) {      // CarEnv truncates at 1000 steps (car_env.py:749)
+                    cur_depth = turn + 1;
                     std::unordered_set<uint64_t> next;
                     for (const uint64_t b : frontier)
                         for (const double w : {val(b) + 5.0, val(b) - 5.0})            // :440-442
                             if (add_rot(bits(w))) next.insert(bits(w));
                     frontier.swap(next);
                 }
-                {   // the rotation table (Math<double>): row i = the R rays' (cos, sin) at rotation i, then (index of rot - 5.0, index of rot + 5.0)
+                {   // the rotation table (Math<double>): row i = the R rays' (cos, sin) at rotation i, then (index of rot - 5.0, index of rot + 5.0), then (rot, -)
                     const int step_deg_ = 360 / e->n_nominal;
                     h.rot_off = (int)dirtab64.size();
                     h.n_rot = (int)rot_list.size();
@@ -555,6 +580,7 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
                         }
                         const auto lk = rid.find(bits(val(b) - 5.0)), rk = rid.find(bits(val(b) + 5.0));
                         dirtab64.push_back(make_double2(lk == rid.end() ? -1.0 : (double)lk->second, rk == rid.end() ? -1.0 : (double)rk->second));
+                        dirtab64.push_back(make_double2(val(b), 0.0));
                     }
                 }
                 const int step_deg = 360 / e->n_nominal;
@@ -581,9 +607,17 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
                 dirhash.insert(dirhash.end(), tab.begin(), tab.end());
             }
             if (dirtab64.empty()) dirtab64.push_back(make_double2(0.0, 0.0));
-            if (dirtab.empty()) dirtab.push_back(make_float2(0.f, 0.f));
+            // the selector's float32 direction lattice (start_rot + j degrees: every angle rot + a is one of them mod 360; the float32
+            // direction only selects, so that cos of the unreduced angle differs in float64's last places does not matter)
+            h.lat_off = (int)dirtab.size();
+            for (int j = 0; j < 360; ++j) {
+                const double a = (t->start_rot + (double)j) * (PC_PI / 180.0);
+                dirtab.push_back(make_float2((float)libm_cos(a), (float)libm_sin(a)));
+            }
+            dirtab.push_back(make_float2(0.f, 0.f));
         } else {
             h.dir_off = (int)dirtab.size();
+            h.lat_off = h.dir_off;
             for (int j = 0; j < 360; ++j) {  // direction lattice: start_rot + j degrees, np.radians then libm cos/sin
                 const double a = (t->start_rot + (double)j) * (PC_PI / 180.0);
                 dirtab.push_back(make_float2((float)libm_cos(a), (float)libm_sin(a)));
@@ -644,7 +678,7 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
         HIPCHK(hipMalloc((void**)&e->dirhash, dirhash.size() * sizeof(F64Dir)));
         HIPCHK(hipMemcpy(e->dirhash, dirhash.data(), dirhash.size() * sizeof(F64Dir), hipMemcpyHostToDevice));
     }
-    if (!f64) {
+    {
         HIPCHK(hipMalloc((void**)&e->rden, rden_floats * sizeof(float)));
         hipLaunchKernelGGL(rden_build_kernel, dim3(64), dim3(256), 0, 0, e->params<float>(), e->n_tracks, e->rden);
         HIPCHK(hipGetLastError());
@@ -746,6 +780,7 @@ int pc_env_reset(pc_env* e, float* obs, void* stream) {
     if (!guard.ok) return PC_ERR_NO_DEVICE;
     const int blocks = (int)((e->N + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
+    e->f64_offgrid = false;
     if (e->dtype == PC_DTYPE_F64)
         hipLaunchKernelGGL(env_reset_kernel<double>, dim3(blocks), dim3(256), 0, st, e->params<double>(), obs);
     else
@@ -884,6 +919,14 @@ int pc_env_set_state(pc_env* e, const double* px, const double* py, const double
             iv[i].z = (int)next_gate[i];
         }
         if (passed) iv[i].w = (int)passed[i];
+    }
+    if (f64) {      // can every env's episode stay inside its track's rotation table?  (what the selector kernel needs: rollout_f64_impl)
+        e->f64_offgrid = false;
+        for (size_t i = 0; i < N && !e->f64_offgrid; ++i) {
+            const std::vector<int>& depth = e->rot_depth[tid[i]];
+            const int id = iv[i].x;
+            e->f64_offgrid = id < 0 || id >= (int)depth.size() || depth[id] > iv[i].y;
+        }
     }
     HIPCHK(hipMemcpy(e->iv, iv.data(), N * sizeof(int4), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->pv, pv.data(), 4 * N * sizeof(double), hipMemcpyHostToDevice));
@@ -1172,9 +1215,52 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
     const int rpl = (e->R + 1) / 2;
     const int epw = e->opt.epw_override >= 128 ? e->opt.epw_override : (e->N <= g_rollout_epw128_max ? 128 : 256);
     const int blocks = (int)((e->N + epw - 1) / epw);
+    hipStream_t st = (hipStream_t)stream;
+    // ---- the SELECTOR form: K9 itself (rollout_kernel<..., LIT>) -- the float32 sweep picks each ray's wall, the reference's literal
+    // float64 arithmetic measures it (env_step_fast's literal form, lit_fast / lit_careful).  What it needs: every track inside the
+    // selector's limits with its rotation table built, the chain-packed sweep's layout (two equal loops of 13 -- big_track.json --
+    // or, mixed, of 13 or 9 vertices), every env's rotation a row of that table for the rest of its episode (f64_offgrid), the
+    // fast modes' shape (16 nominal rays, fp16 x 2 policy arithmetic) and LDS for the tables.  Anything else: the filter form below.
+    {
+        int max_G = 0, max_nV = 0;
+        bool all_nv28 = e->opt.nv28 != 0, all_loops = e->opt.nv28 != 0, tabs = true;
+        for (const TrackHdr& h : e->hdr_host) {
+            max_G = std::max(max_G, h.G);
+            max_nV = std::max(max_nV, h.nV);
+            tabs = tabs && h.sel_ok && h.rot_off >= 0 && h.lat_off >= 0;
+            all_nv28 = all_nv28 && h.nV == 28 && h.n_chain == 26 && h.brk2 == 13 && h.vtxp_off >= 0;
+            all_loops = all_loops && h.vtxp_off >= 0 && (h.brk2 == 13 || h.brk2 == 9) && h.n_chain == 2 * h.brk2 && h.nV == 4 * ((h.brk2 + 1) / 2);
+        }
+        const int img = polx_image_dwords(prec, pol_ng(KS));
+        const int rden_lds = 361 * max_nV;
+        const size_t lds_sel = (size_t)(img + 256 * e->D + 256 + ft_floats(false, true) + rden_lds) * sizeof(float);
+        const bool shape = KS == 6 && rpl == 9 && prec == 2 && e->n_nominal == 16 && e->D >= 17 && e->D <= 40 && max_G <= TAB_MAX_GATES &&
+                           max_nV <= FT_VTX_MAX && e->opt.fast && e->opt.rden != 0 && (!e->track_id || e->track_block >= epw) &&
+                           lds_sel <= 160 * 1024;
+        if (tabs && shape && !e->f64_offgrid && (all_nv28 || all_loops)) {
+            const int vec_ok = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
+            EnvParams<float> prm = e->params<float>();
+            prm.lg = 1;
+#define PC_ROLL_LIT(MD)                                                                                                  \
+    do {                                                                                                                 \
+        static bool attr_set[64] = {false};                                                                              \
+        if (e->device >= 64 || !attr_set[e->device]) {                                                                    \
+            HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<6, 9, 2, MD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            if (e->device < 64) attr_set[e->device] = true;                                                                \
+        }                                                                                                                \
+        hipLaunchKernelGGL((rollout_kernel<6, 9, 2, MD, true>), dim3(blocks), dim3(512), lds_sel, st, prm, image, A, (int)T, reward_scale, seed, \
+                           offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs,  \
+                           next_term, next_trunc, rden_lds, epw, vec_ok, last_value, reward_sum);                        \
+    } while (0)
+            if (all_nv28) PC_DEV(3, PC_ROLL_LIT(3));
+            else PC_FULL(PC_ROLL_LIT(5));
+#undef PC_ROLL_LIT
+            HIPCHK(hipGetLastError());
+            return PC_OK;
+        }
+    }
     const size_t lds = (size_t)(polx_image_dwords(prec, pol_ng(KS)) + 256 * (4 * KS + 1)) * sizeof(float);
     if (lds > 160 * 1024) return PC_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
     const EnvParams<double> prm = [&] { EnvParams<double> q = e->params<double>(); q.lg = 1; return q; }();
 #define PC_ROLLD(KSV, RPLV, PRC)                                                                                         \
     do {                                                                                                                 \
@@ -1188,7 +1274,7 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
                            next_term, next_trunc, epw, last_value, reward_sum);                                          \
     } while (0)
     if (KS == 5 && rpl == 6) { PC_FULL(if (prec == 2) PC_ROLLD(5, 6, 2); else PC_ROLLD(5, 6, 1)); }              // 12 rays, D = 18
-    else if (KS == 6 && rpl == 9) { if (prec == 2) PC_DEV(3, PC_ROLLD(6, 9, 2)); else return PC_ERR_UNSUPPORTED; }   // 16 -> 17 rays, D = 23 (bf16 x 3 there spills 3 registers: not built)
+    else if (KS == 6 && rpl == 9) { if (prec == 2) PC_DEV(4, PC_ROLLD(6, 9, 2)); else return PC_ERR_UNSUPPORTED; }   // 16 -> 17 rays, D = 23 (bf16 x 3 there spills 3 registers: not built)
     else return PC_ERR_UNSUPPORTED;     // (32 -> 33 rays: 17 float64 ray slots per lane beside the policy state spill 96 registers -- not built;
                                         //  the per-step kernels run that shape)
 #undef PC_ROLLD
