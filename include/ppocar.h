@@ -336,8 +336,23 @@ int pc_env_launch_info(const pc_env* e, int* lanes_per_env, int* rays_per_lane, 
  * and -- F32 handles -- how many wall segments carry the "resolve by the float64 chain scan" mark (walls that cross or touch
  * without being chain neighbours, spikes, walls shorter than the corner margin: exact, but every ray that selects one of them
  * costs an O(n_walls) float64 scan).  A track where that is a large share of the walls runs correctly and SLOWLY in dtype f32: the
- * Python host layer warns above 25 %.  0 for F64 handles.  Any pointer may be NULL. */
+ * Python host layer warns above 25 %.  F64 handles: the same count where the persistent kernel's selector form can run on the track
+ * (PC_KERNEL_K9_LITERAL), else 0.  Any pointer may be NULL. */
 int pc_env_track_info(const pc_env* e, int track, int* n_walls, int* n_chain_vertices, int* n_scan_segments);
+/* Which persistent kernel the last successful pc_rollout on this handle launched (0 before the first; for bench.py, the tests and
+ * DESIGN.md -- every kernel fills the same buffers bit for bit, this only says which one did):
+ *   PC_KERNEL_K9          big form, float32-selector env step with float64 refinement (F32 handles)
+ *   PC_KERNEL_K9S         small form (F32 handles, small batches)
+ *   PC_KERNEL_K9_LITERAL  big form on an F64 handle: the float32 sweep selects each ray's wall, the reference's literal float64
+ *                         arithmetic measures it (16 nominal rays, tracks of two equal wall loops, every env's rotation on the track's
+ *                         rotation table: what reset and stepping produce)
+ *   PC_KERNEL_K9D_FILTER  F64 handle, the filter form: every (ray, wall) pair in float64 (any track; 12 / 16 nominal rays) */
+#define PC_KERNEL_NONE 0
+#define PC_KERNEL_K9 1
+#define PC_KERNEL_K9S 2
+#define PC_KERNEL_K9_LITERAL 3
+#define PC_KERNEL_K9D_FILTER 4
+int pc_env_last_rollout_kernel(const pc_env* e);
 /* Override the lanes-per-env choice (power of two 1..64; 0 = automatic).  Tuning knob for bench.py. */
 int pc_env_set_lanes_per_env(pc_env* e, int lanes_per_env);
 

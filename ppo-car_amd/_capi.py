@@ -17,6 +17,7 @@ PC_ERR_INVALID_ARG, PC_ERR_IO, PC_ERR_PARSE, PC_ERR_HIP, PC_ERR_UNSUPPORTED, PC_
 PC_XCHG_HANDLE_BYTES = 128
 PC_DTYPE_F32, PC_DTYPE_F64 = 0, 1
 PC_OPT_ROLLOUT_FORM, PC_OPT_ROLLOUT_EPW, PC_OPT_ROLLOUT_FAST = 1, 2, 3
+PC_KERNEL_NAMES = {0: "none", 1: "K9", 2: "K9s", 3: "K9-literal", 4: "K9d-filter"}     # pc_env_last_rollout_kernel
 DTYPES = {"f32": PC_DTYPE_F32, "float32": PC_DTYPE_F32, "f64": PC_DTYPE_F64, "float64": PC_DTYPE_F64}
 
 
@@ -106,6 +107,7 @@ _sig = {
     "pc_env_launch_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "pc_env_set_lanes_per_env": (_i, [_vp, _i]),
     "pc_env_track_info": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "pc_env_last_rollout_kernel": (_i, [_vp]),
 }
 for _name, (_res, _args) in _sig.items():
     _f = getattr(lib, _name)  # AttributeError here = the library does not export what ppocar.h declares

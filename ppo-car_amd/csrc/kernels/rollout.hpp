@@ -332,11 +332,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
 #pragma unroll
         for (int jj = 0; jj < 4 / G; ++jj) {
             if constexpr (LIT) {
-#ifdef PC_EXP1
-                gate_hit |= cast_d(gate, opx, opy, gdir[jj].x, gdir[jj].y) < 10.0;
-#else
                 gate_hit |= cast_ref(gate.x1, gate.y1, gate.x2, gate.y2, opx, opy, gdir[jj].x, gdir[jj].y) < 10.0;  // :387,:390
-#endif
             } else {
                 const f64x2 cs = dir64_at(k80o + gq[jj]);
                 gate_hit |= cast_d(gate, opx, opy, cs.x, cs.y) < 10.0;  // :387,:390
@@ -516,11 +512,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
             if (s < RPL && (PARTS == 1 || s % PARTS == part)) {
                 bool ok = true;
                 double d = 500.0 + sg[j].x1 * 1e-9 + d64[j].x * 1e-9;
-#ifdef PC_EXP2
-                if constexpr (LIT) d = refine_fast(sg[j], npx, npy, d64[j].x, d64[j].y, ok);
-#else
                 if constexpr (LIT) d = lit_fast(sg[j], npx, npy, d64[j].x, d64[j].y, ok);
-#endif
                 else if constexpr (!(PC_ABLATE & 16)) d = refine_fast(sg[j], npx, npy, d64[j].x, d64[j].y, ok);
                 todo |= ok ? 0u : 1u << s;
                 uint64_t col_lanes = 0;
@@ -549,11 +541,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
             double d;
             if constexpr (LIT) {
                 const double2 e = rot_row_new[ray_of(s0)];
-#ifdef PC_EXP3
-                d = refine_careful((int)(sel & h.idx_mask), segs, h.nV, npx, npy, e.x, e.y);
-#else
                 d = lit_careful((int)(sel & h.idx_mask), segs, p.segs + h.wall_off, h.S, npx, npy, e.x, e.y);
-#endif
             } else {
                 const f64x2 d64 = dir64_at(s0 + 1 < RPL ? ms : min(ms, m_last));
                 d = refine_careful((int)(sel & h.idx_mask), segs, h.nV, npx, npy, d64.x, d64.y);

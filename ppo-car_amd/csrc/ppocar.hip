@@ -162,6 +162,7 @@ struct pc_env {
     F64Dir* dirhash = nullptr;
     std::vector<std::unordered_map<uint64_t, int>> rot_ids;   // F64, host only: per track, rotation bits -> row of the rotation table (pc_env_set_state)
     std::vector<std::vector<int>> rot_depth;                  // F64, host only: per track and row, how many turns from start_rot reach it
+    int last_kernel = 0;           // PC_KERNEL_*: what the last successful pc_rollout launched (pc_env_last_rollout_kernel)
     bool f64_offgrid = false;      // F64: pc_env_set_state left an env whose episode can leave the rotation table (a rotation that is not a
                                    // row, or a row more turns from start_rot than the env's time step): the selector kernel needs rows
     float* reset_obs = nullptr;
@@ -759,9 +760,11 @@ int pc_env_track_info(const pc_env* e, int track, int* n_walls, int* n_chain_ver
     const TrackHdr& h = e->hdr_host[track];
     if (n_walls) *n_walls = h.S;
     if (n_chain_vertices) *n_chain_vertices = h.n_chain;
-    if (n_scan_segments) *n_scan_segments = e->dtype == PC_DTYPE_F32 ? h.n_scan : 0;
+    if (n_scan_segments) *n_scan_segments = (e->dtype == PC_DTYPE_F32 || h.sel_ok) ? h.n_scan : 0;
     return PC_OK;
 }
+
+int pc_env_last_rollout_kernel(const pc_env* e) { return e ? e->last_kernel : PC_ERR_INVALID_ARG; }
 
 int pc_env_launch_info(const pc_env* e, int* lanes_per_env, int* rays_per_lane, int* blocks, int* threads) {
     g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
@@ -1256,6 +1259,7 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
             else PC_FULL(PC_ROLL_LIT(5));
 #undef PC_ROLL_LIT
             HIPCHK(hipGetLastError());
+            e->last_kernel = PC_KERNEL_K9_LITERAL;
             return PC_OK;
         }
     }
@@ -1279,6 +1283,7 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
                                         //  the per-step kernels run that shape)
 #undef PC_ROLLD
     HIPCHK(hipGetLastError());
+    e->last_kernel = PC_KERNEL_K9D_FILTER;
     return PC_OK;
 }
 
@@ -1419,6 +1424,7 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
 #undef PC_ROLLS
 #undef PC_ROLL
     HIPCHK(hipGetLastError());
+    e->last_kernel = small ? PC_KERNEL_K9S : PC_KERNEL_K9;
     return PC_OK;
 }
 

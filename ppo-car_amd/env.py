@@ -265,6 +265,14 @@ class VecCarEnv:
         check(lib.pc_env_launch_info(self._h, *[C.byref(x) for x in v]), "pc_env_launch_info")
         return dict(lanes_per_env=v[0].value, rays_per_lane=v[1].value, blocks=v[2].value, threads=v[3].value)
 
+    def last_rollout_kernel(self):
+        """which persistent kernel the last pc_rollout on this handle launched: "K9", "K9s", "K9-literal", "K9d-filter" or "none" (every one fills the same buffers bit for bit)"""
+        from ._capi import PC_KERNEL_NAMES
+        code = lib.pc_env_last_rollout_kernel(self._h)
+        if code < 0:
+            check(code, "pc_env_last_rollout_kernel")
+        return PC_KERNEL_NAMES[code]
+
     def set_lanes_per_env(self, lanes):
         check(lib.pc_env_set_lanes_per_env(self._h, int(lanes)), "pc_env_set_lanes_per_env")
 

@@ -119,3 +119,103 @@ def test_f64_shapes_outside_the_persistent_menu_fall_back_to_the_per_step_kernel
     snap = _snap(tr)
     tr.close()
     _oracle_exact(cfg, snap, first, TRACKS["big_track"], np.arange(0, 512, 4))
+
+
+# ---- the SELECTOR form of the persistent float64 rollout (PC_KERNEL_K9_LITERAL: K9 with the literal arithmetic behind the float32 sweep)
+
+def _cross_track(path, start=(560.0, 135.0), angle=0.0):
+    """Two plus-shaped wall loops (12 walls each: the chain-packed sweep's layout) on INTEGER pixel coordinates, the start pose on the
+    line of an inner wall, heading along an axis: rays run exactly through vertices, exactly along walls and exactly parallel to
+    them -- every tie the literal arithmetic decides by its roundings (cast_exact's comment) -- at every reset and beyond."""
+    import json
+    W, H = 1280.0, 720.0
+    outer = [(480, 90), (800, 90), (800, 270), (1120, 270), (1120, 450), (800, 450), (800, 630), (480, 630), (480, 450), (160, 450), (160, 270),
+             (480, 270), (480, 90)]
+    inner = [(560, 180), (720, 180), (720, 315), (960, 315), (960, 405), (720, 405), (720, 540), (560, 540), (560, 405), (320, 405), (320, 315),
+             (560, 315), (560, 180)]
+    gates = [(704, 90), (704, 180), (880, 270), (880, 315), (1120, 360), (960, 360), (880, 450), (880, 405)]
+    frac = lambda pts: [[x / W, y / H] for x, y in pts]
+    for x, y in outer + inner:
+        assert (x / W) * W == x and (y / H) * H == y      # the loader's x * 1280, y * 720 give the integers back
+    with open(path, "w") as f:
+        json.dump({"outer_track_points": frac(outer), "inner_track_points": frac(inner), "reward_gates": frac(gates),
+                   "initial_position": [start[0] / W, start[1] / H], "initial_angle": angle}, f)
+    return str(path)
+
+
+def _rollouts(cfg_kw, n_rollouts=2):
+    tr = Trainer(PPOConfig(**cfg_kw), device="cuda")
+    first = tr.next_obs.clone()
+    snaps, kernels = [], []
+    for _ in range(n_rollouts):
+        tr.rollout()
+        torch.cuda.synchronize()
+        snaps.append(_snap(tr))
+        kernels.append(tr.envs.last_rollout_kernel() if tr.rollout_mode == "mega" else tr.rollout_mode)
+        tr.buffer.ptr = 0
+    state = tr.envs.get_state()
+    tr.close()
+    return first, snaps, kernels, state
+
+
+def test_f64_selector_form_runs_by_default_and_equals_the_filter_form_bit_for_bit():
+    """big_track, 16 rays: the default dispatch of an F64 handle is the selector form; PC_OPT_ROLLOUT_FAST = 0 takes the filter form
+    (every ray x wall pair in float64); both fill every buffer and leave the float64 state with the same bits -- two rollouts each,
+    the second from mid-episode states -- and a sample of the envs replays through the oracle bit for bit."""
+    kw = dict(n_envs=8192, n_steps=160, num_rays=16, track=TRACKS["big_track"], env_dtype="f64", use_graphs=False, seed=33, rollout_kernel="mega")
+    first, sel, k_sel, st_sel = _rollouts(dict(kw))
+    _, fil, k_fil, st_fil = _rollouts(dict(kw, rollout_fast=0))
+    assert k_sel == ["K9-literal"] * 2 and k_fil == ["K9d-filter"] * 2, (k_sel, k_fil)
+    for ep in range(2):
+        for i, (a, b) in enumerate(zip(sel[ep][:10], fil[ep][:10])):
+            assert torch.equal(a, b), (ep, i)
+    for k in st_sel:
+        assert np.array_equal(st_sel[k], st_fil[k]), k
+    cfg = PPOConfig(**kw)
+    assert _oracle_exact(cfg, sel[0], first, TRACKS["big_track"], np.arange(0, 8192, 32)) > 0
+
+
+@pytest.mark.parametrize("start,angle", [((560.0, 135.0), 0.0), ((640.0, 135.0), 90.0), ((480.0 + 40.0, 180.0), 45.0)])
+def test_f64_selector_form_on_a_track_of_ties(tmp_path, start, angle):
+    """The cross track (integer coordinates, axis-parallel walls, the start pose on a wall's line): rays through vertices, along walls,
+    parallel to walls.  The selector form flags what float32 cannot decide and resolves it with the literal loop over all walls:
+    bitwise the per-step float64 kernels, and bitwise the oracle for every env replayed."""
+    track = _cross_track(tmp_path / "cross.json", start, angle)
+    kw = dict(n_envs=4096, n_steps=128, num_rays=16, track=track, env_dtype="f64", use_graphs=False, seed=5, policy_split=0)
+    first, mega, k_mega, st_mega = _rollouts(dict(kw, rollout_kernel="mega"))
+    _, steps, k_steps, st_steps = _rollouts(dict(kw, rollout_kernel="steps"))
+    assert k_mega == ["K9-literal"] * 2 and k_steps == ["steps-eager"] * 2, (k_mega, k_steps)
+    for ep in range(2):
+        for i, (a, b) in enumerate(zip(mega[ep][:10], steps[ep][:10])):
+            assert torch.equal(a, b), (ep, i)
+    for k in st_mega:
+        assert np.array_equal(st_mega[k], st_steps[k]), k
+    cfg = PPOConfig(**kw)
+    assert _oracle_exact(cfg, mega[0], first, track, np.arange(0, 4096, 16)) > 0
+
+
+def test_f64_selector_form_needs_rotations_on_the_table_and_set_state_can_take_them_off():
+    """pc_env_set_state with a rotation no episode reaches (or a row further from start_rot than the env's time step allows): the
+    next pc_rollout takes the filter form -- which hashes / evaluates such angles -- and still equals the per-step kernels; after
+    pc_env_reset the selector form is back."""
+    res = {}
+    for mode in ("mega", "steps"):
+        tr = Trainer(PPOConfig(n_envs=2048, n_steps=48, num_rays=16, track=TRACKS["big_track"], env_dtype="f64", use_graphs=False, seed=8,
+                               rollout_kernel=mode, policy_split=0), device="cuda")
+        st = tr.envs.get_state()
+        rot = st["rot"].copy()
+        rot[::7] += 0.125                 # not start_rot + 5 k: no row of the rotation table
+        tr.envs.set_state(rot=rot)
+        tr.rollout()
+        torch.cuda.synchronize()
+        res[mode] = _snap(tr)
+        if mode == "mega":
+            assert tr.envs.last_rollout_kernel() == "K9d-filter"
+            tr.next_obs.copy_(tr.envs.reset()[0])
+            tr.buffer.ptr = 0
+            tr.rollout()
+            torch.cuda.synchronize()
+            assert tr.envs.last_rollout_kernel() == "K9-literal"
+        tr.close()
+    for i, (a, b) in enumerate(zip(res["mega"][:10], res["steps"][:10])):      # (obs row 0 is the pre-set_state observation in both)
+        assert torch.equal(a, b), i
