@@ -1221,9 +1221,10 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
     hipStream_t st = (hipStream_t)stream;
     // ---- the SELECTOR form: K9 itself (rollout_kernel<..., LIT>) -- the float32 sweep picks each ray's wall, the reference's literal
     // float64 arithmetic measures it (env_step_fast's literal form, lit_fast / lit_careful).  What it needs: every track inside the
-    // selector's limits with its rotation table built, the chain-packed sweep's layout (two equal loops of 13 -- big_track.json --
-    // or, mixed, of 13 or 9 vertices), every env's rotation a row of that table for the rest of its episode (f64_offgrid), the
-    // fast modes' shape (16 nominal rays, fp16 x 2 policy arithmetic) and LDS for the tables.  Anything else: the filter form below.
+    // selector's limits with its rotation table built, every env's rotation a row of that table for the rest of its episode
+    // (f64_offgrid), the fast modes' shape (12 or 16 nominal rays, fp16 x 2 policy arithmetic, PC_OPT_ROLLOUT_FAST not 0) and LDS for
+    // the tables and the 1/den table.  The sweep is chosen as for F32 handles: chain-packed for two equal loops of 13 vertices
+    // (big_track.json) or, mixed, of 13 or 9; the generic sweeps for any other track.  Anything else: the filter form below.
     {
         int max_G = 0, max_nV = 0;
         bool all_nv28 = e->opt.nv28 != 0, all_loops = e->opt.nv28 != 0, tabs = true;
@@ -1237,26 +1238,29 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
         const int img = polx_image_dwords(prec, pol_ng(KS));
         const int rden_lds = 361 * max_nV;
         const size_t lds_sel = (size_t)(img + 256 * e->D + 256 + ft_floats(false, true) + rden_lds) * sizeof(float);
-        const bool shape = KS == 6 && rpl == 9 && prec == 2 && e->n_nominal == 16 && e->D >= 17 && e->D <= 40 && max_G <= TAB_MAX_GATES &&
+        const bool rays16 = KS == 6 && rpl == 9 && e->n_nominal == 16, rays12 = KS == 5 && rpl == 6 && e->n_nominal == 12;
+        const bool shape = (rays16 || rays12) && prec == 2 && e->D >= 17 && e->D <= 40 && max_G <= TAB_MAX_GATES &&
                            max_nV <= FT_VTX_MAX && e->opt.fast && e->opt.rden != 0 && (!e->track_id || e->track_block >= epw) &&
                            lds_sel <= 160 * 1024;
-        if (tabs && shape && !e->f64_offgrid && (all_nv28 || all_loops)) {
+        if (tabs && shape && !e->f64_offgrid) {
             const int vec_ok = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
             EnvParams<float> prm = e->params<float>();
             prm.lg = 1;
-#define PC_ROLL_LIT(MD)                                                                                                  \
+#define PC_ROLL_LIT(KSV, RPLV, MD)                                                                                       \
     do {                                                                                                                 \
         static bool attr_set[64] = {false};                                                                              \
         if (e->device >= 64 || !attr_set[e->device]) {                                                                    \
-            HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<6, 9, 2, MD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<KSV, RPLV, 2, MD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             if (e->device < 64) attr_set[e->device] = true;                                                                \
         }                                                                                                                \
-        hipLaunchKernelGGL((rollout_kernel<6, 9, 2, MD, true>), dim3(blocks), dim3(512), lds_sel, st, prm, image, A, (int)T, reward_scale, seed, \
+        hipLaunchKernelGGL((rollout_kernel<KSV, RPLV, 2, MD, true>), dim3(blocks), dim3(512), lds_sel, st, prm, image, A, (int)T, reward_scale, seed, \
                            offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs,  \
                            next_term, next_trunc, rden_lds, epw, vec_ok, last_value, reward_sum);                        \
     } while (0)
-            if (all_nv28) PC_DEV(3, PC_ROLL_LIT(3));
-            else PC_FULL(PC_ROLL_LIT(5));
+            if (rays16 && all_nv28) PC_DEV(3, PC_ROLL_LIT(6, 9, 3));            // big_track.json's layout
+            else if (rays16 && all_loops) PC_FULL(PC_ROLL_LIT(6, 9, 5));        // ... mixed with track.json's
+            else if (rays16) PC_FULL(PC_ROLL_LIT(6, 9, 2));                     // any other track: the generic sweeps
+            else PC_FULL(PC_ROLL_LIT(5, 6, 2));                                 // 12 rays
 #undef PC_ROLL_LIT
             HIPCHK(hipGetLastError());
             e->last_kernel = PC_KERNEL_K9_LITERAL;

@@ -123,7 +123,7 @@ def test_f64_shapes_outside_the_persistent_menu_fall_back_to_the_per_step_kernel
 
 # ---- the SELECTOR form of the persistent float64 rollout (PC_KERNEL_K9_LITERAL: K9 with the literal arithmetic behind the float32 sweep)
 
-def _cross_track(path, start=(560.0, 135.0), angle=0.0):
+def _cross_track(path, start=(560.0, 135.0), angle=0.0, inner="plus"):
     """Two plus-shaped wall loops (12 walls each: the chain-packed sweep's layout) on INTEGER pixel coordinates, the start pose on the
     line of an inner wall, heading along an axis: rays run exactly through vertices, exactly along walls and exactly parallel to
     them -- every tie the literal arithmetic decides by its roundings (cast_exact's comment) -- at every reset and beyond."""
@@ -133,6 +133,8 @@ def _cross_track(path, start=(560.0, 135.0), angle=0.0):
              (480, 270), (480, 90)]
     inner = [(560, 180), (720, 180), (720, 315), (960, 315), (960, 405), (720, 405), (720, 540), (560, 540), (560, 405), (320, 405), (320, 315),
              (560, 315), (560, 180)]
+    if inner == "octagon":      # 12 + 8 walls: NOT two equal loops -- the generic sweeps instead of the chain-packed one
+        inner = [(600, 180), (680, 180), (760, 315), (760, 405), (680, 540), (600, 540), (520, 405), (520, 315), (600, 180)]
     gates = [(704, 90), (704, 180), (880, 270), (880, 315), (1120, 360), (960, 360), (880, 450), (880, 405)]
     frac = lambda pts: [[x / W, y / H] for x, y in pts]
     for x, y in outer + inner:
@@ -175,13 +177,16 @@ def test_f64_selector_form_runs_by_default_and_equals_the_filter_form_bit_for_bi
     assert _oracle_exact(cfg, sel[0], first, TRACKS["big_track"], np.arange(0, 8192, 32)) > 0
 
 
-@pytest.mark.parametrize("start,angle", [((560.0, 135.0), 0.0), ((640.0, 135.0), 90.0), ((480.0 + 40.0, 180.0), 45.0)])
-def test_f64_selector_form_on_a_track_of_ties(tmp_path, start, angle):
+@pytest.mark.parametrize("start,angle,inner,num_rays", [((560.0, 135.0), 0.0, "plus", 16), ((640.0, 135.0), 90.0, "plus", 16),
+                                                        ((520.0, 180.0), 45.0, "plus", 16), ((600.0, 135.0), 0.0, "octagon", 16),
+                                                        ((560.0, 135.0), 0.0, "plus", 12), ((600.0, 135.0), 180.0, "octagon", 12)])
+def test_f64_selector_form_on_a_track_of_ties(tmp_path, start, angle, inner, num_rays):
     """The cross track (integer coordinates, axis-parallel walls, the start pose on a wall's line): rays through vertices, along walls,
     parallel to walls.  The selector form flags what float32 cannot decide and resolves it with the literal loop over all walls:
-    bitwise the per-step float64 kernels, and bitwise the oracle for every env replayed."""
-    track = _cross_track(tmp_path / "cross.json", start, angle)
-    kw = dict(n_envs=4096, n_steps=128, num_rays=16, track=track, env_dtype="f64", use_graphs=False, seed=5, policy_split=0)
+    bitwise the per-step float64 kernels, and bitwise the oracle for every env replayed.  Two equal loops take the chain-packed sweep,
+    the octagon variant (12 + 8 walls) and 12 rays the generic ones."""
+    track = _cross_track(tmp_path / "cross.json", start, angle, inner)
+    kw = dict(n_envs=4096, n_steps=128, num_rays=num_rays, track=track, env_dtype="f64", use_graphs=False, seed=5, policy_split=0)
     first, mega, k_mega, st_mega = _rollouts(dict(kw, rollout_kernel="mega"))
     _, steps, k_steps, st_steps = _rollouts(dict(kw, rollout_kernel="steps"))
     assert k_mega == ["K9-literal"] * 2 and k_steps == ["steps-eager"] * 2, (k_mega, k_steps)
@@ -219,3 +224,20 @@ def test_f64_selector_form_needs_rotations_on_the_table_and_set_state_can_take_t
         tr.close()
     for i, (a, b) in enumerate(zip(res["mega"][:10], res["steps"][:10])):      # (obs row 0 is the pre-set_state observation in both)
         assert torch.equal(a, b), i
+
+
+def test_f64_selector_form_on_walls_that_cross_and_touch(tmp_path):
+    """test_env_gpu's junction track (a T-junction and two walls that cross: segments the host marks PC_SEG_SCAN, where a float32
+    selector cannot order hits by looking at chain neighbours): every ray that selects one of them takes the literal loop over all
+    walls.  Bitwise the per-step float64 kernels and the oracle -- with NO tolerance, unlike the float32 dtype on this track."""
+    from test_env_gpu import _junction_track_json
+    track = _junction_track_json(str(tmp_path / "junction.json"))
+    kw = dict(n_envs=4096, n_steps=160, num_rays=16, track=track, env_dtype="f64", use_graphs=False, seed=19, policy_split=0)
+    first, mega, k_mega, st_mega = _rollouts(dict(kw, rollout_kernel="mega"), 1)
+    _, steps, k_steps, st_steps = _rollouts(dict(kw, rollout_kernel="steps"), 1)
+    assert k_mega == ["K9-literal"] and k_steps == ["steps-eager"]
+    for i, (a, b) in enumerate(zip(mega[0][:10], steps[0][:10])):
+        assert torch.equal(a, b), i
+    for k in st_mega:
+        assert np.array_equal(st_mega[k], st_steps[k]), k
+    assert _oracle_exact(PPOConfig(**kw), mega[0], first, track, np.arange(0, 4096, 16)) > 0
