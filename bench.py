@@ -27,7 +27,8 @@ Extra objects on the JSON line:
                   this box for a bounded sample (`host_cores`, `usable_cores`, `threads` stated; `env_only_value` = CarEnv.step alone,
                   `value` = env + torch-CPU policy; `env_only_one_thread_value` beside the reference's Python figure per core).
   exact_f64_value -- the same workload with the env in float64 throughout (dtype "f64": bit-exact against the reference, state included),
-                  3 epochs after the timed region: the throughput of the configuration that is exact BY CONSTRUCTION.
+                  3 epochs after the timed region: the throughput of the configuration that is exact BY CONSTRUCTION (`kernel` names the
+                  persistent kernel that ran: "K9-literal" = float32 selection + the reference's literal arithmetic).
   other_workloads -- every other single-GPU BASELINE configuration (cfg1 = configs[1], cfg2 = configs[2], cfg4 = the per-GPU shard of
                   configs[4]; `target` when another workload is the headline), 5 epochs each after the timed region, with its own
                   ms_per_step, rollout-launch duration by HIP events and roofline fraction.
@@ -375,6 +376,7 @@ def main():
                                f"n_envs={c_.n_envs}, n_steps={c_.n_steps}, batch_size={c_.batch_size}, train_iters={c_.train_iters}",
                    "value": units_ * epochs / d_, "unit": "env steps/s", "epochs": epochs, "ms_per_step": d_ / epochs * 1e3,
                    "dtype": env_dtype, "rollout": t_.rollout_mode,
+                   "kernel": t_.envs.last_rollout_kernel() if t_.rollout_mode == "mega" else "per-step kernels",
                    "epoch_split": {"rollout_ms": r_ms, "gae_update_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in t_.phase_events]))},
                    "roofline": {"bound": "valu", "launch_us": sec_ * 1e6,
                                 "launch_us_method": ("HIP events on the launch stream around each pc_rollout launch inside the timed epochs" if mega is not None
@@ -595,12 +597,14 @@ def main():
                                              if world > 1 else None),
                        "replicas_bit_identical": replicas_equal,      # (None on one rank)
                        "env_kernel": info, "policy_step": args.policy, "rollout": rollout_mode,
+                       "rollout_kernel": tr.envs.last_rollout_kernel() if rollout_mode == "mega" else "per-step kernels",
                        "policy_gemm_arithmetic": POLICY_ARITH, "hip_graphs": bool(cfg.use_graphs),
                        "fused_update": bool(cfg.fused_update), "custom_mlp_update": custom, "epoch_split": split,
                        "env_knobs": knobs, "ablate_build": int(_lib.pc_build_ablate()),
                        "numerics": "float64 kinematic state; float32 selection of each ray's wall segment, float64 refinement of the selected "
                                    "segment (observations, < 10 px tests)" if args.env_dtype == "f32"
-                       else "float64 throughout (reference operation order)"},
+                       else "float64 throughout: every value in the reference's operation order (glibc cos / sin by table); a float32 sweep only selects "
+                            "which wall each ray's literal cast is evaluated on (ties and near-ties resolved by the literal loop over all walls)"},
             "roofline": roof,
         }
         traffic_file = os.path.join(ROOT, "profiles", "k1_traffic.json")

@@ -129,12 +129,15 @@ __device__ __forceinline__ LitR cast_ref_t(double x1, double y1, double x2, doub
     const double x4 = x3 + dx, y4 = y3 + dy;                                  // :169
     const double den = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4);         // :171
     const double t = ((x1 - x3) * (y3 - y4) - (y1 - y3) * (x3 - x4)) / den;   // :175
-    const double u = -((x1 - x2) * (y1 - y3) - (y1 - y2) * (x1 - x3)) / den;  // :176
+    // u = -un / den (:176) enters only through `u > 0` (:178): with IEEE division that is "the numerator -un and den are nonzero
+    // and of one sign" (a quotient of these magnitudes cannot underflow to zero) -- no second division
+    const double un = (x1 - x2) * (y1 - y3) - (y1 - y2) * (x1 - x3);
+    const bool u_pos = ((un < 0) & (den > 0)) | ((un > 0) & (den < 0));
     const double ptx = x1 + t * (x2 - x1), pty = y1 + t * (y2 - y1);          // :180-181
     const double d0 = x3 - ptx, d1 = y3 - pty;
     const double d = sqrt(fma(d1, d1, d0 * d0));
     LitR r;
-    r.hit = (0 < t) & (t < 1) & (u > 0) & (den != 0);                         // :172, :178
+    r.hit = (0 < t) & (t < 1) & u_pos;                                        // :172 (den == 0: u_pos is false), :178
     r.t = t;
     r.d = r.hit ? d : 1000.0;
     return r;

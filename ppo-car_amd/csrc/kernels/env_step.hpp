@@ -452,7 +452,10 @@ __device__ __forceinline__ void wall_sweep_loops(const VtxP* vp, const float pxr
 // 2^lg lanes of this group hold in `st` (updated in place, identically in every lane).  Lane g sweeps rays
 // g, g + G, ...  Observation entries go to orow (global row), frow (pre-reset obs, optional) and lrow (an LDS
 // copy for the persistent rollout kernel, optional).  The per-env scalars come back in registers.
-template <typename T, int RPL, int PARTS = 1, bool TAB = false, bool TWOPASS = false>
+// SEL (T = double, the per-step kernel): on a track inside the selector's limits (TrackHdr::sel_ok) the walls are not tested pair by
+// pair: the float32 sweep selects each ray's wall and the literal arithmetic measures it (lit_fast / lit_careful, env_math.hpp) --
+// the same bits as the filter form below, which stays for every other track and for the persistent filter kernel (K9d).
+template <typename T, int RPL, int PARTS = 1, bool TAB = false, bool TWOPASS = false, bool SEL = false>
 __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int trk, const int g, const int lg, EnvRegs& st,
                                               const int64_t a, const double reward_scale, float* __restrict__ orow,
                                               float* __restrict__ frow, float* lrow, float& reward_f, bool& term, bool& trunc,
@@ -656,6 +659,52 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
                 todo &= todo - 1;
             }
         }
+    } else if (SEL && h.sel_ok) {      // (wave-uniform)
+        // F64 on a track the float32 selector handles: the sweep on the literal directions rounded to float32 (what it is priced for:
+        // flag_threshold), then the reference's literal arithmetic on each selection.  A slot without a ray sweeps slot 0's direction
+        // (a zero direction would flag its pair partner at every step) and is not looked at.
+        float dxf[RPL], dyf[RPL];
+        int di[RPL];
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const bool valid = g + s * G < p.R;
+            dxf[s] = valid ? (float)dx[s] : (float)dx[0];
+            dyf[s] = valid ? (float)dy[s] : (float)dy[0];
+            di[s] = 0;
+        }
+        unsigned bb[2 * ((RPL + 1) / 2)];
+        wall_sweep_f32<RPL, 1, false>(p.vtx + h.vtx_off, h.nV, 0, (float)(npx - h.ax0), (float)(npy - h.ay0), dxf, dyf, di, nullptr,
+                                      flag_threshold(h, npx, npy), h.idx_mask, bb);
+        const SegD* sg64 = p.seg64 + h.vtx_off;      // (F64 handles: (ex, ey) carry the wall's second endpoint)
+        const auto segs = [sg64](const int k) { return sg64[k]; };
+        uint64_t todo = 0;
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            if (g + s * G < p.R) {
+                bool ok;
+                const double d = lit_fast(sg64[bb[s] & h.idx_mask], npx, npy, dx[s], dy[s], ok);
+                best[s] = d < 1000.0 ? d : 1000.0;      // :198
+                todo |= ok ? 0ull : 1ull << s;
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one literal cast at a time (see cast_ref_t)
+        }
+        while (__builtin_expect(__builtin_amdgcn_ballot_w64(todo != 0) != 0, 0)) {
+            const int s0 = todo ? __builtin_ctzll(todo) : -1;
+            unsigned sel = 0;
+            double ddx = 0.0, ddy = 0.0;
+#pragma unroll
+            for (int s = 0; s < RPL; ++s) {
+                sel = s == s0 ? bb[s] : sel;
+                ddx = s == s0 ? (double)dx[s] : ddx;
+                ddy = s == s0 ? (double)dy[s] : ddy;
+            }
+            if (s0 >= 0) {
+                const double d = lit_careful((int)(sel & h.idx_mask), segs, p.segs + h.wall_off, h.S, npx, npy, ddx, ddy);
+#pragma unroll
+                for (int s = 0; s < RPL; ++s) best[s] = s == s0 ? (d < 1000.0 ? d : 1000.0) : best[s];
+                todo &= todo - 1;
+            }
+        }
     } else {
         // F64: Ray.get_distance (:186-213) over all walls, the reference's own arithmetic -- in two passes per block of 32 walls.
         //   Pass 1 FILTERS: Ray.cast's numerators and denominator formed exactly as cast_ref forms them (the rounded differences
@@ -836,8 +885,8 @@ __device__ __forceinline__ void env_step_body(const EnvParams<T>& p, const int t
     float rw;
     bool term, trunc;
     int passed;
-    env_step_core<T, RPL>(p, trk, g, p.lg, st, actions[e], reward_scale, obs + (size_t)e * p.D,
-                          final_obs ? final_obs + (size_t)e * p.D : nullptr, nullptr, rw, term, trunc, passed);
+    env_step_core<T, RPL, 1, false, false, sizeof(T) == 8>(p, trk, g, p.lg, st, actions[e], reward_scale, obs + (size_t)e * p.D,
+                                                           final_obs ? final_obs + (size_t)e * p.D : nullptr, nullptr, rw, term, trunc, passed);
     if (g == 0) {
         reward[e] = rw;
         term_out[e] = term ? 1.0f : 0.0f;

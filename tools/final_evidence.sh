@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer tool (GPU box): the round's closing evidence in one call -- the full -m gpu suite, the default bench line, rocprofv3 --stats of
-# the bench command in the float64 dtype, the K9d PMC passes, the determinism check.  Output under gpurun_out/ (copy what is cited into profiles/).
+# the bench command in the float64 dtype, the PMC passes of both float64 persistent kernels, the determinism check.  Output under gpurun_out/ (copy what is cited into profiles/).
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd $ROOT
 mkdir -p gpurun_out/r5
@@ -18,6 +18,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r5/prof_f64 -
     > gpurun_out/r5/bench_under_prof_f64.json 2> gpurun_out/r5/prof_f64.err
 cp $(ls gpurun_out/r5/prof_f64/*/*kernel_stats.csv | head -1) gpurun_out/r5/f64_kernel_stats.csv; rm -rf gpurun_out/r5/prof_f64
 head -4 gpurun_out/r5/f64_kernel_stats.csv | cut -c1-140
-tools/pmc_k9d.sh r5d 2>&1 | tail -1
-python tools/pmc_summary.py gpurun_out/r5d/pmc r5_k9d_raw 65536 16 f64 rollout_f64_kernel 256 > gpurun_out/r5d/summary.json 2>/dev/null
+tools/pmc_k9d.sh r5d 2>&1 | tail -1          # the default dispatch of an F64 handle: K9 in its literal form (rollout_kernel<..., true>)
+python tools/pmc_summary.py gpurun_out/r5d/pmc r5_k9lit_raw 65536 16 f64 rollout_kernel 256 > gpurun_out/r5d/summary.json 2>/dev/null
+K9D_FAST=0 tools/pmc_k9d.sh r5d_filter 2>&1 | tail -1   # the filter form (PC_OPT_ROLLOUT_FAST = 0): rollout_f64_kernel
+python tools/pmc_summary.py gpurun_out/r5d_filter/pmc r5_k9d_raw 65536 16 f64 rollout_f64_kernel 256 > gpurun_out/r5d_filter/summary.json 2>/dev/null
 python tools/determinism_check.py 4 f64 2>&1 | grep -v amdgpu
