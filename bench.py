@@ -469,6 +469,7 @@ def main():
              "gae_update_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in tr.phase_events]))}
     mega_us = float(np.mean([a.elapsed_time(b) for a, b in tr.mega_events]) * 1e3) if tr.mega_events else None
     rollout_mode, obs_dim, custom = tr.rollout_mode, tr.obs_dim[0], bool(tr.learner.custom)
+    rollout_kernel_name = tr.envs.last_rollout_kernel() if rollout_mode == "mega" else "per-step kernels"
     captured = tr.learner._epoch_graph is not None
     tr.mega_events = None
     tr.phase_events = None
@@ -597,7 +598,7 @@ def main():
                                              if world > 1 else None),
                        "replicas_bit_identical": replicas_equal,      # (None on one rank)
                        "env_kernel": info, "policy_step": args.policy, "rollout": rollout_mode,
-                       "rollout_kernel": tr.envs.last_rollout_kernel() if rollout_mode == "mega" else "per-step kernels",
+                       "rollout_kernel": rollout_kernel_name,
                        "policy_gemm_arithmetic": POLICY_ARITH, "hip_graphs": bool(cfg.use_graphs),
                        "fused_update": bool(cfg.fused_update), "custom_mlp_update": custom, "epoch_split": split,
                        "env_knobs": knobs, "ablate_build": int(_lib.pc_build_ablate()),

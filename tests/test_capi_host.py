@@ -238,3 +238,25 @@ def test_bench_algorithmic_counts_are_surveys_figures_for_every_ray_count_and_tr
     assert b.step_flops(17, [16, 24]) == (b.step_flops(17, [16]) + b.step_flops(17, [24])) / 2
     host, usable, quota = b.usable_cpus()
     assert 1 <= usable <= host and (quota is None or quota > 0)
+
+
+def test_bench_main_never_reads_a_name_after_deleting_it_or_shadows_a_module_function():
+    """bench.py's main() is 400 lines that only run end to end on a GPU box: two slips of the kind a CPU suite can still catch --
+    a local read after its `del` (the trainer is deleted before the side measurements), a local that shadows a module-level
+    function it later calls."""
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    top = {n.name for n in tree.body if isinstance(n, ast.FunctionDef)}
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    own = lambda f: [n for n in ast.walk(f)]
+    deleted = {}
+    for n in own(main):
+        if isinstance(n, ast.Delete):
+            for tg in n.targets:
+                if isinstance(tg, ast.Name):
+                    deleted[tg.id] = max(deleted.get(tg.id, 0), n.lineno)
+    stores = {n.id for n in own(main) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store)}
+    late = [(n.id, n.lineno) for n in own(main) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id in deleted and n.lineno > deleted[n.id]]
+    # (names assigned again after their del -- tr2, tr3 inside their own blocks -- are stores, not loads; a load after the last del is the slip)
+    assert not late, late
+    assert not (stores & top), stores & top
