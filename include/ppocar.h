@@ -44,7 +44,9 @@ extern "C" {
                         * entry, the < 10 px tests) recomputed in float64 under the reference's strict test: the throughput path */
 #define PC_DTYPE_F64 1 /* float64 throughout, in the reference's operation order, with glibc's cos / sin values looked up for every
                         * angle an episode can reach (up to 16 tracks per handle; other angles use the device's): the exact-parity
-                        * path -- observations, rewards, events and the float64 state equal the reference's bit for bit */
+                        * path -- observations, rewards, events and the float64 state equal the reference's bit for bit.  (Where a
+                        * float32 sweep runs first it only chooses WHICH wall's literal cast is evaluated; every produced value is
+                        * the literal arithmetic's.) */
 
 typedef struct pc_track pc_track;
 typedef struct pc_env pc_env;
@@ -123,7 +125,8 @@ int pc_env_info(pc_env* e, int32_t* gates_passed, int32_t* time_passed, void* st
  *   PC_OPT_ROLLOUT_FAST  1 (default) = batches whose workgroups each lie on one track take the mode whose gather tables sit in LDS
  *                        behind LDS pointers -- at 16 (17) rays in the kernels compiled for the chain layout of the reference's tracks
  *                        when every track of the batch has it; 2 = that mode but never those specialised kernels; 0 = always the
- *                        generic mode (what mixed-track batches whose workgroups straddle tracks take) */
+ *                        generic mode (what mixed-track batches whose workgroups straddle tracks take).  F64 handles: 1 / 2 = the
+ *                        selector form (with / without the specialised sweeps), 0 = the filter form */
 #define PC_OPT_ROLLOUT_FORM 1
 #define PC_OPT_ROLLOUT_EPW 2
 #define PC_OPT_ROLLOUT_FAST 3
@@ -205,6 +208,10 @@ int pc_policy_act(const pc_policy* p, const float* obs, int64_t N, const float* 
  * F64 handles (PC_DTYPE_F64) take the same call: the launch then steps the env in the reference's own float64 (the per-step
  * kernel's env_step arithmetic, bit for bit: observations, rewards, events and the float64 state equal the reference's) -- Discrete(9),
  * the split-operand policy forms, 12 or 16 nominal rays; other shapes are PC_ERR_UNSUPPORTED (the caller's per-step kernels run them).
+ * Two kernels fill the same bits (pc_env_last_rollout_kernel says which ran): by default the selector form -- K9 with a float32
+ * sweep that only SELECTS each ray's wall and the reference's literal arithmetic on that wall (fp16 x 2 policy arithmetic, tracks of
+ * at most 8192 chain vertices inside 2000 px, every env's rotation one that reset and stepping produce) --, else the filter form,
+ * which tests every (ray, wall) pair in float64 (any track, any state, bf16 x 3 at 12 rays).
  * PC_ERR_UNSUPPORTED for mixed-track handles whose track ids change inside an aligned block of 32 envs, ray
  * counts whose slots per lane are not on the kernel menu (12 / 16 / 32 run the table-driven fast mode; 17 and 18 share the
  * slots of 16 and run the generic mode), shapes whose LDS footprint exceeds 160 KB (33 rays with the fp32 or bf16x3 weight
