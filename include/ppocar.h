@@ -207,11 +207,11 @@ int pc_policy_act(const pc_policy* p, const float* obs, int64_t N, const float* 
  *                of train.py:272's average reward without re-reading rew_buf.
  * F64 handles (PC_DTYPE_F64) take the same call: the launch then steps the env in the reference's own float64 (the per-step
  * kernel's env_step arithmetic, bit for bit: observations, rewards, events and the float64 state equal the reference's) -- Discrete(9),
- * the split-operand policy forms, 12 or 16 nominal rays; other shapes are PC_ERR_UNSUPPORTED (the caller's per-step kernels run them).
+ * the split-operand policy forms, 12, 16 or 32 nominal rays; other shapes are PC_ERR_UNSUPPORTED (the caller's per-step kernels run them).
  * Two kernels fill the same bits (pc_env_last_rollout_kernel says which ran): by default the selector form -- K9 with a float32
  * sweep that only SELECTS each ray's wall and the reference's literal arithmetic on that wall (fp16 x 2 policy arithmetic, tracks of
  * at most 8192 chain vertices inside 2000 px, every env's rotation one that reset and stepping produce) --, else the filter form,
- * which tests every (ray, wall) pair in float64 (any track, any state, bf16 x 3 at 12 rays).
+ * which tests every (ray, wall) pair in float64 (any track, any state, bf16 x 3 at 12 rays; not built for 32 rays).
  * PC_ERR_UNSUPPORTED for mixed-track handles whose track ids change inside an aligned block of 32 envs, ray
  * counts whose slots per lane are not on the kernel menu (12 / 16 / 32 run the table-driven fast mode; 17 and 18 share the
  * slots of 16 and run the generic mode), shapes whose LDS footprint exceeds 160 KB (33 rays with the fp32 or bf16x3 weight
@@ -351,8 +351,8 @@ int pc_env_track_info(const pc_env* e, int track, int* n_walls, int* n_chain_ver
  *   PC_KERNEL_K9          big form, float32-selector env step with float64 refinement (F32 handles)
  *   PC_KERNEL_K9S         small form (F32 handles, small batches)
  *   PC_KERNEL_K9_LITERAL  big form on an F64 handle: the float32 sweep selects each ray's wall, the reference's literal float64
- *                         arithmetic measures it (16 nominal rays, tracks of two equal wall loops, every env's rotation on the track's
- *                         rotation table: what reset and stepping produce)
+ *                         arithmetic measures it (12 / 16 / 32 nominal rays, tracks inside the selector's limits, every env's rotation
+ *                         on the track's rotation table: what reset and stepping produce)
  *   PC_KERNEL_K9D_FILTER  F64 handle, the filter form: every (ray, wall) pair in float64 (any track; 12 / 16 nominal rays) */
 #define PC_KERNEL_NONE 0
 #define PC_KERNEL_K9 1

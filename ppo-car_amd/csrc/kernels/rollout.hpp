@@ -831,7 +831,7 @@ __device__ __forceinline__ EnvParams<float> stage_tables(const EnvParams<float>&
 //         kernel schedules worse without the generic branch -- it spills -- and keeps it).
 //         MODE 5 = 2 for batches whose tracks are all two equal chains of 13 OR of 9 vertices (big_track.json and track.json
 //         mixed: BASELINE configs[4]): the chain-packed sweep for both lengths, chosen per workgroup.
-//         LIT (modes 2, 3 and 5): the handle is PC_DTYPE_F64 -- env_step_fast's literal form; state with the float64 rotation and
+//         LIT (the fast modes): the handle is PC_DTYPE_F64 -- env_step_fast's literal form; state with the float64 rotation and
 //         its row of the rotation table (env_load<double>).
 template <int KS, int RPL, int PREC, int MODE, bool LIT = false>
 __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, const float* __restrict__ image, const int A,
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const TrackHdr h0 = cload(p.hdr + trk_wg);
     EnvParams<float> q = p;
     FastTabs ft = {};
-    static_assert(!LIT || MODE == 2 || MODE == 3 || MODE == 5, "the literal form: fast modes with the 1/den table");
+    static_assert(!LIT || FAST, "the literal form: the fast modes (LDS tables)");
     if constexpr (FAST) ft = stage_fast_tables<false, RPL != 17, LIT>(p, h0, trk_wg, sTab, tid, 512);
     else q = stage_tables(p, sTab, tid, 512);
     // the track's 1/den table, when the host found room for it (rden_lds != 0; sized for the batch's largest track)

@@ -76,7 +76,8 @@
 // ------------------------------------------------------------------------------------------
 // Developer-only quick build (tools/ab_run.sh with -DPC_DEV_MIN=<mask>; never the product: the host layer refuses it like the
 // ablation build): the dispatch tables keep only the benchmarked kernels -- bit 0: rollout_kernel<6, 9, 2, 3> (target), bit 1:
-// rollout_small_kernel<6, 5, 2, 1, 16> (cfg1), bit 2: rollout_kernel<10, 17, 2, 1> (cfg2); the fp16x2 policy kernels, the
+// rollout_small_kernel<6, 5, 2, 1, 16> (cfg1), bit 2: rollout_kernel<10, 17, 2, 1> (cfg2), bits 3 / 5: the literal form of bits 0 / 2
+// for F64 handles, bit 4: rollout_f64_kernel<6, 9, 2> (the filter form); the fp16x2 policy kernels, the
 // float32 env-step kernels and the update kernels stay -- so that one kernel experiment compiles in seconds instead of 75.
 #ifdef PC_DEV_MIN
 #define PC_FULL(...) return PC_ERR_UNSUPPORTED
@@ -1222,8 +1223,8 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
     // ---- the SELECTOR form: K9 itself (rollout_kernel<..., LIT>) -- the float32 sweep picks each ray's wall, the reference's literal
     // float64 arithmetic measures it (env_step_fast's literal form, lit_fast / lit_careful).  What it needs: every track inside the
     // selector's limits with its rotation table built, every env's rotation a row of that table for the rest of its episode
-    // (f64_offgrid), the fast modes' shape (12 or 16 nominal rays, fp16 x 2 policy arithmetic, PC_OPT_ROLLOUT_FAST not 0) and LDS for
-    // the tables and the 1/den table.  The sweep is chosen as for F32 handles: chain-packed for two equal loops of 13 vertices
+    // (f64_offgrid), the fast modes' shape (12, 16 or 32 nominal rays, fp16 x 2 policy arithmetic, PC_OPT_ROLLOUT_FAST not 0) and LDS
+    // for the tables and (12 / 16 rays) the 1/den table.  The sweep is chosen as for F32 handles: chain-packed for two equal loops of 13 vertices
     // (big_track.json) or, mixed, of 13 or 9; the generic sweeps for any other track.  Anything else: the filter form below.
     {
         int max_G = 0, max_nV = 0;
@@ -1236,10 +1237,11 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
             all_loops = all_loops && h.vtxp_off >= 0 && (h.brk2 == 13 || h.brk2 == 9) && h.n_chain == 2 * h.brk2 && h.nV == 4 * ((h.brk2 + 1) / 2);
         }
         const int img = polx_image_dwords(prec, pol_ng(KS));
-        const int rden_lds = 361 * max_nV;
-        const size_t lds_sel = (size_t)(img + 256 * e->D + 256 + ft_floats(false, true) + rden_lds) * sizeof(float);
         const bool rays16 = KS == 6 && rpl == 9 && e->n_nominal == 16, rays12 = KS == 5 && rpl == 6 && e->n_nominal == 12;
-        const bool shape = (rays16 || rays12) && prec == 2 && e->D >= 17 && e->D <= 40 && max_G <= TAB_MAX_GATES &&
+        const bool rays33 = KS == 10 && rpl == 17 && e->n_nominal == 32;
+        const int rden_lds = rays33 ? 0 : 361 * max_nV;      // (33 rays: no room for the table -- the sweep forms 1/den itself, as for F32 handles)
+        const size_t lds_sel = (size_t)(img + 256 * e->D + 256 + ft_floats(false, !rays33) + rden_lds) * sizeof(float);
+        const bool shape = (rays16 || rays12 || rays33) && prec == 2 && e->D >= 17 && e->D <= 40 && max_G <= TAB_MAX_GATES &&
                            max_nV <= FT_VTX_MAX && e->opt.fast && e->opt.rden != 0 && (!e->track_id || e->track_block >= epw) &&
                            lds_sel <= 160 * 1024;
         if (tabs && shape && !e->f64_offgrid) {
@@ -1260,6 +1262,7 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
             if (rays16 && all_nv28) PC_DEV(3, PC_ROLL_LIT(6, 9, 3));            // big_track.json's layout
             else if (rays16 && all_loops) PC_FULL(PC_ROLL_LIT(6, 9, 5));        // ... mixed with track.json's
             else if (rays16) PC_FULL(PC_ROLL_LIT(6, 9, 2));                     // any other track: the generic sweeps
+            else if (rays33) PC_DEV(5, PC_ROLL_LIT(10, 17, 1));                 // 32 -> 33 rays: no room for the 1/den table
             else PC_FULL(PC_ROLL_LIT(5, 6, 2));                                 // 12 rays
 #undef PC_ROLL_LIT
             HIPCHK(hipGetLastError());

@@ -107,18 +107,27 @@ def test_f64_persistent_rollout_mixed_tracks_and_whole_epochs():
     tr.close()
 
 
-def test_f64_shapes_outside_the_persistent_menu_fall_back_to_the_per_step_kernels():
-    """33 rays in float64 (17 ray slots per lane beside the policy state: not built) -> pc_rollout answers PC_ERR_UNSUPPORTED and the
-    trainer runs the per-step kernels: the rollout still happens, bit-exact against the oracle."""
-    cfg = PPOConfig(n_envs=512, n_steps=48, num_rays=32, track=TRACKS["big_track"], env_dtype="f64", use_graphs=False, seed=2)
-    tr = Trainer(cfg, device="cuda")
-    first = tr.next_obs.clone()
-    tr.rollout()
-    torch.cuda.synchronize()
-    assert tr.rollout_mode == "steps-eager"
-    snap = _snap(tr)
-    tr.close()
-    _oracle_exact(cfg, snap, first, TRACKS["big_track"], np.arange(0, 512, 4))
+def test_f64_at_33_rays_selector_form_and_the_fallback_to_the_per_step_kernels():
+    """33 rays in float64: the selector form runs it as one persistent launch (17 ray slots per lane in two sweep passes, no 1/den
+    table: K9's cfg2 kernel with the literal arithmetic); the FILTER form is not built at that width (17 float64 slots beside the
+    policy state spilled) -- with PC_OPT_ROLLOUT_FAST = 0 pc_rollout answers PC_ERR_UNSUPPORTED and the trainer runs the per-step
+    kernels.  Bitwise each other and bit-exact against the oracle."""
+    res = {}
+    for fast in (1, 0):
+        cfg = PPOConfig(n_envs=2048, n_steps=64, num_rays=32, track=TRACKS["big_track"], env_dtype="f64", use_graphs=False, seed=2, rollout_fast=fast,
+                        policy_split=0)
+        tr = Trainer(cfg, device="cuda")
+        first = tr.next_obs.clone()
+        tr.rollout()
+        torch.cuda.synchronize()
+        assert tr.rollout_mode == ("mega" if fast else "steps-eager")
+        if fast:
+            assert tr.envs.last_rollout_kernel() == "K9-literal"
+        res[fast] = _snap(tr)
+        tr.close()
+    for i, (a, b) in enumerate(zip(res[1][:10], res[0][:10])):
+        assert torch.equal(a, b), i
+    assert _oracle_exact(cfg, res[1], first, TRACKS["big_track"], np.arange(0, 2048, 8)) > 0
 
 
 # ---- the SELECTOR form of the persistent float64 rollout (PC_KERNEL_K9_LITERAL: K9 with the literal arithmetic behind the float32 sweep)
