@@ -332,7 +332,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
 #pragma unroll
         for (int jj = 0; jj < 4 / G; ++jj) {
             if constexpr (LIT) {
-                gate_hit |= cast_ref(gate.x1, gate.y1, gate.x2, gate.y2, opx, opy, gdir[jj].x, gdir[jj].y) < 10.0;  // :387,:390
+                gate_hit |= cast_ref_t(gate.x1, gate.y1, gate.x2, gate.y2, opx, opy, gdir[jj].x, gdir[jj].y).d < 10.0;  // :387,:390 (straight-line form, one division)
             } else {
                 const f64x2 cs = dir64_at(k80o + gq[jj]);
                 gate_hit |= cast_d(gate, opx, opy, cs.x, cs.y) < 10.0;  // :387,:390
