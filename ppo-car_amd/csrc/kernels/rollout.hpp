@@ -643,20 +643,34 @@ __device__ __forceinline__ void env_reset_fast(const TrackHdr& h, EnvRegs& st, i
 // ballot -- where the eight-wave form paid two LDS exchanges and two workgroup barriers per step (the selections, the verdicts)
 // plus the one between the draw and the env step (a wave draws for exactly the two envs it steps: the action never leaves it).
 // lane = 32 (env of the wave) + 4 part + g.
-template <int RPL, bool TAB>
+// LIT: the literal form for PC_DTYPE_F64 handles, as in env_step_fast (rotation table rows, cast_ref_t, lit_fast / lit_careful).
+template <int RPL, bool TAB, bool LIT = false>
 __device__ __forceinline__ bool env_step_wave(const EnvParams<float>& p, const TrackHdr& h, const FastTabs& ft, const FastLane& fl,
                                               const int gq0, const int g, const int part, EnvRegs& st, int& k72, const int a,
                                               const double reward_scale, lds_fp lrow, float& reward_f, float& term_f, float& trunc_f,
-                                              const int lane, const int t = 0, const int wave = 0) {   // (t, wave: the developer stamps)
+                                              const int lane, const int t = 0, const int wave = 0, f64x2* hcar = nullptr) {   // (t, wave: the developer stamps)
     constexpr int G = 4, PARTS = 8, NP = (RPL + 1) / 2;
+    const double2* rot_tab = p.dirtab64 + h.rot_off;      // LIT: the track's rotation table (see env_step_fast)
+    const int rot_ld = p.R + 2;
     static_assert(RPL <= PARTS && RPL <= 12, "one refinement per lane, one sweep pass");
     // ---- action, heading, Car.update physics: env_step_fast's, instruction for instruction
     const f64x2 Lf = ft.act[2 * a];
     const i32x2 Li = *(lds_ci2)(ft.act + 2 * a + 1);
     struct { double thrust, fric; int dk, fwd; } L = {Lf.x, Lf.y, Li.x, Li.y};
-    const f64x2 cs0 = ft.head[k72];
     const int k72n = ft.wrap[k72 + L.dk + 1];
-    const f64x2 cs1 = ft.head[k72n];
+    f64x2 cs0, cs1, gdir = {0.0, 0.0};
+    int kid_new = st.k;
+    if constexpr (LIT) {
+        cs0 = *hcar;
+        const double2* row = rot_tab + st.k * rot_ld;
+        const double2 lr = row[p.R], e = row[g * p.q];       // (rot - 5, rot + 5)'s rows; collision ray j = g at the previous pose
+        gdir = (f64x2){e.x, e.y};
+        if (L.dk < 0) kid_new = (int)lr.x;      // :440
+        if (L.dk > 0) kid_new = (int)lr.y;      // :442
+    } else {
+        cs0 = ft.head[k72];
+        cs1 = ft.head[k72n];
+    }
     double nvx = (st.vx + cs0.x * L.thrust) * L.fric, nvy = (st.vy + cs0.y * L.thrust) * L.fric;
     nvx = fmin(fmax(nvx, -10.0), 10.0);
     nvy = fmin(fmax(nvy, -10.0), 10.0);
@@ -681,7 +695,9 @@ __device__ __forceinline__ bool env_step_wave(const EnvParams<float>& p, const T
     const f64x4 gv = ft.gates[st.next];
     const Seg gate = {gv.x, gv.y, gv.z, gv.w};
     bool gate_hit;
-    {
+    if constexpr (LIT) {
+        gate_hit = cast_ref_t(gate.x1, gate.y1, gate.x2, gate.y2, opx, opy, gdir.x, gdir.y).d < 10.0;
+    } else {
         const f64x2 cs = *(lds_cd2)(size_t)(unsigned)(80 * k72 + gq0 + FT_D64_BYTES);
         gate_hit = cast_d(gate, opx, opy, cs.x, cs.y) < 10.0;
     }
@@ -713,21 +729,29 @@ __device__ __forceinline__ bool env_step_wave(const EnvParams<float>& p, const T
     for (int s = 1; s < RPL; ++s) sel = slot == s ? bb[s] : sel;
     const int ms = m0 + slot * fl.rstep;
     const bool is_last = slot == RPL - 1;
-    const f64x2 d64 = *(lds_cd2)(size_t)(unsigned)((is_last ? min(ms, m_last) : ms) + FT_D64_BYTES);
+    f64x2 d64;
+    if constexpr (LIT) {
+        const double2 e = rot_tab[kid_new * rot_ld + min(g + G * slot, p.R - 1)];
+        d64 = (f64x2){e.x, e.y};
+    } else {
+        d64 = *(lds_cd2)(size_t)(unsigned)((is_last ? min(ms, m_last) : ms) + FT_D64_BYTES);
+    }
     const SegD sg = segs((int)(sel & h.idx_mask));
     bool ok = true;
-    double d = refine_fast(sg, npx, npy, d64.x, d64.y, ok);
+    double d = LIT ? lit_fast(sg, npx, npy, d64.x, d64.y, ok) : refine_fast(sg, npx, npy, d64.x, d64.y, ok);
+    const auto obs_of = [](const double dd) { return LIT ? Math<double>::norm_dist(dd < 1000.0 ? dd : 1000.0) : obs_dist(dd); };   // :198, :593
     bool todo = active & !ok;
     const bool col = (bool)((fl.colmask >> slot) & 1) & active;
     bool hit = col & ok & (d < 10.0);                                                              // :387-390 on Car.check_collision's rays
     const lds_fp dst = is_last ? fl.llast : fl.lray + G * slot;
-    if (active) dst[0] = obs_dist(d);                                                              // :593
+    if (active) dst[0] = obs_of(d);
     PC_STAMP(8)
     while (__builtin_expect(__builtin_amdgcn_ballot_w64(todo) != 0, 0)) {   // the rare rest: the careful path
         if (todo) {
-            d = refine_careful((int)(sel & h.idx_mask), segs, h.nV, npx, npy, d64.x, d64.y);
+            if constexpr (LIT) d = lit_careful((int)(sel & h.idx_mask), segs, p.segs + h.wall_off, h.S, npx, npy, d64.x, d64.y);
+            else d = refine_careful((int)(sel & h.idx_mask), segs, h.nV, npx, npy, d64.x, d64.y);
             hit = col & (d < 10.0);
-            dst[0] = obs_dist(d);
+            dst[0] = obs_of(d);
             todo = false;
         }
     }
@@ -754,11 +778,16 @@ __device__ __forceinline__ bool env_step_wave(const EnvParams<float>& p, const T
     reward_f = (float)(rw * reward_scale);
     term_f = destroyed ? 1.0f : 0.0f;
     trunc_f = trunc ? 1.0f : 0.0f;
+    if constexpr (LIT) {      // the heading after the turn, read only now
+        const double2 e1 = rot_tab[kid_new * rot_ld];
+        cs1 = (f64x2){e1.x, e1.y};
+    }
     if (g == 0 && part == 0) {
-        lrow[0] = Math<float>::norm(npx, 1280.0);
-        lrow[1] = Math<float>::norm(npy, 720.0);
-        lrow[2] = Math<float>::norm(nvx, 10.0);
-        lrow[3] = Math<float>::norm(nvy, 10.0);
+        using M = Math<std::conditional_t<LIT, double, float>>;
+        lrow[0] = M::norm(npx, 1280.0);
+        lrow[1] = M::norm(npy, 720.0);
+        lrow[2] = M::norm(nvx, 10.0);
+        lrow[3] = M::norm(nvy, 10.0);
         lrow[4] = (float)cs1.x;
         lrow[5] = (float)cs1.y;
     }
@@ -766,7 +795,12 @@ __device__ __forceinline__ bool env_step_wave(const EnvParams<float>& p, const T
     st.py = npy;
     st.vx = nvx;
     st.vy = nvy;
-    st.k += L.dk;
+    if constexpr (LIT) {
+        st.k = kid_new;
+        *hcar = cs1;
+    } else {
+        st.k += L.dk;
+    }
     k72 = k72n;
     st.time = time;
     st.next = next;
@@ -1357,7 +1391,8 @@ __global__ __launch_bounds__(512) void rollout_f64_kernel(const EnvParams<double
 // 32 actions, then all 512 lanes run the env step with 16 lanes per env.  Three workgroup barriers per step.
 // MODE as in rollout_kernel: 0 = generic tables, env_step_core; 1 / 2 = single track, A = 9, every table in LDS behind LDS
 // pointers, env_step_fast (2: with the 1/den table), dense observation rows copied out by three waves in 16-byte stores.
-template <int KS, int RPL, int PREC, int MODE, int EPW>
+// LIT (EPW 16 only): the handle is PC_DTYPE_F64 -- env_step_wave's literal form, state with the rotation's row of the rotation table.
+template <int KS, int RPL, int PREC, int MODE, int EPW, bool LIT = false>
 __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<float> p, const float* __restrict__ image, const int A,
                                                             const int T, const double reward_scale, const uint64_t seed,
                                                             const uint64_t offset, const uint64_t* __restrict__ offset_dev,
@@ -1403,7 +1438,8 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     const TrackHdr h0 = cload(p.hdr + trk_wg);
     EnvParams<float> q = p;
     FastTabs ft = {};
-    if constexpr (FAST) ft = stage_fast_tables<true, true>(p, h0, trk_wg, sTab, tid, 512);
+    static_assert(!LIT || (EPW == 16 && FAST), "the literal form: wave-owned envs");
+    if constexpr (FAST) ft = stage_fast_tables<true, true, LIT>(p, h0, trk_wg, sTab, tid, 512);
     else q = stage_tables(p, sTab, tid, 512);
     // the track's 1/den table, when the host found room for it (rden_lds != 0; sized for the batch's largest track)
     float* sRden = sTab + (FAST ? ft_floats(true, true) : TAB_FLOATS);
@@ -1428,8 +1464,10 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     const int64_t e_wg = (int64_t)blockIdx.x * EPW;
     const int64_t e_env = e_wg + el;
     const bool e_valid = e_env < N;
+    using StateT = std::conditional_t<LIT, double, float>;
+    const EnvParams<StateT>& ps = reinterpret_cast<const EnvParams<StateT>&>(p);     // (one layout: EnvParams does not depend on its parameter)
     EnvRegs st = {};
-    if (e_valid) st = env_load<float>(p, e_env);
+    if (e_valid) st = env_load<StateT>(ps, e_env);
     // mixed-track batch: this wave's envs share one track (the host checked every aligned block of 32 envs)
     const int trk = p.track_id ? (int)p.track_id[e_valid ? e_env : N - 1] : 0;
     for (int f = g + 4 * part; f < (FAST ? D : 4 * KS); f += 4 * PARTS) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
@@ -1444,9 +1482,19 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
         gq[0] = (int)(size_t)ft.dir + 16 * g * p.q * p.step_deg;            // Car.get_passed_gate's ray j * (n // 4), j = g (byte address)
         k72 = Math<float>::mod72(st.k);
     }
+    f64x2 hcar = {1.0, 0.0};      // LIT: (cos, sin) of the env's current rotation (see rollout_kernel)
+    if constexpr (LIT) {
+        k72 = Math<float>::mod72((int)__builtin_rint((st.rot - h0.start_rot) / 5.0));
+        if (e_valid) {
+            const double2 e0 = p.dirtab64[h0.rot_off + st.k * (p.R + 2)];
+            hcar = (f64x2){e0.x, e0.y};
+        }
+        st.rot = 0.0;
+    }
     const lds_fp lrow = (lds_fp)(sObs + el * LDX);
     __syncthreads();
     asm volatile("" : "+v"(st.px), "+v"(st.py), "+v"(st.vx), "+v"(st.vy), "+v"(st.k), "+v"(st.time), "+v"(st.next), "+v"(st.passed), "+v"(k72));
+    if constexpr (LIT) asm volatile("" : "+v"(hcar));
 
     const int TT = last_val ? T + 1 : T;   // pc_rollout_ex: tail iteration t == T = the final observation's value only (see rollout_kernel)
     float rsum = 0.0f;
@@ -1543,8 +1591,8 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                     const int a0 = __builtin_amdgcn_readlane(act, 0), a1 = __builtin_amdgcn_readlane(act, 16);
                     const int a = e_valid ? (lane < 32 ? a0 : a1) : 8;
                     done = rden_lds   // (uniform)
-                        ? env_step_wave<RPL, true>(p, h0, ft, fl, gq[0], g, part, st, k72, a, reward_scale, lrow, rw, tf, cf, lane, t, wave)
-                        : env_step_wave<RPL, false>(p, h0, ft, fl, gq[0], g, part, st, k72, a, reward_scale, lrow, rw, tf, cf, lane, t, wave);
+                        ? env_step_wave<RPL, true, LIT>(p, h0, ft, fl, gq[0], g, part, st, k72, a, reward_scale, lrow, rw, tf, cf, lane, t, wave, &hcar)
+                        : env_step_wave<RPL, false, LIT>(p, h0, ft, fl, gq[0], g, part, st, k72, a, reward_scale, lrow, rw, tf, cf, lane, t, wave, &hcar);
                 } else {
                     const int a = e_valid ? sAct[el] : 8;
                     done = rden_lds   // (uniform)
@@ -1564,6 +1612,10 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                                 if (g + 4 * j < DC) lrow[g + 4 * j] = ro[j];
                         }
                         env_reset_fast(h0, st, k72);
+                        if constexpr (LIT) {
+                            const double2 e0 = p.dirtab64[h0.rot_off];      // row 0 = start_rot
+                            hcar = (f64x2){e0.x, e0.y};
+                        }
                     }
                 }
                 if (part == 0) {   // (uniform) the row-writing wave: per-env scalars
@@ -1617,7 +1669,8 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
         }
     }
     if (e_valid && g == 0 && part == 0) {
-        env_store<float>(p, e_env, st);
+        if constexpr (LIT) st.rot = p.dirtab64[h0.rot_off + st.k * (p.R + 2) + p.R + 1].x;
+        env_store<StateT>(ps, e_env, st);
         if (rew_sum) rew_sum[e_env] = rsum;
     }
 }

@@ -77,7 +77,7 @@
 // Developer-only quick build (tools/ab_run.sh with -DPC_DEV_MIN=<mask>; never the product: the host layer refuses it like the
 // ablation build): the dispatch tables keep only the benchmarked kernels -- bit 0: rollout_kernel<6, 9, 2, 3> (target), bit 1:
 // rollout_small_kernel<6, 5, 2, 1, 16> (cfg1), bit 2: rollout_kernel<10, 17, 2, 1> (cfg2), bits 3 / 5: the literal form of bits 0 / 2
-// for F64 handles, bit 4: rollout_f64_kernel<6, 9, 2> (the filter form); the fp16x2 policy kernels, the
+// for F64 handles, bit 4: rollout_f64_kernel<6, 9, 2> (the filter form), bit 6: the literal form of bit 1; the fp16x2 policy kernels, the
 // float32 env-step kernels and the update kernels stay -- so that one kernel experiment compiles in seconds instead of 75.
 #ifdef PC_DEV_MIN
 #define PC_FULL(...) return PC_ERR_UNSUPPORTED
@@ -1244,6 +1244,36 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
         const bool shape = (rays16 || rays12 || rays33) && prec == 2 && e->D >= 17 && e->D <= 40 && max_G <= TAB_MAX_GATES &&
                            max_nV <= FT_VTX_MAX && e->opt.fast && e->opt.rden != 0 && (!e->track_id || e->track_block >= epw) &&
                            lds_sel <= 160 * 1024;
+        // ... and up to 4096 envs at 16 rays the SMALL form (K9s at 16 envs per workgroup, wave-owned envs: env_step_wave's literal form),
+        // chosen as for F32 handles (PC_OPT_ROLLOUT_FORM / _EPW)
+        const RolloutOpts& o = e->opt;
+        const bool small = o.form == 1 || (o.form < 0 && e->N <= PC_SPLIT_MAX_ENVS);
+        const bool epw16 = o.epw_override == 16 || (o.epw_override == 0 && e->N <= 4096);
+        const int rden_small = 361 * max_nV;
+        size_t lds_small = (size_t)(img + 8 * 32 * 17 + 32 * 40 + 32 + 128 + ft_floats(true, true)) * sizeof(float);
+        const int rden_small_lds = (o.rden != 0 && lds_small + (size_t)rden_small * sizeof(float) <= 160 * 1024) ? rden_small : 0;
+        lds_small += (size_t)rden_small_lds * sizeof(float);
+        const bool shape_small = rays16 && prec == 2 && small && epw16 && max_G <= TAB_MAX_GATES && max_nV <= FT_VTX_MAX && o.fast &&
+                                 lds_small <= 160 * 1024;
+        if (tabs && shape_small && !e->f64_offgrid) {
+            const int vec_ok = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
+            EnvParams<float> prm = e->params<float>();
+            prm.lg = 2;
+            const int blocks_small = (int)((e->N + 15) / 16);
+            PC_DEV(6, {
+                static bool attr_set[64] = {false};
+                if (e->device >= 64 || !attr_set[e->device]) {
+                    HIPCHK(hipFuncSetAttribute((const void*)rollout_small_kernel<6, 5, 2, 1, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    if (e->device < 64) attr_set[e->device] = true;
+                }
+                hipLaunchKernelGGL((rollout_small_kernel<6, 5, 2, 1, 16, true>), dim3(blocks_small), dim3(512), lds_small, st, prm, image, A, (int)T,
+                                   reward_scale, seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf,
+                                   next_obs, next_term, next_trunc, rden_small_lds, vec_ok, last_value, reward_sum);
+            });
+            HIPCHK(hipGetLastError());
+            e->last_kernel = PC_KERNEL_K9S_LITERAL;
+            return PC_OK;
+        }
         if (tabs && shape && !e->f64_offgrid) {
             const int vec_ok = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
             EnvParams<float> prm = e->params<float>();

@@ -14,6 +14,18 @@ from conftest import TRACKS
 pytestmark = pytest.mark.gpu
 
 
+def _split(num_rays, n_envs, precision=2):
+    """the policy step's work decomposition whose bits the persistent launch reproduces: up to 4096 envs at 16 rays an F64 handle takes
+    the SMALL form (K9s, hidden tiles split over the waves: policy_kernel<SPLIT>'s summation order), else the big form (unsplit)"""
+    return 1 if (num_rays == 16 and n_envs <= 4096 and precision == 2) else 0
+
+
+def _expected_kernel(num_rays, n_envs, precision=2):
+    if precision != 2:
+        return "K9d-filter"
+    return "K9s-literal" if _split(num_rays, n_envs) else "K9-literal"
+
+
 def _snap(tr):
     b = tr.buffer
     return [t.clone() for t in (b.obs_buf, b.act_buf, b.rew_buf, b.val_buf, b.logprob_buf, b.term_buf, b.trunc_buf,
@@ -48,7 +60,7 @@ def test_f64_persistent_rollout_is_bitwise_the_per_step_kernels_and_the_oracle(n
     res, first = {}, None
     for mode in ("mega", "steps"):
         cfg = PPOConfig(n_envs=n_envs, n_steps=n_steps, num_rays=num_rays, track=TRACKS["big_track"], rollout_kernel=mode, env_dtype="f64",
-                        use_graphs=False, seed=21, policy_precision=precision, policy_split=0)
+                        use_graphs=False, seed=21, policy_precision=precision, policy_split=_split(num_rays, n_envs, precision))
         tr = Trainer(cfg, device="cuda")
         if first is None:
             first = tr.next_obs.clone()
@@ -56,6 +68,8 @@ def test_f64_persistent_rollout_is_bitwise_the_per_step_kernels_and_the_oracle(n
             tr.rollout()
             torch.cuda.synchronize()
             assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager"), tr.rollout_mode
+            if mode == "mega":
+                assert tr.envs.last_rollout_kernel() == _expected_kernel(num_rays, n_envs, precision)
             res[(mode, ep)] = _snap(tr)
             tr.buffer.ptr = 0
         res[mode + "_state"] = tr.envs.get_state()
@@ -92,7 +106,7 @@ def test_f64_persistent_rollout_mixed_tracks_and_whole_epochs():
     res = {}
     for mode in ("mega", "steps"):
         tr = Trainer(PPOConfig(n_envs=2048, n_steps=64, num_rays=16, track=tracks, rollout_kernel=mode, env_dtype="f64", use_graphs=False, seed=9,
-                               policy_split=0), device="cuda")
+                               policy_split=_split(16, 2048)), device="cuda")
         tr.rollout()
         torch.cuda.synchronize()
         assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
@@ -189,23 +203,25 @@ def test_f64_selector_form_runs_by_default_and_equals_the_filter_form_bit_for_bi
 @pytest.mark.parametrize("start,angle,inner,num_rays", [((560.0, 135.0), 0.0, "plus", 16), ((640.0, 135.0), 90.0, "plus", 16),
                                                         ((520.0, 180.0), 45.0, "plus", 16), ((600.0, 135.0), 0.0, "octagon", 16),
                                                         ((560.0, 135.0), 0.0, "plus", 12), ((600.0, 135.0), 180.0, "octagon", 12)])
-def test_f64_selector_form_on_a_track_of_ties(tmp_path, start, angle, inner, num_rays):
+@pytest.mark.parametrize("n_envs", [4096, 8192])
+def test_f64_selector_form_on_a_track_of_ties(tmp_path, start, angle, inner, num_rays, n_envs):
     """The cross track (integer coordinates, axis-parallel walls, the start pose on a wall's line): rays through vertices, along walls,
     parallel to walls.  The selector form flags what float32 cannot decide and resolves it with the literal loop over all walls:
     bitwise the per-step float64 kernels, and bitwise the oracle for every env replayed.  Two equal loops take the chain-packed sweep,
-    the octagon variant (12 + 8 walls) and 12 rays the generic ones."""
+    the octagon variant (12 + 8 walls) and 12 rays the generic ones; 4096 envs at 16 rays the small form (K9s, the sweep out of LDS)."""
     track = _cross_track(tmp_path / "cross.json", start, angle, inner)
-    kw = dict(n_envs=4096, n_steps=128, num_rays=num_rays, track=track, env_dtype="f64", use_graphs=False, seed=5, policy_split=0)
+    kw = dict(n_envs=n_envs, n_steps=128, num_rays=num_rays, track=track, env_dtype="f64", use_graphs=False, seed=5,
+              policy_split=_split(num_rays, n_envs))
     first, mega, k_mega, st_mega = _rollouts(dict(kw, rollout_kernel="mega"))
     _, steps, k_steps, st_steps = _rollouts(dict(kw, rollout_kernel="steps"))
-    assert k_mega == ["K9-literal"] * 2 and k_steps == ["steps-eager"] * 2, (k_mega, k_steps)
+    assert k_mega == [_expected_kernel(num_rays, n_envs)] * 2 and k_steps == ["steps-eager"] * 2, (k_mega, k_steps)
     for ep in range(2):
         for i, (a, b) in enumerate(zip(mega[ep][:10], steps[ep][:10])):
             assert torch.equal(a, b), (ep, i)
     for k in st_mega:
         assert np.array_equal(st_mega[k], st_steps[k]), k
     cfg = PPOConfig(**kw)
-    assert _oracle_exact(cfg, mega[0], first, track, np.arange(0, 4096, 16)) > 0
+    assert _oracle_exact(cfg, mega[0], first, track, np.arange(0, n_envs, n_envs // 256)) > 0
 
 
 def test_f64_selector_form_needs_rotations_on_the_table_and_set_state_can_take_them_off():
@@ -215,7 +231,7 @@ def test_f64_selector_form_needs_rotations_on_the_table_and_set_state_can_take_t
     res = {}
     for mode in ("mega", "steps"):
         tr = Trainer(PPOConfig(n_envs=2048, n_steps=48, num_rays=16, track=TRACKS["big_track"], env_dtype="f64", use_graphs=False, seed=8,
-                               rollout_kernel=mode, policy_split=0), device="cuda")
+                               rollout_kernel=mode, policy_split=0, rollout_form=0), device="cuda")
         st = tr.envs.get_state()
         rot = st["rot"].copy()
         rot[::7] += 0.125                 # not start_rot + 5 k: no row of the rotation table
@@ -229,24 +245,25 @@ def test_f64_selector_form_needs_rotations_on_the_table_and_set_state_can_take_t
             tr.buffer.ptr = 0
             tr.rollout()
             torch.cuda.synchronize()
-            assert tr.envs.last_rollout_kernel() == "K9-literal"
+            assert tr.envs.last_rollout_kernel() == "K9-literal"      # (rollout_form = 0: the big form at any batch size)
         tr.close()
     for i, (a, b) in enumerate(zip(res["mega"][:10], res["steps"][:10])):      # (obs row 0 is the pre-set_state observation in both)
         assert torch.equal(a, b), i
 
 
-def test_f64_selector_form_on_walls_that_cross_and_touch(tmp_path):
+@pytest.mark.parametrize("n_envs", [4096, 8192])
+def test_f64_selector_form_on_walls_that_cross_and_touch(tmp_path, n_envs):
     """test_env_gpu's junction track (a T-junction and two walls that cross: segments the host marks PC_SEG_SCAN, where a float32
     selector cannot order hits by looking at chain neighbours): every ray that selects one of them takes the literal loop over all
     walls.  Bitwise the per-step float64 kernels and the oracle -- with NO tolerance, unlike the float32 dtype on this track."""
     from test_env_gpu import _junction_track_json
     track = _junction_track_json(str(tmp_path / "junction.json"))
-    kw = dict(n_envs=4096, n_steps=160, num_rays=16, track=track, env_dtype="f64", use_graphs=False, seed=19, policy_split=0)
+    kw = dict(n_envs=n_envs, n_steps=160, num_rays=16, track=track, env_dtype="f64", use_graphs=False, seed=19, policy_split=_split(16, n_envs))
     first, mega, k_mega, st_mega = _rollouts(dict(kw, rollout_kernel="mega"), 1)
     _, steps, k_steps, st_steps = _rollouts(dict(kw, rollout_kernel="steps"), 1)
-    assert k_mega == ["K9-literal"] and k_steps == ["steps-eager"]
+    assert k_mega == [_expected_kernel(16, n_envs)] and k_steps == ["steps-eager"]
     for i, (a, b) in enumerate(zip(mega[0][:10], steps[0][:10])):
         assert torch.equal(a, b), i
     for k in st_mega:
         assert np.array_equal(st_mega[k], st_steps[k]), k
-    assert _oracle_exact(PPOConfig(**kw), mega[0], first, track, np.arange(0, 4096, 16)) > 0
+    assert _oracle_exact(PPOConfig(**kw), mega[0], first, track, np.arange(0, n_envs, n_envs // 256)) > 0
