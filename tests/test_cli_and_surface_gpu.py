@@ -301,7 +301,8 @@ def test_bench_default_line_carries_every_baseline_config_and_the_exact_dtype():
     """`python bench.py` as the driver runs it (shortened: 2 timed epochs): ONE JSON line whose headline is the target workload and
     which also holds the bit-exact dtype's value on the same workload, every other single-GPU BASELINE config with its own
     ms_per_step / launch duration / roofline fraction, the all-usable-cores CPU baseline with its core counts, and the live
-    parity check -- measured, finite, from the kernels the headline claims (persistent launches, K9d for f64)."""
+    parity check -- measured, finite, from the kernels the headline claims (persistent launches; for f64 K9's literal form, at
+    configs[1] inside the small form), and every other config in the bit-exact dtype as well."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -318,12 +319,16 @@ def test_bench_default_line_carries_every_baseline_config_and_the_exact_dtype():
     assert rf["bound"] == "valu" and 0.1 < rf["frac"] < 1.0 and rf["launch_us"] > 0 and rf["traffic"] is not None
     assert d["parity_check"]["ok"] is True
     e = d["exact_f64_value"]
-    assert e["dtype"] == "f64" and e["rollout"] == "mega" and e["value"] > 3e8 and 0 < e["roofline"]["frac"] < rf["frac"]
+    assert e["dtype"] == "f64" and e["rollout"] == "mega" and e["kernel"] == "K9-literal" and e["value"] > 1e9 and 0 < e["roofline"]["frac"] < rf["frac"]
+    assert d["config"]["rollout_kernel"] == "K9"
     ow = d["other_workloads"]
     assert set(ow) == {"cfg1", "cfg2", "cfg4"}
     for k, v in ow.items():
         assert "error" not in v, (k, v)
         assert v["rollout"] == "mega" and v["value"] > 1e8 and v["ms_per_step"] > 0 and 0 < v["roofline"]["frac"] < 1 and v["roofline"]["flops_per_env_step"] > 0
+        x = v["exact_f64"]
+        assert "error" not in x, (k, x)
+        assert x["kernel"] == ("K9s-literal" if k == "cfg1" else "K9-literal") and 0.5 * v["value"] < x["value"] < v["value"]
     assert "33 actual" in ow["cfg2"]["workload"] and "track.json + big_track.json" in ow["cfg4"]["workload"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["threads"] == c["cores"] == c["usable_cores"] <= c["host_cores"]
