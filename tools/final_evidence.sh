@@ -5,13 +5,13 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd $ROOT
 mkdir -p gpurun_out/r5
 python -m pytest tests -m gpu -q > gpurun_out/final_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/final_pytest.log | cut -c1-200
-python bench.py > gpurun_out/r5_bench_target.json 2> gpurun_out/r5_bench_target.err
+(time python bench.py > gpurun_out/r5_bench_target.json 2> gpurun_out/r5_bench_target.err) 2>&1 | grep real
 python - <<'PY'
 import json
 d = json.load(open("gpurun_out/r5_bench_target.json"))
 e = d["exact_f64_value"]
 print(round(d["value"] / 1e6), round(d["ms_per_step"], 2), round(d["roofline"]["frac"], 3), "| f64", round(e["value"] / 1e6), round(e["ms_per_step"], 2),
-      round(e["roofline"]["launch_us"]), round(e["roofline"]["frac"], 3), round(e["roofline"]["hbm_frac"], 3), "|", {k: round(v["value"] / 1e6) for k, v in d["other_workloads"].items()})
+      round(e["roofline"]["launch_us"]), round(e["roofline"]["frac"], 3), round(e["roofline"]["hbm_frac"], 3), "|", {k: (round(v["value"] / 1e6), round(v["exact_f64"]["value"] / 1e6), v["exact_f64"]["kernel"]) for k, v in d["other_workloads"].items()})
 PY
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r5/prof_f64 -- python3 bench.py --env-dtype f64 --steps 3 --warmup 1 --no-cpu-baseline --no-extras \
