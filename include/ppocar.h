@@ -117,7 +117,7 @@ int pc_env_info(pc_env* e, int32_t* gates_passed, int32_t* time_passed, void* st
 
 /* Per-handle launch options of pc_rollout (below).  Every choice gives bit-identical buffers; they exist so that the variant a
  * benchmark size takes can be checked at other batch sizes, and for A/B timing.
- *   PC_OPT_ROLLOUT_FORM  -1 (default) automatic: above 16384 envs independent waves of 32 envs, 256 envs per workgroup (128 up to
+ *   PC_OPT_ROLLOUT_FORM  -1 (default) automatic: above 8192 envs independent waves of 32 envs, 256 envs per workgroup (128 up to
  *                        32768 envs), else 16 / 32 envs per workgroup with the policy's hidden tiles and the wall sweep split over the
  *                        waves; 0 / 1 force the first / second form; 2 / 3 = forms 0 / 1 with the env step forming 1/den
  *                        arithmetically instead of reading the track's 1/den table from LDS (what happens anyway when it does not fit)
@@ -168,7 +168,7 @@ int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, 
  *                scaled domain.  Needs D <= 40, A <= 9, else the shape gets form 0.
  *              1 bf16x3: three bf16 pieces per operand, six piece products (v_mfma_f32_16x16x32_bf16); 1.0e-7; same shapes.
  *              0 fp32-input MFMA (v_mfma_f32_16x16x4_f32), bit-for-bit an fp32 fmaf chain.
- *   split      -1 automatic (hidden tiles split across the waves of a workgroup up to 16384 envs), 0 never, 1 always; the two
+ *   split      -1 automatic (hidden tiles split across the waves of a workgroup up to 8192 envs), 0 never, 1 always; the two
  *              forms differ in fp32 summation order (last-bit differences).
  * pc_policy_create: PC_ERR_UNSUPPORTED unless H == 256, A <= 15, D <= 40 (the caller then uses its own GEMMs + pc_sample).
  * pc_policy_get reports the form the shape actually got and the number of floats its weight image needs.

@@ -259,7 +259,7 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
                                               const int wave = 0, const int part = 0, float* exch = nullptr, const bool write_row = true,
                                               int* hitw = nullptr, f64x2* hcar = nullptr) {
     constexpr int G = 1 << LG;
-    static_assert(!LIT || (LG == 1 && PARTS == 1), "the literal form exists for the big form only");
+    static_assert(!LIT || PARTS != 8, "the literal form: the big form and the four-part small form (wave-owned envs take env_step_wave)");
     const double2* rot_tab = p.dirtab64 + h.rot_off;      // LIT: row k = the R rays' (cos, sin) at rotation k, then (row of rot - 5, row of rot + 5), (rot, -)
     const int rot_ld = p.R + 2;
     // the float64 twin of the lattice entry at LDS byte address m (see FT_D64_BYTES)
@@ -332,7 +332,8 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
 #pragma unroll
         for (int jj = 0; jj < 4 / G; ++jj) {
             if constexpr (LIT) {
-                gate_hit |= cast_ref_t(gate.x1, gate.y1, gate.x2, gate.y2, opx, opy, gdir[jj].x, gdir[jj].y).d < 10.0;  // :387,:390 (straight-line form, one division)
+                gate_hit |= cast_ref(gate.x1, gate.y1, gate.x2, gate.y2, opx, opy, gdir[jj].x, gdir[jj].y) < 10.0;  // :387,:390 (the branchy form: the
+                                                                                                                          // straight-line one costs the mixed-track kernel 14 spilled registers)
             } else {
                 const f64x2 cs = dir64_at(k80o + gq[jj]);
                 gate_hit |= cast_d(gate, opx, opy, cs.x, cs.y) < 10.0;  // :387,:390
@@ -1391,7 +1392,7 @@ __global__ __launch_bounds__(512) void rollout_f64_kernel(const EnvParams<double
 // 32 actions, then all 512 lanes run the env step with 16 lanes per env.  Three workgroup barriers per step.
 // MODE as in rollout_kernel: 0 = generic tables, env_step_core; 1 / 2 = single track, A = 9, every table in LDS behind LDS
 // pointers, env_step_fast (2: with the 1/den table), dense observation rows copied out by three waves in 16-byte stores.
-// LIT (EPW 16 only): the handle is PC_DTYPE_F64 -- env_step_wave's literal form, state with the rotation's row of the rotation table.
+// LIT: the handle is PC_DTYPE_F64 -- env_step_wave's / env_step_fast's literal form, state with the rotation's row of the rotation table.
 template <int KS, int RPL, int PREC, int MODE, int EPW, bool LIT = false>
 __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<float> p, const float* __restrict__ image, const int A,
                                                             const int T, const double reward_scale, const uint64_t seed,
@@ -1438,7 +1439,7 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     const TrackHdr h0 = cload(p.hdr + trk_wg);
     EnvParams<float> q = p;
     FastTabs ft = {};
-    static_assert(!LIT || (EPW == 16 && FAST), "the literal form: wave-owned envs");
+    static_assert(!LIT || FAST, "the literal form: the fast modes");
     if constexpr (FAST) ft = stage_fast_tables<true, true, LIT>(p, h0, trk_wg, sTab, tid, 512);
     else q = stage_tables(p, sTab, tid, 512);
     // the track's 1/den table, when the host found room for it (rden_lds != 0; sized for the batch's largest track)
@@ -1596,8 +1597,8 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 } else {
                     const int a = e_valid ? sAct[el] : 8;
                     done = rden_lds   // (uniform)
-                        ? env_step_fast<RPL, true, 2, PARTS>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0, sHit + el * PARTS)
-                        : env_step_fast<RPL, false, 2, PARTS>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0, sHit + el * PARTS);
+                        ? env_step_fast<RPL, true, 2, PARTS, 0, true, LIT>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0, sHit + el * PARTS, &hcar)
+                        : env_step_fast<RPL, false, 2, PARTS, 0, true, LIT>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0, sHit + el * PARTS, &hcar);
                 }
                 rsum += rw;
                 if (__builtin_amdgcn_ballot_w64(done) != 0) {

@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 
 def _split(num_rays, n_envs, precision=2):
     """the policy step's work decomposition whose bits the persistent launch reproduces: up to 4096 envs at 16 rays an F64 handle takes
-    the SMALL form (K9s, hidden tiles split over the waves: policy_kernel<SPLIT>'s summation order), else the big form (unsplit)"""
-    return 1 if (num_rays == 16 and n_envs <= 4096 and precision == 2) else 0
+    the SMALL form (up to 8192 envs; K9s, hidden tiles split over the waves: policy_kernel<SPLIT>'s summation order), else the big form (unsplit)"""
+    return 1 if (num_rays == 16 and n_envs <= 8192 and precision == 2) else 0
 
 
 def _expected_kernel(num_rays, n_envs, precision=2):
@@ -184,10 +184,10 @@ def _rollouts(cfg_kw, n_rollouts=2):
 
 
 def test_f64_selector_form_runs_by_default_and_equals_the_filter_form_bit_for_bit():
-    """big_track, 16 rays: the default dispatch of an F64 handle is the selector form; PC_OPT_ROLLOUT_FAST = 0 takes the filter form
+    """big_track, 16 rays, 20480 envs (the big form): the default dispatch of an F64 handle is the selector form; PC_OPT_ROLLOUT_FAST = 0 takes the filter form
     (every ray x wall pair in float64); both fill every buffer and leave the float64 state with the same bits -- two rollouts each,
     the second from mid-episode states -- and a sample of the envs replays through the oracle bit for bit."""
-    kw = dict(n_envs=8192, n_steps=160, num_rays=16, track=TRACKS["big_track"], env_dtype="f64", use_graphs=False, seed=33, rollout_kernel="mega")
+    kw = dict(n_envs=20480, n_steps=160, num_rays=16, track=TRACKS["big_track"], env_dtype="f64", use_graphs=False, seed=33, rollout_kernel="mega")
     first, sel, k_sel, st_sel = _rollouts(dict(kw))
     _, fil, k_fil, st_fil = _rollouts(dict(kw, rollout_fast=0))
     assert k_sel == ["K9-literal"] * 2 and k_fil == ["K9d-filter"] * 2, (k_sel, k_fil)
@@ -197,18 +197,19 @@ def test_f64_selector_form_runs_by_default_and_equals_the_filter_form_bit_for_bi
     for k in st_sel:
         assert np.array_equal(st_sel[k], st_fil[k]), k
     cfg = PPOConfig(**kw)
-    assert _oracle_exact(cfg, sel[0], first, TRACKS["big_track"], np.arange(0, 8192, 32)) > 0
+    assert _oracle_exact(cfg, sel[0], first, TRACKS["big_track"], np.arange(0, 20480, 80)) > 0
 
 
 @pytest.mark.parametrize("start,angle,inner,num_rays", [((560.0, 135.0), 0.0, "plus", 16), ((640.0, 135.0), 90.0, "plus", 16),
                                                         ((520.0, 180.0), 45.0, "plus", 16), ((600.0, 135.0), 0.0, "octagon", 16),
                                                         ((560.0, 135.0), 0.0, "plus", 12), ((600.0, 135.0), 180.0, "octagon", 12)])
-@pytest.mark.parametrize("n_envs", [4096, 8192])
+@pytest.mark.parametrize("n_envs", [4096, 8192, 20480])
 def test_f64_selector_form_on_a_track_of_ties(tmp_path, start, angle, inner, num_rays, n_envs):
     """The cross track (integer coordinates, axis-parallel walls, the start pose on a wall's line): rays through vertices, along walls,
     parallel to walls.  The selector form flags what float32 cannot decide and resolves it with the literal loop over all walls:
     bitwise the per-step float64 kernels, and bitwise the oracle for every env replayed.  Two equal loops take the chain-packed sweep,
-    the octagon variant (12 + 8 walls) and 12 rays the generic ones; 4096 envs at 16 rays the small form (K9s, the sweep out of LDS)."""
+    the octagon variant (12 + 8 walls) and 12 rays the generic ones; 4096 / 8192 envs at 16 rays the small form's two variants (K9s,
+    the sweep out of LDS), 20480 the big form."""
     track = _cross_track(tmp_path / "cross.json", start, angle, inner)
     kw = dict(n_envs=n_envs, n_steps=128, num_rays=num_rays, track=track, env_dtype="f64", use_graphs=False, seed=5,
               policy_split=_split(num_rays, n_envs))
@@ -251,7 +252,7 @@ def test_f64_selector_form_needs_rotations_on_the_table_and_set_state_can_take_t
         assert torch.equal(a, b), i
 
 
-@pytest.mark.parametrize("n_envs", [4096, 8192])
+@pytest.mark.parametrize("n_envs", [4096, 8192, 20480])
 def test_f64_selector_form_on_walls_that_cross_and_touch(tmp_path, n_envs):
     """test_env_gpu's junction track (a T-junction and two walls that cross: segments the host marks PC_SEG_SCAN, where a float32
     selector cannot order hits by looking at chain neighbours): every ray that selects one of them takes the literal loop over all

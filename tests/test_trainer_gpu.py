@@ -225,7 +225,7 @@ def test_persistent_rollout_kernel_is_bitwise_the_two_kernel_rollout(num_rays, n
 
 
 def test_rollout_forms_agree_with_default_dispatch():
-    """Automatic dispatch: up to 16384 envs pc_rollout takes the 32-env-per-workgroup form and the per-step policy
+    """Automatic dispatch: up to 8192 envs pc_rollout takes the 32-env-per-workgroup form and the per-step policy
     kernel its split form -- the two must still be bit-identical (this is what a user switching rollout_kernel sees)."""
     res = {}
     for mode in ("steps", "mega"):
