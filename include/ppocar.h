@@ -210,7 +210,7 @@ int pc_policy_act(const pc_policy* p, const float* obs, int64_t N, const float* 
  * the split-operand policy forms, 12, 16 or 32 nominal rays; other shapes are PC_ERR_UNSUPPORTED (the caller's per-step kernels run them).
  * Two kernels fill the same bits (pc_env_last_rollout_kernel says which ran): by default the selector form -- K9 with a float32
  * sweep that only SELECTS each ray's wall and the reference's literal arithmetic on that wall (fp16 x 2 policy arithmetic, tracks of
- * at most 8192 chain vertices inside 2000 px, every env's rotation one that reset and stepping produce; up to 4096 envs at 16 rays
+ * at most 8192 chain vertices inside 2000 px, every env's rotation one that reset and stepping produce; up to 8192 envs at 12 / 16 rays
  * inside the small form, whose policy arithmetic is the split policy step's) --, else the filter form,
  * which tests every (ray, wall) pair in float64 (any track, any state, bf16 x 3 at 12 rays; not built for 32 rays).
  * PC_ERR_UNSUPPORTED for mixed-track handles whose track ids change inside an aligned block of 32 envs, ray
@@ -354,7 +354,7 @@ int pc_env_track_info(const pc_env* e, int track, int* n_walls, int* n_chain_ver
  *   PC_KERNEL_K9_LITERAL  big form on an F64 handle: the float32 sweep selects each ray's wall, the reference's literal float64
  *                         arithmetic measures it (12 / 16 / 32 nominal rays, tracks inside the selector's limits, every env's rotation
  *                         on the track's rotation table: what reset and stepping produce)
- *   PC_KERNEL_K9S_LITERAL the same literal form inside the small form (F64 handles, 16 nominal rays, up to 4096 envs)
+ *   PC_KERNEL_K9S_LITERAL the same literal form inside the small form (F64 handles, 12 / 16 nominal rays, up to 8192 envs)
  *   PC_KERNEL_K9D_FILTER  F64 handle, the filter form: every (ray, wall) pair in float64 (any track; 12 / 16 nominal rays) */
 #define PC_KERNEL_NONE 0
 #define PC_KERNEL_K9 1

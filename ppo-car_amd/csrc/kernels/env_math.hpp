@@ -96,6 +96,15 @@ template <typename T> struct EnvParams {
     const SegD* __restrict__ seg64;         // F32 only: the wall chains for the refinement, indexed like vtx
     const struct F64Dir* __restrict__ dirhash;   // F64 only: glibc's cos / sin of every angle an episode can reach (Math<double>)
     const float* __restrict__ reset_obs;    // [n_tracks][D]
+    // The parameter only selects the arithmetic of the functions that take the struct (Math<T>, env_load<T>): the members do not depend
+    // on it.  A kernel launched with EnvParams<float> that steps an F64 handle (the persistent kernels' literal form) reads the state
+    // through the same members under the other name.
+    template <typename U> __host__ __device__ EnvParams<U> as() const {
+        static_assert(sizeof(EnvParams<U>) == sizeof(EnvParams<T>), "one layout");
+        EnvParams<U> q;
+        __builtin_memcpy(&q, this, sizeof(q));
+        return q;
+    }
 };
 
 #define PC_PI 3.141592653589793238462643383279502884 /* NPY_PI */

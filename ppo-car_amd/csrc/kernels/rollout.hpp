@@ -946,7 +946,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const int64_t e_env = e_wave + (lane >> 1);
     const bool e_valid = e_env < N;
     using StateT = std::conditional_t<LIT, double, float>;
-    const EnvParams<StateT>& ps = reinterpret_cast<const EnvParams<StateT>&>(p);     // (one layout: EnvParams does not depend on its parameter)
+    const EnvParams<StateT> ps = p.template as<StateT>();
     EnvRegs st = {};
     if (e_valid) st = env_load<StateT>(ps, e_env);
     // mixed-track batch: this wave's envs share one track (the host checked every aligned block of 32 envs)
@@ -1466,7 +1466,7 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     const int64_t e_env = e_wg + el;
     const bool e_valid = e_env < N;
     using StateT = std::conditional_t<LIT, double, float>;
-    const EnvParams<StateT>& ps = reinterpret_cast<const EnvParams<StateT>&>(p);     // (one layout: EnvParams does not depend on its parameter)
+    const EnvParams<StateT> ps = p.template as<StateT>();
     EnvRegs st = {};
     if (e_valid) st = env_load<StateT>(ps, e_env);
     // mixed-track batch: this wave's envs share one track (the host checked every aligned block of 32 envs)

@@ -1247,7 +1247,7 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
         const bool shape = (rays16 || rays12 || rays33) && prec == 2 && e->D >= 17 && e->D <= 40 && max_G <= TAB_MAX_GATES &&
                            max_nV <= FT_VTX_MAX && e->opt.fast && e->opt.rden != 0 && (!e->track_id || e->track_block >= epw) &&
                            lds_sel <= 160 * 1024;
-        // ... and up to 16384 envs at 16 rays the SMALL form (K9s: 16 envs per workgroup up to 4096 envs, wave-owned envs -- env_step_wave's
+        // ... and up to PC_SPLIT_MAX_ENVS envs at 12 / 16 rays the SMALL form (K9s: 16 envs per workgroup up to 4096 envs, wave-owned envs -- env_step_wave's
         // literal form --, else 32 with the sweep parts on four waves), chosen as for F32 handles (PC_OPT_ROLLOUT_FORM / _EPW)
         const RolloutOpts& o = e->opt;
         const bool small = o.form == 1 || (o.form < 0 && e->N <= PC_SPLIT_MAX_ENVS);
@@ -1256,26 +1256,31 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
         size_t lds_small = (size_t)(img + 8 * 32 * 17 + 32 * 40 + 32 + 128 + ft_floats(true, true)) * sizeof(float);
         const int rden_small_lds = (o.rden != 0 && lds_small + (size_t)rden_small * sizeof(float) <= 160 * 1024) ? rden_small : 0;
         lds_small += (size_t)rden_small_lds * sizeof(float);
-        const bool shape_small = rays16 && prec == 2 && small && max_G <= TAB_MAX_GATES && max_nV <= FT_VTX_MAX && o.fast &&
+        const bool shape_small = (rays16 || rays12) && prec == 2 && small && max_G <= TAB_MAX_GATES && max_nV <= FT_VTX_MAX && o.fast &&
                                  lds_small <= 160 * 1024;
         if (tabs && shape_small && !e->f64_offgrid) {
             const int vec_ok = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
             EnvParams<float> prm = e->params<float>();
             prm.lg = 2;
-#define PC_ROLLS_LIT(EPWV)                                                                                               \
+#define PC_ROLLS_LIT(KSV, RPLV, EPWV)                                                                                    \
     do {                                                                                                                 \
         const int blocks_small = (int)((e->N + EPWV - 1) / EPWV);                                                        \
         static bool attr_set[64] = {false};                                                                              \
         if (e->device >= 64 || !attr_set[e->device]) {                                                                    \
-            HIPCHK(hipFuncSetAttribute((const void*)rollout_small_kernel<6, 5, 2, 1, EPWV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HIPCHK(hipFuncSetAttribute((const void*)rollout_small_kernel<KSV, RPLV, 2, 1, EPWV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             if (e->device < 64) attr_set[e->device] = true;                                                                \
         }                                                                                                                \
-        hipLaunchKernelGGL((rollout_small_kernel<6, 5, 2, 1, EPWV, true>), dim3(blocks_small), dim3(512), lds_small, st, prm, image, A, (int)T, \
+        hipLaunchKernelGGL((rollout_small_kernel<KSV, RPLV, 2, 1, EPWV, true>), dim3(blocks_small), dim3(512), lds_small, st, prm, image, A, (int)T, \
                            reward_scale, seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, \
                            next_obs, next_term, next_trunc, rden_small_lds, vec_ok, last_value, reward_sum);             \
     } while (0)
-            if (epw16) PC_DEV(6, PC_ROLLS_LIT(16));      // wave-owned envs (env_step_wave)
-            else PC_FULL(PC_ROLLS_LIT(32));              // four sweep parts = waves (env_step_fast<..., 2, 4>)
+            if (rays16) {
+                if (epw16) PC_DEV(6, PC_ROLLS_LIT(6, 5, 16));      // wave-owned envs (env_step_wave)
+                else PC_FULL(PC_ROLLS_LIT(6, 5, 32));              // four sweep parts = waves (env_step_fast<..., 2, 4>)
+            } else {                                               // 12 rays: three ray slots per lane
+                if (epw16) PC_FULL(PC_ROLLS_LIT(5, 3, 16));
+                else PC_FULL(PC_ROLLS_LIT(5, 3, 32));
+            }
 #undef PC_ROLLS_LIT
             HIPCHK(hipGetLastError());
             e->last_kernel = PC_KERNEL_K9S_LITERAL;

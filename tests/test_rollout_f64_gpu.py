@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 
 def _split(num_rays, n_envs, precision=2):
     """the policy step's work decomposition whose bits the persistent launch reproduces: up to 4096 envs at 16 rays an F64 handle takes
-    the SMALL form (up to 8192 envs; K9s, hidden tiles split over the waves: policy_kernel<SPLIT>'s summation order), else the big form (unsplit)"""
-    return 1 if (num_rays == 16 and n_envs <= 8192 and precision == 2) else 0
+    the SMALL form (12 / 16 rays, up to 8192 envs; K9s, hidden tiles split over the waves: policy_kernel<SPLIT>'s summation order), else the big form (unsplit)"""
+    return 1 if (num_rays in (12, 16) and n_envs <= 8192 and precision == 2) else 0
 
 
 def _expected_kernel(num_rays, n_envs, precision=2):
