@@ -112,18 +112,25 @@ def test_generated_circuit_steps_like_the_oracle_and_through_the_persistent_kern
             assert alive.mean() > 0.95, alive.mean()         # and (nearly) every env's events identical over 300 steps
         env.close()
     # the persistent rollout kernel on this track (1/den table too large for LDS above ~90 walls: arithmetic path)
-    res = {}
-    for mode in ("steps", "mega"):
-        cfg = PPOConfig(n_envs=512, n_steps=64, num_rays=n, track=path, rollout_kernel=mode, use_graphs=False, seed=3)
-        tr = Trainer(cfg, device="cuda")
-        tr.rollout()
-        torch.cuda.synchronize()
-        assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
-        b = tr.buffer
-        res[mode] = [x.clone() for x in (b.obs_buf, b.act_buf, b.rew_buf, b.term_buf, tr.next_obs)]
-        tr.close()
-    for x, y in zip(res["steps"], res["mega"]):
-        assert torch.equal(x, y)
+    # ... in both dtypes.  float64: 48 walls fit the selector's LDS tables (the small form's literal kernel, without the 1/den table);
+    # the larger circuits take the filter form, a big-form kernel (the unsplit policy arithmetic)
+    for dtype in ("f32", "f64"):
+        small_lit = dtype == "f64" and points == 24
+        res = {}
+        for mode in ("steps", "mega"):
+            cfg = PPOConfig(n_envs=512, n_steps=64, num_rays=n, track=path, rollout_kernel=mode, use_graphs=False, seed=3, env_dtype=dtype,
+                            policy_split=-1 if (dtype == "f32" or small_lit) else 0)
+            tr = Trainer(cfg, device="cuda")
+            tr.rollout()
+            torch.cuda.synchronize()
+            assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
+            if mode == "mega" and dtype == "f64":
+                assert tr.envs.last_rollout_kernel() == ("K9s-literal" if small_lit else "K9d-filter")
+            b = tr.buffer
+            res[mode] = [x.clone() for x in (b.obs_buf, b.act_buf, b.rew_buf, b.val_buf, b.term_buf, tr.next_obs)]
+            tr.close()
+        for x, y in zip(res["steps"], res["mega"]):
+            assert torch.equal(x, y), dtype
 
 
 def test_rasteriser_draws_track_car_and_rays(tmp_path):
