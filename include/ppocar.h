@@ -212,7 +212,8 @@ int pc_policy_act(const pc_policy* p, const float* obs, int64_t N, const float* 
  * sweep that only SELECTS each ray's wall and the reference's literal arithmetic on that wall (fp16 x 2 policy arithmetic, tracks of
  * at most 8192 chain vertices inside 2000 px, every env's rotation one that reset and stepping produce; up to 8192 envs at 12 / 16 rays
  * inside the small form, whose policy arithmetic is the split policy step's) --, else the filter form,
- * which tests every (ray, wall) pair in float64 (any track, any state, bf16 x 3 at 12 rays; not built for 32 rays).
+ * which tests every (ray, wall) pair in float64 (any track, any state, bf16 x 3 at 12 rays; not built for 32 rays); tracks of more
+ * than 64 chain vertices and rotations set off the table take the generic kernel with the selector step (PC_KERNEL_K9D_SELECTOR).
  * PC_ERR_UNSUPPORTED for mixed-track handles whose track ids change inside an aligned block of 32 envs, ray
  * counts whose slots per lane are not on the kernel menu (12 / 16 / 32 run the table-driven fast mode; 17 and 18 share the
  * slots of 16 and run the generic mode), shapes whose LDS footprint exceeds 160 KB (33 rays with the fp32 or bf16x3 weight
@@ -355,6 +356,8 @@ int pc_env_track_info(const pc_env* e, int track, int* n_walls, int* n_chain_ver
  *                         arithmetic measures it (12 / 16 / 32 nominal rays, tracks inside the selector's limits, every env's rotation
  *                         on the track's rotation table: what reset and stepping produce)
  *   PC_KERNEL_K9S_LITERAL the same literal form inside the small form (F64 handles, 12 / 16 nominal rays, up to 8192 envs)
+ *   PC_KERNEL_K9D_SELECTOR F64 handle, the generic kernel with the per-step kernel's selector step (sweep over the wall chain in
+ *                         global memory + literal cast): tracks of more than 64 chain vertices, bf16 x 3, rotations off the table
  *   PC_KERNEL_K9D_FILTER  F64 handle, the filter form: every (ray, wall) pair in float64 (any track; 12 / 16 nominal rays) */
 #define PC_KERNEL_NONE 0
 #define PC_KERNEL_K9 1
@@ -362,6 +365,7 @@ int pc_env_track_info(const pc_env* e, int track, int* n_walls, int* n_chain_ver
 #define PC_KERNEL_K9_LITERAL 3
 #define PC_KERNEL_K9D_FILTER 4
 #define PC_KERNEL_K9S_LITERAL 5
+#define PC_KERNEL_K9D_SELECTOR 6
 int pc_env_last_rollout_kernel(const pc_env* e);
 /* Override the lanes-per-env choice (power of two 1..64; 0 = automatic).  Tuning knob for bench.py. */
 int pc_env_set_lanes_per_env(pc_env* e, int lanes_per_env);

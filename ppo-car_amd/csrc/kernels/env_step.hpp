@@ -455,7 +455,9 @@ __device__ __forceinline__ void wall_sweep_loops(const VtxP* vp, const float pxr
 // SEL (T = double, the per-step kernel): on a track inside the selector's limits (TrackHdr::sel_ok) the walls are not tested pair by
 // pair: the float32 sweep selects each ray's wall and the literal arithmetic measures it (lit_fast / lit_careful, env_math.hpp) --
 // the same bits as the filter form below, which stays for every other track and for the persistent filter kernel (K9d).
-template <typename T, int RPL, int PARTS = 1, bool TAB = false, bool TWOPASS = false, bool SEL = false>
+// (SEL 0: never; 1: where the track allows it, decided at run time -- both forms compiled in; 2: always -- the host has checked every
+// track of the handle: the persistent generic kernel, which has no registers for both forms)
+template <typename T, int RPL, int PARTS = 1, bool TAB = false, bool TWOPASS = false, int SEL = 0>
 __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int trk, const int g, const int lg, EnvRegs& st,
                                               const int64_t a, const double reward_scale, float* __restrict__ orow,
                                               float* __restrict__ frow, float* lrow, float& reward_f, bool& term, bool& trunc,
@@ -659,22 +661,37 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
                 todo &= todo - 1;
             }
         }
-    } else if (SEL && h.sel_ok) {      // (wave-uniform)
+    } else if (SEL == 2 || (SEL == 1 && h.sel_ok)) {      // (wave-uniform)
         // F64 on a track the float32 selector handles: the sweep on the literal directions rounded to float32 (what it is priced for:
         // flag_threshold), then the reference's literal arithmetic on each selection.  A slot without a ray sweeps slot 0's direction
         // (a zero direction would flag its pair partner at every step) and is not looked at.
-        float dxf[RPL], dyf[RPL];
-        int di[RPL];
+        unsigned bb[2 * ((RPL + 1) / 2) + 2];
+        const float pxr = (float)(npx - h.ax0), pyr = (float)(npy - h.ay0), tau = flag_threshold(h, npx, npy);
+        // one pass over the chain for the slots [S0, S0 + RN): their float32 directions are formed here, not kept beside the float64 ones
+        auto sweep_pass = [&](auto S0C, auto RNC) {
+            constexpr int S0 = decltype(S0C)::value, RN = decltype(RNC)::value;
+            float dxf[RN], dyf[RN];
+            int di[RN];
 #pragma unroll
-        for (int s = 0; s < RPL; ++s) {
-            const bool valid = g + s * G < p.R;
-            dxf[s] = valid ? (float)dx[s] : (float)dx[0];
-            dyf[s] = valid ? (float)dy[s] : (float)dy[0];
-            di[s] = 0;
+            for (int s = 0; s < RN; ++s) {
+                const bool valid = g + (S0 + s) * G < p.R;
+                dxf[s] = valid ? (float)dx[S0 + s] : (float)dx[0];
+                dyf[s] = valid ? (float)dy[S0 + s] : (float)dy[0];
+                di[s] = 0;
+            }
+            unsigned ba[2 * ((RN + 1) / 2)];
+            wall_sweep_f32<RN, 1, false>(p.vtx + h.vtx_off, h.nV, 0, pxr, pyr, dxf, dyf, di, nullptr, tau, h.idx_mask, ba);
+#pragma unroll
+            for (int s = 0; s < RN; ++s) bb[S0 + s] = ba[s];
+        };
+        if constexpr (TWOPASS && RPL >= 9) {      // inside a persistent kernel: the slots in two passes over the chain (see the float32 branch)
+            constexpr int R1 = (RPL + 1) / 2;
+            sweep_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, R1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            sweep_pass(std::integral_constant<int, R1>{}, std::integral_constant<int, RPL - R1>{});
+        } else {
+            sweep_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, RPL>{});
         }
-        unsigned bb[2 * ((RPL + 1) / 2)];
-        wall_sweep_f32<RPL, 1, false>(p.vtx + h.vtx_off, h.nV, 0, (float)(npx - h.ax0), (float)(npy - h.ay0), dxf, dyf, di, nullptr,
-                                      flag_threshold(h, npx, npy), h.idx_mask, bb);
         const SegD* sg64 = p.seg64 + h.vtx_off;      // (F64 handles: (ex, ey) carry the wall's second endpoint)
         const auto segs = [sg64](const int k) { return sg64[k]; };
         uint64_t todo = 0;
@@ -705,7 +722,7 @@ __device__ __forceinline__ void env_step_core(const EnvParams<T>& p, const int t
                 todo &= todo - 1;
             }
         }
-    } else {
+    } else if constexpr (SEL != 2) {
         // F64: Ray.get_distance (:186-213) over all walls, the reference's own arithmetic -- in two passes per block of 32 walls.
         //   Pass 1 FILTERS: Ray.cast's numerators and denominator formed exactly as cast_ref forms them (the rounded differences
         //   x3 - x4, y3 - y4 included, :166-176) and the hit test `0 < t < 1 and u > 0` (:178) decided on them WITHOUT a division --
@@ -885,7 +902,7 @@ __device__ __forceinline__ void env_step_body(const EnvParams<T>& p, const int t
     float rw;
     bool term, trunc;
     int passed;
-    env_step_core<T, RPL, 1, false, false, sizeof(T) == 8>(p, trk, g, p.lg, st, actions[e], reward_scale, obs + (size_t)e * p.D,
+    env_step_core<T, RPL, 1, false, false, sizeof(T) == 8 ? 1 : 0>(p, trk, g, p.lg, st, actions[e], reward_scale, obs + (size_t)e * p.D,
                                                            final_obs ? final_obs + (size_t)e * p.D : nullptr, nullptr, rw, term, trunc, passed);
     if (g == 0) {
         reward[e] = rw;

@@ -1237,7 +1237,11 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
 // float64 wall records come through scalar loads, the direction hash table through the vector cache (both L2-resident).
 // Bit-identical to T x (policy_kernel<KS, false, PREC>; env_step_kernel<double>): same arithmetic, same Philox counters.
 // (train.py:173-195 with the env of car_env.py:693-760 in its own float64)
-template <int KS, int RPL, int PREC>
+// SEL (every track of the handle inside the selector's limits: host-checked): the env step is the per-step kernel's selector step (env_step_core<double, ..., SEL>: the
+// float32 sweep over the chain in global memory, then the literal cast) -- what a track too long for the LDS tables of K9's literal
+// kernels gets; without it every (ray, wall) pair is tested in float64 (the FILTER form).  Two instantiations: both paths in one
+// kernel spilled 43 registers.
+template <int KS, int RPL, int PREC, bool SEL = false>
 __global__ __launch_bounds__(512) void rollout_f64_kernel(const EnvParams<double> p, const float* __restrict__ image, const int A,
                                                           const int T, const double reward_scale, const uint64_t seed,
                                                           const uint64_t offset, const uint64_t* __restrict__ offset_dev,
@@ -1367,7 +1371,8 @@ __global__ __launch_bounds__(512) void rollout_f64_kernel(const EnvParams<double
             float rw;
             bool term, trunc;
             int passed;
-            env_step_core<double, RPL>(p, trk, g, 1, st, (int64_t)act_reg, reward_scale, orow, nullptr, sObs + el * LDX, rw, term, trunc, passed);
+            env_step_core<double, RPL, 1, false, true, SEL ? 2 : 0>(p, trk, g, 1, st, (int64_t)act_reg, reward_scale, orow, nullptr, sObs + el * LDX, rw, term,
+                                                             trunc, passed);
             rsum += rw;
             if (g == 0) {
                 rew_buf[(int64_t)t * N + e_env] = rw;

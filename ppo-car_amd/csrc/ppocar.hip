@@ -1314,25 +1314,37 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
     }
     const size_t lds = (size_t)(polx_image_dwords(prec, pol_ng(KS)) + 256 * (4 * KS + 1)) * sizeof(float);
     if (lds > 160 * 1024) return PC_ERR_UNSUPPORTED;
+    // K9d: the generic kernel.  With PC_OPT_ROLLOUT_FAST = 0 every (ray, wall) pair is tested in float64 (the FILTER form: no float32
+    // anywhere); otherwise tracks inside the selector's limits step as the per-step kernel does (sweep over the chain in global
+    // memory, literal cast: rollout_f64_kernel<..., SEL>) -- what is left for this kernel by default are tracks too long for the
+    // LDS tables and rotations off the table; bf16 x 3 keeps the filter.
+    bool all_sel = true;
+    for (const TrackHdr& h : e->hdr_host) all_sel = all_sel && h.sel_ok;
+    const int sel_on = (e->opt.fast && all_sel) ? 1 : 0;
     const EnvParams<double> prm = [&] { EnvParams<double> q = e->params<double>(); q.lg = 1; return q; }();
-#define PC_ROLLD(KSV, RPLV, PRC)                                                                                         \
+#define PC_ROLLD(KSV, RPLV, PRC, SELV)                                                                                   \
     do {                                                                                                                 \
         static bool attr_set[64] = {false};                                                                              \
         if (e->device >= 64 || !attr_set[e->device]) {                                                                    \
-            HIPCHK(hipFuncSetAttribute((const void*)rollout_f64_kernel<KSV, RPLV, PRC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HIPCHK(hipFuncSetAttribute((const void*)rollout_f64_kernel<KSV, RPLV, PRC, SELV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             if (e->device < 64) attr_set[e->device] = true;                                                                \
         }                                                                                                                \
-        hipLaunchKernelGGL((rollout_f64_kernel<KSV, RPLV, PRC>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, seed, \
+        hipLaunchKernelGGL((rollout_f64_kernel<KSV, RPLV, PRC, SELV>), dim3(blocks), dim3(512), lds, st, prm, image, A, (int)T, reward_scale, seed, \
                            offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs,  \
                            next_term, next_trunc, epw, last_value, reward_sum);                                          \
     } while (0)
-    if (KS == 5 && rpl == 6) { PC_FULL(if (prec == 2) PC_ROLLD(5, 6, 2); else PC_ROLLD(5, 6, 1)); }              // 12 rays, D = 18
-    else if (KS == 6 && rpl == 9) { if (prec == 2) PC_DEV(4, PC_ROLLD(6, 9, 2)); else return PC_ERR_UNSUPPORTED; }   // 16 -> 17 rays, D = 23 (bf16 x 3 there spills 3 registers: not built)
+    // (the selector variant for the fp16 x 2 forms only: bf16 x 3 -- 12 rays -- keeps the filter)
+    const bool sel_k = sel_on && prec == 2;
+    if (KS == 5 && rpl == 6) { PC_FULL(if (sel_k) PC_ROLLD(5, 6, 2, true); else if (prec == 2) PC_ROLLD(5, 6, 2, false); else PC_ROLLD(5, 6, 1, false)); }              // 12 rays, D = 18
+    else if (KS == 6 && rpl == 9) {                                                                                    // 16 -> 17 rays, D = 23 (bf16 x 3 there spills 3 registers: not built)
+        if (prec != 2) return PC_ERR_UNSUPPORTED;
+        if (sel_k) PC_FULL(PC_ROLLD(6, 9, 2, true)); else PC_DEV(4, PC_ROLLD(6, 9, 2, false));
+    }
     else return PC_ERR_UNSUPPORTED;     // (32 -> 33 rays: 17 float64 ray slots per lane beside the policy state spill 96 registers -- not built;
                                         //  the per-step kernels run that shape)
 #undef PC_ROLLD
     HIPCHK(hipGetLastError());
-    e->last_kernel = PC_KERNEL_K9D_FILTER;
+    e->last_kernel = sel_k ? PC_KERNEL_K9D_SELECTOR : PC_KERNEL_K9D_FILTER;
     return PC_OK;
 }
 

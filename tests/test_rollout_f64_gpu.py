@@ -227,8 +227,8 @@ def test_f64_selector_form_on_a_track_of_ties(tmp_path, start, angle, inner, num
 
 def test_f64_selector_form_needs_rotations_on_the_table_and_set_state_can_take_them_off():
     """pc_env_set_state with a rotation no episode reaches (or a row further from start_rot than the env's time step allows): the
-    next pc_rollout takes the filter form -- which hashes / evaluates such angles -- and still equals the per-step kernels; after
-    pc_env_reset the selector form is back."""
+    next pc_rollout takes the generic kernel K9d -- which hashes / evaluates such angles -- and still equals the per-step kernels; after
+    pc_env_reset the literal form of K9 is back."""
     res = {}
     for mode in ("mega", "steps"):
         tr = Trainer(PPOConfig(n_envs=2048, n_steps=48, num_rays=16, track=TRACKS["big_track"], env_dtype="f64", use_graphs=False, seed=8,
@@ -241,7 +241,7 @@ def test_f64_selector_form_needs_rotations_on_the_table_and_set_state_can_take_t
         torch.cuda.synchronize()
         res[mode] = _snap(tr)
         if mode == "mega":
-            assert tr.envs.last_rollout_kernel() == "K9d-filter"
+            assert tr.envs.last_rollout_kernel() == "K9d-selector"      # (the generic kernel: angles off the table are hashed / evaluated)
             tr.next_obs.copy_(tr.envs.reset()[0])
             tr.buffer.ptr = 0
             tr.rollout()

@@ -113,7 +113,7 @@ def test_generated_circuit_steps_like_the_oracle_and_through_the_persistent_kern
         env.close()
     # the persistent rollout kernel on this track (1/den table too large for LDS above ~90 walls: arithmetic path)
     # ... in both dtypes.  float64: 48 walls fit the selector's LDS tables (the small form's literal kernel, without the 1/den table);
-    # the larger circuits take the filter form, a big-form kernel (the unsplit policy arithmetic)
+    # the larger circuits take the generic kernel K9d with the per-step kernel's selector step, a big-form kernel (the unsplit policy arithmetic)
     for dtype in ("f32", "f64"):
         small_lit = dtype == "f64" and points == 24
         res = {}
@@ -125,7 +125,7 @@ def test_generated_circuit_steps_like_the_oracle_and_through_the_persistent_kern
             torch.cuda.synchronize()
             assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
             if mode == "mega" and dtype == "f64":
-                assert tr.envs.last_rollout_kernel() == ("K9s-literal" if small_lit else "K9d-filter")
+                assert tr.envs.last_rollout_kernel() == ("K9s-literal" if small_lit else "K9d-selector")
             b = tr.buffer
             res[mode] = [x.clone() for x in (b.obs_buf, b.act_buf, b.rew_buf, b.val_buf, b.term_buf, tr.next_obs)]
             tr.close()
