@@ -351,6 +351,7 @@ int pc_env_track_info(const pc_env* e, int track, int* n_walls, int* n_chain_ver
 /* Which persistent kernel the last successful pc_rollout on this handle launched (0 before the first; for bench.py, the tests and
  * DESIGN.md -- every kernel fills the same buffers bit for bit, this only says which one did):
  *   PC_KERNEL_K9          big form, float32-selector env step with float64 refinement (F32 handles)
+ *   PC_KERNEL_K9M / _LITERAL  K9 with 16 envs per wave (4 lanes per env): 8193 .. 32768 envs at 16 rays (F32 / F64 handles)
  *   PC_KERNEL_K9S         small form (F32 handles, small batches)
  *   PC_KERNEL_K9_LITERAL  big form on an F64 handle: the float32 sweep selects each ray's wall, the reference's literal float64
  *                         arithmetic measures it (12 / 16 / 32 nominal rays, tracks inside the selector's limits, every env's rotation
@@ -366,6 +367,8 @@ int pc_env_track_info(const pc_env* e, int track, int* n_walls, int* n_chain_ver
 #define PC_KERNEL_K9D_FILTER 4
 #define PC_KERNEL_K9S_LITERAL 5
 #define PC_KERNEL_K9D_SELECTOR 6
+#define PC_KERNEL_K9M 7
+#define PC_KERNEL_K9M_LITERAL 8
 int pc_env_last_rollout_kernel(const pc_env* e);
 /* Override the lanes-per-env choice (power of two 1..64; 0 = automatic).  Tuning knob for bench.py. */
 int pc_env_set_lanes_per_env(pc_env* e, int lanes_per_env);

@@ -17,7 +17,7 @@ PC_ERR_INVALID_ARG, PC_ERR_IO, PC_ERR_PARSE, PC_ERR_HIP, PC_ERR_UNSUPPORTED, PC_
 PC_XCHG_HANDLE_BYTES = 128
 PC_DTYPE_F32, PC_DTYPE_F64 = 0, 1
 PC_OPT_ROLLOUT_FORM, PC_OPT_ROLLOUT_EPW, PC_OPT_ROLLOUT_FAST = 1, 2, 3
-PC_KERNEL_NAMES = {0: "none", 1: "K9", 2: "K9s", 3: "K9-literal", 4: "K9d-filter", 5: "K9s-literal", 6: "K9d-selector"}     # pc_env_last_rollout_kernel
+PC_KERNEL_NAMES = {0: "none", 1: "K9", 2: "K9s", 3: "K9-literal", 4: "K9d-filter", 5: "K9s-literal", 6: "K9d-selector", 7: "K9m", 8: "K9m-literal"}     # pc_env_last_rollout_kernel
 DTYPES = {"f32": PC_DTYPE_F32, "float32": PC_DTYPE_F32, "f64": PC_DTYPE_F64, "float64": PC_DTYPE_F64}
 
 

@@ -868,7 +868,12 @@ __device__ __forceinline__ EnvParams<float> stage_tables(const EnvParams<float>&
 //         mixed: BASELINE configs[4]): the chain-packed sweep for both lengths, chosen per workgroup.
 //         LIT (the fast modes): the handle is PC_DTYPE_F64 -- env_step_fast's literal form; state with the float64 rotation and
 //         its row of the rotation table (env_load<double>).
-template <int KS, int RPL, int PREC, int MODE, bool LIT = false>
+//         LGE = log2 of the lanes per env: 1 (default) = a wave owns 32 envs, two policy column tiles; 2 (round 5, fast modes at 17
+//         rays) = 16 envs per wave, 4 lanes per env, ONE column tile, five ray slots per lane -- the form for 8193 .. 32768 envs,
+//         where 32-env waves leave every SIMD with a single wave (9.8 us per step whatever the batch): two 16-env waves per SIMD
+//         hide each other's latency.  More vector instructions per env (the per-wave work -- physics, draw, bookkeeping -- is shared
+//         by 16 envs, not 32), so it loses again where 32-env waves already come in pairs (above 32768 envs).  Same bits.
+template <int KS, int RPL, int PREC, int MODE, bool LIT = false, int LGE = 1>
 __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, const float* __restrict__ image, const int A,
                                                       const int T, const double reward_scale, const uint64_t seed,
                                                       const uint64_t offset, const uint64_t* __restrict__ offset_dev,
@@ -880,13 +885,15 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                                                       const int rden_lds, const int epw, const int vec_ok,
                                                       float* __restrict__ last_val, float* __restrict__ rew_sum) {
     constexpr int dbg = PC_ABLATE;  // 0 in the product build (see PC_ABLATE)
-    constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), ET = 2;
+    constexpr int GE = 1 << LGE, EPWV = 64 / GE;      // lanes per env, envs per wave
+    constexpr int HID = 256, NT = 2 * HID / 16, LD1 = pol_ld1(KS), ET = EPWV / 16;
+    static_assert(LGE == 1 || (LGE == 2 && MODE != 0 && PREC != 0), "16 envs per wave: fast modes, split operand forms");
     constexpr int NG = pol_ng(KS), KB = pol_kb(KS);
     constexpr int IMG = PREC ? polx_image_dwords(PREC, NG) : pol_image_padded(KS);
     constexpr bool FAST = MODE != 0;
     // row stride of a wave's output tile [32 envs][LDO]: 16-byte rows (one ds_write_b128 per env tile, 16-byte reads in the draw);
     // the tile aliases the wave's 32 observation rows, so at 12 rays (18 floats per dense row) the stride is 16, else 20
-    constexpr int LDO = (FAST && RPL == 6) ? 16 : 20;
+    constexpr int LDO = (FAST && RPL == 6 && LGE == 1) ? 16 : 20;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sW1 = lds;
     float* sB1 = PREC ? lds + polx_w1_dwords(PREC, NG) + polx_w2_dwords(PREC) : sW1 + 2 * HID * LD1;
@@ -896,13 +903,14 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const unsigned* sW2p = sW1p + polx_w1_dwords(PREC ? PREC : 1, NG);
     const float* sW2c = sB2 + 16;                  // PREC 1: critic output weights [256]
     const int64_t N = p.N;
-    constexpr int DC = RPL == 6 ? 18 : (RPL == 9 ? 23 : 39);   // FAST: 6 + the ray count the 2-lanes-per-env menu implies (12 / 17 / 33)
+    // FAST: 6 + the ray count the lanes-per-env menu implies (12 / 17 / 33 rays: 6 / 9 / 17 slots on two lanes, 3 / 5 / 9 on four)
+    constexpr int DC = LGE == 1 ? (RPL == 6 ? 18 : (RPL == 9 ? 23 : 39)) : (RPL == 3 ? 18 : (RPL == 5 ? 23 : 39));
     const int D = FAST ? DC : p.D;
     // observation of the step in flight, [256 envs][LDX]: FAST keeps the rows dense (LDX = D, exactly the rollout buffer's
     // layout: a wave's 32 rows are one contiguous block there and here)
     const int LDX = FAST ? D : 4 * KS + 1;
     float* sObs = lds + IMG;
-    int* sAct = reinterpret_cast<int*>(sObs + 256 * LDX);
+    int* sAct = reinterpret_cast<int*>(sObs + 8 * EPWV * LDX);
     float* sTab = reinterpret_cast<float*>(sAct + 256);    // staged per-track tables
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform by construction: everything derived from it lives in SGPRs)
     const int lc = lane & 15, lk = lane >> 4;
@@ -938,12 +946,12 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const lds_cfp rdl = (lds_cfp)sRden;
 
     // this wave's 32 envs: local rows [pbase, pbase + 32); env-step identity: 2 lanes per env
-    const int pbase = wave * 32;
-    const int el = pbase + (lane >> 1), g = lane & 1;
+    const int pbase = wave * EPWV;
+    const int el = pbase + (lane >> LGE), g = lane & (GE - 1);
     // epw = envs per workgroup: 256 (all 8 waves) or 128 (waves 4..7 only help to stage LDS and leave: at <= 32768 envs
     // that doubles the workgroups, one wave per SIMD on all 256 CUs instead of two on half of them)
     const int64_t e_wave = (int64_t)blockIdx.x * epw + pbase;      // first env of this wave
-    const int64_t e_env = e_wave + (lane >> 1);
+    const int64_t e_env = e_wave + (lane >> LGE);
     const bool e_valid = e_env < N;
     using StateT = std::conditional_t<LIT, double, float>;
     const EnvParams<StateT> ps = p.template as<StateT>();
@@ -951,11 +959,12 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     if (e_valid) st = env_load<StateT>(ps, e_env);
     // mixed-track batch: this wave's envs share one track (the host checked every aligned block of 32 envs)
     const int trk = p.track_id ? (int)p.track_id[e_valid ? e_env : N - 1] : 0;
-    for (int f = g; f < (FAST ? D : 4 * KS); f += 2) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
+    for (int f = g; f < (FAST ? D : 4 * KS); f += GE) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
     // this wave's output tile [32 envs][LDO] lives in its own observation rows: they are dead from the policy pass's
     // operand load until the env step stores the next observation (32 * LDX >= 32 * LDO floats: D >= 17 on the host's menu)
     static_assert(4 * KS + 1 >= 20, "the output tile must fit the wave's observation rows");
-    float* myOut = sObs + wave * 32 * LDX;
+    static_assert(LGE == 1 || DC >= LDO, "the output tile [16 envs][LDO] must fit the wave's 16 observation rows");
+    float* myOut = sObs + wave * EPWV * LDX;
     const uint64_t off0 = offset + (offset_dev ? *offset_dev : 0);
     PhiloxBlock rnd = {};  // the sampling lanes' current Philox block (4 steps' draws)
     // FAST: per-lane invariants of the env step.  Ray slot s of lane g is ray min(g + 2 s, R - 1): the odd slot that 17 or
@@ -963,8 +972,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     int gq[2] = {0, 0}, k72 = 0;
     FastLane fl = {};
     if constexpr (FAST) {
-        fl = fast_lane<RPL, 2>(p, ft, g, sObs + el * LDX);
-        gq[0] = (int)(size_t)ft.dir + 16 * g * p.q * p.step_deg;            // Car.get_passed_gate's rays j * (n // 4), j = g and g + 2,
+        fl = fast_lane<RPL, GE>(p, ft, g, sObs + el * LDX);
+        gq[0] = (int)(size_t)ft.dir + 16 * g * p.q * p.step_deg;            // Car.get_passed_gate's rays j * (n // 4), j = g and (two lanes per env) g + 2,
         gq[1] = (int)(size_t)ft.dir + 16 * (g + 2) * p.q * p.step_deg;      // as byte addresses into the direction table
         k72 = Math<float>::mod72(st.k);
     }
@@ -1061,10 +1070,10 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                         x[et][kb] = split8<PREC>(v);
                     }
                 }
-                float val[ET] = {0.0f, 0.0f};
+                float val[ET] = {};
                 __builtin_amdgcn_s_setprio(0);
                 PC_STAMP(1)
-                if (!(dbg & 1)) policy_pass16<PREC, KB>(sW1p, sW2p, sB1, sW2c, 0, NT / 2, x, out, val, lc, lk);
+                if (!(dbg & 1)) policy_pass16<PREC, KB, ET>(sW1p, sW2p, sB1, sW2c, 0, NT / 2, x, out, val, lc, lk);
                 PC_STAMP(2)
                 __builtin_amdgcn_s_setprio(3);
 #pragma unroll
@@ -1085,7 +1094,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
             if (FAST || A == 9) {     // Discrete(9): the env's two lanes draw together (policy_tail_pair); the action stays with them
                 if (e_valid) {
                     float w[5];
-                    pair_outputs<LDO>(myOut, lane >> 1, g, PolScale<PREC>::so_inv, sB2, w);
+                    // (four lanes per env: lanes 2, 3 repeat lanes 0, 1 -- the same values, the action in all four)
+                    pair_outputs<LDO>(myOut, lane >> LGE, g & 1, PolScale<PREC>::so_inv, sB2, w);
                     float lp, val;
                     if (t == 0 || (o & 3) == 0) {   // uniform: ten rounds per 4 steps
                         uint64_t ctr = (uint64_t)e_env;             // (opaque: the first round's products of the lane's counter are formed here,
@@ -1093,7 +1103,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                         rnd = philox_block(seed, o >> 2, ctr);
                     }
                     if constexpr (PC_ABLATE & 4) { act_reg = (int)(o & 7); lp = w[0]; val = w[4]; }
-                    else policy_tail_pair(w, g, philox_word_uniform(rnd, (unsigned)(o & 3)), act_reg, lp, val);
+                    else policy_tail_pair(w, g & 1, philox_word_uniform(rnd, (unsigned)(o & 3)), act_reg, lp, val);
                     if constexpr (!FAST) { if (g == 0) sAct[el] = act_reg; }
                     if (g == 0) {
                         if (tail) {   // (once per launch: the address is formed here, not kept in two registers for T steps -- at 33 rays they were spilled)
@@ -1141,7 +1151,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 // ---------------- E(t)
                 float rw, tf, cf;
                 const int a = e_valid ? act_reg : 8;
-                const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3 || MODE == 5, 1, 1, (MODE == 5 ? 5 : (MODE >= 3 ? 7 : 0)), RPL != 17, LIT>(
+                const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3 || MODE == 5, LGE, 1, (MODE == 5 ? 5 : (MODE >= 3 ? 7 : 0)), RPL != 17, LIT>(
                     p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, 0, nullptr, true, nullptr, &hcar);
                 rsum += rw;
                 PC_STAMP(6)
@@ -1151,12 +1161,12 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                         // the reset observation's entries f = g, g + 2, ...: all reads issued, then the writes (rolled, every
                         // entry is an LDS round trip in series -- and some env of a wave finishes in a third of the steps of a
                         // young policy)
-                        float ro[(DC + 1) / 2];
+                        float ro[(DC + GE - 1) / GE];
 #pragma unroll
-                        for (int j = 0; j < (DC + 1) / 2; ++j) ro[j] = ft.reset[g + 2 * j];     // (the table has 40 slots: in bounds)
+                        for (int j = 0; j < (DC + GE - 1) / GE; ++j) ro[j] = ft.reset[g + GE * j];     // (the table has 40 slots: in bounds)
 #pragma unroll
-                        for (int j = 0; j < (DC + 1) / 2; ++j)
-                            if (g + 2 * j < DC) lrow[g + 2 * j] = ro[j];
+                        for (int j = 0; j < (DC + GE - 1) / GE; ++j)
+                            if (g + GE * j < DC) lrow[g + GE * j] = ro[j];
                         env_reset_fast(h0, st, k72);
                         if constexpr (LIT) {
                             const double2 e0 = p.dirtab64[h0.rot_off];      // row 0 = start_rot
@@ -1176,14 +1186,15 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 // rows -> rollout buffer: the wave's 32 rows are contiguous there (32 * D floats), 16-byte stores when aligned
                 float* dstg = (last ? next_obs : obs_buf + (int64_t)(t + 1) * N * D) + e_wave * D;
                 const int64_t left = N - e_wave;                       // valid envs from this wave's first on
-                const int n_rows = left >= 32 ? 32 : (int)left;
+                const int n_rows = left >= EPWV ? EPWV : (int)left;
                 const float* srcl = sObs + pbase * LDX;
                 if constexpr (PC_ABLATE & 256) {
-                } else if (vec_ok && n_rows == 32) {
+                } else if (vec_ok && n_rows == EPWV) {
+                    constexpr int NF4 = EPWV / 4 * DC;                  // the wave's rows as float4s: 8 D (32 envs: 3 or 5 stores per lane) or 4 D
 #pragma unroll
-                    for (int j = 0; j < (8 * DC + 63) / 64; ++j) {      // 8 * D float4s: 3 (D = 18, 23) or 5 (D = 39) stores per lane
+                    for (int j = 0; j < (NF4 + 63) / 64; ++j) {
                         const int i = lane + 64 * j;
-                        if (64 * j + 63 < 8 * DC || i < 8 * DC) reinterpret_cast<f32x4*>(dstg)[i] = reinterpret_cast<const f32x4*>(srcl)[i];
+                        if (64 * j + 63 < NF4 || i < NF4) reinterpret_cast<f32x4*>(dstg)[i] = reinterpret_cast<const f32x4*>(srcl)[i];
                     }
                 } else {
                     // (the unaligned caller's path: its addresses are formed here from opaque copies, not hoisted into registers that

@@ -981,6 +981,9 @@ static int policy_ks(int D) { return D <= 20 ? 5 : (D <= 24 ? 6 : 10); }
 // workgroups of independent waves: its 256 workgroups of 32 envs fill the chip once; one env more starts a second round of them and the
 // step takes 11.8 us where the big form takes 9.8 (tools/form_sweep.py, profiles/r5_form_sweep.txt: 16384 until round 5)
 #define PC_SPLIT_MAX_ENVS 8192
+// ... and up to this many the 16-envs-per-wave form of the big kernels (rollout_kernel<..., LGE = 2>: two waves per SIMD where 32-env
+// waves leave one) beats them; above, 32-env waves come in pairs themselves
+#define PC_MEDIUM_MAX_ENVS 32768
 static const int64_t g_rollout_epw128_max = 32768;  // big form at or below this many envs: 128 envs (4 waves) per workgroup
 
 // the arithmetic form a (D, A) shape gets when `requested` is asked for: the split forms cover D <= 40, A <= 9
@@ -1028,9 +1031,9 @@ int pc_env_set_option(pc_env* e, int option, int value) {
     if (!e) return PC_ERR_INVALID_ARG;
     switch (option) {
         case PC_OPT_ROLLOUT_FORM:
-            if (value < -1 || value > 3) return PC_ERR_INVALID_ARG;
-            e->opt.rden = value >= 2 ? 0 : 1;
-            e->opt.form = value >= 2 ? value - 2 : value;
+            if (value < -1 || value > 4) return PC_ERR_INVALID_ARG;
+            e->opt.rden = (value == 2 || value == 3) ? 0 : 1;
+            e->opt.form = (value == 2 || value == 3) ? value - 2 : value;      // (4: the 16-envs-per-wave form, where the shape has one)
             return PC_OK;
         case PC_OPT_ROLLOUT_EPW:
             if (value != 0 && value != 16 && value != 32 && value != 128 && value != 256) return PC_ERR_INVALID_ARG;
@@ -1286,6 +1289,35 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
             e->last_kernel = PC_KERNEL_K9S_LITERAL;
             return PC_OK;
         }
+        // ... between PC_SPLIT_MAX_ENVS and PC_MEDIUM_MAX_ENVS envs at 16 rays the 16-envs-per-wave form (as for F32 handles)
+        {
+            const bool want = o.form == 4 || (o.form < 0 && o.epw_override == 0 && e->N > PC_SPLIT_MAX_ENVS && e->N <= PC_MEDIUM_MAX_ENVS);
+            const int rden_m = 361 * max_nV;
+            const size_t lds_m = (size_t)(img + 128 * e->D + 128 + ft_floats(false, true) + rden_m) * sizeof(float);
+            if (want && tabs && shape && rays16 && !e->f64_offgrid && (all_nv28 || all_loops) && (!e->track_id || e->track_block >= 128) &&
+                lds_m <= 160 * 1024) {
+                const int vec_ok = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
+                EnvParams<float> prm = e->params<float>();
+                prm.lg = 2;
+                const int blocks_m = (int)((e->N + 127) / 128);
+#define PC_ROLL_MEDL(MD)                                                                                                 \
+    do {                                                                                                                 \
+        static bool attr_set[64] = {false};                                                                              \
+        if (e->device >= 64 || !attr_set[e->device]) {                                                                    \
+            HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<6, 5, 2, MD, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            if (e->device < 64) attr_set[e->device] = true;                                                                \
+        }                                                                                                                \
+        hipLaunchKernelGGL((rollout_kernel<6, 5, 2, MD, true, 2>), dim3(blocks_m), dim3(512), lds_m, st, prm, image, A, (int)T, reward_scale, seed, \
+                           offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs,  \
+                           next_term, next_trunc, rden_m, 128, vec_ok, last_value, reward_sum);                          \
+    } while (0)
+                if (all_nv28) PC_DEV(8, PC_ROLL_MEDL(3)); else PC_FULL(PC_ROLL_MEDL(5));
+#undef PC_ROLL_MEDL
+                HIPCHK(hipGetLastError());
+                e->last_kernel = PC_KERNEL_K9M_LITERAL;
+                return PC_OK;
+            }
+        }
         if (tabs && shape && !e->f64_offgrid) {
             const int vec_ok = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
             EnvParams<float> prm = e->params<float>();
@@ -1419,6 +1451,34 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
     hipStream_t st = (hipStream_t)stream;
     EnvParams<float> prm = e->params<float>();
     prm.lg = small ? 2 : 1;
+    // ---- the 16-envs-per-wave form (rollout_kernel<6, 5, 2, MD, LIT, 2>): 17 rays, fp16 x 2, the chain-packed sweeps' track layouts, the
+    // 1/den table in LDS; automatic between PC_SPLIT_MAX_ENVS and PC_MEDIUM_MAX_ENVS envs, PC_OPT_ROLLOUT_FORM = 4 at any size
+    {
+        const bool want = o.form == 4 || (o.form < 0 && o.epw_override == 0 && e->N > PC_SPLIT_MAX_ENVS && e->N <= PC_MEDIUM_MAX_ENVS);
+        const int rden_m = 361 * max_nV;
+        const size_t lds_m = (size_t)(img + 128 * e->D + 128 + ft_floats(false, true) + rden_m) * sizeof(float);
+        if (want && KS == 6 && prec == 2 && e->n_nominal == 16 && fast_shape && o.rden != 0 && max_nV <= FT_VTX_MAX && (all_nv28 || all_loops) &&
+            (!e->track_id || e->track_block >= 128) && lds_m <= 160 * 1024) {
+            const int blocks_m = (int)((e->N + 127) / 128);
+            prm.lg = 2;
+#define PC_ROLL_MED(MD)                                                                                                  \
+    do {                                                                                                                 \
+        static bool attr_set[64] = {false};                                                                              \
+        if (e->device >= 64 || !attr_set[e->device]) {                                                                    \
+            HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<6, 5, 2, MD, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            if (e->device < 64) attr_set[e->device] = true;                                                                \
+        }                                                                                                                \
+        hipLaunchKernelGGL((rollout_kernel<6, 5, 2, MD, false, 2>), dim3(blocks_m), dim3(512), lds_m, st, prm, image, A, (int)T, reward_scale, seed, \
+                           offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs,  \
+                           next_term, next_trunc, rden_m, 128, vec_ok, last_value, reward_sum);                          \
+    } while (0)
+            if (all_nv28) PC_DEV(7, PC_ROLL_MED(3)); else PC_FULL(PC_ROLL_MED(5));
+#undef PC_ROLL_MED
+            HIPCHK(hipGetLastError());
+            e->last_kernel = PC_KERNEL_K9M;
+            return PC_OK;
+        }
+    }
 #define PC_ROLL_M(KSV, RPLV, PRC, MD)                                                                                    \
     do {                                                                                                                 \
         static bool attr_set[64] = {false};                                                                              \

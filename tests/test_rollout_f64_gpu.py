@@ -20,10 +20,13 @@ def _split(num_rays, n_envs, precision=2):
     return 1 if (num_rays in (12, 16) and n_envs <= 8192 and precision == 2) else 0
 
 
-def _expected_kernel(num_rays, n_envs, precision=2):
+def _expected_kernel(num_rays, n_envs, precision=2, two_equal_loops=True):
     if precision != 2:
         return "K9d-filter"
-    return "K9s-literal" if _split(num_rays, n_envs) else "K9-literal"
+    if _split(num_rays, n_envs):
+        return "K9s-literal"
+    # 8193 .. 32768 envs at 16 rays on the chain-packed sweeps' track layouts: 16 envs per wave
+    return "K9m-literal" if (num_rays == 16 and 8192 < n_envs <= 32768 and two_equal_loops) else "K9-literal"
 
 
 def _snap(tr):
@@ -146,7 +149,7 @@ def test_f64_at_33_rays_selector_form_and_the_fallback_to_the_per_step_kernels()
 
 # ---- the SELECTOR form of the persistent float64 rollout (PC_KERNEL_K9_LITERAL: K9 with the literal arithmetic behind the float32 sweep)
 
-def _cross_track(path, start=(560.0, 135.0), angle=0.0, inner="plus"):
+def _cross_track(path, start=(560.0, 135.0), angle=0.0, inner_kind="plus"):
     """Two plus-shaped wall loops (12 walls each: the chain-packed sweep's layout) on INTEGER pixel coordinates, the start pose on the
     line of an inner wall, heading along an axis: rays run exactly through vertices, exactly along walls and exactly parallel to
     them -- every tie the literal arithmetic decides by its roundings (cast_exact's comment) -- at every reset and beyond."""
@@ -156,7 +159,7 @@ def _cross_track(path, start=(560.0, 135.0), angle=0.0, inner="plus"):
              (480, 270), (480, 90)]
     inner = [(560, 180), (720, 180), (720, 315), (960, 315), (960, 405), (720, 405), (720, 540), (560, 540), (560, 405), (320, 405), (320, 315),
              (560, 315), (560, 180)]
-    if inner == "octagon":      # 12 + 8 walls: NOT two equal loops -- the generic sweeps instead of the chain-packed one
+    if inner_kind == "octagon":      # 12 + 8 walls: NOT two equal loops -- the generic sweeps instead of the chain-packed one
         inner = [(600, 180), (680, 180), (760, 315), (760, 405), (680, 540), (600, 540), (520, 405), (520, 315), (600, 180)]
     gates = [(704, 90), (704, 180), (880, 270), (880, 315), (1120, 360), (960, 360), (880, 450), (880, 405)]
     frac = lambda pts: [[x / W, y / H] for x, y in pts]
@@ -190,7 +193,7 @@ def test_f64_selector_form_runs_by_default_and_equals_the_filter_form_bit_for_bi
     kw = dict(n_envs=20480, n_steps=160, num_rays=16, track=TRACKS["big_track"], env_dtype="f64", use_graphs=False, seed=33, rollout_kernel="mega")
     first, sel, k_sel, st_sel = _rollouts(dict(kw))
     _, fil, k_fil, st_fil = _rollouts(dict(kw, rollout_fast=0))
-    assert k_sel == ["K9-literal"] * 2 and k_fil == ["K9d-filter"] * 2, (k_sel, k_fil)
+    assert k_sel == ["K9m-literal"] * 2 and k_fil == ["K9d-filter"] * 2, (k_sel, k_fil)
     for ep in range(2):
         for i, (a, b) in enumerate(zip(sel[ep][:10], fil[ep][:10])):
             assert torch.equal(a, b), (ep, i)
@@ -215,7 +218,7 @@ def test_f64_selector_form_on_a_track_of_ties(tmp_path, start, angle, inner, num
               policy_split=_split(num_rays, n_envs))
     first, mega, k_mega, st_mega = _rollouts(dict(kw, rollout_kernel="mega"))
     _, steps, k_steps, st_steps = _rollouts(dict(kw, rollout_kernel="steps"))
-    assert k_mega == [_expected_kernel(num_rays, n_envs)] * 2 and k_steps == ["steps-eager"] * 2, (k_mega, k_steps)
+    assert k_mega == [_expected_kernel(num_rays, n_envs, 2, inner == "plus")] * 2 and k_steps == ["steps-eager"] * 2, (k_mega, k_steps)
     for ep in range(2):
         for i, (a, b) in enumerate(zip(mega[ep][:10], steps[ep][:10])):
             assert torch.equal(a, b), (ep, i)
@@ -262,7 +265,7 @@ def test_f64_selector_form_on_walls_that_cross_and_touch(tmp_path, n_envs):
     kw = dict(n_envs=n_envs, n_steps=160, num_rays=16, track=track, env_dtype="f64", use_graphs=False, seed=19, policy_split=_split(16, n_envs))
     first, mega, k_mega, st_mega = _rollouts(dict(kw, rollout_kernel="mega"), 1)
     _, steps, k_steps, st_steps = _rollouts(dict(kw, rollout_kernel="steps"), 1)
-    assert k_mega == [_expected_kernel(16, n_envs)] and k_steps == ["steps-eager"]
+    assert k_mega == [_expected_kernel(16, n_envs, 2, False)] and k_steps == ["steps-eager"]      # (the junction track: one loop of 4, one chain of 5)
     for i, (a, b) in enumerate(zip(mega[0][:10], steps[0][:10])):
         assert torch.equal(a, b), i
     for k in st_mega:

@@ -241,6 +241,48 @@ def test_rollout_forms_agree_with_default_dispatch():
         assert torch.equal(a, b), i
 
 
+@pytest.mark.parametrize("env_dtype", ["f32", "f64"])
+@pytest.mark.parametrize("n_envs,mixed", [(20480, False), (32768, True), (12345, False)])
+def test_sixteen_envs_per_wave_form_fills_the_same_buffers(n_envs, mixed, env_dtype):
+    """8193 .. 32768 envs at 16 rays: pc_rollout takes K9 with 16 envs per wave (4 lanes per env, one policy column tile) -- two waves
+    per SIMD where 32-env waves leave one.  Bitwise the 32-envs-per-wave form (PC_OPT_ROLLOUT_FORM = 0) and the per-step kernels, on
+    big_track and on the mixed batch of BASELINE configs[4]'s shard, with a ragged last workgroup (12345 envs), in both dtypes; the
+    form can be forced at any size (PC_OPT_ROLLOUT_FORM = 4)."""
+    track = [TRACKS["track"], TRACKS["big_track"]] if mixed else TRACKS["big_track"]
+    res, kern = {}, {}
+    for name, kw in (("auto", dict(rollout_kernel="mega")), ("classic", dict(rollout_kernel="mega", rollout_form=0)), ("steps", dict(rollout_kernel="steps"))):
+        tr = Trainer(_cfg(track=track, use_graphs=False, n_envs=n_envs, n_steps=40, num_rays=16, env_dtype=env_dtype, policy_split=0, **kw), device="cuda")
+        for _ in range(2):
+            tr.rollout()
+            tr.buffer.ptr = 0
+        torch.cuda.synchronize()
+        kern[name] = tr.envs.last_rollout_kernel() if tr.rollout_mode == "mega" else tr.rollout_mode
+        b = tr.buffer
+        res[name] = [t.clone() for t in (b.obs_buf, b.act_buf, b.rew_buf, b.val_buf, b.logprob_buf, b.term_buf, b.trunc_buf, tr.next_obs)]
+        st = tr.envs.get_state()
+        res[name].append(torch.from_numpy(np.stack([st[k].astype(np.float64) for k in sorted(st)])))
+        tr.close()
+    lit = "-literal" if env_dtype == "f64" else ""
+    assert kern == {"auto": "K9m" + lit, "classic": "K9" + lit, "steps": "steps-eager"}, kern
+    for other in ("classic", "steps"):
+        for i, (a, b) in enumerate(zip(res["auto"], res[other])):
+            assert torch.equal(a, b), (other, i)
+
+
+def test_sixteen_envs_per_wave_form_can_be_forced_at_any_size():
+    res = {}
+    for form in (-1, 4):
+        tr = Trainer(_cfg(use_graphs=False, n_envs=65536, n_steps=24, num_rays=16, rollout_kernel="mega", rollout_form=form), device="cuda")
+        tr.rollout()
+        torch.cuda.synchronize()
+        assert tr.envs.last_rollout_kernel() == ("K9m" if form == 4 else "K9")
+        b = tr.buffer
+        res[form] = [t.clone() for t in (b.obs_buf, b.act_buf, b.rew_buf, b.val_buf, b.logprob_buf, b.term_buf, b.trunc_buf, tr.next_obs)]
+        tr.close()
+    for i, (a, b) in enumerate(zip(res[-1], res[4])):
+        assert torch.equal(a, b), i
+
+
 @pytest.mark.parametrize("n_envs,form", [(4096, -1), (1000, 0), (8192, 0), (1000, 1), (65536, -1)])
 def test_mixed_track_batches_through_the_persistent_rollout_kernel(n_envs, form):
     """BASELINE configs[4] (track.json and big_track.json in one batch): with every aligned block of 32 envs on one track
