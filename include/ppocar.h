@@ -119,7 +119,8 @@ int pc_env_info(pc_env* e, int32_t* gates_passed, int32_t* time_passed, void* st
  * benchmark size takes can be checked at other batch sizes, and for A/B timing.
  *   PC_OPT_ROLLOUT_FORM  -1 (default) automatic: above 8192 envs independent waves of 32 envs, 256 envs per workgroup (128 up to
  *                        32768 envs), else 16 / 32 envs per workgroup with the policy's hidden tiles and the wall sweep split over the
- *                        waves; 0 / 1 force the first / second form; 2 / 3 = forms 0 / 1 with the env step forming 1/den
+ *                        waves; between 8193 and 32768 envs at 16 rays the first form with 16 envs per wave; 0 / 1 force the first /
+ *                        second form, 4 the 16-envs-per-wave one (where the shape has it); 2 / 3 = forms 0 / 1 with the env step forming 1/den
  *                        arithmetically instead of reading the track's 1/den table from LDS (what happens anyway when it does not fit)
  *   PC_OPT_ROLLOUT_EPW   envs per workgroup: 0 (default) automatic; 128 / 256 force the big form's choice, 16 / 32 the small form's
  *   PC_OPT_ROLLOUT_FAST  1 (default) = batches whose workgroups each lie on one track take the mode whose gather tables sit in LDS

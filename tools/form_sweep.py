@@ -9,7 +9,7 @@ dtype = sys.argv[1] if len(sys.argv) > 1 else "f32"
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 for N in (2048, 4096, 6144, 8192, 12288, 16384, 24576, 32768):
     row = []
-    for form, epw in ((1, 16), (1, 32), (0, 128), (0, 256)):
+    for form, epw in ((1, 16), (1, 32), (4, 0), (0, 128), (0, 256)):      # (4: 16 envs per wave, 128 per workgroup)
         try:
             tr = Trainer(PPOConfig(n_envs=N, n_steps=T, num_rays=16, track=f"{ROOT}/tracks/big_track.json", rollout_kernel="mega", seed=3, env_dtype=dtype,
                                    rollout_form=form, rollout_epw=epw, use_graphs=False), device="cuda")
