@@ -140,6 +140,9 @@ __device__ __forceinline__ void policy_pass(const float* sW1, const float* sB1, 
 //   layer 1: k = feature (D <= 24: one K block, group 3 is zero padding), rows = 16 hidden units, cols = 16 envs
 //   layer 2: K block = TWO hidden tiles; k-slot j of group g <-> tile (j >> 2), hidden row 4g + (j & 3): exactly the
 //            accumulator registers the lane already holds for its env column -- again no data movement.
+#ifndef PC_POL_INTERLEAVE
+#define PC_POL_INTERLEAVE 2      /* vector instructions asked for after each layer-1 MFMA of the split policy pass (0: hipcc's own schedule; 2: -1.4 % per epoch at the target shape, 3: nothing -- profiles/r5_ab_experiments.txt) */
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -469,28 +472,52 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
         load1(tp, oa);
         load1(tp + 1, ob);
         mfma1(oa, accA);
+        // Round 5 (PC_POL_INTERLEAVE): the next pair's layer-1 MFMAs and this pair's vector epilogue are independent, but left to itself
+        // hipcc issues the twelve MFMAs in a row and the forty vector instructions after them -- in order, so a lone wave pays
+        // 12 x 16 cycles of matrix pipe and then 40 x 4 of issue (its policy pass: 7.8 k cycles for 3.8 k of pipe time,
+        // profiles/r5_k9_phase_timeline.txt).  An MFMA holds the issue port for 8 of its 16 cycles (tools/ubench_shadow.hip): the
+        // schedule asked for here is MFMA, three vector instructions, MFMA, ... -- the same instructions, the same bits.
+#if PC_POL_INTERLEAVE
+#define PC_SGB1 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, PC_POL_INTERLEAVE, 0);
+#define PC_SGB_PAIR { PC_SGB1 PC_SGB1 PC_SGB1 PC_SGB1 PC_SGB1 PC_SGB1 if constexpr (ET == 2) { PC_SGB1 PC_SGB1 PC_SGB1 PC_SGB1 PC_SGB1 PC_SGB1 } }
+#else
+#define PC_SGB_PAIR
+#endif
 #pragma unroll 1
         for (; tp < ta1 && tp + 2 < tp1; tp += 2) {
+            __builtin_amdgcn_sched_barrier(0);
             mfma1(ob, accB);
             load1(tp + 2, oa);
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!PC_POL_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
             epilogue_actor(tp, accA);
+            PC_SGB_PAIR
+            __builtin_amdgcn_sched_barrier(0);
             mfma1(oa, accA);
             load1(tp + 3 < 16 ? tp + 3 : 15, ob);
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!PC_POL_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
             epilogue_actor(tp + 1, accB);
+            PC_SGB_PAIR
         }
 #pragma unroll 1
         for (; tp + 2 < tp1; tp += 2) {
+            __builtin_amdgcn_sched_barrier(0);
             mfma1(ob, accB);
             load1(tp + 2, oa);
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!PC_POL_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
             epilogue_critic(tp, accA);
+            PC_SGB_PAIR
+            __builtin_amdgcn_sched_barrier(0);
             mfma1(oa, accA);
             load1(tp + 3 < 16 ? tp + 3 : 15, ob);
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!PC_POL_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
             epilogue_critic(tp + 1, accB);
+            PC_SGB_PAIR
         }
+        __builtin_amdgcn_sched_barrier(0);
+#undef PC_SGB_PAIR
+#if PC_POL_INTERLEAVE
+#undef PC_SGB1
+#endif
         mfma1(ob, accB);       // the last two pairs
         if (tp < 8) {              // (uniform)
             epilogue_actor(tp, accA);

@@ -1,7 +1,7 @@
 """Developer tool: phase timeline of the big-form persistent rollout kernel (K9) from the -DPC_STAMPS build.
 
     make -C ppo-car_amd/csrc stamps         # build/stamps_pkg/: a copy of the package around libppocar.so built with -DPC_STAMPS
-    python tools/k9_timeline.py [n_envs] [n_steps]
+    python tools/k9_timeline.py [n_envs] [n_steps] [rollout_form]
 
 Workgroup 0's eight waves stamp s_memtime at the phase boundaries of steps 64..71.  Waves w and w + 4 share a SIMD.
 Phases: 0 step start, 1 operand split done / policy pass starts, 2 policy pass done, 3 draw + action stores done,
@@ -24,7 +24,8 @@ from ppo_car_amd.ppo import PPOConfig, Trainer  # noqa: E402
 assert _capi.lib_path().startswith(PKG), _capi.lib_path()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-tr = Trainer(PPOConfig(n_envs=N, n_steps=T, num_rays=16, track=f"{ROOT}/tracks/big_track.json", rollout_kernel="mega", use_graphs=False), device="cuda")
+FORM = int(sys.argv[3]) if len(sys.argv) > 3 else -1      # PC_OPT_ROLLOUT_FORM: 0 = 32 envs per wave at any size, 4 = 16 envs per wave
+tr = Trainer(PPOConfig(n_envs=N, n_steps=T, num_rays=16, track=f"{ROOT}/tracks/big_track.json", rollout_kernel="mega", use_graphs=False, rollout_form=FORM), device="cuda")
 for _ in range(3):
     tr.rollout(); tr.buffer.ptr = 0
 torch.cuda.synchronize()
@@ -46,7 +47,7 @@ if not big:              # the small form's env step carries three more stamps: 
 if big:                  # the big form carries no stamps inside the env step (they made it spill): phases 3..6 are one
     st = st[:, :, [0, 1, 2, 3, 6, 7]]
     names = ["split", "policy", "draw", "env step", "copy-out"]
-print(f"rollout mode {tr.rollout_mode}; cycles (s_memtime ticks) per phase, mean over {NT} steps")
+print(f"rollout mode {tr.rollout_mode} ({tr.envs.last_rollout_kernel()}); cycles (s_memtime ticks) per phase, mean over {NT} steps")
 print("wave " + " ".join(f"{n:>9s}" for n in names) + "   step total")
 for w in range(8):
     d = np.diff(st[w], axis=1).mean(0)
