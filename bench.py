@@ -32,7 +32,7 @@ Extra objects on the JSON line:
   other_workloads -- every other single-GPU BASELINE configuration (cfg1 = configs[1], cfg2 = configs[2], cfg4 = the per-GPU shard of
                   configs[4]; `target` when another workload is the headline), 5 epochs each after the timed region, with its own
                   ms_per_step, rollout-launch duration by HIP events and roofline fraction -- and `exact_f64`: the same
-                  configuration in the bit-exact dtype (3 epochs).
+                  configuration in the bit-exact dtype (8 epochs).
   parity_check -- one more pc_rollout launch of the same trainer AFTER the timed region: one env of every 32-env wave x 64 steps
                   replayed through the CPU oracle (observations within one float32 ulp; rewards / flags exact; an env may leave the
                   oracle's trajectory only at a step whose threshold margin is below 1e-9 px: 0 departures above that margin).
@@ -530,8 +530,8 @@ def main():
                 others[name] = side_measurement(name, WORKLOADS[name], env_dtype="f32", epochs=5)
             except Exception as ex:
                 others[name] = {"error": repr(ex)}
-            try:      # ... and the same configuration in the bit-exact dtype (3 epochs): value, ms per epoch, the kernel that ran
-                f64 = side_measurement(name, WORKLOADS[name], env_dtype="f64", epochs=3)
+            try:      # ... and the same configuration in the bit-exact dtype (8 epochs): value, ms per epoch, the kernel that ran
+                f64 = side_measurement(name, WORKLOADS[name], env_dtype="f64", epochs=8)      # (8: three epochs of configs[1] are 20 ms, one hiccup halves the figure)
                 others[name]["exact_f64"] = {k: f64[k] for k in ("value", "unit", "ms_per_step", "kernel", "epoch_split")}
             except Exception as ex:
                 others[name]["exact_f64"] = {"error": repr(ex)}
