@@ -36,6 +36,8 @@ Extra objects on the JSON line:
   parity_check -- one more pc_rollout launch of the same trainer AFTER the timed region: one env of every 32-env wave x 64 steps
                   replayed through the CPU oracle (observations within one float32 ulp; rewards / flags exact; an env may leave the
                   oracle's trajectory only at a step whose threshold margin is below 1e-9 px: 0 departures above that margin).
+                  `rare_branches`: the same check on a fresh trainer of the same workload started from INJECTED states (and, at 17 rays,
+                  the trained policy fixture): laps, time limits, terminated-at-the-limit, +-990 turns of heading -- `events_replayed`.
   strict_fp32_value -- the same metric with the policy GEMMs as exact-fp32 MFMAs (3 epochs, outside the headline timing).
   fp32_grade_bf16x3_value -- the same with the bf16 x 3 split (six piece products: fp32-grade error, not the fp32 chain's bits).
 """
@@ -232,6 +234,7 @@ def parity_check(tr, cfg, torch, np, envs=1024, steps=64):
     n, step_deg = cfg.num_rays, 360 // cfg.num_rays
     col = list(range(0, n, n // 4))            # Car.check_collision's rays (car_env.py:389)
     worst, flips, checked, n_cmp, n_eq, worst_margin, waves = 0.0, 0, 0, 0, 0, 0.0, set()
+    events = dict(gates=0, laps=0, truncations=0, terminated_at_time_limit=0, episodes_ended=0)    # what the replay went through (car_env.py:726-750)
     for k, path in enumerate(tracks):
         mine = np.nonzero(tid == k)[0]
         wave0 = np.unique(mine // 32) * 32                                   # first env of every 32-env wave on this track
@@ -253,8 +256,15 @@ def parity_check(tr, cfg, torch, np, envs=1024, steps=64):
         alive = np.ones(P, bool)
         worst = max(worst, float(np.abs(OB[0] - first_all[idx].cpu().numpy()).max()))
         for t in range(T):
-            pre = {f: getattr(ora, f).copy() for f in ("px", "py", "rot", "next_gate")}
+            pre = {f: getattr(ora, f).copy() for f in ("px", "py", "rot", "next_gate", "time_step")}
             o, r, te, trn, fin = ora.step(acts[t], want_final_obs=True)
+            x = r.astype(np.float64) / cfg.reward_scaling        # raw reward: 0.01 forward + 1 gate + 10 lap - 3 crash
+            lap = x > 5.0
+            events["laps"] += int((lap & alive).sum())
+            events["gates"] += int((((x - 10.0 * lap + 3.0 * te) > 0.5) & alive).sum())
+            events["truncations"] += int((trn & alive).sum())
+            events["terminated_at_time_limit"] += int((te & (pre["time_step"] >= 999) & alive).sum())   # `elif`: terminated wins (car_env.py:746-750)
+            events["episodes_ended"] += int(((te | trn) & alive).sum())
             bad = (TE[t + 1] != te) | (TR[t + 1] != trn) | (RW[t] != r.astype(np.float32))
             for e in np.nonzero(bad & alive)[0]:     # a departure: how close to a threshold was the reference itself?
                 walls = [abs(float(fin[e, 6 + c]) * 1000.0 - 10.0) for c in col]
@@ -272,9 +282,45 @@ def parity_check(tr, cfg, torch, np, envs=1024, steps=64):
     return {"kernel": tr.rollout_mode, "envs": checked, "waves_sampled": len(waves), "waves_total": (cfg.n_envs + 31) // 32, "tracks": nt, "steps": T,
             "obs_max_abs_err": worst, "obs_tolerance": OBS_TOL, "obs_entries_bit_equal": n_eq / max(1, n_cmp),
             "envs_left_oracle_trajectory": flips, "largest_threshold_margin_px_of_a_departure": worst_margin, "margin_tolerance_px": MARGIN_PX,
-            "rewards_and_flags": "exact on every env still on the oracle's trajectory",
+            "rewards_and_flags": "exact on every env still on the oracle's trajectory", "events_replayed": events,
             "ok": bool(worst <= OBS_TOL and worst_margin <= MARGIN_PX),     # i.e. 0 departures above the margin, however many envs
             "checker": "oracle/carenv_oracle.c (float64 restatement of car_env.py:693-760), teacher-forced by the stored actions"}
+
+
+def parity_check_rare(make_trainer, wl, track, torch, np, steps=64):
+    """The second parity leg: the SAME kernel (same shape, tracks, dtype and arithmetic: a fresh trainer of the benchmarked workload with a
+    short buffer) driven into the bookkeeping branches a young policy never reaches -- the lap wrap (car_env.py:730-737), the time limit
+    and its `elif` (:746-750), heading drift of up to 990 turns -- by injected states (oracle/scenarios.py: cars on the approach to the last
+    gate with next_gate = G - 1, time steps 997 .. 999, cars about to hit a wall as the limit falls due) and, at 16 -> 17 rays, by the
+    trained policy fixture (tests/golden/policy_trained.npz); then parity_check's replay from those states.  `ok` also requires that the
+    replay actually went through laps, truncations and a terminated-at-the-time-limit step."""
+    from oracle.scenarios import injected_state, load_trained_policy
+    wl_ = dict(wl, n_steps=steps + 1)
+    cfg_, t_ = make_trainer(wl_=wl_, track_=track)
+    try:
+        trained = t_.obs_dim[0] == 23
+        if trained:
+            load_trained_policy(t_.agent)
+        tracks = list(track) if isinstance(track, (list, tuple)) else [track]
+        i = np.arange(cfg_.n_envs)
+        tid = np.minimum((i // 32 * 32) * len(tracks) // cfg_.n_envs, len(tracks) - 1)
+        full = None
+        for k, path in enumerate(tracks):
+            mine = np.nonzero(tid == k)[0]
+            part = injected_state(path, mine)
+            if full is None:
+                full = {f: np.zeros(cfg_.n_envs, v.dtype) for f, v in part.items()}
+            for f, v in part.items():
+                full[f][mine] = v
+        t_.envs.set_state(**full)
+        res = parity_check(t_, cfg_, torch, np, envs=2560, steps=steps)
+        ev = res["events_replayed"]
+        res["policy"] = "tests/golden/policy_trained.npz" if trained else "freshly initialised (the fixture is a 17-ray policy)"
+        res["states"] = "oracle/scenarios.py: injected_state (approach to the last gate, time steps 995 .. 999, +-80 .. 990 turns of heading, cars about to crash at the time limit)"
+        res["ok"] = bool(res["ok"] and ev["laps"] > 0 and ev["truncations"] > 0 and ev["terminated_at_time_limit"] > 0)
+        return res
+    finally:
+        t_.close()
 
 
 def main():
@@ -481,6 +527,10 @@ def main():
             extras["parity_check"] = parity_check(tr, cfg, torch, np)
         except Exception as ex:                      # the check must never take the benchmark line down with it
             extras["parity_check"] = {"ok": False, "error": repr(ex)}
+        try:
+            extras["parity_check"]["rare_branches"] = parity_check_rare(make_trainer, wl, track, torch, np)
+        except Exception as ex:
+            extras["parity_check"]["rare_branches"] = {"ok": False, "error": repr(ex)}
     tr.close()
     del tr
     if world == 1 and not args.no_extras and args.policy_arith != "fp32" and args.policy == "fused" and not args.force_collective:

@@ -36,6 +36,11 @@ __device__ unsigned long long g_stamps_u[16];    // the minibatch kernel (K10), 
 //     global memory with 16-byte stores (three per lane instead of 23 scattered dword stores), and an env that finished its
 //     episode gets its reset observation in a rarely taken, wave-uniformly skipped fix-up.
 // ------------------------------------------------------------------------------------------
+#ifdef PC_EXP_NOPRIO
+#define PC_SETPRIO(x)
+#else
+#define PC_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
 constexpr int TAB_MAX_GATES = 128;  // reward gates of a track staged in LDS (32 bytes each)
 struct ActLut {          // one per action 0..15 (9..15: no-op, car_env.py:721), 32 bytes
     double thrust;       // acc = heading * thrust: +0.8 forward, -0.8 backward, 0 none (car_env.py:423-438)
@@ -79,6 +84,12 @@ constexpr int FT_HEAD = 0, FT_WRAP = FT_HEAD + 72 * 4, FT_ACT = FT_WRAP + 76, FT
 constexpr int FT_D64_BYTES = (FT_DIR64 - FT_DIR) * 4;
 __host__ __device__ constexpr int ft_seg_small(bool twice) { return FT_DIR64 + (twice ? 720 : 360) * 4; }
 __host__ __device__ constexpr int ft_floats(bool small, bool twice) { return ft_seg_small(twice) + (small ? FT_VTX_MAX * 12 : 0); }
+// Dynamic LDS of rollout_kernel's fast modes in floats: weight image, the workgroup's 8 x (envs per wave) dense observation rows, the
+// action slots, the gather tables, the 1/den table.  The ONE expression the kernel's carve-up and the host's launch size share.
+constexpr int K9_ACT_SLOTS = 256;
+__host__ __device__ constexpr int k9_fast_lds_floats(int img, int envs_per_wave, int D, bool twice, int rden_floats) {
+    return img + 8 * envs_per_wave * D + K9_ACT_SLOTS + ft_floats(false, twice) + rden_floats;
+}
 static_assert(FT_ACT % 4 == 0 && FT_GATES % 4 == 0 && FT_DIR % 4 == 0 && FT_VTX % 4 == 0 && FT_DIR64 % 4 == 0,
               "16-byte aligned records");
 
@@ -271,6 +282,9 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
             return *(lds_cd2)(size_t)(dir_b + (unsigned)FT_D64_BYTES + min(off, off - 5760u));
         }
     };
+#if defined(PC_EXP_WAITPASS) && PC_EXP_WAITPASS == 2
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
     // ---- action, heading before and after the turn (car_env.py:698-722, :440-442)
     const f64x2 Lf = ft.act[2 * a];                                     // (thrust, fric)
     const i32x2 Li = *(lds_ci2)(ft.act + 2 * a + 1);                    // (dk, fwd)
@@ -347,7 +361,11 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     // (33 rays, 17 slots per lane: two passes, 9 + 8.  The chain-packed sweep at 33 rays -- three passes of 6 + 6 + 5 slots fit the
     // registers but for 9 of them -- was built in round 5: 3-4 % faster per launch, and ONE observation entry in 3e8 differed from
     // the per-step kernels in one run of two: not shipped, profiles/r5_ab_experiments.txt)
+#ifdef PC_EXP_CFG2_PACKED    // developer build only (tools/soak_cfg2_packed.py): the chain-packed sweep at 33 rays, three passes of 6 + 6 + 5 slots
+    constexpr int NPASS = RPL > 12 ? (SWP == 7 ? PC_EXP_CFG2_PACKED + 2 : 2) : 1;    // -DPC_EXP_CFG2_PACKED=1: three passes; =0: two
+#else
     constexpr int NPASS = RPL > 12 ? 2 : 1;
+#endif
     constexpr int R1 = (RPL + NPASS - 1) / NPASS;
     unsigned bb[RPL + 2];
     const float tau = flag_threshold(h, npx, npy);
@@ -360,6 +378,11 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         // one pass over the chain for the slots [S0, S0 + RN)
         auto sweep_pass = [&](auto S0C, auto RNC) {
             constexpr int S0 = decltype(S0C)::value, RN = decltype(RNC)::value;
+#if defined(PC_EXP_WAITPASS) && PC_EXP_WAITPASS == 1       // developer experiments: nothing outstanding at a pass's start / a pure delay before the later passes
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#elif defined(PC_EXP_WAITPASS) && PC_EXP_WAITPASS == 3
+            if constexpr (S0 > 0) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
+#endif
             float dxp[RN], dyp[RN];
             int dip[RN];
             if constexpr (DIR_PER_PASS) {
@@ -378,8 +401,23 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
             unsigned ba[2 * ((RN + 1) / 2)];
             if (PARTS > 1)                  // small form: latency-oriented sweep over the LDS copy of the chain
                 wall_sweep_lds<RN, PARTS, TAB, true>(ft.vtx, h.nV, part, pxr, pyr, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
-            else if constexpr (SWP == 7)       // the host guarantees big_track's layout (two loops of 13 vertices, packed: TrackHdr::vtxp_off)
-                wall_sweep_loops<RN, TAB, 13, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);
+            else if constexpr (SWP == 7) {     // the host guarantees big_track's layout (two loops of 13 vertices, packed: TrackHdr::vtxp_off)
+                const VtxP* vpp = p.vtxp + h.vtxp_off;
+#ifdef PC_EXP_RELOAD      // developer experiment: every pass loads the vertex records itself (nothing of a pass is kept for the next)
+                asm volatile("" : "+s"(vpp));
+#endif
+#ifdef PC_EXP_DEBUG
+                float pxo = pxr, pyo = pyr;
+                asm volatile("" : "+v"(pxo), "+v"(pyo));
+                wall_sweep_loops<RN, TAB, 13, true>(vpp, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba, pxo, pyo, (unsigned)S0 | ((unsigned)t << 8));
+#elif defined(PC_EXP_REPOS)       // developer experiment: every pass recomputes the per-vertex VGPR values (a = p - pos, un'); the vertex records stay in SGPRs
+                float pxo = pxr, pyo = pyr;
+                asm volatile("" : "+v"(pxo), "+v"(pyo));
+                wall_sweep_loops<RN, TAB, 13, true>(vpp, pxo, pyo, dxa, dya, dia, ft.rden, tau, ba);
+#else
+                wall_sweep_loops<RN, TAB, 13, true>(vpp, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);
+#endif
+            }
             else if constexpr (SWP == 5) {     // ... or two loops of 13 or of 9 vertices per track (track.json: 8 walls each): a mixed batch, workgroup-uniform
                 if (h.brk2 == 13) wall_sweep_loops<RN, TAB, 13, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);
                 else wall_sweep_loops<RN, TAB, 9, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);
@@ -911,7 +949,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const int LDX = FAST ? D : 4 * KS + 1;
     float* sObs = lds + IMG;
     int* sAct = reinterpret_cast<int*>(sObs + 8 * EPWV * LDX);
-    float* sTab = reinterpret_cast<float*>(sAct + 256);    // staged per-track tables
+    float* sTab = reinterpret_cast<float*>(sAct + K9_ACT_SLOTS);    // staged per-track tables (k9_fast_lds_floats: the host's size)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform by construction: everything derived from it lives in SGPRs)
     const int lc = lane & 15, lk = lane >> 4;
     policy_stage_image<IMG>(image, lds, tid);
@@ -1004,10 +1042,21 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const int TT = last_val ? T + 1 : T;
     float rsum = 0.0f;
     int act_reg = 8;     // the action drawn for this lane pair's env (the pair draw leaves it in both lanes)
+#ifdef PC_EXP_V255       // developer experiment: the kernel allocates all 256 VGPRs
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
+#endif
+#ifdef PC_EXP_SCRATCH    // developer experiment: the kernel has a private segment and touches it every step
+    volatile int scr_probe[8];
+    scr_probe[tid & 7] = tid;
+#endif
 #pragma unroll 1
     for (int t = 0; t < TT; ++t) {
         const bool tail = t == T;      // (uniform)
         PC_STAMP(0)
+#ifdef PC_EXP_SCRATCH
+        scr_probe[t & 7] = t;
+        if (scr_probe[(t + 3) & 7] == -12345) rsum += 1.0f;
+#endif
         {
             // ---------------- P(t)
             f32x4 out[ET];
@@ -1028,9 +1077,9 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 // SIMD are in opposite phases most of the time; with equal priorities the issue arbiter interleaves them
                 // instruction by instruction and both crawl, with the env-step wave preferred the matrix pipe still gets
                 // its instructions in the gaps.  Measured inside the benchmark's epochs: 20.5 -> 18.7 ms per rollout.
-                __builtin_amdgcn_s_setprio(0);
+                PC_SETPRIO(0);
                 if (!(dbg & 1)) policy_pass<KS>(sW1, sB1, sW2, 0, NT, x, out, lc, lk, lane);  // dbg: timing ablations only
-                __builtin_amdgcn_s_setprio(3);
+                PC_SETPRIO(3);
             } else if constexpr (pol_wide(PREC)) {
                 // fp16 x 2: the wave's 32 envs as ONE column tile of v_mfma_f32_32x32x16_f16 (policy_pass32).  Observation loads are
                 // unconditional (K padding reads a few floats into the next row / the tables behind: inside the workgroup's LDS)
@@ -1043,11 +1092,11 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o32[i] = 0.0f;
                 float v32 = 0.0f;
-                __builtin_amdgcn_s_setprio(0);
+                PC_SETPRIO(0);
                 PC_STAMP(1)
                 if (!(dbg & 1)) policy_pass32<KSTEPS, NG>(sW1p, sW2p, sB1, sW2c, xs, o32, v32, lane);
                 PC_STAMP(2)
-                __builtin_amdgcn_s_setprio(3);
+                PC_SETPRIO(3);
                 store_out32<LDO>(myOut, o32, v32, A, lane);
             } else {
                 Pieces<PREC> x[ET][KB];
@@ -1071,11 +1120,11 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                     }
                 }
                 float val[ET] = {};
-                __builtin_amdgcn_s_setprio(0);
+                PC_SETPRIO(0);
                 PC_STAMP(1)
                 if (!(dbg & 1)) policy_pass16<PREC, KB, ET>(sW1p, sW2p, sB1, sW2c, 0, NT / 2, x, out, val, lc, lk);
                 PC_STAMP(2)
-                __builtin_amdgcn_s_setprio(3);
+                PC_SETPRIO(3);
 #pragma unroll
                 for (int et = 0; et < ET; ++et) {
                     float tv = val[et];
@@ -1147,7 +1196,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
         PC_STAMP(3)
         if constexpr (FAST) {
             if (!(dbg & 2)) {
-                __builtin_amdgcn_s_setprio(2);
+                PC_SETPRIO(2);
                 // ---------------- E(t)
                 float rw, tf, cf;
                 const int a = e_valid ? act_reg : 8;
@@ -1209,7 +1258,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 PC_STAMP(7)
             }
         } else if (e_valid && !(dbg & 2)) {
-            __builtin_amdgcn_s_setprio(2);
+            PC_SETPRIO(2);
             // ---------------- E(t)
             float* orow = last ? next_obs + e_env * D : obs_buf + ((int64_t)(t + 1) * N + e_env) * D;
             float rw;

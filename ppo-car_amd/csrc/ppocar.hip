@@ -841,6 +841,17 @@ int pc_build_ablate(void) { return 0x100 | PC_ABLATE; }     // a developer quick
 int pc_build_ablate(void) { return PC_ABLATE; }
 #endif
 
+#ifdef PC_EXP_DEBUG
+// developer build only: the debug records of wall_sweep_loops (count, then 8 words per record); clears them
+int pc_debug_read_dbg(unsigned* out, int n) {
+    if (n < 8 + 8 * 1024) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), (8 + 8 * 1024) * sizeof(unsigned)) != hipSuccess) return -3;
+    unsigned zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &zero, sizeof(unsigned)) != hipSuccess) return -4;
+    return (int)out[0];
+}
+#endif
 #ifdef PC_STAMPS
 // developer build only (not declared in ppocar.h): copy the phase stamps of the last pc_rollout launch to the host
 int pc_debug_read_stamps(unsigned long long* out, int n) {
@@ -924,17 +935,19 @@ int pc_env_set_state(pc_env* e, const double* px, const double* py, const double
         }
         if (passed) iv[i].w = (int)passed[i];
     }
+    bool offgrid = false;
     if (f64) {      // can every env's episode stay inside its track's rotation table?  (what the selector kernel needs: rollout_f64_impl)
-        e->f64_offgrid = false;
-        for (size_t i = 0; i < N && !e->f64_offgrid; ++i) {
+        for (size_t i = 0; i < N && !offgrid; ++i) {
             const std::vector<int>& depth = e->rot_depth[tid[i]];
             const int id = iv[i].x;
-            e->f64_offgrid = id < 0 || id >= (int)depth.size() || depth[id] > iv[i].y;
+            offgrid = id < 0 || id >= (int)depth.size() || depth[id] > iv[i].y;
         }
+        e->f64_offgrid = true;      // (until the copies below have succeeded: a half-written state must not reach the literal kernels)
     }
     HIPCHK(hipMemcpy(e->iv, iv.data(), N * sizeof(int4), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->pv, pv.data(), 4 * N * sizeof(double), hipMemcpyHostToDevice));
     if (f64 && rot) HIPCHK(hipMemcpy(e->rot, rot, N * sizeof(double), hipMemcpyHostToDevice));
+    if (f64) e->f64_offgrid = offgrid;
     return PC_OK;
 }
 
@@ -1246,7 +1259,7 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
         const bool rays16 = KS == 6 && rpl == 9 && e->n_nominal == 16, rays12 = KS == 5 && rpl == 6 && e->n_nominal == 12;
         const bool rays33 = KS == 10 && rpl == 17 && e->n_nominal == 32;
         const int rden_lds = rays33 ? 0 : 361 * max_nV;      // (33 rays: no room for the table -- the sweep forms 1/den itself, as for F32 handles)
-        const size_t lds_sel = (size_t)(img + 256 * e->D + 256 + ft_floats(false, !rays33) + rden_lds) * sizeof(float);
+        const size_t lds_sel = (size_t)k9_fast_lds_floats(img, 32, e->D, !rays33, rden_lds) * sizeof(float);
         const bool shape = (rays16 || rays12 || rays33) && prec == 2 && e->D >= 17 && e->D <= 40 && max_G <= TAB_MAX_GATES &&
                            max_nV <= FT_VTX_MAX && e->opt.fast && e->opt.rden != 0 && (!e->track_id || e->track_block >= epw) &&
                            lds_sel <= 160 * 1024;
@@ -1293,7 +1306,7 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
         {
             const bool want = o.form == 4 || (o.form < 0 && o.epw_override == 0 && e->N > PC_SPLIT_MAX_ENVS && e->N <= PC_MEDIUM_MAX_ENVS);
             const int rden_m = 361 * max_nV;
-            const size_t lds_m = (size_t)(img + 128 * e->D + 128 + ft_floats(false, true) + rden_m) * sizeof(float);
+            const size_t lds_m = (size_t)k9_fast_lds_floats(img, 16, e->D, true, rden_m) * sizeof(float);
             if (want && tabs && shape && rays16 && !e->f64_offgrid && (all_nv28 || all_loops) && (!e->track_id || e->track_block >= 128) &&
                 lds_m <= 160 * 1024) {
                 const int vec_ok = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
@@ -1417,7 +1430,7 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
     const bool fast_shape = A == 9 && fast_rays && e->D >= 17 && e->D <= 40 && max_G <= TAB_MAX_GATES && o.fast;
     // (the float64 refinement gathers the chain from LDS: at most FT_VTX_MAX vertices; a shape whose fast-mode tables do not fit
     // beside the weight image -- the fp32 image at 33 rays -- takes the generic mode)
-    const size_t lds_fast_big = (size_t)(img + 256 * e->D + 256 + ft_floats(false, KS != 10)) * sizeof(float);   // (33 rays: one turn of the float64 lattice)
+    const size_t lds_fast_big = (size_t)k9_fast_lds_floats(img, 32, e->D, KS != 10, 0) * sizeof(float);   // (33 rays: one turn of the float64 lattice)
     const bool fast = !small && fast_shape && max_nV <= FT_VTX_MAX && (!e->track_id || e->track_block >= epw) && lds_fast_big <= 160 * 1024;
     const size_t lds_big = fast ? lds_fast_big : (size_t)(img + 256 * (4 * KS + 1) + 256 + TAB_FLOATS) * sizeof(float);
     const size_t lds_fast_small = (size_t)(img + 8 * 32 * 17 + 32 * 40 + 32 + 128 + ft_floats(true, true)) * sizeof(float);
@@ -1456,7 +1469,7 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
     {
         const bool want = o.form == 4 || (o.form < 0 && o.epw_override == 0 && e->N > PC_SPLIT_MAX_ENVS && e->N <= PC_MEDIUM_MAX_ENVS);
         const int rden_m = 361 * max_nV;
-        const size_t lds_m = (size_t)(img + 128 * e->D + 128 + ft_floats(false, true) + rden_m) * sizeof(float);
+        const size_t lds_m = (size_t)k9_fast_lds_floats(img, 16, e->D, true, rden_m) * sizeof(float);
         if (want && KS == 6 && prec == 2 && e->n_nominal == 16 && fast_shape && o.rden != 0 && max_nV <= FT_VTX_MAX && (all_nv28 || all_loops) &&
             (!e->track_id || e->track_block >= 128) && lds_m <= 160 * 1024) {
             const int blocks_m = (int)((e->N + 127) / 128);
@@ -1536,6 +1549,9 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
         // tracks, fast mode switched off -- spilled 100+ registers beside the split operands' policy state: not built either; that
         // shape is PC_ERR_UNSUPPORTED here and runs through the per-step kernels, bit-identical by construction)
         if (!mode) return PC_ERR_UNSUPPORTED;
+#ifdef PC_EXP_CFG2_PACKED    // developer build only: rollout_kernel<10, 17, 2, 4> (round 5's chain-packed 33-ray variant, see tools/soak_cfg2_packed.py)
+        if (prec == 2 && all_nv28 && o.fast == 1) { PC_DEV(2, PC_ROLL_M(10, 17, 2, 4)); HIPCHK(hipGetLastError()); e->last_kernel = PC_KERNEL_K9; return PC_OK; }
+#endif
         if (prec == 2) PC_DEV(2, PC_ROLL_M(10, 17, 2, 1));
         else PC_FULL(PC_ROLL_M(10, 17, 1, 1));
     }

@@ -142,12 +142,12 @@ def test_product_never_touches_the_oracle():
 
 
 def test_bench_uses_the_oracle_only_as_checker_and_cpu_baseline():
-    """bench.py may touch oracle/ in exactly two places: the `cpu_baseline` leg and the `parity_check` leg (both run AFTER the
-    timed region, on rank 0).  Nothing else in the file -- the timed region in main() least of all -- names it."""
+    """bench.py may touch oracle/ in exactly two places: the `cpu_baseline` leg and the `parity_check` legs (parity_check and its second,
+    rare-branch leg parity_check_rare; all run AFTER the timed region, on rank 0).  Nothing else in the file -- the timed region in main() least of all -- names it."""
     import ast
     src = open(os.path.join(ROOT, "bench.py")).read()
     tree = ast.parse(src)
-    allowed = {"cpu_baseline", "parity_check"}
+    allowed = {"cpu_baseline", "parity_check", "parity_check_rare"}
     users = set()
 
     def walk(node, fn):

@@ -318,6 +318,8 @@ def test_bench_default_line_carries_every_baseline_config_and_the_exact_dtype():
     rf = d["roofline"]
     assert rf["bound"] == "valu" and 0.1 < rf["frac"] < 1.0 and rf["launch_us"] > 0 and rf["traffic"] is not None
     assert d["parity_check"]["ok"] is True
+    rb = d["parity_check"]["rare_branches"]      # the second leg: injected states + the trained policy, the same kernel
+    assert rb["ok"] is True and rb["events_replayed"]["laps"] > 0 and rb["events_replayed"]["truncations"] > 0 and rb["events_replayed"]["terminated_at_time_limit"] > 0, rb
     e = d["exact_f64_value"]
     assert e["dtype"] == "f64" and e["rollout"] == "mega" and e["kernel"] == "K9-literal" and e["value"] > 1e9 and 0 < e["roofline"]["frac"] < rf["frac"]
     assert d["config"]["rollout_kernel"] == "K9"

@@ -66,10 +66,15 @@ def strided_population(n_envs, per_wave=4, wave=32, limit=None):
     return np.unique(sel)
 
 
-def _oracle_replay_check(cfg, snaps, first_obs, what, sel=None, stats=None, bit_equal=BIT_EQUAL):
+def _oracle_replay_check(cfg, snaps, first_obs, what, sel=None, stats=None, bit_equal=BIT_EQUAL, init_state=None, exact=False,
+                         min_alive=0.97):
     """Replay the stored actions of the envs `sel` (default: the first REPLAY) through the oracle and compare with the buffers
-    of the persistent rollout.  `stats` (a dict) receives the observation-error histogram and the list of departures."""
-    obs_buf, act_buf, rew_buf, _val, _lp, term_buf, trunc_buf, next_obs, next_term, next_trunc = snaps
+    of the persistent rollout.  `stats` (a dict) receives the observation-error histogram, the list of departures and the counts of
+    the bookkeeping events the replay went through (car_env.py:726-750: gates, laps, truncations, terminated at time_step >= 1000).
+    init_state: the rollout did not start from reset -- a dict of full-batch state arrays (pc_env_set_state's fields) the oracle's
+    envs start from (the launch's first policy input is then whatever next_obs held: not compared).
+    exact: the bit-exact dtype -- every observation, reward and flag of every env must be the oracle's bits, no departures."""
+    obs_buf, act_buf, rew_buf, _val, _lp, term_buf, trunc_buf, next_obs, next_term, next_trunc = snaps[:10]
     T, n = cfg.n_steps, cfg.num_rays
     if sel is None:
         sel = np.arange(min(REPLAY, obs_buf.shape[1]))
@@ -80,9 +85,13 @@ def _oracle_replay_check(cfg, snaps, first_obs, what, sel=None, stats=None, bit_
     track = oracle.Track(cfg.track)
     ora = oracle.OracleVecEnv(track, P, num_rays=n, reward_scaling=cfg.reward_scaling, threads=8)
     o = ora.reset()
-    assert np.abs(first_obs[idx].cpu().numpy() - o).max() <= 1e-6
+    if init_state is None:
+        assert np.abs(first_obs[idx].cpu().numpy() - o).max() <= (0.0 if exact else 1e-6)
+    else:
+        ora.set_state(**{k: np.asarray(v)[sel] for k, v in init_state.items()})
     alive = np.ones(P, bool)                 # env has not yet left the oracle's trajectory
     worst, ties, n_done, n_cmp, n_eq = 0.0, 0, 0, 0, 0
+    ev = dict(gates=0, laps=0, truncations=0, terminated_at_time_limit=0, max_abs_turns=0)
     edges = np.array([0.0, 1e-9, 3e-8, 6e-8, 1.2e-7, 2.5e-7, 5e-7, 1e-6, 1e-5, 1e-4, np.inf])
     hist = np.zeros(len(edges) - 1, np.int64)
     departures = []
@@ -91,9 +100,22 @@ def _oracle_replay_check(cfg, snaps, first_obs, what, sel=None, stats=None, bit_
         TEt = (term_buf[t + 1] if t + 1 < T else next_term)[idx].cpu().numpy() != 0
         TRt = (trunc_buf[t + 1] if t + 1 < T else next_trunc)[idx].cpu().numpy() != 0
         RWt = rew_buf[t][idx].cpu().numpy()
-        st = {k: getattr(ora, k).copy() for k in ("px", "py", "rot", "next_gate")}
+        st = {k: getattr(ora, k).copy() for k in ("px", "py", "rot", "next_gate", "time_step", "passed")}
         o, r, te, trn, fin = ora.step(acts[t], want_final_obs=True)
+        # the bookkeeping events of this step, from the oracle's own counters (on the envs still compared)
+        x = r.astype(np.float64) / cfg.reward_scaling                # the step's raw reward: 0.01 forward + 1 gate + 10 lap - 3 crash (car_env.py:700-748)
+        lap = x > 5.0                                                # +10 survives even a crash's -3 in the same step
+        gate = (x - 10.0 * lap + 3.0 * te) > 0.5
+        assert not (lap & (st["next_gate"] != track.G - 1)).any()    # a lap is the pass of the LAST gate (:730-737)
+        ev["gates"] += int((gate & alive).sum())
+        ev["laps"] += int((lap & alive).sum())
+        ev["truncations"] += int((trn & alive).sum())
+        ev["terminated_at_time_limit"] += int((te & (st["time_step"] >= 999) & alive).sum())        # Q7: terminated wins (car_env.py:746-750)
+        ev["max_abs_turns"] = max(ev["max_abs_turns"], int(np.abs(np.rint((st["rot"] - track.start_rot) / 5.0)).max()))
         ev_bad = (TEt != te) | (TRt != trn) | (RWt != r.astype(np.float32))
+        if exact:
+            assert not ev_bad.any(), f"{what}: step {t}: flags / rewards differ from the oracle's in the bit-exact dtype (envs {sel[np.nonzero(ev_bad)[0][:8]]})"
+            assert np.array_equal(OBt, o), f"{what}: step {t}: observations differ from the oracle's in the bit-exact dtype"
         for e in np.nonzero(ev_bad & alive)[0]:
             m = _near_tie(track, n, st, fin, e)
             departures.append((int(sel[e]), t, float(m)))
@@ -108,10 +130,11 @@ def _oracle_replay_check(cfg, snaps, first_obs, what, sel=None, stats=None, bit_
             n_eq += int((err == 0).sum())
         n_done += int((te | trn)[alive].sum())
     assert worst <= OBS_TOL, f"{what}: obs error {worst} before the first near-tie"
-    assert alive.mean() > 0.97, f"{what}: {P - alive.sum()} of {P} envs left the oracle's trajectory"
+    assert alive.mean() > min_alive, f"{what}: {P - alive.sum()} of {P} envs left the oracle's trajectory"
     assert n_done > 0                       # episodes ended (auto-reset rows were compared)
     assert n_eq >= bit_equal * n_cmp, f"{what}: only {n_eq} of {n_cmp} observation entries bit-equal"
     if stats is not None:
+        stats.update(events=ev)
         stats.update(envs=P, steps=T, entries=n_cmp, bit_equal=n_eq, obs_max_err=worst, hist_edges=[float(x) for x in edges[:-1]],
                      hist=[int(x) for x in hist], departures=departures, episodes_ended=n_done, on_trajectory=float(alive.mean()))
     return worst, ties, float(alive.mean())
