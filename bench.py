@@ -116,9 +116,24 @@ def parse_args():
     return ap.parse_args()
 
 
+def visible_gpus():
+    """How many devices this process can see, WITHOUT initialising HIP (torch.cuda.device_count() only enumerates on this image; the
+    parent must stay GPU-free so that it may start the ranks as child processes)."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:      # noqa: BLE001 -- no torch / no driver: the ranks will say so themselves
+        return -1
+
+
 def spawn_ranks(args):
     """--gpus N > 1 without a launcher: start N fresh rank processes (torch.distributed.run, one per GPU) as a child of this
     process, which has not initialised HIP (nothing here imports the extension or calls torch.cuda), and pass its exit code on."""
+    have = visible_gpus()
+    if not args.same_device and 0 <= have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} device(s) are visible to this process (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); "
+              "use --same-device --backend gloo for a one-device rehearsal", file=sys.stderr)
+        return 2
     port = args.master_port or (29500 + os.getpid() % 2000)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -350,6 +365,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path for the hot path")
     if args.same_device:
         local_rank = 0
+    elif torch.cuda.device_count() < world:      # (a launcher started the ranks: the same one-line reason, non-zero exit on every rank)
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} device(s) are visible to rank {rank}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -480,6 +497,8 @@ def main():
     tr.k1_events = []
     tr.phase_events = []
     tr.mega_events = []
+    if tr.learner.collective and not tr.learner._can_capture_update():
+        tr.learner.exchange_events = []      # HIP events around every eagerly enqueued exchange of the timed epochs (a captured one cannot be bracketed)
     dt = timed(tr, args.steps)
     for _ in range(args.steps):          # the stand-alone K1 probe, outside the timed region (it is not part of the path)
         run_probe()
@@ -497,6 +516,28 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+    # the exchange step of the timed epochs, by HIP events on the stream: from the end of K11 (this rank's gradient is complete) to the end of
+    # the all-reduce -- the wait for the slowest peer included.  THE multi-GPU number: the message is 59 KB, the step is latency-bound.
+    exchange_us, rollout_ranks_ms, rccl_live = None, None, 0
+    if tr.learner.exchange_events:
+        ex = np.sort(np.array([a.elapsed_time(b) * 1e3 for a, b in tr.learner.exchange_events]))
+        exchange_us = {"mean": float(ex.mean()), "p50": float(ex[len(ex) // 2]), "p90": float(ex[int(len(ex) * 0.9)]), "max": float(ex[-1]), "n": int(len(ex)),
+                       "method": "HIP events on the launch stream around every exchange of the timed epochs, rank 0 (includes the wait for the slowest rank's gradient)"}
+    elif tr.learner.collective:
+        exchange_us = {"mean": None, "note": "the exchanges are captured inside the epoch's update graph (--capture-collectives): not bracketed; run without it"}
+    tr.learner.exchange_events = None
+    if dist is not None and world > 1:
+        mine_ms = torch.tensor([float(np.mean([e[0].elapsed_time(e[1]) for e in tr.phase_events])),
+                                float(np.mean([e[1].elapsed_time(e[2]) for e in tr.phase_events]))], dtype=torch.float64,
+                               device=dev if dist.get_backend() == "nccl" else "cpu")
+        allr = [torch.empty_like(mine_ms) for _ in range(world)]
+        dist.all_gather(allr, mine_ms)
+        ro, up = [float(t[0]) for t in allr], [float(t[1]) for t in allr]
+        rollout_ranks_ms = {"min": min(ro), "max": max(ro), "gae_update_min": min(up), "gae_update_max": max(up), "per_rank": ro}
+    if dist is not None and dist.get_backend() == "nccl":
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)                 # the LIVE communicator's size: how many ranks actually took part in an RCCL collective
+        rccl_live = int(one.item())
     replicas_equal = None
     if dist is not None and world > 1:
         # the replicas after the timed epochs: every rank's flat parameter buffer against rank 0's, bit for bit (clip + Adam are
@@ -646,7 +687,9 @@ def main():
                                    f"train_iters={cfg.train_iters}; one step = one PPO epoch (rollout + GAE + update)",
                        "n_envs_total": cfg.n_envs * world, "parallelism": f"env-sharded dp{world}, 1 flat grad all-reduce/minibatch",
                        "ranks": dist.get_world_size() if dist is not None else 1,
-                       "rccl_ranks": dist.get_world_size() if (dist is not None and dist.get_backend() == "nccl") else 0,   # 0: no RCCL communicator exists
+                       "rccl_ranks": rccl_live,   # ranks counted by an all-reduce of ones on the live RCCL communicator (0: no RCCL communicator exists)
+                       "exchange_us": exchange_us, "rollout_ms_over_ranks": rollout_ranks_ms,
+                       "visible_devices": torch.cuda.device_count(),
                        "update_path": ("multi-rank (all-reduce + clip/Adam per minibatch), " + ("captured in the epoch graph" if captured else "enqueued eagerly"))
                        if (world > 1 or args.force_collective) else "single-rank epoch graph",
                        "backend": (dist.get_backend() if dist is not None else None),

@@ -102,19 +102,12 @@ __device__ __forceinline__ unsigned sgpr_const(const unsigned v) {   // a consta
 // (a & m) | k with the vertex index as an inline constant (unrolled sweeps) or in a VGPR (loops)
 template <int K> __device__ __forceinline__ unsigned and_or_k(unsigned a, unsigned m) {
     static_assert(K >= 0 && K <= 64, "inline constant");
-#ifdef PC_EXP_NOASM
-    return (a & m) | (unsigned)K;
-#endif
     unsigned d;
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(m), "n"(K));
     return d;
 }
 // v_pk_mul_f32 with the clamp modifier: clamp01(a * b) on two ray slots at once
 __device__ __forceinline__ f32x2 pk_mul_clamp(const f32x2 a, const f32x2 b) {
-#ifdef PC_EXP_NOASM
-    const f32x2 pr = a * b;
-    return (f32x2){__builtin_fminf(__builtin_fmaxf(pr.x, 0.0f), 1.0f), __builtin_fminf(__builtin_fmaxf(pr.y, 0.0f), 1.0f)};
-#endif
     f32x2 d;
     asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
     return d;
@@ -344,14 +337,10 @@ __device__ __forceinline__ void wall_sweep_unrolled(const Vtx* vt, const int n_c
 //   * both chain starts are position 0: their candidates are not formed, no sentinel is computed.
 // Every candidate is the same arithmetic on the same operands as in wall_sweep_f32: the same bits, and the minimum is exact.
 // Vertex records: wave-uniform scalar loads of VtxP (48 bytes).  rdl rows: [4 * ((L + 1) / 2)] floats.
-#ifdef PC_EXP_DEBUG      // developer experiment (tools/soak_cfg2_packed.py --debug): records of retained-vs-recomputed per-vertex values that differ
-__device__ unsigned g_dbg[8 + 8 * 1024];
-#endif
 template <int RPL, bool TAB, int L, bool ADDR = false>
 __device__ __forceinline__ void wall_sweep_loops(const VtxP* vp, const float pxr, const float pyr, const float (&dx)[RPL],
                                                  const float (&dy)[RPL], const int (&didx)[RPL], lds_cfp rdl, const float tau,
-                                                 unsigned (&bb)[2 * ((RPL + 1) / 2)], const float pxchk = 0.0f, const float pychk = 0.0f,
-                                                 const unsigned dbg_tag = 0u) {
+                                                 unsigned (&bb)[2 * ((RPL + 1) / 2)]) {
     static_assert(2 * L <= 32, "five index bits");
     constexpr int NG = (L + 1) / 2, ROW = 4 * NG;
     const unsigned keep = sgpr_const(0xffffffe0u);
@@ -372,7 +361,6 @@ __device__ __forceinline__ void wall_sweep_loops(const VtxP* vp, const float pxr
         }
     }
     // side values of position i of both chains: a = p - pos, c[s] = cross(a, dir_s), and the smallest |c| per slot
-    [[maybe_unused]] int dbg_pos = 0;
     auto side = [&](const VtxP& v, f32x2& ax, f32x2& ay, f32x2(&c)[RPL]) {
 #ifdef PC_AB_UNPACK   // developer A/B (tools/ab_run.sh build unpack "-DPC_AB_UNPACK -fno-slp-vectorize"): the same arithmetic as plain
                       // v_sub / v_mul / v_fma_f32 per component instead of v_pk_* (same bits: every operation is the same IEEE operation)
@@ -381,22 +369,6 @@ __device__ __forceinline__ void wall_sweep_loops(const VtxP* vp, const float pxr
 #else
         ax = v.xr - px2;
         ay = v.yr - py2;
-#endif
-#ifdef PC_EXP_DEBUG
-        {   // the same two differences from an opaque copy of the position (computed here, now): do the values this pass uses equal them?
-            const f32x2 axf = v.xr - (f32x2){pxchk, pxchk}, ayf = v.yr - (f32x2){pychk, pychk};
-            const bool bad = (__float_as_uint(axf.x) != __float_as_uint(ax.x)) | (__float_as_uint(axf.y) != __float_as_uint(ax.y)) |
-                             (__float_as_uint(ayf.x) != __float_as_uint(ay.x)) | (__float_as_uint(ayf.y) != __float_as_uint(ay.y));
-            if (bad) {
-                const unsigned k = atomicAdd(&g_dbg[0], 1u);
-                if (k < 1024u) {
-                    unsigned* r = g_dbg + 8 + 8 * k;
-                    r[0] = dbg_tag | ((unsigned)dbg_pos << 24); r[1] = threadIdx.x | (blockIdx.x << 10);
-                    r[2] = __float_as_uint(ax.x); r[3] = __float_as_uint(axf.x); r[4] = __float_as_uint(ax.y); r[5] = __float_as_uint(axf.y);
-                    r[6] = __float_as_uint(ay.x) ^ __float_as_uint(ayf.x); r[7] = __float_as_uint(ay.y) ^ __float_as_uint(ayf.y);
-                }
-            }
-        }
 #endif
 #pragma unroll
         for (int s = 0; s < RPL; ++s) {
@@ -459,13 +431,11 @@ __device__ __forceinline__ void wall_sweep_loops(const VtxP* vp, const float pxr
         }
         {
             const VtxP v = cload(vp + 2 * gq);
-            dbg_pos = 2 * gq;
             side(v, axA, ayA, cA);
             if constexpr (gq > 0) cand(std::integral_constant<int, 2 * gq>{}, v, axB, ayB, cB, cA, rd);
         }
         if constexpr (2 * gq + 1 < L) {
             const VtxP v = cload(vp + 2 * gq + 1);
-            dbg_pos = 2 * gq + 1;
             side(v, axB, ayB, cB);
             cand(std::integral_constant<int, 2 * gq + 1>{}, v, axA, ayA, cA, cB, rd);
         }

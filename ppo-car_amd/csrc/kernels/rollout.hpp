@@ -36,11 +36,6 @@ __device__ unsigned long long g_stamps_u[16];    // the minibatch kernel (K10), 
 //     global memory with 16-byte stores (three per lane instead of 23 scattered dword stores), and an env that finished its
 //     episode gets its reset observation in a rarely taken, wave-uniformly skipped fix-up.
 // ------------------------------------------------------------------------------------------
-#ifdef PC_EXP_NOPRIO
-#define PC_SETPRIO(x)
-#else
-#define PC_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
-#endif
 constexpr int TAB_MAX_GATES = 128;  // reward gates of a track staged in LDS (32 bytes each)
 struct ActLut {          // one per action 0..15 (9..15: no-op, car_env.py:721), 32 bytes
     double thrust;       // acc = heading * thrust: +0.8 forward, -0.8 backward, 0 none (car_env.py:423-438)
@@ -282,9 +277,6 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
             return *(lds_cd2)(size_t)(dir_b + (unsigned)FT_D64_BYTES + min(off, off - 5760u));
         }
     };
-#if defined(PC_EXP_WAITPASS) && PC_EXP_WAITPASS == 2
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
     // ---- action, heading before and after the turn (car_env.py:698-722, :440-442)
     const f64x2 Lf = ft.act[2 * a];                                     // (thrust, fric)
     const i32x2 Li = *(lds_ci2)(ft.act + 2 * a + 1);                    // (dk, fwd)
@@ -358,14 +350,10 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     // the vertex chain, 9 + 8 slots: one pass would need ~40 more registers than the 256 a wave has at two waves per SIMD (it
     // spilled 67 of them to scratch); the second pass repeats only the per-vertex position arithmetic (4 of ~50 instructions per
     // vertex and pass).
-    // (33 rays, 17 slots per lane: two passes, 9 + 8.  The chain-packed sweep at 33 rays -- three passes of 6 + 6 + 5 slots fit the
-    // registers but for 9 of them -- was built in round 5: 3-4 % faster per launch, and ONE observation entry in 3e8 differed from
-    // the per-step kernels in one run of two: not shipped, profiles/r5_ab_experiments.txt)
-#ifdef PC_EXP_CFG2_PACKED    // developer build only (tools/soak_cfg2_packed.py): the chain-packed sweep at 33 rays, three passes of 6 + 6 + 5 slots
-    constexpr int NPASS = RPL > 12 ? (SWP == 7 ? PC_EXP_CFG2_PACKED + 2 : 2) : 1;    // -DPC_EXP_CFG2_PACKED=1: three passes; =0: two
-#else
+    // (33 rays, 17 slots per lane: two passes, 9 + 8.  The chain-packed sweep at 33 rays in three passes of 6 + 6 + 5 slots was built in
+    // round 5 -- 3-4 % faster because hipcc shared the per-vertex work between the passes -- and was wrong about once in 1e9 entries:
+    // exactly that sharing, see the RULE in sweep_pass and profiles/r6_cfg2_packed_rootcause.md.  Without it the variant gains 1 %: not built.)
     constexpr int NPASS = RPL > 12 ? 2 : 1;
-#endif
     constexpr int R1 = (RPL + NPASS - 1) / NPASS;
     unsigned bb[RPL + 2];
     const float tau = flag_threshold(h, npx, npy);
@@ -378,11 +366,6 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
         // one pass over the chain for the slots [S0, S0 + RN)
         auto sweep_pass = [&](auto S0C, auto RNC) {
             constexpr int S0 = decltype(S0C)::value, RN = decltype(RNC)::value;
-#if defined(PC_EXP_WAITPASS) && PC_EXP_WAITPASS == 1       // developer experiments: nothing outstanding at a pass's start / a pure delay before the later passes
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#elif defined(PC_EXP_WAITPASS) && PC_EXP_WAITPASS == 3
-            if constexpr (S0 > 0) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
-#endif
             float dxp[RN], dyp[RN];
             int dip[RN];
             if constexpr (DIR_PER_PASS) {
@@ -399,33 +382,27 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
             const float(&dya)[RN] = DIR_PER_PASS ? dyp : *reinterpret_cast<const float(*)[RN]>(&dy[DIR_PER_PASS ? 0 : S0]);
             const int(&dia)[RN] = DIR_PER_PASS ? dip : *reinterpret_cast<const int(*)[RN]>(&didx[DIR_PER_PASS ? 0 : S0]);
             unsigned ba[2 * ((RN + 1) / 2)];
+            // RULE (profiles/r6_cfg2_packed_rootcause.md): a sweep in several passes keeps NOTHING per-vertex from one pass to the next.
+            // Left alone, hipcc computes the slot-independent per-vertex values (a = p - pos, un') in the first pass and keeps them in
+            // VGPRs for the later ones; packed-fp32 instructions that read such long-lived registers while the SIMD's other wave is active
+            // returned a wrong candidate about once in 1e9 entries (round 5's three-pass variant).  Every pass therefore works from its own
+            // opaque copy of the car's position and of the chain's address: it loads and derives everything itself.
+            float pxp = pxr, pyp = pyr;
+            const Vtx* vtp = p.vtx + h.vtx_off;
+            const VtxP* vpp = p.vtxp + h.vtxp_off;
+            if constexpr (NPASS > 1) asm volatile("" : "+v"(pxp), "+v"(pyp), "+s"(vtp), "+s"(vpp));
             if (PARTS > 1)                  // small form: latency-oriented sweep over the LDS copy of the chain
-                wall_sweep_lds<RN, PARTS, TAB, true>(ft.vtx, h.nV, part, pxr, pyr, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
-            else if constexpr (SWP == 7) {     // the host guarantees big_track's layout (two loops of 13 vertices, packed: TrackHdr::vtxp_off)
-                const VtxP* vpp = p.vtxp + h.vtxp_off;
-#ifdef PC_EXP_RELOAD      // developer experiment: every pass loads the vertex records itself (nothing of a pass is kept for the next)
-                asm volatile("" : "+s"(vpp));
-#endif
-#ifdef PC_EXP_DEBUG
-                float pxo = pxr, pyo = pyr;
-                asm volatile("" : "+v"(pxo), "+v"(pyo));
-                wall_sweep_loops<RN, TAB, 13, true>(vpp, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba, pxo, pyo, (unsigned)S0 | ((unsigned)t << 8));
-#elif defined(PC_EXP_REPOS)       // developer experiment: every pass recomputes the per-vertex VGPR values (a = p - pos, un'); the vertex records stay in SGPRs
-                float pxo = pxr, pyo = pyr;
-                asm volatile("" : "+v"(pxo), "+v"(pyo));
-                wall_sweep_loops<RN, TAB, 13, true>(vpp, pxo, pyo, dxa, dya, dia, ft.rden, tau, ba);
-#else
-                wall_sweep_loops<RN, TAB, 13, true>(vpp, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);
-#endif
-            }
+                wall_sweep_lds<RN, PARTS, TAB, true>(ft.vtx, h.nV, part, pxp, pyp, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
+            else if constexpr (SWP == 7)       // the host guarantees big_track's layout (two loops of 13 vertices, packed: TrackHdr::vtxp_off)
+                wall_sweep_loops<RN, TAB, 13, true>(vpp, pxp, pyp, dxa, dya, dia, ft.rden, tau, ba);
             else if constexpr (SWP == 5) {     // ... or two loops of 13 or of 9 vertices per track (track.json: 8 walls each): a mixed batch, workgroup-uniform
-                if (h.brk2 == 13) wall_sweep_loops<RN, TAB, 13, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);
-                else wall_sweep_loops<RN, TAB, 9, true>(p.vtxp + h.vtxp_off, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);
+                if (h.brk2 == 13) wall_sweep_loops<RN, TAB, 13, true>(vpp, pxp, pyp, dxa, dya, dia, ft.rden, tau, ba);
+                else wall_sweep_loops<RN, TAB, 9, true>(vpp, pxp, pyp, dxa, dya, dia, ft.rden, tau, ba);
             }
             else if (h.nV == 28)               // (wave-uniform) a chain of 28: the unrolled sweep
-                wall_sweep_unrolled<RN, TAB, 7, true>(p.vtx + h.vtx_off, h.n_chain, pxr, pyr, dxa, dya, dia, ft.rden, tau, ba);   // chain length
+                wall_sweep_unrolled<RN, TAB, 7, true>(vtp, h.n_chain, pxp, pyp, dxa, dya, dia, ft.rden, tau, ba);   // chain length
             else if constexpr (SWP == 0)       // and the generic loop is not even compiled in (1 % from the shorter kernel alone)
-                wall_sweep_f32<RN, PARTS, TAB, true>(p.vtx + h.vtx_off, h.nV, part, pxr, pyr, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
+                wall_sweep_f32<RN, PARTS, TAB, true>(vtp, h.nV, part, pxp, pyp, dxa, dya, dia, ft.rden, tau, h.idx_mask, ba);
 #pragma unroll
             for (int s = 0; s < RN; ++s) bb[S0 + s] = ba[s];
         };
@@ -1042,21 +1019,10 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const int TT = last_val ? T + 1 : T;
     float rsum = 0.0f;
     int act_reg = 8;     // the action drawn for this lane pair's env (the pair draw leaves it in both lanes)
-#ifdef PC_EXP_V255       // developer experiment: the kernel allocates all 256 VGPRs
-    asm volatile("v_mov_b32 v255, 0" ::: "v255");
-#endif
-#ifdef PC_EXP_SCRATCH    // developer experiment: the kernel has a private segment and touches it every step
-    volatile int scr_probe[8];
-    scr_probe[tid & 7] = tid;
-#endif
 #pragma unroll 1
     for (int t = 0; t < TT; ++t) {
         const bool tail = t == T;      // (uniform)
         PC_STAMP(0)
-#ifdef PC_EXP_SCRATCH
-        scr_probe[t & 7] = t;
-        if (scr_probe[(t + 3) & 7] == -12345) rsum += 1.0f;
-#endif
         {
             // ---------------- P(t)
             f32x4 out[ET];
@@ -1077,9 +1043,9 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 // SIMD are in opposite phases most of the time; with equal priorities the issue arbiter interleaves them
                 // instruction by instruction and both crawl, with the env-step wave preferred the matrix pipe still gets
                 // its instructions in the gaps.  Measured inside the benchmark's epochs: 20.5 -> 18.7 ms per rollout.
-                PC_SETPRIO(0);
+                __builtin_amdgcn_s_setprio(0);
                 if (!(dbg & 1)) policy_pass<KS>(sW1, sB1, sW2, 0, NT, x, out, lc, lk, lane);  // dbg: timing ablations only
-                PC_SETPRIO(3);
+                __builtin_amdgcn_s_setprio(3);
             } else if constexpr (pol_wide(PREC)) {
                 // fp16 x 2: the wave's 32 envs as ONE column tile of v_mfma_f32_32x32x16_f16 (policy_pass32).  Observation loads are
                 // unconditional (K padding reads a few floats into the next row / the tables behind: inside the workgroup's LDS)
@@ -1092,11 +1058,11 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o32[i] = 0.0f;
                 float v32 = 0.0f;
-                PC_SETPRIO(0);
+                __builtin_amdgcn_s_setprio(0);
                 PC_STAMP(1)
                 if (!(dbg & 1)) policy_pass32<KSTEPS, NG>(sW1p, sW2p, sB1, sW2c, xs, o32, v32, lane);
                 PC_STAMP(2)
-                PC_SETPRIO(3);
+                __builtin_amdgcn_s_setprio(3);
                 store_out32<LDO>(myOut, o32, v32, A, lane);
             } else {
                 Pieces<PREC> x[ET][KB];
@@ -1120,11 +1086,11 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                     }
                 }
                 float val[ET] = {};
-                PC_SETPRIO(0);
+                __builtin_amdgcn_s_setprio(0);
                 PC_STAMP(1)
                 if (!(dbg & 1)) policy_pass16<PREC, KB, ET>(sW1p, sW2p, sB1, sW2c, 0, NT / 2, x, out, val, lc, lk);
                 PC_STAMP(2)
-                PC_SETPRIO(3);
+                __builtin_amdgcn_s_setprio(3);
 #pragma unroll
                 for (int et = 0; et < ET; ++et) {
                     float tv = val[et];
@@ -1196,7 +1162,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
         PC_STAMP(3)
         if constexpr (FAST) {
             if (!(dbg & 2)) {
-                PC_SETPRIO(2);
+                __builtin_amdgcn_s_setprio(2);
                 // ---------------- E(t)
                 float rw, tf, cf;
                 const int a = e_valid ? act_reg : 8;
@@ -1258,7 +1224,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 PC_STAMP(7)
             }
         } else if (e_valid && !(dbg & 2)) {
-            PC_SETPRIO(2);
+            __builtin_amdgcn_s_setprio(2);
             // ---------------- E(t)
             float* orow = last ? next_obs + e_env * D : obs_buf + ((int64_t)(t + 1) * N + e_env) * D;
             float rw;

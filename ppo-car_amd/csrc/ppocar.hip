@@ -841,17 +841,6 @@ int pc_build_ablate(void) { return 0x100 | PC_ABLATE; }     // a developer quick
 int pc_build_ablate(void) { return PC_ABLATE; }
 #endif
 
-#ifdef PC_EXP_DEBUG
-// developer build only: the debug records of wall_sweep_loops (count, then 8 words per record); clears them
-int pc_debug_read_dbg(unsigned* out, int n) {
-    if (n < 8 + 8 * 1024) return -1;
-    if (hipDeviceSynchronize() != hipSuccess) return -2;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), (8 + 8 * 1024) * sizeof(unsigned)) != hipSuccess) return -3;
-    unsigned zero = 0;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &zero, sizeof(unsigned)) != hipSuccess) return -4;
-    return (int)out[0];
-}
-#endif
 #ifdef PC_STAMPS
 // developer build only (not declared in ppocar.h): copy the phase stamps of the last pc_rollout launch to the host
 int pc_debug_read_stamps(unsigned long long* out, int n) {
@@ -1549,9 +1538,6 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
         // tracks, fast mode switched off -- spilled 100+ registers beside the split operands' policy state: not built either; that
         // shape is PC_ERR_UNSUPPORTED here and runs through the per-step kernels, bit-identical by construction)
         if (!mode) return PC_ERR_UNSUPPORTED;
-#ifdef PC_EXP_CFG2_PACKED    // developer build only: rollout_kernel<10, 17, 2, 4> (round 5's chain-packed 33-ray variant, see tools/soak_cfg2_packed.py)
-        if (prec == 2 && all_nv28 && o.fast == 1) { PC_DEV(2, PC_ROLL_M(10, 17, 2, 4)); HIPCHK(hipGetLastError()); e->last_kernel = PC_KERNEL_K9; return PC_OK; }
-#endif
         if (prec == 2) PC_DEV(2, PC_ROLL_M(10, 17, 2, 1));
         else PC_FULL(PC_ROLL_M(10, 17, 1, 1));
     }
@@ -1760,6 +1746,7 @@ struct pc_xchg {
     int n_pad = 0, n_chunks = 0;
     char* local = nullptr;                       // this rank's staging allocation (uncached device memory)
     char* peer[XCHG_MAX_RANKS] = {nullptr};      // every rank's allocation as mapped here (peer[rank] == local)
+    bool ipc[XCHG_MAX_RANKS] = {false};          // peer[r] came from hipIpcOpenMemHandle (closed at destroy); false: a pointer of this process
     bool connected = false;
     double timeout_s = 20.0;
     size_t data_bytes() const { return (size_t)2 * world * n_pad * sizeof(float); }
@@ -1831,6 +1818,7 @@ int pc_xchg_local_handle(pc_xchg* x, void* handle_out) {
     static_assert(sizeof(hipIpcMemHandle_t) == 64 && PC_XCHG_HANDLE_BYTES == 128, "handle layout");
     g_hip_err.clear();
     DeviceGuard guard(x->device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
     hipIpcMemHandle_t h;
     HIPCHK(hipIpcGetMemHandle(&h, x->local));
     char* out = static_cast<char*>(handle_out);
@@ -1888,8 +1876,40 @@ int pc_xchg_connect(pc_xchg* x, const void* all_handles) {
         const hipError_t oe = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
         if (oe != hipSuccess || !q) return fail(PC_ERR_HIP, std::string("hipIpcOpenMemHandle(rank ") + std::to_string(r) + "): " + hipGetErrorString(oe));
         x->peer[r] = static_cast<char*>(q);
+        x->ipc[r] = true;
         opened.push_back(r);
     }
+    x->connected = true;
+    return PC_OK;
+}
+
+// The same exchange with every rank's handle in THIS process (one process driving several devices, or -- the tests' use -- several
+// ranks on one device, each on its own stream): the peers' staging buffers are plain pointers here, no IPC handle is involved.
+int pc_xchg_connect_local(pc_xchg* x, pc_xchg* const* ranks) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
+    if (!x || !ranks) return PC_ERR_INVALID_ARG;
+    for (int r = 0; r < x->world; ++r) {
+        const pc_xchg* q = ranks[r];
+        if (!q || q->rank != r || q->world != x->world || q->n != x->n || (r == x->rank && q != x)) return PC_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(x->device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    for (int r = 0; r < x->world; ++r) {
+        if (r == x->rank || ranks[r]->device == x->device) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, x->device, ranks[r]->device) != hipSuccess || !can) {
+            g_hip_err = "pc_xchg_connect_local: device " + std::to_string(x->device) + " has no peer access to device " + std::to_string(ranks[r]->device);
+            return PC_ERR_UNSUPPORTED;
+        }
+        const hipError_t pe = hipDeviceEnablePeerAccess(ranks[r]->device, 0);
+        (void)hipGetLastError();
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+            g_hip_err = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe);
+            return PC_ERR_HIP;
+        }
+    }
+    for (int r = 0; r < x->world; ++r)
+        if (r != x->rank) { x->peer[r] = ranks[r]->local; x->ipc[r] = false; }
     x->connected = true;
     return PC_OK;
 }
@@ -1927,7 +1947,7 @@ void pc_xchg_destroy(pc_xchg* x) {
     DeviceGuard guard(x->device);
     (void)hipDeviceSynchronize();
     for (int r = 0; r < x->world; ++r)
-        if (r != x->rank && x->peer[r]) (void)hipIpcCloseMemHandle(x->peer[r]);
+        if (r != x->rank && x->peer[r] && x->ipc[r]) (void)hipIpcCloseMemHandle(x->peer[r]);
     (void)hipFree(x->local);
     delete x;
 }

@@ -132,6 +132,12 @@ class ExchangeTimeout(RuntimeError):
     the handle) are WRONG and this rank's replica has diverged.  The job must stop; the launcher tears the other ranks down."""
 
 
+class P2PUnavailable(RuntimeError):
+    """The one-shot exchange could not be set up on SOME rank (a peer's device hidden from a process, no peer access, an IPC mapping
+    refused -- e.g. ranks in containers with separate IPC namespaces).  Raised on EVERY rank (the connect results are all-gathered),
+    so that the job can fall back to exchange = "rccl" collectively."""
+
+
 class P2PExchange:
     """pc_xchg_*: the flat gradient bucket summed over the ranks of one node by a one-shot exchange over hipIpc-mapped staging
     buffers (include/ppocar.h).  The IPC handles travel through torch.distributed (any backend); the exchange itself is one
@@ -166,7 +172,17 @@ class P2PExchange:
         handles = [None] * world_size
         dist.all_gather_object(handles, bytes(mine.raw))
         blob = b"".join(handles)
-        check(lib.pc_xchg_connect(h, C.c_char_p(blob)), "pc_xchg_connect")
+        # every rank learns every rank's connect result: a connect that fails on SOME ranks only (peers in containers with their own IPC
+        # namespace, a device hidden from one process) must not leave the others exchanging with a rank that is not there
+        rc = lib.pc_xchg_connect(h, C.c_char_p(blob))
+        why = lib.pc_last_hip_error().decode() if rc != 0 else ""
+        results = [None] * world_size
+        dist.all_gather_object(results, (int(rc), why))
+        bad = [(r, c, w) for r, (c, w) in enumerate(results) if c != 0]
+        if bad:
+            lib.pc_xchg_destroy(h)
+            self._h = None
+            raise P2PUnavailable("pc_xchg_connect failed on rank(s) " + "; ".join(f"{r}: code {c} {w}" for r, c, w in bad))
         dist.barrier()              # every rank has mapped every peer before the first exchange
 
     def __call__(self):
@@ -230,9 +246,16 @@ class PPOLearner:
         if cfg.exchange not in ("rccl", "p2p"):
             raise ValueError(f"PPOConfig.exchange must be 'rccl' or 'p2p', not {cfg.exchange!r}")
         self.p2p = None
+        self.exchange_events = None      # bench.py: a list -> (start, end) HIP events around every eagerly enqueued exchange
         if cfg.exchange == "p2p" and world_size > 1 and self.device.type == "cuda":
-            self.p2p = P2PExchange(self.flat_grad, rank, world_size, self.device, timeout_s=cfg.exchange_timeout_s)
-            self.exchange = self._exchange_and_average      # the torch-op update paths (fused_update off) exchange through it too
+            try:
+                self.p2p = P2PExchange(self.flat_grad, rank, world_size, self.device, timeout_s=cfg.exchange_timeout_s)
+                self.exchange = self._exchange_and_average      # the torch-op update paths (fused_update off) exchange through it too
+            except P2PUnavailable as ex:      # raised on every rank alike: the whole job falls back together
+                import sys
+                print(f"[ppo_car_amd] rank {rank}: exchange = 'p2p' is not available ({ex}); falling back to exchange = 'rccl' on all ranks",
+                      file=sys.stderr, flush=True)
+                self.p2p = None
         self._capture_failed = False
         self.graphs = bool(cfg.use_graphs) and self.device.type == "cuda"
         self.fused = bool(cfg.fused_update) and self.device.type == "cuda" and 2 <= cfg.batch_size <= 1024
@@ -315,11 +338,18 @@ class PPOLearner:
 
     def _sum_gradients(self):
         """The one exchange step per minibatch: flat_grad := SUM over ranks (the 1/W is folded into the clip + Adam kernels)."""
+        ev = None
+        if self.exchange_events is not None and not torch.cuda.is_current_stream_capturing():
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         if self.p2p is not None:
             self.p2p()
         else:
             import torch.distributed as dist
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+        if ev is not None:
+            ev[1].record()
+            self.exchange_events.append(ev)
 
     def _custom_apply(self):
         """clip + Adam after the gradient exchange of the custom (hand-written kernel) minibatch step: the step counter was

@@ -260,3 +260,14 @@ def test_bench_main_never_reads_a_name_after_deleting_it_or_shadows_a_module_fun
     # (names assigned again after their del -- tr2, tr3 inside their own blocks -- are stores, not loads; a load after the last del is the slip)
     assert not late, late
     assert not (stores & top), stores & top
+
+
+def test_bench_refuses_more_gpus_than_are_visible_without_starting_ranks():
+    """`python bench.py --gpus N` where fewer than N devices are visible (here: none) and no --same-device: the PARENT exits with code 2
+    and a one-line reason on stderr before it starts any rank -- the first real multi-GPU run must not die inside a rendezvous for this."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2 and r.stdout.strip() == ""
+    assert "--gpus 8 but only" in r.stderr and "--same-device" in r.stderr

@@ -297,6 +297,47 @@ def test_bench_self_spawned_two_ranks_on_one_device(exchange, capture):
     assert out["value"] > 0 and c["rollout"] == "mega"
 
 
+@pytest.mark.parametrize("world,exchange", [(4, "rccl"), (6, "p2p")])
+def test_bench_self_spawned_four_and_six_ranks_on_one_device(world, exchange):
+    """The driver's N > 1 entry at larger world sizes, rehearsed on one device (six: as many processes as this pool lets one job put on a
+    card; the 8-way line differs only in the count): exit code 0, ONE JSON line, the ranks counted, no RCCL communicator claimed over
+    gloo, the replicas bit-identical -- and the fields the first real multi-GPU run needs to explain itself: `exchange_us`
+    {mean, p50, p90, max} by HIP events around every eagerly enqueued exchange, the rollout's min / max over the ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--same-device", "--backend", "gloo", "--exchange", exchange,
+           "--workload", "cfg1", "--n-envs", "1024", "--n-steps", "64", "--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--no-extras"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    c = out["config"]
+    assert out["n_gpus"] == world and c["ranks"] == world and c["n_envs_total"] == 1024 * world and c["rccl_ranks"] == 0 and c["backend"] == "gloo"
+    assert c["replicas_bit_identical"] is True and ("one-shot" in c["gradient_exchange"]) == (exchange == "p2p")
+    ex = c["exchange_us"]
+    assert ex["n"] == 2 * 40 * 1 and 0 < ex["p50"] <= ex["p90"] <= ex["max"] and ex["mean"] > 0, ex      # 2 timed epochs x 40 iterations x ceil(64 / 512) minibatches
+    ro = c["rollout_ms_over_ranks"]
+    assert len(ro["per_rank"]) == world and 0 < ro["min"] <= ro["max"]
+    assert c["visible_devices"] >= 1
+
+
+def test_bench_refuses_more_gpus_than_are_visible():
+    """`--gpus N` with fewer than N devices visible and no --same-device: a one-line reason on stderr and a non-zero exit code from the
+    PARENT, before any rank is started (the first real multi-GPU run must not die somewhere inside a rendezvous for this reason)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(max(2, n))], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2 and r.stdout.strip() == ""
+    assert "device(s) are visible" in r.stderr and "--same-device" in r.stderr
+
+
 def test_bench_default_line_carries_every_baseline_config_and_the_exact_dtype():
     """`python bench.py` as the driver runs it (shortened: 2 timed epochs): ONE JSON line whose headline is the target workload and
     which also holds the bit-exact dtype's value on the same workload, every other single-GPU BASELINE config with its own

@@ -35,6 +35,7 @@ def _free_port():
 
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(50 + rank)                 # DIFFERENT init per rank: the learner must broadcast rank 0's
     agent = Agent(D, A)
@@ -102,6 +103,20 @@ def test_two_rank_full_update_keeps_replicas_identical(tmp_path):
     assert not torch.equal(r0["init"], r0["final"])
     assert r0["lr"] == r1["lr"] == pytest.approx(3e-4 * 0.99)
     assert not torch.equal(r0["metrics"], r1["metrics"])   # losses are per-shard quantities
+
+
+def test_eight_rank_full_update_keeps_replicas_identical(tmp_path):
+    """The world size of BASELINE configs[3] / [4] (8 ranks, gloo on the CPU): rank 0's parameters broadcast to all, eight different
+    shards and index streams, one all-reduce of the flat bucket per minibatch (train.py:259-260) -- every replica ends on the same bits."""
+    world = 8
+    torch.set_num_threads(1)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+    for r in rs[1:]:
+        assert torch.equal(rs[0]["init"], r["init"]) and torch.equal(rs[0]["final"], r["final"])
+        assert r["lr"] == rs[0]["lr"]
+    assert not torch.equal(rs[0]["init"], rs[0]["final"])
+    assert len({tuple(r["metrics"].tolist()) for r in rs}) == world      # losses are per-shard quantities
 
 
 def test_single_rank_learner_follows_reference_loop_bounds():

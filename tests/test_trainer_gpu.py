@@ -379,7 +379,7 @@ def _two_rank_worker(rank, world, port, out_dir, use_graphs, exchange="rccl"):
     dist.init_process_group("gloo", rank=rank, world_size=world)     # both ranks share cuda:0 here; RCCL needs one GPU per rank
     torch.cuda.set_device(0)
     cfg = _cfg(n_envs=512, n_steps=64, batch_size=32, train_iters=2, use_graphs=use_graphs, seed=11, exchange=exchange,
-               capture_collectives=exchange == "p2p")
+               capture_collectives=exchange == "p2p" and use_graphs)
     tr = Trainer(cfg, device="cuda:0", rank=rank, world_size=world)
     s1 = tr.run_epoch()
     s2 = tr.run_epoch()
@@ -469,7 +469,7 @@ def _xchg_worker(rank, world, port, out_dir, n, epochs):
         # a peer whose device this process cannot resolve (here: a PCI bus id no device has) is refused AT CONNECT TIME with its own
         # message, nothing stays mapped, no HIP error stays behind -- and the handle then connects normally
         bogus = list(handles)
-        peer = 1 - rank
+        peer = (rank + 1) % world
         bogus[peer] = bogus[peer][:64] + b"ffff:ff:1f.7".ljust(HB - 64, b"\0")
         assert lib.pc_xchg_connect(h, C.c_char_p(b"".join(bogus))) == -5          # PC_ERR_UNSUPPORTED
         msg = lib.pc_last_hip_error().decode()
@@ -500,11 +500,12 @@ def _xchg_worker(rank, world, port, out_dir, n, epochs):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [1, 2])
+@pytest.mark.parametrize("world", [1, 2, 4, 6])
 def test_one_shot_exchange_kernel_directly_many_epochs(tmp_path, world):
     """pc_xchg_allreduce on its own, 300 back-to-back exchanges (both epoch parities, the double buffering, 15 independent chunks
     for a 14858-float bucket): bit-equal rank-ordered sums on every rank and PC_OK -- on one rank (the sum of one bucket is the
-    bucket) and between two processes sharing cuda:0.  Plain launches, no whole-epoch graphs: nothing here can starve a peer, so
+    bucket) and between 2, 4 and 6 processes sharing cuda:0 (6: as many processes as a GPU box of this pool lets one job put on its
+    card; the slot / flag layout at the full 8 ranks runs in ONE process: test_one_shot_exchange_eight_ranks_in_one_process).  Plain launches, no whole-epoch graphs: nothing here can starve a peer, so
     a PC_ERR_TIMEOUT in THIS test is a synchronisation bug in the kernel.  (train.py:259-260)"""
     import socket
     import torch.multiprocessing as mp
@@ -514,6 +515,73 @@ def test_one_shot_exchange_kernel_directly_many_epochs(tmp_path, world):
     mp.spawn(_xchg_worker, args=(world, port, str(tmp_path), 14858, 300), nprocs=world, join=True)
     for r in range(world):
         assert torch.load(tmp_path / f"x{r}.pt")["bad"] == 0
+
+
+@pytest.mark.parametrize("world,n", [(8, 14858), (8, 23050), (5, 12298), (3, 1000)])
+def test_one_shot_exchange_eight_ranks_in_one_process(world, n):
+    """K13's slot / flag layout at the FULL world size (XCHG_MAX_RANKS = 8: 2 parities x 8 writers x n_pad floats and 2 x 8 x n_chunks
+    flags per rank) -- which no multi-process rehearsal on a one-GPU box can reach (at most 6 processes per card): all `world` ranks'
+    handles live in this process (pc_xchg_connect_local), every rank launches its exchange kernel on its OWN stream, so the grids
+    are co-resident and wait for each other exactly as eight devices would.  100 exchanges, buckets of irregular magnitude: every
+    rank's bucket must be the rank-ordered float32 sum, bit for bit, and every handle PC_OK.  (train.py:259-260)"""
+    import ctypes as C
+    from ppo_car_amd._capi import check, lib
+    hs = []
+    for r in range(world):
+        h = C.c_void_p()
+        check(lib.pc_xchg_create(0, r, world, n, C.byref(h)), "pc_xchg_create")
+        check(lib.pc_xchg_set_timeout(h, 10.0), "pc_xchg_set_timeout")
+        hs.append(h)
+    arr = (C.c_void_p * world)(*[h.value for h in hs])
+    assert lib.pc_xchg_allreduce(hs[1], torch.zeros(n, device="cuda").data_ptr(), None) == -1      # unconnected: refused, not launched
+    wrong = (C.c_void_p * world)(*[hs[(r + 1) % world].value for r in range(world)])
+    assert lib.pc_xchg_connect_local(hs[0], wrong) == -1                                            # handles out of rank order: refused
+    for h in hs:
+        check(lib.pc_xchg_connect_local(h, arr), "pc_xchg_connect_local")
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    idx = torch.arange(n, device="cuda", dtype=torch.float32)
+    gen = lambda r, ep: torch.sin(idx * (0.37 + r) + ep * 1.7) * (1.0 + 1000.0 * (ep % 3)) + r
+    torch.cuda.synchronize()
+    bad = 0
+    for ep in range(100):
+        buckets = [gen(r, ep) for r in range(world)]
+        want = buckets[0].clone()
+        for r in range(1, world):
+            want = want + buckets[r]
+        torch.cuda.synchronize()
+        for r in range(world):
+            with torch.cuda.stream(streams[r]):
+                check(lib.pc_xchg_allreduce(hs[r], buckets[r].data_ptr(), streams[r].cuda_stream), "pc_xchg_allreduce")
+        torch.cuda.synchronize()
+        for r in range(world):
+            bad += int((buckets[r] != want).sum())
+    for h in hs:
+        assert lib.pc_xchg_status(h) == 0
+    assert bad == 0
+    for h in hs:
+        lib.pc_xchg_destroy(h)
+
+
+@pytest.mark.parametrize("world", [4])
+def test_four_ranks_on_one_gpu_keep_replicas_identical_both_exchanges(tmp_path, world):
+    """The trainer at world size 4 (four processes sharing cuda:0, gloo for the rendezvous): env shards and action streams differ per
+    rank, the per-minibatch exchange -- torch.distributed's all_reduce and the library's one-shot exchange, eagerly enqueued --
+    leaves all four replicas bit-identical, and both exchanges give the same parameters up to the summation order of four terms
+    (the one-shot exchange sums in rank order; gloo's ring does not promise one).  (train.py:259-261)"""
+    import socket
+    import torch.multiprocessing as mp
+    res = {}
+    for exchange in ("rccl", "p2p"):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mp.spawn(_two_rank_worker, args=(world, port, str(tmp_path), False, exchange), nprocs=world, join=True)
+        res[exchange] = [torch.load(tmp_path / f"r{r}_0_{exchange}.pt") for r in range(world)]
+        for r in range(1, world):
+            assert torch.equal(res[exchange][0]["param"], res[exchange][r]["param"]), (exchange, r)     # replicas bit-identical
+            assert not torch.equal(res[exchange][0]["acts"], res[exchange][r]["acts"])
+        assert res[exchange][0]["step"] == 2 * world * 512 * 64
+    assert float((res["rccl"][0]["param"] - res["p2p"][0]["param"]).abs().max()) < 1e-5
 
 
 @pytest.mark.parametrize("B,D,A", [(512, 23, 9), (100, 18, 9), (1024, 39, 9), (256, 23, 6), (64, 39, 13)])

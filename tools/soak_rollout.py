@@ -2,9 +2,10 @@
 and then find out WHICH side was wrong and WHERE the wrong value lives.
 
 Written for round 5's unexplained event (profiles/r5_ab_experiments.txt): the chain-packed 33-ray variant rollout_kernel<10, 17, 2, 4>
-(a developer build, -DPC_EXP_CFG2_PACKED=1) gave ONE observation entry of 3.3e8 different from the per-step kernels in one run of two.
+gave ONE observation entry of 3.3e8 different from the per-step kernels in one run of two.  The record of the hunt -- and of the shipped
+kernels' soaks -- is profiles/r6_cfg2_packed_rootcause.md (the -DPC_EXP_* developer flags it names exist in commit 171d065 only).
 
-    python tools/soak_cfg2_packed.py <package dir with the build under test> [--launches N] [--n-envs 65536] [--n-steps 128] [--rays 32]
+    python tools/soak_rollout.py <package dir with the build under test> [--launches N] [--n-envs 65536] [--n-steps 128] [--rays 32]
                                      [--fast 1] [--dtype f32] [--out FILE]
 
 Two trainers of one seed advance in lockstep: A = pc_rollout (the build under test), B = the per-step kernels K5 + K1 of the same library.
@@ -30,11 +31,11 @@ ap.add_argument("--n-steps", type=int, default=128)
 ap.add_argument("--rays", type=int, default=32)
 ap.add_argument("--fast", type=int, default=1)
 ap.add_argument("--dtype", default="f32")
+ap.add_argument("--mixed", action="store_true", help="track.json + big_track.json in halves (configs[4]'s layout)")
 ap.add_argument("--form", type=int, default=-1, help="PPOConfig.rollout_form (2: the big form without the 1/den table in LDS)")
 ap.add_argument("--train-every", type=int, default=25, help="one PPO update every k launches (both sides: the policy moves, identically)")
 ap.add_argument("--repeats", type=int, default=10, help="on an event: repeat the rollout launch this many times from the saved state")
 ap.add_argument("--max-events", type=int, default=5)
-ap.add_argument("--debug", action="store_true", help="a -DPC_EXP_DEBUG build: read wall_sweep_loops' retained-vs-recomputed records after every rollout launch")
 ap.add_argument("--out", default=None)
 args = ap.parse_args()
 sys.path.insert(0, os.path.abspath(args.pkg))
@@ -52,7 +53,7 @@ def bufs(tr):
 
 
 def make(mode):
-    cfg = PPOConfig(n_envs=args.n_envs, n_steps=args.n_steps, num_rays=args.rays, track=f"{ROOT}/tracks/big_track.json", rollout_kernel=mode,
+    cfg = PPOConfig(n_envs=args.n_envs, n_steps=args.n_steps, num_rays=args.rays, track=([f"{ROOT}/tracks/track.json", f"{ROOT}/tracks/big_track.json"] if args.mixed else f"{ROOT}/tracks/big_track.json"), rollout_kernel=mode,
                     use_graphs=False, seed=11, env_dtype=args.dtype, rollout_fast=args.fast, rollout_form=args.form, bootstrap_value="fp32", policy_split=1 if args.n_envs <= 8192 else 0)
     return Trainer(cfg, device="cuda")
 
@@ -75,33 +76,11 @@ def launch(tr):
 
 
 A, B = make("mega"), make("steps")
-dbg_total = 0
-if args.debug:
-    import ctypes
-    from ppo_car_amd._capi import lib as _lib
-    _dbg = (ctypes.c_uint * (8 + 8 * 1024))()
-
-
-def read_dbg(it):
-    global dbg_total
-    n = _lib.pc_debug_read_dbg(_dbg, len(_dbg))
-    if n > 0:
-        dbg_total += n
-        recs = []
-        for k in range(min(n, 24)):
-            r = [_dbg[8 + 8 * k + j] for j in range(8)]
-            recs.append({"pass_first_slot": r[0] & 255, "step": (r[0] >> 8) & 0xffff, "position": r[0] >> 24, "thread": r[1] & 1023, "block": r[1] >> 10,
-                         "ax_lo_used": hex(r[2]), "ax_lo_fresh": hex(r[3]), "ax_hi_used": hex(r[4]), "ax_hi_fresh": hex(r[5]), "ay_lo_xor": hex(r[6]), "ay_hi_xor": hex(r[7])})
-        print(json.dumps({"launch": it, "debug_records": n, "first": recs}), flush=True)
-
 out = open(args.out, "a") if args.out else None
 events, entries, t0, cols = [], 0, time.time(), {}
 for it in range(args.launches):
     sd = save(B)
-    ra = launch(A)
-    if args.debug:
-        read_dbg(it)
-    rb = launch(B)
+    ra, rb = launch(A), launch(B)
     assert A.rollout_mode == "mega", A.rollout_mode
     entries += sum(t.numel() for t in ra)
     diff = [i for i, (x, y) in enumerate(zip(ra, rb)) if not torch.equal(x, y)]
@@ -162,7 +141,7 @@ for it in range(args.launches):
     if it % 50 == 49:
         print(f"# {it + 1} launches, {entries:.3e} entries compared, {len(events)} events, {time.time() - t0:.0f} s", flush=True)
 summary = {"summary": True, "pkg": args.pkg, "kernel": A.envs.last_rollout_kernel(), "launches": args.launches, "n_envs": args.n_envs, "n_steps": args.n_steps,
-           "rays": args.rays, "fast": args.fast, "dtype": args.dtype, "entries_compared": entries, "events": len(events), "obs_columns_of_primary_differences": {str(k): v for k, v in sorted(cols.items())}, "seconds": time.time() - t0}
+           "rays": args.rays, "mixed": args.mixed, "fast": args.fast, "dtype": args.dtype, "entries_compared": entries, "events": len(events), "obs_columns_of_primary_differences": {str(k): v for k, v in sorted(cols.items())}, "seconds": time.time() - t0}
 print(json.dumps(summary), flush=True)
 if out:
     out.write(json.dumps(summary) + "\n")
