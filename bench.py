@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark: env steps/sec of the whole PPO loop (rollout + GAE + update, the
 `charts/SPS` definition of the reference, train.py:174,292) on big_track.json, "16 rays" (17 actual).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|cfg1|cfg2|cfg4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|cfg1|cfg2|cfg4|cfg4i]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
@@ -61,6 +61,9 @@ WORKLOADS = {
     "cfg2": dict(n_envs=65536, n_steps=128, num_rays=32, batch_size=512, train_iters=40),
     # the per-GPU shard of BASELINE.json configs[4] (262144 envs on 8 GPUs, track.json and big_track.json in one batch)
     "cfg4": dict(n_envs=32768, n_steps=1024, num_rays=16, batch_size=512, train_iters=40, mixed=True),
+    # ... and its INTERLEAVED variant (`track_id = i & 1`, every wave holds both tracks -- what car_env.py:621-628 makes
+    # legal per env): the persistent kernel's generic mode, the env step once per distinct track of a wave
+    "cfg4i": dict(n_envs=32768, n_steps=1024, num_rays=16, batch_size=512, train_iters=40, mixed=True, interleave=True),
 }
 # SURVEY 8(d) / BASELINE.md section 4, per env step: state 64 B + action 8 B + observation 4 (6 + R) B + reward / flags 12 B
 # = 156 / 176 / 240 B at 12 / 17 / 33 actual rays; 28 flop per ray-segment test x (R S + 4 gate tests) + R sincos pairs + ~30 physics
@@ -245,7 +248,7 @@ def parity_check(tr, cfg, torch, np, envs=1024, steps=64):
     torch.cuda.synchronize()
     b = tr.buffer
     i = np.arange(cfg.n_envs)
-    tid = np.minimum((i // 32 * 32) * nt // cfg.n_envs, nt - 1)
+    tid = i % nt if cfg.track_interleave else np.minimum((i // 32 * 32) * nt // cfg.n_envs, nt - 1)      # ppo.Trainer's two layouts
     n, step_deg = cfg.num_rays, 360 // cfg.num_rays
     col = list(range(0, n, n // 4))            # Car.check_collision's rays (car_env.py:389)
     worst, flips, checked, n_cmp, n_eq, worst_margin, waves = 0.0, 0, 0, 0, 0, 0.0, set()
@@ -318,7 +321,7 @@ def parity_check_rare(make_trainer, wl, track, torch, np, steps=64):
             load_trained_policy(t_.agent)
         tracks = list(track) if isinstance(track, (list, tuple)) else [track]
         i = np.arange(cfg_.n_envs)
-        tid = np.minimum((i // 32 * 32) * len(tracks) // cfg_.n_envs, len(tracks) - 1)
+        tid = i % len(tracks) if cfg_.track_interleave else np.minimum((i // 32 * 32) * len(tracks) // cfg_.n_envs, len(tracks) - 1)
         full = None
         for k, path in enumerate(tracks):
             mine = np.nonzero(tid == k)[0]
@@ -395,6 +398,9 @@ def main():
     if args.n_steps:
         wl["n_steps"] = args.n_steps
     mixed = wl.pop("mixed", False)
+    interleave = wl.pop("interleave", False)
+    if interleave:
+        wl["track_interleave"] = True
     track = ([os.path.join(ROOT, "tracks", "track.json"), os.path.join(ROOT, "tracks", "big_track.json")] if mixed
              else os.path.join(ROOT, "tracks", "big_track.json"))
 
@@ -422,6 +428,9 @@ def main():
         launch by HIP events on the launch stream inside those epochs; the launch priced against the same roofs."""
         wl_ = dict(wl_in)
         mixed_ = wl_.pop("mixed", False)
+        inter_ = wl_.pop("interleave", False) or wl_.get("track_interleave", False)
+        if inter_:
+            wl_["track_interleave"] = True
         trk = tracks_of(mixed_)
         c_, t_ = make_trainer(wl_=wl_, env_dtype=env_dtype, track_=trk)
         try:
@@ -436,7 +445,7 @@ def main():
             r_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in t_.phase_events]))
             mega = float(np.mean([a.elapsed_time(b) for a, b in t_.mega_events]) * 1e3) if t_.mega_events else None
             sec_ = (mega if mega is not None else r_ms * 1e3) * 1e-6     # per-step kernels (f64): the rollout phase of the epoch
-            res = {"workload": f"{name}: {'track.json + big_track.json (halves)' if mixed_ else 'big_track.json'}, num_rays={c_.num_rays} ({R_} actual), "
+            res = {"workload": f"{name}: {('track.json + big_track.json (' + ('interleaved env by env' if inter_ else 'halves') + ')') if mixed_ else 'big_track.json'}, num_rays={c_.num_rays} ({R_} actual), "
                                f"n_envs={c_.n_envs}, n_steps={c_.n_steps}, batch_size={c_.batch_size}, train_iters={c_.train_iters}",
                    "value": units_ * epochs / d_, "unit": "env steps/s", "epochs": epochs, "ms_per_step": d_ / epochs * 1e3,
                    "dtype": env_dtype, "rollout": t_.rollout_mode,
@@ -608,13 +617,13 @@ def main():
         # the bit-exact configuration (float64 throughout, the reference's own operation order: observations, rewards, events AND
         # the float64 state equal the reference's bit for bit) on the SAME workload ...
         try:
-            extras["exact_f64_value"] = side_measurement(args.workload, WORKLOADS[args.workload] if not (args.n_envs or args.n_steps) else dict(wl, mixed=mixed),
+            extras["exact_f64_value"] = side_measurement(args.workload, WORKLOADS[args.workload] if not (args.n_envs or args.n_steps) else dict(wl, mixed=mixed, interleave=interleave),
                                                          env_dtype="f64", epochs=3)
         except Exception as ex:
             extras["exact_f64_value"] = {"error": repr(ex)}
         # ... and every other single-GPU BASELINE configuration, each with its own ms_per_step and roofline fraction
         others = {}
-        for name in ("target", "cfg1", "cfg2", "cfg4"):
+        for name in ("target", "cfg1", "cfg2", "cfg4", "cfg4i"):
             if name == args.workload:
                 continue
             try:
@@ -626,6 +635,8 @@ def main():
                 others[name]["exact_f64"] = {k: f64[k] for k in ("value", "unit", "ms_per_step", "kernel", "epoch_split")}
             except Exception as ex:
                 others[name]["exact_f64"] = {"error": repr(ex)}
+        if "cfg4" in others and "cfg4i" in others and "value" in others["cfg4"] and "value" in others["cfg4i"]:
+            others["cfg4i"]["ratio_to_halves_layout"] = others["cfg4i"]["value"] / others["cfg4"]["value"]
         extras["other_workloads"] = others
 
     if rank == 0:
@@ -652,7 +663,7 @@ def main():
         D, A = obs_dim, 9
         mlp_flops = 2 * (2 * D * 256 + 256 * A + 256)                       # both MLPs, one env step (model.py:14-32)
         n_prod = {"fp16x2": 3, "bf16x3": 6, "fp32": 1}[args.policy_arith]
-        track_name = "track.json + big_track.json (halves)" if mixed else "big_track.json"
+        track_name = ("track.json + big_track.json (" + ("interleaved env by env" if interleave else "halves") + ")") if mixed else "big_track.json"
         roof = {"kernel": dom_name, "bound": "valu",
                 "achieved": per_step_flops * units / sec / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": per_step_flops * units / sec / 1e12 / VALU_PEAK_TFLOPS, "traffic": None,

@@ -176,6 +176,13 @@ int pc_sample(int device, const float* logits, int64_t N, int A, uint64_t seed, 
  * The weights do not change during a rollout, so they are packed ONCE into the kernel's LDS image:
  *   pc_policy_pack  builds the image (device buffer `image`) from the eight torch.nn.Linear tensors: aW1 [H][D], ab1 [H],
  *                   aW2 [A][H], ab2 [A], cW1 [H][D], cb1 [H], cW2 [1][H], cb2 [1]
+ *   pc_policy_pack_checked  the same, and *range_status (a DEVICE int32, written asynchronously on `stream`) := 0 or a mask of
+ *                   PC_POLICY_RANGE_*: the weights leave precision 2's numeric domain -- a weight saturates in its scaled fp16 domain
+ *                   (|W1| > 4094, |W2| > 1023.5), or a hidden unit can reach the hidden layer's saturation point 255.87 on observations
+ *                   within +-4 (|b1| + 4 sum_j |W1_uj| > 255.87; CarEnv's observations lie in [-1, 1.6]).  With the status 0 NO operand of
+ *                   the policy pass can saturate, so the rollout kernels carry no run-time check.  A set bit means: results of
+ *                   pc_policy_act / pc_rollout with this image are NOT model.py's within 4e-6 -- pack with a precision-0 handle instead
+ *                   (the host layer does: Agent.pack_policy).  Forms 0 and 1 have no scaled domains: always 0.
  *   pc_policy_act   one policy step for obs [N][D] using the image.  RNG as pc_sample, with offset = `offset` + *offset_dev when
  *                   offset_dev != NULL (a device counter, so a captured HIP graph can be replayed with a fresh stream of draws).
  *                   action [N] int64; action_f32 [N] (the float copy Buffer.act_buf stores, buffer.py:13) or NULL; logprob,
@@ -185,6 +192,11 @@ void pc_policy_destroy(pc_policy* p);
 int pc_policy_get(const pc_policy* p, int* precision, int* split, int64_t* image_floats);
 int pc_policy_pack(const pc_policy* p, const float* aW1, const float* ab1, const float* aW2, const float* ab2, const float* cW1,
                    const float* cb1, const float* cW2, const float* cb2, float* image, void* stream);
+#define PC_POLICY_RANGE_W1 1       /* a first-layer weight (actor or critic) saturates in its scaled fp16 domain */
+#define PC_POLICY_RANGE_W2 2       /* an actor output-layer weight does */
+#define PC_POLICY_RANGE_HIDDEN 4   /* a hidden activation can */
+int pc_policy_pack_checked(const pc_policy* p, const float* aW1, const float* ab1, const float* aW2, const float* ab2, const float* cW1,
+                           const float* cb1, const float* cW2, const float* cb2, float* image, int32_t* range_status, void* stream);
 int pc_policy_act(const pc_policy* p, const float* obs, int64_t N, const float* image, uint64_t seed, uint64_t offset,
                   const uint64_t* offset_dev, int64_t* action, float* action_f32, float* logprob, float* value, float* logits_out,
                   void* stream);

@@ -80,6 +80,7 @@ _sig = {
     "pc_policy_destroy": (None, [_vp]),
     "pc_policy_get": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64)]),
     "pc_policy_pack": (_i, [_vp] + [_vp] * 8 + [_vp, _vp]),
+    "pc_policy_pack_checked": (_i, [_vp] + [_vp] * 8 + [_vp, _vp, _vp]),
     "pc_policy_act": (_i, [_vp, _vp, _i64, _vp, C.c_uint64, C.c_uint64, _vp] + [_vp] * 5 + [_vp]),
     "pc_rollout": (_i, [_vp, _vp, _vp, _i64, _d, C.c_uint64, C.c_uint64, _vp] + [_vp] * 12 + [_vp]),
     "pc_env_set_option": (_i, [_vp, _i, _i]),

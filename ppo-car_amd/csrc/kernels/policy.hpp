@@ -189,6 +189,7 @@ template <int PREC> struct Pieces { u32x4 p[pol_np(PREC)]; };  // eight fp32 val
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 #define PC_H_MAX 65504.0f
+#define PC_OBS_ABS_MAX 4.0f  /* the bound on |observation| the pack-time range check assumes (CarEnv: [-1, 1.6]) */
 #define PC_SX 16.0f          /* observations */
 #define PC_S1 16.0f          /* first-layer weights */
 #define PC_SH 256.0f         /* hidden layer = PC_SX * PC_S1 */
@@ -277,7 +278,14 @@ __global__ __launch_bounds__(256) void policy_pack16_kernel(const int D, const i
                                                             const float* __restrict__ ab1, const float* __restrict__ aW2,
                                                             const float* __restrict__ ab2, const float* __restrict__ cW1,
                                                             const float* __restrict__ cb1, const float* __restrict__ cW2,
-                                                            const float* __restrict__ cb2, unsigned* __restrict__ image) {
+                                                            const float* __restrict__ cb2, unsigned* __restrict__ image,
+                                                            int* __restrict__ status) {
+    // status (optional; the host zeroes it before the launch): the fp16 x 2 form's NUMERIC DOMAIN, checked while the weights pass through
+    // (PC_POLICY_RANGE_*, include/ppocar.h): bit 0 / 1 -- a first- / output-layer weight saturates in its scaled domain (|W1| > 4094,
+    // |W2| > 1023.5); bit 2 -- a hidden unit CAN reach the hidden layer's saturation point: |b1| + PC_OBS_ABS_MAX * sum_j |W1_uj| > 255.87
+    // (observations of CarEnv lie in [-1, 1.6]: positions / 1280 on a track inside the 2000 px box, everything else in [-1, 1];
+    // PC_OBS_ABS_MAX = 4 leaves a factor 2.5).  With all three clear no operand of the policy pass can saturate, whatever the kernels
+    // are fed: the guard costs the rollout kernels nothing.  (model.py:14-32 has no such limit: a set bit means "use precision 0".)
     constexpr int HID = 256, NP = pol_np(PREC);
     constexpr int n1 = 32 * NP * NG * 16, n2 = 8 * NP * 4 * 10;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2 + 512 + 16 + 256; i += gridDim.x * blockDim.x) {
@@ -305,15 +313,30 @@ __global__ __launch_bounds__(256) void policy_pack16_kernel(const int D, const i
                 }
             }
             if constexpr (PREC == 2) {
+                bool big = false;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = clamp_h(v[j]);
+                for (int j = 0; j < 8; ++j) {
+                    big |= !(__builtin_fabsf(v[j]) <= PC_H_MAX);      // (a NaN weight is out of range too)
+                    v[j] = clamp_h(v[j]);
+                }
+                if (big && status) atomicOr(status, i < n1 ? 1 : 2);
             }
             const Pieces<PREC> sp = split8<PREC>(v);
             reinterpret_cast<u32x4*>(image)[i] = sp.p[pc];
         } else {
             const int b = i - n1 - n2;
             float v;
-            if (b < 512) v = (b < HID ? ab1[b] : cb1[b - HID]) * PolScale<PREC>::sh;   // hidden layer's scaled domain
+            if (b < 512) {
+                v = (b < HID ? ab1[b] : cb1[b - HID]) * PolScale<PREC>::sh;   // hidden layer's scaled domain
+                if constexpr (PREC == 2) {
+                    if (status) {      // the largest pre-activation hidden unit b can see on observations within +-PC_OBS_ABS_MAX
+                        const float* row = b < HID ? aW1 + b * D : cW1 + (b - HID) * D;
+                        float bound = __builtin_fabsf(b < HID ? ab1[b] : cb1[b - HID]);
+                        for (int f = 0; f < D; ++f) bound = __builtin_fmaf(__builtin_fabsf(row[f]), PC_OBS_ABS_MAX, bound);
+                        if (!(bound * PolScale<PREC>::sh <= PC_H_MAX)) atomicOr(status, 4);
+                    }
+                }
+            }
             else if (b < 528) {
                 const int o = b - 512;
                 v = o < A ? ab2[o] : (o == A ? cb2[0] : 0.0f);   // added after the outputs are scaled back

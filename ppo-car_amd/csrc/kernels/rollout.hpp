@@ -1233,9 +1233,21 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
             if (rden_lds)  // uniform
                 env_step_core<float, RPL, 1, true, true>(q, trk, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw,
                                                    term, trunc, passed, 0, nullptr, rdl);
-            else
-                env_step_core<float, RPL, 1, false, true>(q, trk, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw, term,
-                                          trunc, passed);
+            else {
+                // The step runs once per DISTINCT TRACK ID among the wave's envs (K1's waterfall): one pass for a single-track batch and
+                // for mixed batches in blocks of 32 envs; with tracks INTERLEAVED inside the wave (car_env.py:621-628 lets every env sit
+                // on its own track; configs[4]'s `track_id = i & 1` variant) one pass per track, so that a pass's track header and wall
+                // chain stay wave-uniform (scalar loads).  The loop is driven by a ballot of the lanes still to do.
+                uint64_t todo = __builtin_amdgcn_ballot_w64(true);
+                do {
+                    const int cur = __builtin_amdgcn_readlane(trk, __builtin_ctzll(todo));
+                    const bool match = trk == cur;
+                    if (match)
+                        env_step_core<float, RPL, 1, false, true>(q, cur, g, 1, st, (int64_t)sAct[el], reward_scale, orow, nullptr, sObs + el * LDX, rw,
+                                                                  term, trunc, passed);
+                    todo &= ~__builtin_amdgcn_ballot_w64(match);
+                } while (todo);
+            }
             rsum += rw;
             if (g == 0) {
                 rew_buf[(int64_t)t * N + e_env] = rw;
@@ -1301,7 +1313,7 @@ __global__ __launch_bounds__(512) void rollout_f64_kernel(const EnvParams<double
     const bool e_valid = e_env < N;
     EnvRegs st = {};
     if (e_valid) st = env_load<double>(p, e_env);
-    const int trk = p.track_id ? (int)p.track_id[e_valid ? e_env : N - 1] : 0;     // (every aligned block of 32 envs shares a track: host check)
+    const int trk = p.track_id ? (int)p.track_id[e_valid ? e_env : N - 1] : 0;     // (per env: a wave may hold several tracks, see E(t))
     for (int f = g; f < 4 * KS; f += 2) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
     static_assert(4 * KS + 1 >= 20, "the output tile must fit the wave's observation rows");
     float* myOut = sObs + wave * 32 * LDX;          // the wave's output tile lives in its own observation rows (see rollout_kernel)
@@ -1397,8 +1409,15 @@ __global__ __launch_bounds__(512) void rollout_f64_kernel(const EnvParams<double
             float rw;
             bool term, trunc;
             int passed;
-            env_step_core<double, RPL, 1, false, true, SEL ? 2 : 0>(p, trk, g, 1, st, (int64_t)act_reg, reward_scale, orow, nullptr, sObs + el * LDX, rw, term,
-                                                             trunc, passed);
+            uint64_t todo = __builtin_amdgcn_ballot_w64(true);      // once per distinct track id among the wave's envs (see rollout_kernel's generic mode)
+            do {
+                const int cur = __builtin_amdgcn_readlane(trk, __builtin_ctzll(todo));
+                const bool match = trk == cur;
+                if (match)
+                    env_step_core<double, RPL, 1, false, true, SEL ? 2 : 0>(p, cur, g, 1, st, (int64_t)act_reg, reward_scale, orow, nullptr, sObs + el * LDX, rw,
+                                                                     term, trunc, passed);
+                todo &= ~__builtin_amdgcn_ballot_w64(match);
+            } while (todo);
             rsum += rw;
             if (g == 0) {
                 rew_buf[(int64_t)t * N + e_env] = rw;

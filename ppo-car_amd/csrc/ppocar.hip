@@ -1066,16 +1066,17 @@ int pc_env_get_option(const pc_env* e, int option, int* value) {
 static int64_t policy_image_floats_impl(int prec, int D) { return prec ? polx_image_dwords(prec, pol_ng(policy_ks(D))) : pol_image_padded(policy_ks(D)); }
 
 static int policy_pack_impl(int device, int prec, int D, int H, int A, const float* aW1, const float* ab1, const float* aW2, const float* ab2,
-                            const float* cW1, const float* cb1, const float* cW2, const float* cb2, float* image, void* stream) {
+                            const float* cW1, const float* cb1, const float* cW2, const float* cb2, float* image, int* status, void* stream) {
     if (!aW1 || !ab1 || !aW2 || !ab2 || !cW1 || !cb1 || !cW2 || !cb2 || !image) return PC_ERR_INVALID_ARG;
     if (H != 256 || A < 1 || A > 15 || D < 1 || D > 40) return PC_ERR_UNSUPPORTED;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1 || device < 0 || device >= count) return PC_ERR_NO_DEVICE;
     DeviceGuard guard(device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
+    if (status) HIPCHK(hipMemsetAsync(status, 0, sizeof(int), (hipStream_t)stream));     // (forms without scaled domains leave it 0: no operand of theirs saturates)
 #define PC_PACK(PRC, NGV)                                                                                                \
     hipLaunchKernelGGL((policy_pack16_kernel<PRC, NGV>), dim3(64), dim3(256), 0, (hipStream_t)stream, D, A, aW1, ab1, aW2, ab2, cW1, \
-                       cb1, cW2, cb2, reinterpret_cast<unsigned*>(image))
+                       cb1, cW2, cb2, reinterpret_cast<unsigned*>(image), status)
     const int ng = pol_ng(policy_ks(D));
     if (prec == 1) { PC_FULL(if (ng == 5) PC_PACK(1, 5); else PC_PACK(1, 3)); }
     else if (prec == 2) { if (ng == 5) PC_PACK(2, 5); else PC_PACK(2, 3); }
@@ -1144,7 +1145,14 @@ int pc_policy_pack(const pc_policy* p, const float* aW1, const float* ab1, const
                    const float* cb1, const float* cW2, const float* cb2, float* image, void* stream) {
     g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!p) return PC_ERR_INVALID_ARG;
-    return policy_pack_impl(p->device, p->precision, p->D, p->H, p->A, aW1, ab1, aW2, ab2, cW1, cb1, cW2, cb2, image, stream);
+    return policy_pack_impl(p->device, p->precision, p->D, p->H, p->A, aW1, ab1, aW2, ab2, cW1, cb1, cW2, cb2, image, nullptr, stream);
+}
+
+int pc_policy_pack_checked(const pc_policy* p, const float* aW1, const float* ab1, const float* aW2, const float* ab2, const float* cW1,
+                           const float* cb1, const float* cW2, const float* cb2, float* image, int32_t* range_status, void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
+    if (!p || !range_status) return PC_ERR_INVALID_ARG;
+    return policy_pack_impl(p->device, p->precision, p->D, p->H, p->A, aW1, ab1, aW2, ab2, cW1, cb1, cW2, cb2, image, range_status, stream);
 }
 
 int pc_policy_act(const pc_policy* p, const float* obs, int64_t N, const float* image, uint64_t seed, uint64_t offset,
@@ -1218,7 +1226,10 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
                             const uint64_t* offset_dev, float* obs_buf, float* act_buf, float* rew_buf, float* val_buf, float* term_buf,
                             float* trunc_buf, float* logprob_buf, float* next_obs, float* next_term, float* next_trunc, float* last_value,
                             float* reward_sum, void* stream) {
-    if ((e->track_id && !e->track_blocks32) || A != 9) return PC_ERR_UNSUPPORTED;
+    if (A != 9) return PC_ERR_UNSUPPORTED;
+    // mixed tracks interleaved inside a wave (no aligned block of 32 envs on one track): the generic kernel K9d, whose env step runs once
+    // per distinct track id of a wave; the literal forms stage ONE track's tables per workgroup
+    const bool interleaved = e->track_id && !e->track_blocks32;
     const int KS = policy_ks(e->D);
     const int prec = policy_prec(prec_request, e->D, A);
     if (prec == 0) return PC_ERR_UNSUPPORTED;
@@ -1263,7 +1274,7 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
         lds_small += (size_t)rden_small_lds * sizeof(float);
         const bool shape_small = (rays16 || rays12) && prec == 2 && small && max_G <= TAB_MAX_GATES && max_nV <= FT_VTX_MAX && o.fast &&
                                  lds_small <= 160 * 1024;
-        if (tabs && shape_small && !e->f64_offgrid) {
+        if (tabs && shape_small && !e->f64_offgrid && !interleaved) {
             const int vec_ok = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
             EnvParams<float> prm = e->params<float>();
             prm.lg = 2;
@@ -1296,7 +1307,7 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
             const bool want = o.form == 4 || (o.form < 0 && o.epw_override == 0 && e->N > PC_SPLIT_MAX_ENVS && e->N <= PC_MEDIUM_MAX_ENVS);
             const int rden_m = 361 * max_nV;
             const size_t lds_m = (size_t)k9_fast_lds_floats(img, 16, e->D, true, rden_m) * sizeof(float);
-            if (want && tabs && shape && rays16 && !e->f64_offgrid && (all_nv28 || all_loops) && (!e->track_id || e->track_block >= 128) &&
+            if (want && tabs && shape && rays16 && !e->f64_offgrid && !interleaved && (all_nv28 || all_loops) && (!e->track_id || e->track_block >= 128) &&
                 lds_m <= 160 * 1024) {
                 const int vec_ok = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
                 EnvParams<float> prm = e->params<float>();
@@ -1320,7 +1331,7 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
                 return PC_OK;
             }
         }
-        if (tabs && shape && !e->f64_offgrid) {
+        if (tabs && shape && !e->f64_offgrid && !interleaved) {
             const int vec_ok = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
             EnvParams<float> prm = e->params<float>();
             prm.lg = 1;
@@ -1393,7 +1404,11 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
     if (e->dtype == PC_DTYPE_F64)
         return rollout_f64_impl(e, prec_request, image, A, T, reward_scale, seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf,
                                 trunc_buf, logprob_buf, next_obs, next_term, next_trunc, last_value, reward_sum, stream);
-    if (e->dtype != PC_DTYPE_F32 || (e->track_id && !e->track_blocks32) || A < 1 || A > 15) return PC_ERR_UNSUPPORTED;
+    if (e->dtype != PC_DTYPE_F32 || A < 1 || A > 15) return PC_ERR_UNSUPPORTED;
+    // mixed tracks interleaved inside a wave (no aligned block of 32 envs on one track; car_env.py:621-628 makes that legal): the BIG
+    // form's generic mode, whose env step runs once per distinct track id of a wave (K1's waterfall) -- the fast modes stage ONE track's
+    // tables per workgroup, and the small form's sweep parts meet across workgroup barriers that a per-wave loop cannot contain
+    const bool interleaved = e->track_id && !e->track_blocks32;
     const int KS = policy_ks(e->D);
     DeviceGuard guard(e->device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
@@ -1402,7 +1417,8 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
     const int img = prec ? polx_image_dwords(prec, pol_ng(KS)) : pol_image_padded(KS);
     // large batches: 256 envs per workgroup, every wave independent; small batches: 32 envs per workgroup, hidden tiles and
     // wall-sweep parts split over the waves
-    const bool small = o.form == 1 || (o.form < 0 && e->N <= PC_SPLIT_MAX_ENVS);
+    if (interleaved && o.form == 1) return PC_ERR_UNSUPPORTED;
+    const bool small = !interleaved && (o.form == 1 || (o.form < 0 && e->N <= PC_SPLIT_MAX_ENVS));
     const int epw = o.epw_override >= 128 ? o.epw_override
                                                   : ((!small && e->N <= g_rollout_epw128_max) ? 128 : 256);   // big form: envs per workgroup
     int max_G = 0, max_nV = 0;

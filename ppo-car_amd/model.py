@@ -14,6 +14,10 @@ def layer_init(layer, std=np.sqrt(2), bias_const=0.0):  # model.py:6-9
     return layer
 
 
+class PolicyRangeError(RuntimeError):
+    """Agent.policy_range = "raise": the weights left the numeric domain of the fused policy step's fp16 x 2 arithmetic."""
+
+
 class Agent(nn.Module):
     def __init__(self, num_inputs, num_outputs, hidden_size=256):  # model.py:12-26
         super().__init__()
@@ -88,11 +92,48 @@ class Agent(nn.Module):
             if h is not None:
                 lib.pc_policy_destroy(h)
 
+    # ---- the fp16 x 2 form's numeric domain (include/ppocar.h: pc_policy_pack_checked).  Its operands SATURATE at fp16's range in
+    # their scaled domains (|W1| > 4094, |W2| > 1023.5, a hidden activation beyond 255.87) -- implausible on this env with sane
+    # training, but a diverging run would be silently wrong.  Every pack therefore writes a range status on the device; it is read
+    # back WITHOUT synchronising (an async copy into pinned memory, looked at on the next pack / wherever the caller synchronises
+    # anyway), and when it is set the agent switches to precision 0 -- the exact fp32 chain, no domain limits -- loudly (stderr, once
+    # per switch) and for good.  `policy_range = "raise"` raises PolicyRangeError instead; check_policy_range(sync=True) looks NOW.
+    policy_range = "fallback"
+
+    def check_policy_range(self, sync=False):
+        """True if the weights of the last pack were inside the arithmetic form's domain (or nothing is known yet).  sync=True waits for the
+        status of the last pack; otherwise only a status that has already arrived is looked at."""
+        ev = self.__dict__.get("_range_event")
+        if ev is None:
+            if not sync or self.__dict__.get("_range_dev") is None:
+                return True
+            mask = int(self._range_dev.item())      # (no copy in flight -- e.g. the pack ran inside a graph: read the device word itself)
+        else:
+            if sync:
+                ev.synchronize()
+            elif not ev.query():
+                return True
+            mask = int(self._range_host[0])
+            self._range_event = None
+        if mask == 0:
+            return True
+        what = ", ".join(n for b, n in ((1, "a first-layer weight beyond 4094"), (2, "an output-layer weight beyond 1023.5"),
+                                        (4, "a hidden unit that can exceed 255.87")) if mask & b)
+        if self.policy_range == "raise":
+            raise PolicyRangeError(f"the policy weights left the fp16x2 form's numeric domain ({what}): use policy_precision = 0")
+        import sys
+        print(f"[ppo_car_amd] policy weights left the fp16x2 form's numeric domain ({what}); the fused policy step now runs in "
+              "precision 0 (fp32-input MFMA, the exact fp32 chain)", file=sys.stderr, flush=True)
+        self.policy_precision = 0
+        self._image_ok = False
+        return False
+
     @torch.no_grad()
     def pack_policy(self):
         """Pack the current weights into the fused policy kernel's LDS image (once per rollout: the weights do
         not change while it runs).  Returns False when the shape is outside the kernel's menu."""
         self._image_ok = False
+        self.check_policy_range()      # the status of an EARLIER pack, if it has arrived: may switch this pack to precision 0
         if not self._std_mlp():
             return False
         a1, a2, c1, c2 = self.actor[0], self.actor[2], self.critic[0], self.critic[2]
@@ -104,9 +145,19 @@ class Agent(nn.Module):
         if getattr(self, "_image", None) is None or self._image.numel() != n or self._image.device != dev:
             self._image = torch.empty(n, dtype=torch.float32, device=dev)
         h = self._policy_handle()
-        check(lib.pc_policy_pack(h, a1.weight.data_ptr(), a1.bias.data_ptr(), a2.weight.data_ptr(), a2.bias.data_ptr(),
-                                   c1.weight.data_ptr(), c1.bias.data_ptr(), c2.weight.data_ptr(), c2.bias.data_ptr(),
-                                   self._image.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "pc_policy_pack")
+        if getattr(self, "_range_dev", None) is None or self._range_dev.device != dev:
+            self._range_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._range_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        check(lib.pc_policy_pack_checked(h, a1.weight.data_ptr(), a1.bias.data_ptr(), a2.weight.data_ptr(), a2.bias.data_ptr(),
+                                           c1.weight.data_ptr(), c1.bias.data_ptr(), c2.weight.data_ptr(), c2.bias.data_ptr(),
+                                           self._image.data_ptr(), self._range_dev.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+              "pc_policy_pack_checked")
+        if form[0] == 2 and not torch.cuda.is_current_stream_capturing() and self.__dict__.get("_range_event") is None:
+            # (one status in flight at a time: the pinned word is not overwritten before it was looked at.  Inside a graph capture the
+            # status stays on the device; check_policy_range(sync=True) reads it there, where the caller synchronises anyway.)
+            self._range_host.copy_(self._range_dev, non_blocking=True)
+            self._range_event = torch.cuda.Event()
+            self._range_event.record()
         self._image_ok = True
         self._image_handle = h       # the image belongs to the handle that packed it
         return True

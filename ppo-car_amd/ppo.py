@@ -49,7 +49,8 @@ class PPOConfig:
     track: str = "tracks/big_track.json"   # replaces the Tk file dialog (train.py:95-111,119).  A list / tuple of paths = a
                                            # mixed-track batch (BASELINE configs[4]): env i runs track (i * n_tracks) // n_envs,
                                            # rounded to blocks of 32 envs (the layout the persistent rollout kernel accepts)
-    track_interleave: bool = False         # mixed tracks env by env instead (i % n_tracks: every wave holds all tracks; per-step kernels only)
+    track_interleave: bool = False         # mixed tracks env by env instead (i % n_tracks: every wave holds all tracks: the persistent kernel's generic mode,
+                                           # its env step once per distinct track of a wave)
     num_rays: int = 12                     # Car(num_rays=...) (car_env.py:227); 16 -> 17 rays, 32 -> 33
     env_dtype: str = "f32"
     seed: int = 0
@@ -89,6 +90,9 @@ class PPOConfig:
                                            # -1 = the library's default (fp16x2).  Per Trainer (a pc_policy handle), not process-wide
     policy_split: int = -1                 # work decomposition of the fused policy step: -1 automatic by batch size, 0 never, 1 always
                                            # (hidden tiles split over a workgroup's waves; differs in fp32 summation order)
+    policy_range: str = "fallback"         # weights outside the fp16x2 form's numeric domain (a weight / hidden activation that saturates in its
+                                           # scaled fp16 domain; checked at every pack, include/ppocar.h pc_policy_pack_checked): "fallback" = switch
+                                           # the fused policy step to precision 0 (exact fp32 chain) with a message on stderr, "raise" = PolicyRangeError
     rollout_form: int = -1                 # pc_rollout's per-handle options (include/ppocar.h PC_OPT_ROLLOUT_*; every choice gives the
     rollout_epw: int = 0                   # same bits): form -1 automatic / 0 big / 1 small / 2, 3 without the LDS 1/den table; envs per
     rollout_fast: int = 1                  # workgroup 0 automatic / 16 / 32 / 128 / 256; fast 1 / 2 / 0 (table-driven modes on / generic sweep / off)
@@ -683,6 +687,9 @@ class Trainer:
         self.agent.rng_seed = cfg.seed * 1000003 + rank
         self.agent.policy_precision = int(cfg.policy_precision)
         self.agent.policy_split = int(cfg.policy_split)
+        if cfg.policy_range not in ("fallback", "raise"):
+            raise ValueError(f"PPOConfig.policy_range must be 'fallback' or 'raise', not {cfg.policy_range!r}")
+        self.agent.policy_range = cfg.policy_range
         for name, default in (("rollout_form", -1), ("rollout_epw", 0), ("rollout_fast", 1)):
             if int(getattr(cfg, name)) != default:
                 self.envs.set_option(name, int(getattr(cfg, name)))
@@ -795,11 +802,15 @@ class Trainer:
             self.rollout_mode = "mega" if done else "steps"
         if not done:
             graphable = cfg.use_graphs and cfg.policy == "fused" and self.device.type == "cuda" and not self.profile_stride
+            if self._rollout_graph is not None and self._rollout_graph_precision != self.agent.policy_precision:
+                self._rollout_graph = None      # the agent left the fp16x2 domain and switched arithmetic: the captured launches are the old form's
+                self._eager_rollouts = 0
             if graphable and self._rollout_graph is None and self._eager_rollouts >= 1:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._rollout_body()
                 self._rollout_graph = g
+                self._rollout_graph_precision = self.agent.policy_precision
             if graphable and self._rollout_graph is not None:
                 self._rollout_graph.replay()
                 self.rollout_mode = "steps-graph"
@@ -841,6 +852,8 @@ class Trainer:
         if not sync:
             return None
         self.check_exchange()       # (synchronises; the scalars below are fetched anyway) a timed-out exchange stops the job HERE
+        if self.device.type == "cuda":
+            self.agent.check_policy_range(sync=True)    # weights outside the policy arithmetic's domain: precision 0 from the next rollout on (or PolicyRangeError)
         m = (self.learner.metrics / self.cfg.train_iters).tolist()   # divided by train_iters, not by #minibatches
         avg_reward = float(rew_mean) / self.cfg.reward_scaling       # train.py:272-274
         if self.world_size > 1:

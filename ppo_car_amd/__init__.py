@@ -11,4 +11,4 @@ __path__.append(_impl)
 from ._capi import PpoCarError, lib_path  # noqa: E402,F401
 from .env import Track, VecCarEnv  # noqa: E402,F401
 from .buffer import Buffer  # noqa: E402,F401
-from .model import Agent, layer_init  # noqa: E402,F401
+from .model import Agent, PolicyRangeError, layer_init  # noqa: E402,F401

@@ -211,6 +211,104 @@ def test_fused_policy_kernel_on_trained_weights_and_harvested_observations(polic
     assert np.abs(lp.cpu().numpy() - lp_ref[np.arange(n), a.cpu().numpy()]).max() < 4e-6
 
 
+def _float64_policy(f, obs, scale):
+    W = {k: f[k].astype(np.float64) for k in f.files if k != "obs" and k != "avg_reward"}
+    x64 = obs.astype(np.float64)
+    lg = np.maximum(x64 @ (scale * W["actor_0_weight"]).T + W["actor_0_bias"], 0) @ W["actor_2_weight"].T + W["actor_2_bias"]
+    v = (np.maximum(x64 @ (scale * W["critic_0_weight"]).T + W["critic_0_bias"], 0) @ W["critic_2_weight"].T + W["critic_2_bias"]).reshape(-1)
+    return lg, v
+
+
+@pytest.mark.parametrize("scale,expect_mask", [(1.0, 0), (30.0, 4), (300.0, 4), (6000.0, 5)])
+def test_fp16x2_domain_guard_falls_back_to_the_fp32_chain(scale, expect_mask, capfd):
+    """The fp16 x 2 form's operands saturate at fp16's range in their scaled domains (policy.hpp: |W1| > 4094, |W2| > 1023.5, hidden
+    activations beyond 255.87) -- silently, until this round.  pc_policy_pack_checked reports, while it packs, whether the weights can
+    get there (include/ppocar.h PC_POLICY_RANGE_*); Agent.pack_policy reads the status without synchronising and switches to
+    precision 0.  Here: the trained fixture's first-layer weights x 1 (inside the domain: status 0, stays fp16x2), x 30 / x 300 (hidden
+    units can pass 255.87: bit 2), x 6000 (a weight beyond 4094 as well: bits 0 and 2).  After the fallback the logits are model.py:34-41
+    in float64 to 4e-6 RELATIVE to their magnitude (x 300 makes the logits hundreds); WITHOUT the guard (policy_range untouched, the
+    status ignored) the x 300 image is wrong by more than 1 %: the failure the guard exists for."""
+    import ctypes as C
+    import os
+    from conftest import GOLDEN
+    from ppo_car_amd._capi import check, lib
+    f = np.load(os.path.join(GOLDEN, "policy_trained.npz"))
+    obs = f["obs"]
+    n = len(obs)
+    agent = pc.Agent(23, 9)
+    sd = {k: torch.from_numpy(f[k.replace(".", "_")]).clone() for k in agent.state_dict()}
+    sd["actor.0.weight"] *= scale
+    sd["critic.0.weight"] *= scale
+    agent.load_state_dict(sd)
+    agent = agent.cuda()
+    agent.rng_seed = 5
+    x = torch.from_numpy(obs).cuda()
+    ref_l, ref_v = _float64_policy(f, obs, scale)
+    mag = max(1.0, float(np.abs(ref_l).max()), float(np.abs(ref_v).max()))
+    # the raw status word through the C-ABI
+    assert agent.pack_policy() and agent.policy_form()[0] == 2
+    assert int(agent._range_dev.item()) == expect_mask
+    # what the fp16x2 image gives when nobody looks at the status
+    logits = torch.empty(n, 9, device="cuda")
+    a, lp, v = agent.act(x, out_logits=logits, repack=False)
+    err_unguarded = float(np.abs(logits.cpu().numpy().astype(np.float64) - ref_l).max()) / mag
+    # the guard: the status of that pack is looked at (here: now), the agent switches form, the next pack / act is the fp32 chain
+    ok = agent.check_policy_range(sync=True)
+    assert ok == (expect_mask == 0)
+    a, lp, v = agent.act(x, out_logits=logits)
+    form = agent.policy_form()[0]
+    assert form == (2 if expect_mask == 0 else 0)
+    err_l = float(np.abs(logits.cpu().numpy().astype(np.float64) - ref_l).max()) / mag
+    err_v = float(np.abs(v.cpu().numpy().astype(np.float64) - ref_v).max()) / mag
+    msg = capfd.readouterr().err
+    print(f"W1 x {scale}: status {expect_mask}, form after the check {form}, |logit|max {np.abs(ref_l).max():.1f}; relative error unguarded {err_unguarded:.2e}, guarded {err_l:.2e} / {err_v:.2e}")
+    assert err_l < 4e-6 and err_v < 4e-6
+    if expect_mask:
+        assert "numeric domain" in msg and "precision 0" in msg
+    else:
+        assert msg == "" and err_unguarded < 4e-6
+    if scale == 300.0:
+        assert err_unguarded > 1e-2
+    # "raise" instead of the fallback
+    if expect_mask:
+        agent2 = pc.Agent(23, 9)
+        agent2.load_state_dict(sd)
+        agent2 = agent2.cuda()
+        agent2.policy_range = "raise"
+        assert agent2.pack_policy()
+        with pytest.raises(pc.PolicyRangeError):
+            agent2.check_policy_range(sync=True)
+
+
+def test_trainer_switches_arithmetic_when_the_weights_leave_the_fp16x2_domain(capfd):
+    """End to end: a trainer whose first-layer weights are blown up between two epochs keeps running -- the persistent rollout kernel in
+    precision 0 from the next rollout on -- and says so; the rollout after the switch equals a precision-0 trainer's bit for bit."""
+    from conftest import TRACKS
+    from ppo_car_amd.ppo import PPOConfig, Trainer
+    cfg = PPOConfig(n_envs=1024, n_steps=32, batch_size=64, train_iters=1, num_rays=16, track=TRACKS["big_track"], seed=2, learning_rate=0.0)
+    tr = Trainer(cfg, device="cuda")
+    tr.run_epoch()
+    assert tr.agent.policy_form()[0] == 2
+    with torch.no_grad():
+        tr.agent.actor[0].weight.mul_(400.0)
+    tr.run_epoch()                   # this rollout still ran on the saturating image; run_epoch's sync point sees the status
+    assert tr.agent.policy_form()[0] == 0 and "numeric domain" in capfd.readouterr().err
+    st = tr.state_dict()
+    tr.rollout()
+    torch.cuda.synchronize()
+    assert tr.rollout_mode == "mega"
+    got = [t.clone() for t in (tr.buffer.obs_buf, tr.buffer.act_buf, tr.buffer.logprob_buf, tr.buffer.val_buf)]
+    tr.close()
+    import dataclasses
+    tr0 = Trainer(dataclasses.replace(cfg, policy_precision=0), device="cuda")
+    tr0.load_state_dict(st)
+    tr0.rollout()
+    torch.cuda.synchronize()
+    for a, b in zip(got, (tr0.buffer.obs_buf, tr0.buffer.act_buf, tr0.buffer.logprob_buf, tr0.buffer.val_buf)):
+        assert torch.equal(a, b)
+    tr0.close()
+
+
 def test_two_policy_handles_with_different_arithmetic_coexist():
     """Every launch option lives in a handle (include/ppocar.h; the library keeps no process-wide setting): two agents with
     different arithmetic forms of the fused policy step, used ALTERNATELY in one process, each produce exactly what a fresh agent of

@@ -6,7 +6,8 @@ oracle, through every path a mixed batch can take:
     configs[4]: big form, 128 envs per workgroup), 65536 (256 per workgroup), 4096 (small form, 16 per workgroup);
   * its generic mode (a workgroup straddles the two tracks: every wave reads its own track's tables from global memory);
   * the per-step kernels K5 + K1 (bitwise the persistent kernel wherever both run), K1 with its per-wave waterfall over the
-    distinct track ids when the tracks are interleaved env by env (pc_rollout refuses that layout).
+    distinct track ids when the tracks are interleaved env by env -- and, since round 6, pc_rollout on that layout too (the big
+    form's generic mode with the same waterfall around its env step), F32 and F64 handles.
 
 Bars as in test_rollout_baseline_gpu.py: observations within one float32 ulp of the oracle's, >= 99.99 % of the entries
 bit-equal; rewards / flags exact on every env still on the oracle's trajectory; an env may leave it only at a step whose
@@ -80,20 +81,52 @@ def test_mixed_tracks_f32_halves_rollout_vs_step_kernels_and_oracle(n_envs, form
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("n_envs", [2048, 20000])
-def test_mixed_tracks_f32_interleaved_step_kernels_vs_oracle(n_envs):
-    """track_id = i & 1: every wave holds both tracks.  pc_rollout reports PC_ERR_UNSUPPORTED and the trainer runs the per-step
-    kernels; K1 steps such a wave once per distinct track id (waterfall)."""
-    cfg = PPOConfig(n_envs=n_envs, n_steps=256, num_rays=16, track=MIXED, track_interleave=True, rollout_kernel="mega",
-                    use_graphs=False, seed=17, env_dtype="f32")
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("n_envs", [2048, 20000, 32768])
+def test_mixed_tracks_interleaved_rollout_vs_step_kernels_and_oracle(n_envs, dtype):
+    """track_id = i & 1 (SURVEY 8(d) C4's second variant; car_env.py:621-628 lets every env sit on its own track): every wave holds both
+    tracks.  pc_rollout runs it in the BIG form's generic mode (K9 / K9d), the env step once per distinct track id of a wave (K1's
+    waterfall, which the per-step path takes too): every buffer bitwise the per-step kernels' (unsplit policy arithmetic: the big
+    form's), then the oracle per track -- one float32 ulp / events exact for F32 handles, every bit for F64 handles."""
+    res, first = {}, None
+    for mode in ("mega", "steps"):
+        cfg = PPOConfig(n_envs=n_envs, n_steps=192, num_rays=16, track=MIXED, track_interleave=True, rollout_kernel=mode,
+                        use_graphs=False, seed=17, env_dtype=dtype, policy_split=0)
+        tr = Trainer(cfg, device="cuda")
+        if first is None:
+            first = tr.next_obs.clone()
+        for _ in range(2):
+            tr.rollout()
+            tr.buffer.ptr = 0
+        torch.cuda.synchronize()
+        assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
+        if mode == "mega":
+            assert tr.envs.last_rollout_kernel() == ("K9" if dtype == "f32" else "K9d-selector")
+        res[mode] = _snap(tr)
+        res[mode + "_state"] = tr.envs.get_state()
+        tr.close()
+        del tr
+    for i, (a, b) in enumerate(zip(res["mega"], res["steps"])):
+        assert torch.equal(a, b), f"buffer {i} differs between pc_rollout and the per-step kernels (interleaved tracks, {dtype})"
+    for k in res["mega_state"]:
+        assert np.array_equal(res["mega_state"][k], res["steps_state"][k]), k
+    assert res["mega_state"]["next_gate"][0::2].max() < 45            # track.json has 45 gates, big_track.json 55
+    # one rollout from reset against the oracle, per track
+    cfg = dataclasses.replace(cfg, rollout_kernel="mega", n_steps=256)
     tr = Trainer(cfg, device="cuda")
     first = tr.next_obs.clone()
     tr.rollout()
     torch.cuda.synchronize()
-    assert tr.rollout_mode == "steps-eager"
-    st = tr.envs.get_state()
-    assert st["next_gate"][0::2].max() < 45
-    out = _replay_per_track(cfg, _snap(tr), first, n_envs, True, f"mixed interleaved N={n_envs}")
-    for k, (worst, ties, alive) in out.items():
-        print(f"mixed interleaved N={n_envs} track {k}: obs max err {worst:.2e}, near-tie flips {ties}, on trajectory {alive:.3f}")
+    assert tr.rollout_mode == "mega"
+    snaps = _snap(tr)
     tr.close()
+    tid = _track_ids(n_envs, True)
+    sel = strided_population(n_envs, per_wave=2 * (4 if n_envs < 4096 else 1), limit=1024)
+    for k, path in enumerate(MIXED):
+        mine = sel[tid[sel] == k]
+        assert len(mine) >= 16
+        worst, ties, alive = _oracle_replay_check(dataclasses.replace(cfg, track=path), snaps, first, f"interleaved N={n_envs} {dtype} track {k}", sel=mine,
+                                                  exact=dtype == "f64")
+        print(f"mixed interleaved N={n_envs} {dtype} track {k}: obs max err {worst:.2e}, near-tie flips {ties}, on trajectory {alive:.3f}")
+    del res
+    torch.cuda.empty_cache()

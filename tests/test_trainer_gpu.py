@@ -500,12 +500,12 @@ def _xchg_worker(rank, world, port, out_dir, n, epochs):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [1, 2, 4, 6])
+@pytest.mark.parametrize("world", [1, 2, 4])
 def test_one_shot_exchange_kernel_directly_many_epochs(tmp_path, world):
     """pc_xchg_allreduce on its own, 300 back-to-back exchanges (both epoch parities, the double buffering, 15 independent chunks
     for a 14858-float bucket): bit-equal rank-ordered sums on every rank and PC_OK -- on one rank (the sum of one bucket is the
-    bucket) and between 2, 4 and 6 processes sharing cuda:0 (6: as many processes as a GPU box of this pool lets one job put on its
-    card; the slot / flag layout at the full 8 ranks runs in ONE process: test_one_shot_exchange_eight_ranks_in_one_process).  Plain launches, no whole-epoch graphs: nothing here can starve a peer, so
+    bucket) and between 2 and 4 processes sharing cuda:0 (a GPU box of this pool lets one job put six processes on its card, the test
+    runner included; the slot / flag layout at the full 8 ranks runs in ONE process: test_one_shot_exchange_eight_ranks_in_one_process).  Plain launches, no whole-epoch graphs: nothing here can starve a peer, so
     a PC_ERR_TIMEOUT in THIS test is a synchronisation bug in the kernel.  (train.py:259-260)"""
     import socket
     import torch.multiprocessing as mp
@@ -520,7 +520,7 @@ def test_one_shot_exchange_kernel_directly_many_epochs(tmp_path, world):
 @pytest.mark.parametrize("world,n", [(8, 14858), (8, 23050), (5, 12298), (3, 1000)])
 def test_one_shot_exchange_eight_ranks_in_one_process(world, n):
     """K13's slot / flag layout at the FULL world size (XCHG_MAX_RANKS = 8: 2 parities x 8 writers x n_pad floats and 2 x 8 x n_chunks
-    flags per rank) -- which no multi-process rehearsal on a one-GPU box can reach (at most 6 processes per card): all `world` ranks'
+    flags per rank) -- which no multi-process rehearsal on a one-GPU box can reach (at most six processes per card): all `world` ranks'
     handles live in this process (pc_xchg_connect_local), every rank launches its exchange kernel on its OWN stream, so the grids
     are co-resident and wait for each other exactly as eight devices would.  100 exchanges, buckets of irregular magnitude: every
     rank's bucket must be the rank-ordered float32 sum, bit for bit, and every handle PC_OK.  (train.py:259-260)"""
