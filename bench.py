@@ -173,37 +173,44 @@ def usable_cpus():
 
 
 def cpu_baseline(cfg, torch, budget_s=5.0):
-    """The same rollout on the host, by the CPU oracle (oracle/: the checker -- `kind: "port"`, the C restatement of car_env.py; the
-    Python reference cannot travel to the GPU box, its own figure is quoted from BASELINE.md).  Three bounded legs on big_track at
-    the workload's ray count, ALL usable host cores (no cap; the count is stated):
+    """The same path on the host, by the CPU oracle (oracle/: the checker -- `kind: "port"`, the C restatement of car_env.py; the
+    Python reference cannot travel to the GPU box, its own figure is quoted from BASELINE.md).  Bounded legs on big_track, ALL usable
+    host cores (no cap; the count is stated):
       env only, 1 thread            -- the per-core figure beside the reference's Python 227 steps/s/core;
-      env only, all usable cores    -- `env_only_value`: CarEnv.step alone, uniform random actions;
-      env + torch-CPU policy        -- `value`: the rollout (policy forward + sample + env step), the PPO update not included."""
+      env only, all usable cores    -- `env_only_value`: CarEnv.step alone, uniform random actions; the envs dealt to POSIX threads in
+                                       static ranges inside ONE C call per 64 steps (oc_vec_rollout_mt: envs never interact, so no
+                                       per-step barrier; best 64-step block of the leg) -- `env_only_scaling` = that / (threads x the one-thread figure);
+      env + torch-CPU policy        -- `value`: the rollout at the workload's ray count (policy forward + sample + env step);
+      configs[0] as BASELINE.json writes it -- `configs0_whole_loop`: big_track, n_envs = 24, n_steps = 1024, 16 rays, the WHOLE loop of
+                                       train.py:171-266 (rollout with the torch policy, GAE, 40 x 2 clipped-PPO minibatches on torch-CPU)."""
     import numpy as np
 
     import oracle
     from ppo_car_amd.model import Agent
+    from ppo_car_amd.ppo import PPOConfig, PPOLearner
     host, usable, quota = usable_cpus()
     threads = usable
     track = oracle.Track(os.path.join(ROOT, "tracks", "big_track.json"))
 
     def env_only(n_threads, n_envs, budget):
-        env = oracle.OracleVecEnv(track, n_envs, num_rays=cfg["num_rays"], reward_scaling=0.1, threads=n_threads)
+        env = oracle.OracleVecEnv(track, n_envs, num_rays=cfg["num_rays"], reward_scaling=0.1, threads=1)
         env.reset()
         rng = np.random.default_rng(0)
-        acts = rng.integers(0, 9, size=(16, n_envs)).astype(np.int64)
-        env.step(acts[0])
-        steps, t0 = 0, time.time()
+        acts = rng.integers(0, 9, size=(64, n_envs)).astype(np.int64)
+        env.run_steps(acts[:2], threads=n_threads)
+        steps, t0, best = 0, time.time(), 0.0
         while True:
-            env.step(acts[steps % 16])
-            steps += 1
-            if time.time() - t0 > budget and steps >= 2:
+            ta = time.time()
+            env.run_steps(acts, threads=n_threads)
+            best = max(best, n_envs * 64 / (time.time() - ta))      # the CPU's best 64-step block (a baseline is owed the benefit of the doubt:
+            steps += 64                                              # the job's cores are a cgroup quota on a shared host)
+            if time.time() - t0 > budget:
                 break
-        return n_envs * steps / (time.time() - t0), steps
+        return best, steps
 
-    n_envs = max(4096, 128 * threads)
+    n_envs = max(8192, 512 * threads)
     one, steps1 = env_only(1, 1024, budget_s * 0.4)
-    allc, steps_all = env_only(threads, n_envs, budget_s)
+    allc, steps_all = env_only(threads, n_envs, budget_s * 0.6)
     torch.set_num_threads(threads)
     env = oracle.OracleVecEnv(track, n_envs, num_rays=cfg["num_rays"], reward_scaling=0.1, threads=threads)
     obs = torch.from_numpy(env.reset())
@@ -215,16 +222,65 @@ def cpu_baseline(cfg, torch, budget_s=5.0):
             o, r, te, tr = env.step(a.numpy())
             obs = torch.from_numpy(o)
             steps += 1
-            if time.time() - t0 > budget_s and steps >= 4:
+            if time.time() - t0 > budget_s * 0.6 and steps >= 4:
                 break
     dt = time.time() - t0
+
+    # ---- configs[0]: "CPU reference: train.py big_track.json n_envs=24 n_steps=1024 16 rays" -- the whole loop on the host
+    def configs0(budget):
+        N0, T0, n0 = 24, 1024, 16
+        th = max(1, min(threads, 8))
+        torch.set_num_threads(th)
+        c0 = PPOConfig(n_envs=N0, n_steps=T0, batch_size=512, train_iters=40, num_rays=n0, seed=0, use_graphs=False, fused_update=False)
+        e0 = oracle.OracleVecEnv(track, N0, num_rays=n0, reward_scaling=c0.reward_scaling, threads=1)
+        ag = Agent(e0.D, 9)
+        learner = PPOLearner(ag, c0, "cpu")
+        nobs = torch.from_numpy(e0.reset())
+        nterm = ntrunc = torch.zeros(N0)
+        obs_b, act_b, rew_b = torch.zeros(T0, N0, e0.D), torch.zeros(T0, N0), torch.zeros(T0, N0)
+        val_b, lp_b, te_b, tr_b = torch.zeros(T0, N0), torch.zeros(T0, N0), torch.zeros(T0, N0), torch.zeros(T0, N0)
+        epochs, t_roll, t_upd, t0_ = 0, 0.0, 0.0, time.time()
+        while True:
+            ta = time.time()
+            with torch.no_grad():
+                for t in range(T0):                                   # train.py:173-195
+                    obs_b[t], te_b[t], tr_b[t] = nobs, nterm, ntrunc
+                    a_, lp_, _, v_ = ag.get_action_and_value(nobs)
+                    o_, r_, te_, tr_ = e0.step(a_.numpy())
+                    act_b[t], lp_b[t], val_b[t] = a_, lp_, v_.view(-1)
+                    rew_b[t] = torch.from_numpy(r_.astype(np.float32))
+                    nobs, nterm, ntrunc = torch.from_numpy(o_), torch.from_numpy(te_.astype(np.float32)), torch.from_numpy(tr_.astype(np.float32))
+                last_v = ag.get_value(nobs).view(-1)                  # :200
+            tb = time.time()
+            adv, ret = oracle.gae(rew_b.numpy(), val_b.numpy(), te_b.numpy(), tr_b.numpy(), last_v.numpy(), nterm.numpy(), ntrunc.numpy(),
+                                  c0.gamma, c0.gae_lambda)            # buffer.py:36-64
+            learner.update(obs_b.view(-1, e0.D), act_b.view(-1), lp_b.view(-1), torch.from_numpy(adv).view(-1), torch.from_numpy(ret).view(-1))
+            tc = time.time()
+            t_roll += tb - ta
+            t_upd += tc - tb
+            epochs += 1
+            if tc - t0_ > budget:
+                break
+        tot = time.time() - t0_
+        return {"value": N0 * T0 * epochs / tot, "unit": "env steps/s", "epochs": epochs, "seconds": tot, "rollout_s_per_epoch": t_roll / epochs,
+                "gae_update_s_per_epoch": t_upd / epochs, "torch_threads": th, "env_threads": 1,
+                "workload": "BASELINE.json configs[0]: big_track.json, n_envs=24, n_steps=1024, 16 -> 17 rays, batch 512, 40 iters: rollout (torch-CPU policy + C "
+                            "oracle env) + GAE (C restatement of buffer.py:36-64) + 80 clipped-PPO minibatches (torch-CPU autograd, train.py:223-266)",
+                "reference_published": {"value": 2300.0, "unit": "env steps/s", "source": "BASELINE.md: the reference README's whole-loop figure (Python env, 16 processes)"}}
+
+    try:
+        c0 = configs0(budget_s)
+    except Exception as ex:      # noqa: BLE001
+        c0 = {"error": repr(ex)}
     py = PY_REFERENCE.get(cfg["num_rays"])
     return {"value": n_envs * steps / dt, "unit": "env steps/s", "cores": threads, "kind": "port",
             "host_cores": host, "usable_cores": usable, "cgroup_cpu_quota": quota, "threads": threads,
             "env_only_value": allc, "env_only_one_thread_value": one, "env_only_scaling": allc / one / threads,
-            "sample": f"big_track, {cfg['num_rays']} rays: (a) env only, 1 thread, 1024 envs x {steps1} steps; (b) env only, {threads} threads, "
-                      f"{n_envs} envs x {steps_all} steps -> env_only_value; (c) rollout = torch-CPU policy ({threads} threads) + C oracle env "
-                      f"({threads} threads), {n_envs} envs x {steps} steps -> value; PPO update not included; every leg bounded to ~{budget_s:.0f} s",
+            "configs0_whole_loop": c0,
+            "sample": f"big_track, {cfg['num_rays']} rays: (a) env only, 1 thread, 1024 envs x {steps1} steps; (b) env only, {threads} POSIX threads over static env "
+                      f"ranges, {n_envs} envs x {steps_all} steps -> env_only_value; (c) rollout = torch-CPU policy ({threads} threads) + C oracle env "
+                      f"({threads} threads), {n_envs} envs x {steps} steps -> value; (d) configs0_whole_loop: 24 envs x 1024 steps x its epochs; every leg bounded "
+                      f"to ~{budget_s * 0.5:.0f}-{budget_s:.0f} s",
             "reference_python": {"value": py, "unit": "env steps/s", "cores": 1,
                                  "source": "BASELINE.md section 2: the reference's Python CarEnv on one Xeon 2.1 GHz core of the survey "
                                            "container (env only, big_track); it cannot travel to the GPU box, so it is quoted, not re-timed"}}

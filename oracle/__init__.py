@@ -48,6 +48,9 @@ def lib():
         L.oc_vec_step.restype = None
         L.oc_vec_step.argtypes = ([_f64p, C.c_int, _f64p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                    C.c_int64] + st + [C.c_void_p] * 6)
+        L.oc_vec_rollout_mt.restype = C.c_double
+        L.oc_vec_rollout_mt.argtypes = ([_f64p, C.c_int, _f64p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                         C.c_int64, C.c_int64, C.c_int] + st + [_i64p])
         L.oc_gae.restype = None
         L.oc_gae.argtypes = [_f32p] * 7 + [C.c_double, C.c_double, C.c_int64, C.c_int64, _f32p, _f32p]
         _LIB = L
@@ -155,6 +158,17 @@ class OracleVecEnv:
         self._run(fn)
         out = (obs, rew, term.astype(bool), trunc.astype(bool))
         return out + (fin,) if want_final_obs else out
+
+
+    def run_steps(self, actions, threads=None):
+        """bench.py's CPU baseline: T vector-env steps (auto-reset, reward scaling) with pre-generated actions [T, N] inside ONE C call,
+        the envs dealt to `threads` POSIX threads in static contiguous ranges (oc_vec_rollout_mt).  Returns the sum of the rewards."""
+        actions = np.ascontiguousarray(actions, np.int64)
+        T, N = actions.shape
+        assert N == self.N
+        t = self.t
+        return lib().oc_vec_rollout_mt(t.walls, t.S, t.gates, t.G, self.n, t.start_x, t.start_y, t.start_rot, self.reward_scaling, N, T,
+                                       int(threads or self.threads), *self._state_ptrs(0), actions)
 
 
 def ray_distance(px, py, angle_deg, segs):

@@ -291,3 +291,75 @@ void oc_gae(const float* rew, const float* val, const float* term, const float* 
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Multi-threaded driver for the CPU BASELINE (bench.py's cpu_baseline leg; not used by the parity tests): T vector-env steps
+ * (train.py:185 -- oc_vec_step: CarEnv.step + TransformReward + same-step auto-reset) of n_envs envs with pre-generated actions
+ * [T][n_envs], the envs dealt to n_threads POSIX threads in contiguous static ranges.  Envs never interact (car_env.py has no
+ * env-env coupling), so a thread runs ALL T steps of its own range without meeting the others: no per-step barrier, no shared
+ * cache line but the two at a range's ends.  Returns the sum of all scaled rewards (a checksum; the final state is left in the
+ * SoA arrays).  Same arithmetic as the single-threaded calls: a thread's range is stepped by oc_vec_step itself.
+ * ------------------------------------------------------------------------------------------------------------------ */
+#include <pthread.h>
+#include <stdlib.h>
+
+typedef struct {
+    const double *walls, *gates;
+    int S, G, n;
+    double start_x, start_y, start_rot, reward_scale;
+    int64_t lo, hi, n_envs, T;
+    double *px, *py, *vx, *vy, *rot;
+    int64_t *time_step, *next_gate, *passed;
+    uint8_t* destroyed;
+    const int64_t* actions;
+    double reward_sum;
+} oc_mt_job;
+
+static void* oc_mt_worker(void* arg) {
+    oc_mt_job* j = (oc_mt_job*)arg;
+    const int64_t m = j->hi - j->lo;
+    const int D = 6 + oc_ray_count(j->n);
+    float* obs = (float*)malloc((size_t)m * D * sizeof(float));
+    double* rew = (double*)malloc((size_t)m * sizeof(double));
+    uint8_t* te = (uint8_t*)malloc((size_t)m);
+    uint8_t* tr = (uint8_t*)malloc((size_t)m);
+    double sum = 0.0;
+    if (obs && rew && te && tr) {
+        for (int64_t t = 0; t < j->T; ++t) {
+            oc_vec_step(j->walls, j->S, j->gates, j->G, j->n, j->start_x, j->start_y, j->start_rot, j->reward_scale, m, j->px + j->lo,
+                        j->py + j->lo, j->vx + j->lo, j->vy + j->lo, j->rot + j->lo, j->time_step + j->lo, j->next_gate + j->lo,
+                        j->passed + j->lo, j->destroyed + j->lo, j->actions + t * j->n_envs + j->lo, obs, rew, te, tr, NULL);
+            for (int64_t e = 0; e < m; ++e) sum += rew[e];
+        }
+    }
+    free(obs); free(rew); free(te); free(tr);
+    j->reward_sum = sum;
+    return NULL;
+}
+
+double oc_vec_rollout_mt(const double* walls, int S, const double* gates, int G, int n, double start_x, double start_y,
+                         double start_rot, double reward_scale, int64_t n_envs, int64_t T, int n_threads, double* px, double* py,
+                         double* vx, double* vy, double* rot, int64_t* time_step, int64_t* next_gate, int64_t* passed,
+                         uint8_t* destroyed, const int64_t* actions) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 1024) n_threads = 1024;
+    if ((int64_t)n_threads > n_envs) n_threads = (int)n_envs;
+    oc_mt_job* jobs = (oc_mt_job*)calloc((size_t)n_threads, sizeof(oc_mt_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
+    double total = 0.0;
+    if (!jobs || !th) { free(jobs); free(th); return 0.0; }
+    for (int k = 0; k < n_threads; ++k) {
+        oc_mt_job* j = &jobs[k];
+        j->walls = walls; j->gates = gates; j->S = S; j->G = G; j->n = n;
+        j->start_x = start_x; j->start_y = start_y; j->start_rot = start_rot; j->reward_scale = reward_scale;
+        j->lo = n_envs * k / n_threads; j->hi = n_envs * (k + 1) / n_threads; j->n_envs = n_envs; j->T = T;
+        j->px = px; j->py = py; j->vx = vx; j->vy = vy; j->rot = rot;
+        j->time_step = time_step; j->next_gate = next_gate; j->passed = passed; j->destroyed = destroyed; j->actions = actions;
+        if (k == 0 || pthread_create(&th[k], NULL, oc_mt_worker, j) != 0) { if (k) oc_mt_worker(j); }
+    }
+    oc_mt_worker(&jobs[0]);      /* the calling thread takes the first range */
+    for (int k = 1; k < n_threads; ++k) if (th[k]) pthread_join(th[k], NULL);
+    for (int k = 0; k < n_threads; ++k) total += jobs[k].reward_sum;
+    free(jobs); free(th);
+    return total;
+}

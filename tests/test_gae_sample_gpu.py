@@ -293,7 +293,8 @@ def test_trainer_switches_arithmetic_when_the_weights_leave_the_fp16x2_domain(ca
         tr.agent.actor[0].weight.mul_(400.0)
     tr.run_epoch()                   # this rollout still ran on the saturating image; run_epoch's sync point sees the status
     assert tr.agent.policy_form()[0] == 0 and "numeric domain" in capfd.readouterr().err
-    st = tr.state_dict()
+    import copy
+    st = copy.deepcopy(tr.state_dict())      # (state_dict hands out the live tensors: the rollout below advances them)
     tr.rollout()
     torch.cuda.synchronize()
     assert tr.rollout_mode == "mega"
