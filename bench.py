@@ -39,6 +39,8 @@ Extra objects on the JSON line:
                   `rare_branches`: the same check on a fresh trainer of the same workload started from INJECTED states (and, at 17 rays,
                   the trained policy fixture): laps, time limits, terminated-at-the-limit, +-990 turns of heading -- `events_replayed`.
   strict_fp32_value -- the same metric with the policy GEMMs as exact-fp32 MFMAs (3 epochs, outside the headline timing).
+  strict_f64_fp32_value -- the strictest cell: dtype f64 (bit-exact env) AND the exact-fp32 policy chain, 3 epochs: every number of the rollout in
+                  the reference's own arithmetic, as one persistent launch.
   fp32_grade_bf16x3_value -- the same with the bf16 x 3 split (six piece products: fp32-grade error, not the fp32 chain's bits).
 """
 import argparse
@@ -478,7 +480,7 @@ def main():
         from ppo_car_amd.env import Track
         return [Track(t).n_walls for t in (track_ if isinstance(track_, (list, tuple)) else [track_])]
 
-    def side_measurement(name, wl_in, env_dtype="f32", epochs=5):
+    def side_measurement(name, wl_in, env_dtype="f32", epochs=5, policy_precision=None):
         """Another workload (or the same one in another env dtype) AFTER the headline's timed region, same process, same box:
         2 warm-up epochs (graphs: one eager, then capture), then `epochs` timed epochs bracketed like the headline; the rollout
         launch by HIP events on the launch stream inside those epochs; the launch priced against the same roofs."""
@@ -488,7 +490,8 @@ def main():
         if inter_:
             wl_["track_interleave"] = True
         trk = tracks_of(mixed_)
-        c_, t_ = make_trainer(wl_=wl_, env_dtype=env_dtype, track_=trk)
+        c_, t_ = (make_trainer(wl_=wl_, env_dtype=env_dtype, track_=trk) if policy_precision is None
+                  else make_trainer(policy_precision=policy_precision, wl_=wl_, env_dtype=env_dtype, track_=trk))
         try:
             for _ in range(2):
                 t_.run_epoch(sync=False)
@@ -677,6 +680,15 @@ def main():
                                                          env_dtype="f64", epochs=3)
         except Exception as ex:
             extras["exact_f64_value"] = {"error": repr(ex)}
+        # ... and THE STRICTEST CELL: float64 env AND the policy GEMMs as the exact fp32 chain -- every number of the rollout in the reference's
+        # own arithmetic (car_env.py in float64, model.py's fp32 Linear chain), still one persistent launch (K9's literal form with the fp32 image)
+        try:
+            sf = side_measurement(args.workload, WORKLOADS[args.workload] if not (args.n_envs or args.n_steps) else dict(wl, mixed=mixed, interleave=interleave),
+                                  env_dtype="f64", epochs=3, policy_precision=0)
+            sf["policy_gemm_arithmetic"] = "fp32-input MFMA (exact fp32 fmaf chain), --policy-arith fp32"
+            extras["strict_f64_fp32_value"] = sf
+        except Exception as ex:
+            extras["strict_f64_fp32_value"] = {"error": repr(ex)}
         # ... and every other single-GPU BASELINE configuration, each with its own ms_per_step and roofline fraction
         others = {}
         for name in ("target", "cfg1", "cfg2", "cfg4", "cfg4i"):

@@ -328,6 +328,11 @@ int pc_ppo_epoch_prepared(int device, const float* prepared, int n_mb, int B, in
  *   pc_xchg_connect_local(x, ranks)                 the in-process form: `ranks` = the world's pc_xchg handles in rank order, all created
  *                                                   in THIS process (one process driving several devices -- peer access is verified /
  *                                                   enabled -- or several ranks on one device, each launching on its own stream);
+ *   pc_xchg_allreduce_group(ranks, buckets, stream) the exchanges of ALL ranks of such an in-process group on ONE device as one launch
+ *                                                   (bucket[r] := the rank-ordered sum, for every r): the ranks' workgroups are then
+ *                                                   co-resident by construction -- separate launches on separate streams are not (HIP
+ *                                                   multiplexes streams onto a few hardware queues) and must not be used with more
+ *                                                   ranks per device than hardware queues;
  *   pc_xchg_set_timeout(x, seconds)                 patience of a wait inside the exchange kernel (default 20 s);
  *   pc_xchg_allreduce(x, bucket, stream)            in place, asynchronous on `stream`, capturable into a HIP graph: bucket[0..n)
  *                                                   := sum over ranks (rank order) of their buckets.  Every rank must make the
@@ -342,6 +347,7 @@ int pc_xchg_create(int device, int rank, int world, int64_t n_floats, pc_xchg** 
 int pc_xchg_local_handle(pc_xchg* x, void* handle_out);
 int pc_xchg_connect(pc_xchg* x, const void* all_handles);
 int pc_xchg_connect_local(pc_xchg* x, pc_xchg* const* ranks);
+int pc_xchg_allreduce_group(pc_xchg* const* ranks, float* const* buckets, void* stream);
 int pc_xchg_set_timeout(pc_xchg* x, double seconds);
 int pc_xchg_allreduce(pc_xchg* x, float* bucket, void* stream);
 int pc_xchg_status(pc_xchg* x);

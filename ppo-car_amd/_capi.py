@@ -100,6 +100,7 @@ _sig = {
     "pc_xchg_local_handle": (_i, [_vp, _vp]),
     "pc_xchg_connect": (_i, [_vp, _vp]),
     "pc_xchg_connect_local": (_i, [_vp, _vp]),
+    "pc_xchg_allreduce_group": (_i, [_vp, _vp, _vp]),
     "pc_xchg_set_timeout": (_i, [_vp, _d]),
     "pc_xchg_allreduce": (_i, [_vp, _vp, _vp]),
     "pc_xchg_status": (_i, [_vp]),

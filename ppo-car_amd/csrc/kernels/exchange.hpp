@@ -35,8 +35,8 @@ struct XchgView {
     unsigned long long timeout_ticks;  // patience of a wait, in s_memrealtime ticks (100 MHz)
 };
 
-__global__ __launch_bounds__(256) void xchg_allreduce_kernel(const XchgView v, float* __restrict__ bucket) {
-    const int c = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void xchg_allreduce_body(const XchgView& v, float* __restrict__ bucket, const int c) {
+    const int tid = threadIdx.x;
     __shared__ unsigned s_ep;
     if (tid == 0) {
         s_ep = v.epoch[c] + 1u;
@@ -84,4 +84,20 @@ __global__ __launch_bounds__(256) void xchg_allreduce_kernel(const XchgView v, f
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if (i0 + j < v.n) bucket[i0 + j] = acc[j];
+}
+
+__global__ __launch_bounds__(256) void xchg_allreduce_kernel(const XchgView v, float* __restrict__ bucket) {
+    xchg_allreduce_body(v, bucket, blockIdx.x);
+}
+
+// The exchanges of ALL ranks of an in-process group (pc_xchg_connect_local) in one launch: blockIdx.y = rank.  The W x n_chunks
+// workgroups are co-resident by construction (8 x 23 at most), which separate launches on separate streams are not: HIP multiplexes
+// streams onto a few hardware queues (4 by default), and ranks whose kernels queue behind each other would wait for flags that
+// cannot be raised.  Same body, same slots, same flags as the per-rank kernel.
+struct XchgGroup {
+    XchgView v[XCHG_MAX_RANKS];
+    float* bucket[XCHG_MAX_RANKS];
+};
+__global__ __launch_bounds__(256) void xchg_allreduce_group_kernel(const XchgGroup g) {
+    xchg_allreduce_body(g.v[blockIdx.y], g.bucket[blockIdx.y], blockIdx.x);
 }

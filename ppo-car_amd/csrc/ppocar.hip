@@ -1232,7 +1232,6 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
     const bool interleaved = e->track_id && !e->track_blocks32;
     const int KS = policy_ks(e->D);
     const int prec = policy_prec(prec_request, e->D, A);
-    if (prec == 0) return PC_ERR_UNSUPPORTED;
     DeviceGuard guard(e->device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
     const int rpl = (e->R + 1) / 2;
@@ -1260,6 +1259,30 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
         const bool rays33 = KS == 10 && rpl == 17 && e->n_nominal == 32;
         const int rden_lds = rays33 ? 0 : 361 * max_nV;      // (33 rays: no room for the table -- the sweep forms 1/den itself, as for F32 handles)
         const size_t lds_sel = (size_t)k9_fast_lds_floats(img, 32, e->D, !rays33, rden_lds) * sizeof(float);
+        if (prec == 0) {
+            // THE STRICTEST CELL: float64 env (the literal form) AND the policy GEMMs as the exact fp32 chain (v_mfma_f32_16x16x4_f32) -- every
+            // number of the rollout in the reference's own arithmetic -- as one persistent launch: K9's literal form with the fp32 weight
+            // image (16 -> 17 rays, the big form, the generic sweeps with the 1/den table in LDS).  Other shapes: the per-step kernels.
+            const int img0 = pol_image_padded(KS);
+            const size_t lds0 = (size_t)k9_fast_lds_floats(img0, 32, e->D, true, 361 * max_nV) * sizeof(float);
+            if (!(tabs && rays16 && !e->f64_offgrid && !interleaved && e->D >= 17 && max_G <= TAB_MAX_GATES && max_nV <= FT_VTX_MAX && e->opt.fast &&
+                  e->opt.rden != 0 && (!e->track_id || e->track_block >= epw) && lds0 <= 160 * 1024))
+                return PC_ERR_UNSUPPORTED;
+            const int vec_ok = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
+            EnvParams<float> prm = e->params<float>();
+            prm.lg = 1;
+            static bool attr_set[64] = {false};
+            if (e->device >= 64 || !attr_set[e->device]) {
+                HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<6, 9, 0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                if (e->device < 64) attr_set[e->device] = true;
+            }
+            PC_FULL(hipLaunchKernelGGL((rollout_kernel<6, 9, 0, 2, true>), dim3(blocks), dim3(512), lds0, st, prm, image, A, (int)T, reward_scale, seed, offset,
+                                       offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, next_term, next_trunc,
+                                       361 * max_nV, epw, vec_ok, last_value, reward_sum));
+            HIPCHK(hipGetLastError());
+            e->last_kernel = PC_KERNEL_K9_LITERAL;
+            return PC_OK;
+        }
         const bool shape = (rays16 || rays12 || rays33) && prec == 2 && e->D >= 17 && e->D <= 40 && max_G <= TAB_MAX_GATES &&
                            max_nV <= FT_VTX_MAX && e->opt.fast && e->opt.rden != 0 && (!e->track_id || e->track_block >= epw) &&
                            lds_sel <= 160 * 1024;
@@ -1944,6 +1967,27 @@ int pc_xchg_allreduce(pc_xchg* x, float* bucket, void* stream) {
     DeviceGuard guard(x->device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
     hipLaunchKernelGGL(xchg_allreduce_kernel, dim3(x->n_chunks), dim3(256), 0, (hipStream_t)stream, x->view(), bucket);
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_xchg_allreduce_group(pc_xchg* const* ranks, float* const* buckets, void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
+    if (!ranks || !buckets || !ranks[0]) return PC_ERR_INVALID_ARG;
+    const int W = ranks[0]->world;
+    XchgGroup g = {};
+    for (int r = 0; r < W; ++r) {
+        const pc_xchg* x = ranks[r];
+        // one device, one launch: every rank's handle connected in this process, all on the launching device
+        if (!x || !buckets[r] || x->rank != r || x->world != W || x->n != ranks[0]->n || !x->connected || x->device != ranks[0]->device) return PC_ERR_INVALID_ARG;
+        for (int q = 0; q < W; ++q)
+            if (x->peer[q] != ranks[q]->local) return PC_ERR_INVALID_ARG;      // (connected to THESE handles: pc_xchg_connect_local)
+        g.v[r] = x->view();
+        g.bucket[r] = buckets[r];
+    }
+    DeviceGuard guard(ranks[0]->device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    hipLaunchKernelGGL(xchg_allreduce_group_kernel, dim3(ranks[0]->n_chunks, W), dim3(256), 0, (hipStream_t)stream, g);
     HIPCHK(hipGetLastError());
     return PC_OK;
 }

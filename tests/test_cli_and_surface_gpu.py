@@ -378,3 +378,5 @@ def test_bench_default_line_carries_every_baseline_config_and_the_exact_dtype():
     assert c["kind"] == "port" and c["threads"] == c["cores"] == c["usable_cores"] <= c["host_cores"]
     assert c["env_only_value"] > 0 and c["env_only_one_thread_value"] > 0 and c["value"] > 0      # (how they compare is the host's business)
     assert d["strict_fp32_value"]["value"] > 0 and d["fp32_grade_bf16x3_value"]["value"] > 0
+    sf = d["strict_f64_fp32_value"]      # float64 env + exact fp32 policy chain: one persistent launch as well
+    assert sf["dtype"] == "f64" and sf["rollout"] == "mega" and sf["kernel"] == "K9-literal" and sf["value"] > 5e8, sf

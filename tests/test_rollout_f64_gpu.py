@@ -271,3 +271,32 @@ def test_f64_selector_form_on_walls_that_cross_and_touch(tmp_path, n_envs):
     for k in st_mega:
         assert np.array_equal(st_mega[k], st_steps[k]), k
     assert _oracle_exact(PPOConfig(**kw), mega[0], first, track, np.arange(0, n_envs, n_envs // 256)) > 0
+
+
+@pytest.mark.parametrize("n_envs,n_steps", [(20000, 160), (65536, 96), (1000, 200)])
+def test_strictest_cell_float64_env_and_exact_fp32_policy_chain_in_one_persistent_launch(n_envs, n_steps):
+    """dtype f64 AND policy_precision 0 (v_mfma_f32_16x16x4_f32: the fp32 fmaf chain of model.py's Linear layers): every number of the
+    rollout in the reference's own arithmetic.  pc_rollout runs it as K9's literal form with the fp32 weight image
+    (rollout_kernel<6, 9, 0, 2, true>, 16 -> 17 rays, the big form): bitwise the per-step kernels (policy_kernel<6, false, 0>;
+    env_step_kernel<double>), float64 state included, and every observation / reward / flag of 256 envs equal to the oracle's."""
+    res, first = {}, None
+    for mode in ("mega", "steps"):
+        cfg = PPOConfig(n_envs=n_envs, n_steps=n_steps, num_rays=16, track=TRACKS["big_track"], rollout_kernel=mode, env_dtype="f64",
+                        use_graphs=False, seed=23, policy_precision=0, policy_split=0)
+        tr = Trainer(cfg, device="cuda")
+        if first is None:
+            first = tr.next_obs.clone()
+        tr.rollout()
+        torch.cuda.synchronize()
+        assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager"), tr.rollout_mode
+        if mode == "mega":
+            assert tr.envs.last_rollout_kernel() == "K9-literal" and tr.agent.policy_form()[0] == 0
+        res[mode] = _snap(tr)
+        res[mode + "_state"] = tr.envs.get_state()
+        tr.close()
+    for i, (a, b) in enumerate(zip(res["mega"][:10], res["steps"][:10])):
+        assert torch.equal(a, b), f"buffer {i} differs between the persistent launch and the per-step kernels (f64 env, fp32 policy chain)"
+    for k in res["mega_state"]:
+        assert np.array_equal(res["mega_state"][k], res["steps_state"][k]), k
+    sel = np.arange(0, n_envs, max(1, n_envs // 256))[:256]
+    assert _oracle_exact(cfg, res["mega"], first, TRACKS["big_track"], sel) > 0

@@ -314,7 +314,7 @@ def test_mixed_track_batches_through_the_persistent_rollout_kernel(n_envs, form)
     tr = Trainer(_cfg(track=tracks, track_interleave=True, rollout_kernel="mega", use_graphs=False, n_envs=512, n_steps=8, num_rays=16),
                  device="cuda")
     tr.rollout()
-    assert tr.rollout_mode == "steps-eager"
+    assert tr.rollout_mode == "mega" and tr.envs.last_rollout_kernel() == "K9"      # (round 6: the big form's generic mode, per-wave track waterfall)
     tr.close()
 
 
@@ -521,8 +521,8 @@ def test_one_shot_exchange_kernel_directly_many_epochs(tmp_path, world):
 def test_one_shot_exchange_eight_ranks_in_one_process(world, n):
     """K13's slot / flag layout at the FULL world size (XCHG_MAX_RANKS = 8: 2 parities x 8 writers x n_pad floats and 2 x 8 x n_chunks
     flags per rank) -- which no multi-process rehearsal on a one-GPU box can reach (at most six processes per card): all `world` ranks'
-    handles live in this process (pc_xchg_connect_local), every rank launches its exchange kernel on its OWN stream, so the grids
-    are co-resident and wait for each other exactly as eight devices would.  100 exchanges, buckets of irregular magnitude: every
+    handles live in this process (pc_xchg_connect_local) and their exchange kernels go out as ONE launch (pc_xchg_allreduce_group:
+    blockIdx.y = rank), so the grids are co-resident and wait for each other exactly as eight devices would.  100 exchanges, buckets of irregular magnitude: every
     rank's bucket must be the rank-ordered float32 sum, bit for bit, and every handle PC_OK.  (train.py:259-260)"""
     import ctypes as C
     from ppo_car_amd._capi import check, lib
@@ -538,23 +538,34 @@ def test_one_shot_exchange_eight_ranks_in_one_process(world, n):
     assert lib.pc_xchg_connect_local(hs[0], wrong) == -1                                            # handles out of rank order: refused
     for h in hs:
         check(lib.pc_xchg_connect_local(h, arr), "pc_xchg_connect_local")
-    streams = [torch.cuda.Stream() for _ in range(world)]
     idx = torch.arange(n, device="cuda", dtype=torch.float32)
     gen = lambda r, ep: torch.sin(idx * (0.37 + r) + ep * 1.7) * (1.0 + 1000.0 * (ep % 3)) + r
     torch.cuda.synchronize()
     bad = 0
+    st = torch.cuda.current_stream().cuda_stream
     for ep in range(100):
         buckets = [gen(r, ep) for r in range(world)]
         want = buckets[0].clone()
         for r in range(1, world):
             want = want + buckets[r]
-        torch.cuda.synchronize()
-        for r in range(world):
-            with torch.cuda.stream(streams[r]):
-                check(lib.pc_xchg_allreduce(hs[r], buckets[r].data_ptr(), streams[r].cuda_stream), "pc_xchg_allreduce")
-        torch.cuda.synchronize()
+        ptrs = (C.c_void_p * world)(*[b.data_ptr() for b in buckets])
+        check(lib.pc_xchg_allreduce_group(arr, ptrs, st), "pc_xchg_allreduce_group")      # all ranks' grids in ONE launch: co-resident
         for r in range(world):
             bad += int((buckets[r] != want).sum())
+    if world <= 3:      # ... and the per-rank launches on separate streams, where the streams fit the hardware queues
+        streams = [torch.cuda.Stream() for _ in range(world)]
+        for ep in range(100, 120):
+            buckets = [gen(r, ep) for r in range(world)]
+            want = buckets[0].clone()
+            for r in range(1, world):
+                want = want + buckets[r]
+            torch.cuda.synchronize()
+            for r in range(world):
+                with torch.cuda.stream(streams[r]):
+                    check(lib.pc_xchg_allreduce(hs[r], buckets[r].data_ptr(), streams[r].cuda_stream), "pc_xchg_allreduce")
+            torch.cuda.synchronize()
+            for r in range(world):
+                bad += int((buckets[r] != want).sum())
     for h in hs:
         assert lib.pc_xchg_status(h) == 0
     assert bad == 0
