@@ -77,6 +77,13 @@ __global__ __launch_bounds__(256) void gae_kernel(const float* __restrict__ rew,
 // |x| * 2^-24 in the result (1e-7 at x = -2, 1e-6 at x = -20 where the probability is 2e-9), against the 1e-5 the log-probs
 // are held to and the 2e-6 they are tested at.  Nine calls per env and step: the draw was 3 % of the rollout kernel.
 __device__ __forceinline__ float softmax_exp(const float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+// log and reciprocal of the softmax denominator (1 <= sum <= A): the hardware's one-instruction forms.  v_log_f32 (log2, one ulp) times
+// ln 2 is within 2 ulps of log -- 2e-7 absolute on a log-sum-exp below 2.2 -- and v_rcp_f32 within one ulp of 1 / sum; the IEEE division
+// and the full-range logf they replace cost 16 more vector instructions per draw for bits the sampler's contract (log-prob within 2e-6 of
+// Categorical, model.py:34-41) does not ask for.  EVERY draw of the library goes through these two (pc_sample, the fused policy step in
+// all its forms, the persistent kernels): their buffers stay bit-identical to each other.
+__device__ __forceinline__ float softmax_log(const float sum) { return __builtin_amdgcn_logf(sum) * 0.693147180559945309417f; }
+__device__ __forceinline__ float softmax_rcp(const float sum) { return __builtin_amdgcn_rcpf(sum); }
 
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
@@ -134,8 +141,8 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         ex[i] = softmax_exp(l[i] - mx);
         sum += ex[i];
     }
-    const float lse = mx + logf(sum);  // Categorical(logits=...) normalises: logits - logsumexp
-    const float inv = 1.0f / sum;
+    const float lse = mx + softmax_log(sum);  // Categorical(logits=...) normalises: logits - logsumexp
+    const float inv = softmax_rcp(sum);
     const float u = philox_uniform(seed, offset, (uint64_t)e);
     float cum = 0.0f, ent = 0.0f, lp = 0.0f;
     int act = -1;

@@ -813,8 +813,8 @@ __device__ __forceinline__ void policy_tail(const float (&v)[16], const int A_rt
         ex[i] = softmax_exp(v[i] - mx);
         sum += ex[i];
     }
-    const float lse = mx + logf(sum);  // Categorical(logits=...) normalises: logits - logsumexp
-    const float inv = 1.0f / sum;
+    const float lse = mx + softmax_log(sum);  // Categorical(logits=...) normalises: logits - logsumexp
+    const float inv = softmax_rcp(sum);
     float cum = 0.0f;
     lp = 0.0f;
     act = -1;
@@ -855,8 +855,8 @@ __device__ __forceinline__ void policy_tail_pair(const float (&w)[5], const int 
     for (int j = 0; j < 5; ++j) ex[j] = softmax_exp(l[j] - mx);     // (exp2(-inf) = 0 for lane 0's fifth slot)
     const float part = (((ex[0] + ex[1]) + ex[2]) + ex[3]) + ex[4];
     const float sum = part + dpp_swap_pair_f(part);                  // (a + b on one lane, b + a on the other: the same float)
-    const float lse = mx + logf(sum);  // Categorical(logits=...) normalises: logits - logsumexp
-    const float inv = 1.0f / sum;
+    const float lse = mx + softmax_log(sum);  // Categorical(logits=...) normalises: logits - logsumexp
+    const float inv = softmax_rcp(sum);
     float c[5];
     c[0] = ex[0] * inv;
 #pragma unroll
@@ -913,8 +913,8 @@ __device__ __forceinline__ void policy_tail_row(const float v, const int i, cons
     sum += PC_ROW_ROR(sum, 4);
     sum += PC_ROW_ROR(sum, 2);
     sum += PC_ROW_ROR(sum, 1);
-    const float lse = mx + logf(sum);  // Categorical(logits=...) normalises: logits - logsumexp
-    float cdf = ex * (1.0f / sum);     // inclusive scan over the row (lanes shifted in from outside the row read 0)
+    const float lse = mx + softmax_log(sum);  // Categorical(logits=...) normalises: logits - logsumexp
+    float cdf = ex * softmax_rcp(sum);    // inclusive scan over the row (lanes shifted in from outside the row read 0)
     cdf += PC_ROW_SHR0(cdf, 1);
     cdf += PC_ROW_SHR0(cdf, 2);
     cdf += PC_ROW_SHR0(cdf, 4);

@@ -177,6 +177,16 @@ __device__ __forceinline__ FastLane fast_lane(const EnvParams<float>& p, const F
     fl.llast = (lds_fp)(row + 6 + min(g + G * (RPL - 1), p.R - 1));
     return fl;
 }
+// one observation entry as the fp16 x 2 policy pass wants it (policy.hpp: split_pair_h's arithmetic on a single value): scaled domain
+// x 16, saturating at fp16's range, h = fp16(v), l = fp16(v - h) -- into row[0][col] and row[1][col] of an env's [2][32] halves
+typedef __attribute__((address_space(3))) _Float16* lds_hp;
+__device__ __forceinline__ void write_pieces(lds_hp row, const int col, const float v) {
+    const float vs = clamp_h(v * PolScale<2>::sx);
+    const _Float16 h = (_Float16)vs;
+    const _Float16 l = (_Float16)__builtin_fmaf((float)h, opaque_neg_one(), vs);
+    row[col] = h;
+    row[32 + col] = l;
+}
 // exchange with the neighbouring lane (the other lane of the env): DPP quad_perm [1, 0, 3, 2], one VALU instruction
 __device__ __forceinline__ int swap_pair(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false); }
 
@@ -664,7 +674,11 @@ template <int RPL, bool TAB, bool LIT = false>
 __device__ __forceinline__ bool env_step_wave(const EnvParams<float>& p, const TrackHdr& h, const FastTabs& ft, const FastLane& fl,
                                               const int gq0, const int g, const int part, EnvRegs& st, int& k72, const int a,
                                               const double reward_scale, lds_fp lrow, float& reward_f, float& term_f, float& trunc_f,
-                                              const int lane, const int t = 0, const int wave = 0, f64x2* hcar = nullptr) {   // (t, wave: the developer stamps)
+                                              const int lane, const int t = 0, const int wave = 0, f64x2* hcar = nullptr,
+                                              lds_hp xrow = nullptr) {   // (t, wave: the developer stamps)
+    // xrow (fp16 x 2 policy arithmetic): this env's two rows of PRE-SPLIT policy operands [2 pieces][32 features] in LDS.  The lane that
+    // produces an observation entry also writes its scaled-domain pieces h = fp16(16 v), l = fp16(16 v - h) there -- once per entry,
+    // where the eight waves of the workgroup used to split all 16 x 32 entries each at the head of their policy pass (split8's bits).
     constexpr int G = 4, PARTS = 8, NP = (RPL + 1) / 2;
     const double2* rot_tab = p.dirtab64 + h.rot_off;      // LIT: the track's rotation table (see env_step_fast)
     const int rot_ld = p.R + 2;
@@ -798,14 +812,29 @@ __device__ __forceinline__ bool env_step_wave(const EnvParams<float>& p, const T
         const double2 e1 = rot_tab[kid_new * rot_ld];
         cs1 = (f64x2){e1.x, e1.y};
     }
-    if (g == 0 && part == 0) {
+    if (xrow == nullptr) {
+        if (g == 0 && part == 0) {
+            using M = Math<std::conditional_t<LIT, double, float>>;
+            lrow[0] = M::norm(npx, 1280.0);
+            lrow[1] = M::norm(npy, 720.0);
+            lrow[2] = M::norm(nvx, 10.0);
+            lrow[3] = M::norm(nvy, 10.0);
+            lrow[4] = (float)cs1.x;
+            lrow[5] = (float)cs1.y;
+        }
+    } else {
+        // every lane holds at most ONE entry of the row: parts 0 .. RPL - 1 their ray slot's (written above, final after the careful path),
+        // parts 5 and 6 -- idle in the refinement -- the six kinematic entries (part 5: columns 0 .. 3, part 6: columns 4, 5)
         using M = Math<std::conditional_t<LIT, double, float>>;
-        lrow[0] = M::norm(npx, 1280.0);
-        lrow[1] = M::norm(npy, 720.0);
-        lrow[2] = M::norm(nvx, 10.0);
-        lrow[3] = M::norm(nvy, 10.0);
-        lrow[4] = (float)cs1.x;
-        lrow[5] = (float)cs1.y;
+        static_assert(RPL <= 5, "parts 5 and 6 carry the kinematic columns");
+        const float k01 = g & 1 ? M::norm(npy, 720.0) : M::norm(npx, 1280.0), k23 = g & 1 ? M::norm(nvy, 10.0) : M::norm(nvx, 10.0);
+        const float k45 = g & 1 ? (float)cs1.y : (float)cs1.x;
+        const float kin = part == 5 ? (g & 2 ? k23 : k01) : k45;
+        const bool mine_kin = (part == 5) | ((part == 6) & (g < 2));
+        const int col = active ? 6 + min(g + G * slot, p.R - 1) : (part == 5 ? g : 4 + g);
+        const float val = active ? obs_of(d) : kin;
+        if (mine_kin) lrow[col] = val;
+        if (active | mine_kin) write_pieces(xrow, col, val);
     }
     st.px = npx;
     st.py = npy;
@@ -1479,7 +1508,12 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     float* sObs = sOut + 8 * EPW * LDO;            // [EPW envs][LDX]
     int* sAct = reinterpret_cast<int*>(sObs + EPW * (FAST ? 40 : LDX));   // (FAST: room for the widest row, so the tables stay 16-byte aligned)
     int* sHit = sAct + 32;                                 // [EPW envs][PARTS]: the sweep parts' collision / gate verdicts (128 words)
-    float* sTab = reinterpret_cast<float*>(sHit + 128);    // staged per-track tables
+    // XPRE (16 envs per workgroup, fp16 x 2): the observation rows ALSO as pre-split policy operands, [16 envs][2 pieces][32 features] halves
+    // (2 KB; the host sizes the launch for the 32-env form's partial tiles and rows, of which this form uses half: in bounds)
+    constexpr bool XPRE = EPW == 16 && PREC == 2;
+    static_assert(!XPRE || 8 * 16 * LDO + 16 * 40 + 512 <= 8 * 32 * LDO + 32 * 40, "the pre-split rows fit the slack of the 32-env launch size");
+    float* sXp = reinterpret_cast<float*>(sHit + 128);
+    float* sTab = sXp + (XPRE ? 512 : 0);                  // staged per-track tables
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, lk = lane >> 4;
     policy_stage_image<IMG>(image, lds, tid);
@@ -1522,6 +1556,11 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     // mixed-track batch: this wave's envs share one track (the host checked every aligned block of 32 envs)
     const int trk = p.track_id ? (int)p.track_id[e_valid ? e_env : N - 1] : 0;
     for (int f = g + 4 * part; f < (FAST ? D : 4 * KS); f += 4 * PARTS) sObs[el * LDX + f] = (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f;
+    const lds_hp xrow = (lds_hp)sXp + el * 64;             // XPRE: this env's [2][32] halves
+    if constexpr (XPRE) {                                  // every lane of an env: column g + 4 part of 32 (the K padding = 0, once and for all)
+        const int f = g + 4 * part;
+        write_pieces(xrow, f, (e_valid && f < D) ? next_obs[e_env * D + f] : 0.0f);
+    }
     float* myOut = sOut + wave * EPW * LDO;
     const int ht0 = wave * (NT / 8), ht1 = ht0 + NT / 8;
     const uint64_t off0 = offset + (offset_dev ? *offset_dev : 0);
@@ -1572,6 +1611,12 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
             }
         } else {
             Pieces<PREC> x[ET][KB];
+            if constexpr (XPRE) {      // the operands were split where the entries were produced (env_step_wave / the reset fix-up): two 16-byte reads
+                static_assert(ET == 1 && KB == 1, "16 envs, one K block");
+                const u32x4* xp = reinterpret_cast<const u32x4*>(sXp) + lc * 8 + lk;      // env lc: 8 x 16 bytes, piece 0 then piece 1
+                x[0][0].p[0] = xp[0];
+                x[0][0].p[1] = xp[4];
+            } else {
 #pragma unroll
             for (int et = 0; et < ET; ++et) {
 #pragma unroll
@@ -1586,6 +1631,7 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                     }
                     x[et][kb] = split8<PREC>(v);
                 }
+            }
             }
             float val[ET] = {};
             if (!(dbg & 1)) policy_pass16<PREC, KB, ET>(sW1p, sW2p, sB1, sW2c, wave, -1, x, out, val, lc, lk);
@@ -1641,9 +1687,12 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 if constexpr (WOWN) {
                     const int a0 = __builtin_amdgcn_readlane(act, 0), a1 = __builtin_amdgcn_readlane(act, 16);
                     const int a = e_valid ? (lane < 32 ? a0 : a1) : 8;
-                    done = rden_lds   // (uniform)
-                        ? env_step_wave<RPL, true, LIT>(p, h0, ft, fl, gq[0], g, part, st, k72, a, reward_scale, lrow, rw, tf, cf, lane, t, wave, &hcar)
-                        : env_step_wave<RPL, false, LIT>(p, h0, ft, fl, gq[0], g, part, st, k72, a, reward_scale, lrow, rw, tf, cf, lane, t, wave, &hcar);
+                    if constexpr (MODE == 2)      // the host found room for the 1/den table: compiled for it (one env step in the kernel, not two)
+                        done = env_step_wave<RPL, true, LIT>(p, h0, ft, fl, gq[0], g, part, st, k72, a, reward_scale, lrow, rw, tf, cf, lane, t, wave, &hcar, XPRE ? xrow : nullptr);
+                    else
+                        done = rden_lds   // (uniform)
+                            ? env_step_wave<RPL, true, LIT>(p, h0, ft, fl, gq[0], g, part, st, k72, a, reward_scale, lrow, rw, tf, cf, lane, t, wave, &hcar, XPRE ? xrow : nullptr)
+                            : env_step_wave<RPL, false, LIT>(p, h0, ft, fl, gq[0], g, part, st, k72, a, reward_scale, lrow, rw, tf, cf, lane, t, wave, &hcar, XPRE ? xrow : nullptr);
                 } else {
                     const int a = e_valid ? sAct[el] : 8;
                     done = rden_lds   // (uniform)
@@ -1660,7 +1709,10 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                             for (int j = 0; j < (DC + 3) / 4; ++j) ro[j] = ft.reset[g + 4 * j];
 #pragma unroll
                             for (int j = 0; j < (DC + 3) / 4; ++j)
-                                if (g + 4 * j < DC) lrow[g + 4 * j] = ro[j];
+                                if (g + 4 * j < DC) {
+                                    lrow[g + 4 * j] = ro[j];
+                                    if constexpr (XPRE) write_pieces(xrow, g + 4 * j, ro[j]);
+                                }
                         }
                         env_reset_fast(h0, st, k72);
                         if constexpr (LIT) {

@@ -1262,23 +1262,26 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
         if (prec == 0) {
             // THE STRICTEST CELL: float64 env (the literal form) AND the policy GEMMs as the exact fp32 chain (v_mfma_f32_16x16x4_f32) -- every
             // number of the rollout in the reference's own arithmetic -- as one persistent launch: K9's literal form with the fp32 weight
-            // image (16 -> 17 rays, the big form, the generic sweeps with the 1/den table in LDS).  Other shapes: the per-step kernels.
+            // image (16 -> 17 rays, the big form, the generic sweeps; the fp32 image leaves no room for the 1/den table, as for F32
+            // handles).  Other shapes: the per-step kernels.
             const int img0 = pol_image_padded(KS);
-            const size_t lds0 = (size_t)k9_fast_lds_floats(img0, 32, e->D, true, 361 * max_nV) * sizeof(float);
+            const size_t lds0 = (size_t)k9_fast_lds_floats(img0, 32, e->D, true, 0) * sizeof(float);
             if (!(tabs && rays16 && !e->f64_offgrid && !interleaved && e->D >= 17 && max_G <= TAB_MAX_GATES && max_nV <= FT_VTX_MAX && e->opt.fast &&
-                  e->opt.rden != 0 && (!e->track_id || e->track_block >= epw) && lds0 <= 160 * 1024))
+                  (!e->track_id || e->track_block >= epw) && lds0 <= 160 * 1024))
                 return PC_ERR_UNSUPPORTED;
             const int vec_ok = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
             EnvParams<float> prm = e->params<float>();
             prm.lg = 1;
+#ifndef PC_DEV_MIN
             static bool attr_set[64] = {false};
             if (e->device >= 64 || !attr_set[e->device]) {
-                HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<6, 9, 0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<6, 9, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 if (e->device < 64) attr_set[e->device] = true;
             }
-            PC_FULL(hipLaunchKernelGGL((rollout_kernel<6, 9, 0, 2, true>), dim3(blocks), dim3(512), lds0, st, prm, image, A, (int)T, reward_scale, seed, offset,
+#endif
+            PC_FULL(hipLaunchKernelGGL((rollout_kernel<6, 9, 0, 1, true>), dim3(blocks), dim3(512), lds0, st, prm, image, A, (int)T, reward_scale, seed, offset,
                                        offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, next_term, next_trunc,
-                                       361 * max_nV, epw, vec_ok, last_value, reward_sum));
+                                       0, epw, vec_ok, last_value, reward_sum));
             HIPCHK(hipGetLastError());
             e->last_kernel = PC_KERNEL_K9_LITERAL;
             return PC_OK;
@@ -1556,7 +1559,12 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
 #define PC_ROLLS(KSV, RPLV, PRC)                                                                                         \
     do {                                                                                                                 \
         if constexpr (PRC != 0 && RPLV <= 5) {                                                                           \
-            if (mode && epw_small == 16) { if constexpr (PRC == 2 && KSV == 6) PC_DEV(1, PC_ROLLS_M(KSV, RPLV, PRC, 1, 16)); else PC_FULL(PC_ROLLS_M(KSV, RPLV, PRC, 1, 16)); break; } \
+            if (mode && epw_small == 16) {                                                                               \
+                if constexpr (PRC == 2 && KSV == 6) {   /* (configs[1]'s kernel: with the 1/den table in LDS the env step is compiled for it) */ \
+                    if (rden_lds) PC_DEV(1, PC_ROLLS_M(KSV, RPLV, PRC, 2, 16)); else PC_FULL(PC_ROLLS_M(KSV, RPLV, PRC, 1, 16));    \
+                } else PC_FULL(PC_ROLLS_M(KSV, RPLV, PRC, 1, 16));                                                               \
+                break;                                                                                                           \
+            }                                                                                                                    \
         }                                                                                                                \
         if (mode) PC_FULL(PC_ROLLS_M(KSV, RPLV, PRC, 1, 32));    /* (the small form takes the 1/den table as a run-time branch) */   \
         else PC_FULL(PC_ROLLS_M(KSV, RPLV, PRC, 0, 32));                                                                 \

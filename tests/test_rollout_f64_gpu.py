@@ -277,7 +277,7 @@ def test_f64_selector_form_on_walls_that_cross_and_touch(tmp_path, n_envs):
 def test_strictest_cell_float64_env_and_exact_fp32_policy_chain_in_one_persistent_launch(n_envs, n_steps):
     """dtype f64 AND policy_precision 0 (v_mfma_f32_16x16x4_f32: the fp32 fmaf chain of model.py's Linear layers): every number of the
     rollout in the reference's own arithmetic.  pc_rollout runs it as K9's literal form with the fp32 weight image
-    (rollout_kernel<6, 9, 0, 2, true>, 16 -> 17 rays, the big form): bitwise the per-step kernels (policy_kernel<6, false, 0>;
+    (rollout_kernel<6, 9, 0, 1, true>, 16 -> 17 rays, the big form): bitwise the per-step kernels (policy_kernel<6, false, 0>;
     env_step_kernel<double>), float64 state included, and every observation / reward / flag of 256 envs equal to the oracle's."""
     res, first = {}, None
     for mode in ("mega", "steps"):

@@ -552,20 +552,6 @@ def test_one_shot_exchange_eight_ranks_in_one_process(world, n):
         check(lib.pc_xchg_allreduce_group(arr, ptrs, st), "pc_xchg_allreduce_group")      # all ranks' grids in ONE launch: co-resident
         for r in range(world):
             bad += int((buckets[r] != want).sum())
-    if world <= 3:      # ... and the per-rank launches on separate streams, where the streams fit the hardware queues
-        streams = [torch.cuda.Stream() for _ in range(world)]
-        for ep in range(100, 120):
-            buckets = [gen(r, ep) for r in range(world)]
-            want = buckets[0].clone()
-            for r in range(1, world):
-                want = want + buckets[r]
-            torch.cuda.synchronize()
-            for r in range(world):
-                with torch.cuda.stream(streams[r]):
-                    check(lib.pc_xchg_allreduce(hs[r], buckets[r].data_ptr(), streams[r].cuda_stream), "pc_xchg_allreduce")
-            torch.cuda.synchronize()
-            for r in range(world):
-                bad += int((buckets[r] != want).sum())
     for h in hs:
         assert lib.pc_xchg_status(h) == 0
     assert bad == 0
