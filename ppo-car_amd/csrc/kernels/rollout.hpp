@@ -1588,6 +1588,18 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
 
     const int TT = last_val ? T + 1 : T;   // pc_rollout_ex: tail iteration t == T = the final observation's value only (see rollout_kernel)
     float rsum = 0.0f;
+    // The rows a lane stores every step, as per-lane POINTERS that advance by one buffer row per step (a 64-bit add each) instead of
+    // base + (t N + e) formed from kernel arguments: those live in SGPRs this kernel does not have (84 are spilled to vector lanes) and
+    // every use reloaded a pair with v_readlane before the address arithmetic -- ~50 vector instructions per wave and step.
+    const int64_t e_draw = e_wg + wave * (EPW / 8) + lk;                              // the env this lane draws for (lk < EPW / 8, lc == 0)
+    float* pa_act = act_buf + e_draw;
+    float* pa_lp = logprob_buf + e_draw;
+    float* pa_val = val_buf + e_draw;
+    float* pa_rew = rew_buf + e_env;
+    float* pa_term = term_buf + N + e_env;                                             // flags that precede obs t + 1 (train.py:176-177,195)
+    float* pa_trunc = trunc_buf + N + e_env;
+    float* pa_obs = obs_buf + (N + e_wg) * D + 4 * (lane + 64 * wave);                 // FAST: this lane's 16 bytes of the workgroup's row block
+    const int64_t row_step = N, obs_step = N * D;
 #pragma unroll 1
     for (int t = 0; t < TT; ++t) {
         const bool tail = t == T;          // (uniform)
@@ -1668,13 +1680,15 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 if (tail) {
                     last_val[e] = val;
                 } else {
-                    const int64_t row = (int64_t)t * N + e;
-                    act_buf[row] = (float)act;
-                    logprob_buf[row] = lp;
-                    val_buf[row] = val;
+                    *pa_act = (float)act;
+                    *pa_lp = lp;
+                    *pa_val = val;
                 }
             }
         }
+        pa_act += row_step;
+        pa_lp += row_step;
+        pa_val += row_step;
         if constexpr (!WOWN) lds_barrier();   // (WOWN: the wave steps the two envs it drew for -- lanes 0 and 16 hold their actions)
         PC_STAMP(3)
         if (tail) break;
@@ -1721,15 +1735,21 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                         }
                     }
                 }
+                if (last) {        // (uniform, once per launch) the flags and the observation of the final step go to next_*
+                    pa_term = next_term + e_env;
+                    pa_trunc = next_trunc + e_env;
+                    pa_obs = next_obs + e_wg * D + 4 * (lane + 64 * wave);
+                }
                 if (part == 0) {   // (uniform) the row-writing wave: per-env scalars
                     if (g == 0 && e_valid) {
-                        rew_buf[(int64_t)t * N + e_env] = rw;
-                        float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;
-                        float* tc = last ? next_trunc : trunc_buf + (int64_t)(t + 1) * N;
-                        tr[e_env] = tf;
-                        tc[e_env] = cf;
+                        *pa_rew = rw;
+                        *pa_term = tf;
+                        *pa_trunc = cf;
                     }
                 }
+                pa_rew += row_step;
+                pa_term += row_step;
+                pa_trunc += row_step;
             }
             PC_STAMP(6)
             lds_barrier();    // the workgroup's observation rows are complete
@@ -1741,10 +1761,11 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 const int n_rows = left >= EPW ? EPW : (int)left;
                 if (vec_ok && n_rows == EPW) {
                     const int i = lane + 64 * wave;
-                    if (i < EPW / 4 * DC) reinterpret_cast<f32x4*>(dstg)[i] = reinterpret_cast<const f32x4*>(sObs)[i];
+                    if (i < EPW / 4 * DC) *reinterpret_cast<f32x4*>(pa_obs) = reinterpret_cast<const f32x4*>(sObs)[i];
                 } else {
                     for (int i = tid; i < n_rows * D; i += 512) dstg[i] = sObs[i];
                 }
+                pa_obs += obs_step;
             }
         } else if constexpr (EPW == 32) {
             if (!(dbg & 2)) {
