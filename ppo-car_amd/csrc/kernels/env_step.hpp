@@ -955,6 +955,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvParams<T> p, con
 __global__ void rden_build_kernel(const EnvParams<float> p, const int n_tracks, float* __restrict__ rden) {
     for (int trk = 0; trk < n_tracks; ++trk) {
         const TrackHdr h = p.hdr[trk];
+        if (h.rden_off < 0) continue;      // (no table for this track: see env_create_impl)
         const int total = 361 * h.nV;
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
             const int idx = i / h.nV, k = i - idx * h.nV;

@@ -57,6 +57,7 @@
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
+#include <climits>
 #include <utility>
 #include <vector>
 
@@ -628,8 +629,15 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
             dirtab.push_back(make_float2(0.f, 0.f));
             dirtab64.push_back(make_double2(0.0, 0.0));
         }
-        h.rden_off = (int)rden_floats;
-        rden_floats += (size_t)361 * h.nV;
+        // the float32 1/den table [361][nV] exists only where a kernel can stage it in LDS: chains of at most FT_VTX_MAX vertices, and on F64
+        // handles only for tracks the selector may run on (a 65535-vertex float64 track would cost 95 MB it can never read)
+        const bool want_rden = h.nV <= FT_VTX_MAX && (!f64 || h.sel_ok);
+        if (rden_floats + (size_t)361 * h.nV > (size_t)INT_MAX) {
+            g_hip_err = "pc_env_create: the tracks' 1/den tables exceed 2^31 floats";
+            return PC_ERR_UNSUPPORTED;
+        }
+        h.rden_off = want_rden ? (int)rden_floats : -1;
+        if (want_rden) rden_floats += (size_t)361 * h.nV;
         if (!f64) h.head_off = (int)headtab.size();
         h.start_collides = 0;
         h.start_x = t->start_x;
@@ -681,7 +689,7 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
         HIPCHK(hipMemcpy(e->dirhash, dirhash.data(), dirhash.size() * sizeof(F64Dir), hipMemcpyHostToDevice));
     }
     {
-        HIPCHK(hipMalloc((void**)&e->rden, rden_floats * sizeof(float)));
+        HIPCHK(hipMalloc((void**)&e->rden, (rden_floats ? rden_floats : 1) * sizeof(float)));
         hipLaunchKernelGGL(rden_build_kernel, dim3(64), dim3(256), 0, 0, e->params<float>(), e->n_tracks, e->rden);
         HIPCHK(hipGetLastError());
     }
@@ -1473,7 +1481,9 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
     // den and its reciprocal itself -- same bits either way.  Mixed batches: in the fast modes only (room for the largest track).
     // (the big form at 33 rays has 4 KB left: no closed track's table fits, so that shape is built without the table mode)
     int rden_lds = 361 * max_nV;
-    if (o.rden == 0 || (e->track_id && !(small ? fast_small : fast)) || lds + (size_t)rden_lds * sizeof(float) > 160 * 1024 ||
+    bool all_rden = true;
+    for (const TrackHdr& h : e->hdr_host) all_rden = all_rden && h.rden_off >= 0;
+    if (!all_rden || o.rden == 0 || (e->track_id && !(small ? fast_small : fast)) || lds + (size_t)rden_lds * sizeof(float) > 160 * 1024 ||
         (!small && KS == 10))
         rden_lds = 0;
     lds += (size_t)rden_lds * sizeof(float);

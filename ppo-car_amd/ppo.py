@@ -885,6 +885,8 @@ class Trainer:
         if sd["fused"] != L.fused:
             raise ValueError("checkpoint was written with a different update path (fused_update)")
         self._aux_valid = False     # bootstrap values / reward totals of an earlier rollout do not belong to the loaded state
+        self._rollout_graph = None  # a captured per-step rollout belongs to the state it was captured for (it is re-captured after one eager pass)
+        self._eager_rollouts = 0
         with torch.no_grad():
             self.agent.load_state_dict(sd["agent"])        # parameters are views into the flat buffer: copied in place
             if L.fused:

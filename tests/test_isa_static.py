@@ -142,7 +142,9 @@ def test_fp16_operand_split_is_compiler_generated_mix_instructions(kernels):
             continue
         ops = [op for op, _ in insts]
         lo, hi, back = ops.count("v_fma_mixlo_f16"), ops.count("v_fma_mixhi_f16"), sum(op.startswith("v_cvt_f32_f16") for op in ops)
-        assert lo > 0 and lo == hi, (name, lo, hi)
+        # (pairs of values: one mixlo + one mixhi; the 16-envs-per-workgroup small form also splits SINGLE observation entries where they
+        # are produced -- rollout.hpp: write_pieces -- with a lone mixlo each)
+        assert hi > 0 and lo >= hi, (name, lo, hi)
         assert back == 0, (name, "the split converts fp16 back to fp32: the five-instruction form")
         checked += 1
     assert checked >= 20
