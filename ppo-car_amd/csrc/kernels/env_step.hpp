@@ -362,23 +362,12 @@ __device__ __forceinline__ void wall_sweep_loops(const VtxP* vp, const float pxr
     }
     // side values of position i of both chains: a = p - pos, c[s] = cross(a, dir_s), and the smallest |c| per slot
     auto side = [&](const VtxP& v, f32x2& ax, f32x2& ay, f32x2(&c)[RPL]) {
-#ifdef PC_AB_UNPACK   // developer A/B (tools/ab_run.sh build unpack "-DPC_AB_UNPACK -fno-slp-vectorize"): the same arithmetic as plain
-                      // v_sub / v_mul / v_fma_f32 per component instead of v_pk_* (same bits: every operation is the same IEEE operation)
-        ax.x = v.xr.x - pxr; ax.y = v.xr.y - pxr;
-        ay.x = v.yr.x - pyr; ay.y = v.yr.y - pyr;
-#else
         ax = v.xr - px2;
         ay = v.yr - py2;
-#endif
 #pragma unroll
         for (int s = 0; s < RPL; ++s) {
             const f32x2 dxs = {dx[s], dx[s]}, dys = {dy[s], dy[s]};
-#ifdef PC_AB_UNPACK
-            c[s].x = __builtin_fmaf(ay.x, dx[s], -(ax.x * dy[s]));
-            c[s].y = __builtin_fmaf(ay.y, dx[s], -(ax.y * dy[s]));
-#else
             c[s] = __builtin_elementwise_fma(ay, dxs, -(ax * dys));
-#endif
             if constexpr (!(PC_ABLATE & 32)) cm[s] = __builtin_fminf(__builtin_fminf(cm[s], __builtin_fabsf(c[s].x)), __builtin_fabsf(c[s].y));   // v_min3_f32 |.|
         }
     };
@@ -386,23 +375,11 @@ __device__ __forceinline__ void wall_sweep_loops(const VtxP* vp, const float pxr
     auto cand = [&](auto IC, const VtxP& v, const f32x2 axp, const f32x2 ayp, const f32x2(&cp)[RPL], const f32x2(&c)[RPL],
                     const f32x4(&rd)[RPL]) {
         constexpr int I = decltype(IC)::value;
-#ifdef PC_AB_UNPACK
-        f32x2 un;
-        un.x = __builtin_fmaf(v.eys.x, axp.x, -(v.exs.x * ayp.x));
-        un.y = __builtin_fmaf(v.eys.y, axp.y, -(v.exs.y * ayp.y));
-#else
         const f32x2 un = __builtin_elementwise_fma(v.eys, axp, -(v.exs * ayp));
-#endif
         um = __builtin_fminf(__builtin_fminf(um, __builtin_fabsf(un.x)), __builtin_fabsf(un.y));
 #pragma unroll
         for (int s = 0; s < RPL; ++s) {
-#ifdef PC_AB_UNPACK
-            f32x2 P;
-            asm("v_mul_f32 %0, %1, %2 clamp" : "=v"(P.x) : "v"(cp[s].x), "v"(c[s].x));
-            asm("v_mul_f32 %0, %1, %2 clamp" : "=v"(P.y) : "v"(cp[s].y), "v"(c[s].y));
-#else
             const f32x2 P = pk_mul_clamp(cp[s], c[s]);
-#endif
             f32x2 r;
             if constexpr (TAB) {
                 r = (I & 1) ? (f32x2){rd[s][2], rd[s][3]} : (f32x2){rd[s][0], rd[s][1]};
@@ -411,13 +388,7 @@ __device__ __forceinline__ void wall_sweep_loops(const VtxP* vp, const float pxr
                 const f32x2 den = __builtin_elementwise_fma(v.ey, dxs, -(v.ex * dys));   // = rden_build_kernel's
                 r = (f32x2){__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
             }
-#ifdef PC_AB_UNPACK
-            f32x2 u;
-            u.x = __builtin_fmaf(un.x, r.x, P.x);
-            u.y = __builtin_fmaf(un.y, r.y, P.y);
-#else
             const f32x2 u = __builtin_elementwise_fma(un, r, P);
-#endif
             bb[s] = min(min(bb[s], and_or_k<I>(__float_as_uint(u.x), keep)), and_or_k<L + I>(__float_as_uint(u.y), keep));   // v_min3_u32
         }
     };

@@ -576,218 +576,8 @@ __device__ __forceinline__ void policy_pass16(const unsigned* sW1p, const unsign
     }
 }
 
-// ---- EXPERIMENT (compiled out by default, see PC_WIDE_MFMA below): the same pass for one wave and its 32 envs on the WIDE matrix
-// instruction, v_mfma_f32_32x32x16_f16 (fp16 x 2 form only).
-// Round 5: per unit of matrix work (16 Kflop) ONE 32x32x16 MFMA holds the vector issue port ~8 cycles where TWO 16x16x32 hold it ~16
-// and, with the fillers a real kernel has, costs 21-29 cycles less per unit and wave at two waves per SIMD
-// (tools/ubench_shadow.hip, profiles/r5_ubench_shadow.jsonl) -- and K9 is bound by that port.
-// Orientation: rows = hidden units (32 per block: actor blocks 0..7, critic blocks 8..15), cols = the wave's 32 envs (ONE column
-// tile: the ET loop is gone), K = features in steps of 16.  Fragment layouts (gfx950): A lane l: row l % 32, k = 8 (l / 32) + j;
-// B lane l: col l % 32, the same k; D lane l: col l % 32, register r <-> row 8 (r / 4) + 4 (l / 32) + r % 4.
-// The weight image is the 16x16x32 form's, read with other addresses -- both forms consume 16-byte records (row, feature group of 8,
-// piece), and the layer-2 records' pairing of hidden rows (4 g + i, 16 + 4 g + i) is exactly what one lane half's accumulator
-// registers hold (q = 0 / 2 for record g = h, q = 1 / 3 for record g = h + 2, h = l / 32): no repacking, one image for the split
-// kernels (16x16x32, 16 envs per tile) and this one.  Products and their order per accumulator: hl, lh, hh per K step, K steps in
-// order -- the fp32 summation order differs from the 16x16x32 form's in the last bits, as the split forms' already does.
-// xs[s] = the observation pieces of K step s (features 16 s + 8 (l / 32) + j of env l % 32); out = the [32 outputs x 32 envs] tile
-// (registers 0..3 = outputs 4 h + i, 4..7 = outputs 8 + 4 h + i; the rest is padding); val = this lane's partial of the critic's
-// output (the caller sums the two lane halves).
-// MEASURED SLOWER IN THE REAL KERNEL, OFF BY DEFAULT (round 5, profiles/r5_ab_experiments.txt): K9 16.5-16.7 against 15.2-15.7 us per
-// vector step with it (both the one-block-ahead pipeline and the paired-chain form below), cfg2 and the float64 kernel unchanged.
-// The microbenchmark's port saving is real, but the wide instruction's dependent latency (~64 cycles: two chains must alternate),
-// its 32-row output tile for nine useful rows in layer 2 (twice the pipe time there) and the longer serial epilogues per block
-// lengthen the wave's own critical path by more than the port gives back.  -DPC_WIDE_MFMA=1 builds it (all -m gpu tests pass with
-// it: the fragment-layout reasoning above is checked).
-#ifndef PC_WIDE_MFMA
-#define PC_WIDE_MFMA 0
-#endif
-__host__ __device__ constexpr bool pol_wide(const int PREC) { return PC_WIDE_MFMA != 0 && PREC == 2; }
-__host__ __device__ constexpr int pol_ksteps(const int KB) { return KB == 1 ? 2 : 3; }   // K steps of 16 features: D <= 24 -> 2, D <= 40 -> 3
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-// PIPE = false: block after block without the one-block-ahead software pipeline (one accumulator set, one operand set: ~50 registers
-// fewer) -- the same operations in the same order per accumulator, i.e. the same bits; for kernels whose other phase needs the registers.
-template <int KSTEPS, int NG, bool PIPE = true>
-__device__ __forceinline__ void policy_pass32(const unsigned* sW1p, const unsigned* sW2p, const float* sB1, const float* sW2c,
-                                              const Pieces<2> (&xs)[KSTEPS], f32x16& out, float& val, const int lane) {
-    constexpr int NP = 2;
-    const int c32 = lane & 31, hf = lane >> 5;
-    const int tile_lc = ((c32 >> 4) * NP * NG) * 16 + (c32 & 15);      // record offset of row c32 inside its block: tile (c32 / 16), lane (c32 % 16)
-    const int oA = c32 < 10 ? c32 : 9;                                  // output rows >= 10 are never read
-    struct Ops { u32x4 a[KSTEPS][NP]; int b; };     // (the weight operands one block ahead; the 16 bias floats are read where the chain starts)
-    auto load1 = [&](const int b, Ops& o) {
-        o.b = b;
-#pragma unroll
-        for (int st = 0; st < KSTEPS; ++st) {
-            const int gi = 2 * st + hf, gA = gi < NG ? gi : NG - 1;      // feature group; groups >= NG are K padding (x is zero there): any finite A
-#pragma unroll
-            for (int pc = 0; pc < NP; ++pc)
-                o.a[st][pc] = *reinterpret_cast<const u32x4*>(sW1p + ((2 * b * NP + pc) * NG + gA) * 64 + tile_lc * 4);
-        }
-    };
-    auto mfma1 = [&](const Ops& o, f32x16& acc) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(sB1 + 32 * o.b + 8 * q + 4 * hf);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[4 * q + i] = bias[i];
-        }
-#pragma unroll
-        for (int st = 0; st < KSTEPS; ++st) {
-#define PC_W1(ia, ib) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, o.a[st][ia]), __builtin_bit_cast(f16x8, xs[st].p[ib]), acc, 0, 0, 0)
-            PC_W1(0, 1); PC_W1(1, 0); PC_W1(0, 0);
-#undef PC_W1
-        }
-    };
-    auto epilogue_actor = [&](const int b, const f32x16& acc) {
-        u32x4 w2[2][NP];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int pc = 0; pc < NP; ++pc) w2[m][pc] = *reinterpret_cast<const u32x4*>(sW2p + (((b * NP + pc) * 4 + hf + 2 * m) * 10 + oA) * 4);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {      // layer-2 K step m: accumulator quads q = m and q = m + 2 (record g = hf + 2 m)
-            float hv[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                hv[i] = __builtin_amdgcn_fmed3f(acc[4 * m + i], 0.0f, PC_H_MAX);          // ReLU, saturating at fp16's range
-                hv[4 + i] = __builtin_amdgcn_fmed3f(acc[4 * (m + 2) + i], 0.0f, PC_H_MAX);
-            }
-            const Pieces<2> h3 = split8<2>(hv);
-#define PC_W2(ia, ib) out = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w2[m][ia]), __builtin_bit_cast(f16x8, h3.p[ib]), out, 0, 0, 0)
-            PC_W2(0, 1); PC_W2(1, 0); PC_W2(0, 0);
-#undef PC_W2
-        }
-    };
-    auto epilogue_critic = [&](const int b, const f32x16& acc) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(sW2c + 32 * (b - 8) + 8 * q + 4 * hf);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) val = __builtin_fmaf(w[i], relu_f(acc[4 * q + i]), val);
-        }
-    };
-    if constexpr (!PIPE) {
-        f32x16 acc;
-        Ops o;
-#pragma unroll 1
-        for (int b = 0; b < 8; ++b) {
-            load1(b, o);
-            mfma1(o, acc);
-            epilogue_actor(b, acc);
-        }
-#pragma unroll 1
-        for (int b = 8; b < 16; ++b) {
-            load1(b, o);
-            mfma1(o, acc);
-            epilogue_critic(b, acc);
-        }
-        return;
-    }
-    // Blocks in PAIRS, their two accumulator chains advancing together product by product: a 32x32x16 MFMA's result is not back
-    // before the next one could issue (dependent latency ~64 cycles against 32 of pipe time), so a single chain of six would
-    // idle the pipe half the time; the layer-2 MFMAs alternate between two output accumulators for the same reason (summed at
-    // the end).  The pair's epilogues follow its MFMAs; the partner wave of the SIMD fills the other phase.
-    f32x16 out2;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) out2[i] = 0.0f;
-    auto mfma_pair = [&](const Ops& o0, const Ops& o1, f32x16& acc0, f32x16& acc1) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sB1 + 32 * o0.b + 8 * q + 4 * hf);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(sB1 + 32 * o1.b + 8 * q + 4 * hf);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { acc0[4 * q + i] = b0[i]; acc1[4 * q + i] = b1[i]; }
-        }
-#pragma unroll
-        for (int st = 0; st < KSTEPS; ++st) {
-#define PC_W1P(ia, ib)                                                                                                                         \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, o0.a[st][ia]), __builtin_bit_cast(f16x8, xs[st].p[ib]), acc0, 0, 0, 0); \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, o1.a[st][ia]), __builtin_bit_cast(f16x8, xs[st].p[ib]), acc1, 0, 0, 0)
-            PC_W1P(0, 1); PC_W1P(1, 0); PC_W1P(0, 0);
-#undef PC_W1P
-        }
-    };
-    // layer 2 of an actor pair: block b0 into `out`, block b0 + 1 into `out2`, alternating
-    auto epilogue_actor_pair = [&](const int b0, const f32x16& acc0, const f32x16& acc1) {
-        u32x4 w2[2][2][NP];
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int pc = 0; pc < NP; ++pc)
-                    w2[k][m][pc] = *reinterpret_cast<const u32x4*>(sW2p + ((((b0 + k) * NP + pc) * 4 + hf + 2 * m) * 10 + oA) * 4);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            float hv0[8], hv1[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                hv0[i] = __builtin_amdgcn_fmed3f(acc0[4 * m + i], 0.0f, PC_H_MAX);
-                hv0[4 + i] = __builtin_amdgcn_fmed3f(acc0[4 * (m + 2) + i], 0.0f, PC_H_MAX);
-                hv1[i] = __builtin_amdgcn_fmed3f(acc1[4 * m + i], 0.0f, PC_H_MAX);
-                hv1[4 + i] = __builtin_amdgcn_fmed3f(acc1[4 * (m + 2) + i], 0.0f, PC_H_MAX);
-            }
-            const Pieces<2> h0 = split8<2>(hv0), h1 = split8<2>(hv1);
-#define PC_W2P(ia, ib)                                                                                                                          \
-    out = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w2[0][m][ia]), __builtin_bit_cast(f16x8, h0.p[ib]), out, 0, 0, 0);   \
-    out2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w2[1][m][ia]), __builtin_bit_cast(f16x8, h1.p[ib]), out2, 0, 0, 0)
-            PC_W2P(0, 1); PC_W2P(1, 0); PC_W2P(0, 0);
-#undef PC_W2P
-        }
-    };
-    f32x16 acc0, acc1;
-    Ops o0, o1;
-#pragma unroll 1
-    for (int b = 0; b < 8; b += 2) {
-        load1(b, o0);
-        load1(b + 1, o1);
-        mfma_pair(o0, o1, acc0, acc1);
-        __builtin_amdgcn_sched_barrier(0);
-        epilogue_actor_pair(b, acc0, acc1);
-    }
-#pragma unroll 1
-    for (int b = 8; b < 16; b += 2) {
-        load1(b, o0);
-        load1(b + 1, o1);
-        mfma_pair(o0, o1, acc0, acc1);
-        __builtin_amdgcn_sched_barrier(0);
-        epilogue_critic(b, acc0);
-        epilogue_critic(b + 1, acc1);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) out[i] += out2[i];      // (registers 8..15 are padding rows)
-}
-// the observation pieces of K step `st` for this lane (env row `row` of the [.][LDX] observation block, D features), scaled domain
-template <typename Load>
-__device__ __forceinline__ Pieces<2> obs_pieces32(const Load& ld, const int st, const int hf, const int D) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int f = 16 * st + 8 * hf + j;
-        const float raw = ld(f);
-        v[j] = clamp_h((f < D ? raw : 0.0f) * PolScale<2>::sx);
-    }
-    return split8<2>(v);
-}
-// the [32 outputs x 32 envs] tile -> the wave's LDS tile [32 envs][LDO] (columns = outputs 0..15), the critic's value into output row A
-template <int LDO>
-__device__ __forceinline__ void store_out32(float* myOut, f32x16& out, const float val, const int A, const int lane) {
-    const int c32 = lane & 31, hf = lane >> 5;
-    float a = val, bq = val;      // the two lane halves' partials (t + t[lane ^ 32])
-    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(bq));
-    const float tv = a + bq;
-    // row A: quad A / 8, half (A % 8) / 4, element A % 4
-    if (((A & 7) >> 2) == hf) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (8 * q + 4 * hf + i == A) out[4 * q + i] += tv;
-    }
-    *reinterpret_cast<f32x4*>(myOut + c32 * LDO + 4 * hf) = (f32x4){out[0], out[1], out[2], out[3]};
-    *reinterpret_cast<f32x4*>(myOut + c32 * LDO + 8 + 4 * hf) = (f32x4){out[4], out[5], out[6], out[7]};
-}
-
+// (Round 5 built the same pass on the wide instruction v_mfma_f32_32x32x16_f16 -- one 32-env column tile per wave; all tests green, 7 % slower
+// in K9: profiles/r5_ab_experiments.txt, profiles/HISTORY.md.  The code left the headers in round 6; it is in the history at commit dd4f33e.)
 // Softmax / Philox draw / log_prob for one env given its 16 output values (logits 0..A-1, value at A).
 // AC > 0: the action count as a compile-time constant (the persistent rollout kernel: CarEnv has Discrete(9), car_env.py:525) --
 // the same operations in the same order as with the run-time count, but fully unrolled over registers (with a run-time count
@@ -1003,21 +793,6 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
                 }
             }
             policy_pass<KS>(sW1, sB1, sW2, ht0, ht1, x, out, lc, lk, lane);
-        } else if constexpr (!SPLIT && pol_wide(PREC)) {
-            // whole-tile form, fp16 x 2: the wave's 32 envs as ONE column tile of the 32x32x16 instruction (policy_pass32)
-            constexpr int KSTEPS = pol_ksteps(KB);
-            const int64_t e = env0 + (lane & 31);
-            Pieces<2> xs[KSTEPS];
-#pragma unroll
-            for (int st = 0; st < KSTEPS; ++st)
-                xs[st] = obs_pieces32([&](const int f) { return (e < N && f < D) ? obs[e * D + f] : 0.0f; }, st, lane >> 5, D);
-            f32x16 o32;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o32[i] = 0.0f;
-            float v32 = 0.0f;
-            policy_pass32<KSTEPS, NG>(sW1p, sW2p, sB1, sW2c, xs, o32, v32, lane);
-            __syncthreads();  // previous pass's readers are done with sOut
-            store_out32<LDO>(myOut, o32, v32, A, lane);
         } else {
             Pieces<PREC> x[ET][KB];
 #pragma unroll
@@ -1046,7 +821,7 @@ __global__ __launch_bounds__(512) void policy_kernel(const float* __restrict__ o
             }
         }
         // ---- out tile -> LDS so that lane = env
-        if constexpr (!(!SPLIT && pol_wide(PREC))) {
+        {
             __syncthreads();  // previous pass's readers are done with sOut
 #pragma unroll
             for (int et = 0; et < ET; ++et) {

@@ -152,6 +152,16 @@ __device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p,
     return ft;
 }
 
+// the same tables `floats` further on in LDS (MODE 6: the second track's block sits at a fixed distance behind the first's)
+__device__ __forceinline__ FastTabs ft_shift(const FastTabs& a, const int floats) {
+    FastTabs b;
+    const int by = 4 * floats;
+#define PC_SH(m) b.m = (decltype(b.m))(size_t)((unsigned)(size_t)a.m + (unsigned)by)
+    PC_SH(head); PC_SH(wrap); PC_SH(act); PC_SH(gates); PC_SH(dir); PC_SH(reset); PC_SH(vtx); PC_SH(seg); PC_SH(dir64); PC_SH(rden);
+#undef PC_SH
+    return b;
+}
+
 struct FastLane {        // per-lane invariants of the env step (a handful of registers instead of three per ray slot)
     int rs0, rstep, rs_last;  // ray slot s of lane g (of G per env) is ray min(g + G s, R - 1): angle offsets step_deg * ray, x 16 (bytes
                               // of the direction table), the table's LDS address folded into rs0 / rs_last
@@ -476,43 +486,6 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     // (LIT: three slots per batch, and one slot's literal cast -- two float64 divisions and a square root -- at a time: interleaved,
     // five of them held 165 registers more than the wave has)
     constexpr int NB = LIT ? 3 : (RPL <= 5 ? RPL : (RPL <= 9 ? (RPL + 1) / 2 : (RPL + 3) / 4));   // (14 registers per slot in flight: all nine of the 17-ray kernel at once spill)
-    if constexpr ((PC_ABLATE & 512) != 0 && PARTS == 1) {
-        // DEVELOPER COST MODEL of an "f32n" tier (never in the product): the observation from the selector's own
-        // float32 distance, the float64 refinement only for the ill-conditioned slots -- modelled as a pseudo-random 1/16 of the
-        // slots (bits of the candidate) plus the flagged ones -- through a per-slot fallback loop.  Results are NOT the product's.
-        unsigned ill_mask = 0;
-#pragma unroll
-        for (int s = 0; s < RPL; ++s) {
-            const unsigned b = bb[s];
-            const bool ill = (((b >> 5) & 15u) == 0u) | ((b & h.idx_mask) == 0u);
-            const float uf = __uint_as_float((b & ~h.idx_mask) | 16u) * 0x1p40f;
-            const float o = __builtin_fminf(uf, 1000.0f) * 0.001f;
-            uint64_t col_lanes = 0;
-#pragma unroll
-            for (int gg = 0; gg < G; ++gg) col_lanes |= ((colm_g[gg] >> s) & 1) ? LANES_G0 << gg : 0ull;
-            hit_mask |= __builtin_amdgcn_ballot_w64(!ill & (uf < 10.0f)) & col_lanes;
-            if (s + 1 < RPL) fl.lray[G * s] = o;
-            else fl.llast[0] = o;
-            ill_mask |= ill ? 1u << s : 0u;
-        }
-        while (__builtin_amdgcn_ballot_w64(ill_mask != 0) != 0) {
-            const int s1 = ill_mask ? __builtin_ctz(ill_mask) : -1;
-            unsigned sel = 0;
-#pragma unroll
-            for (int s = 0; s < RPL; ++s) sel = s == s1 ? bb[s] : sel;
-            if (s1 >= 0) {
-                const int ms = m0 + s1 * fl.rstep;
-                const f64x2 d64 = dir64_at(s1 + 1 < RPL ? ms : min(ms, m_last));
-                bool ok;
-                const double d = refine_fast(segs((int)(sel & h.idx_mask)), npx, npy, d64.x, d64.y, ok);
-                todo |= ok ? 0u : 1u << s1;
-                wall_hit |= (bool)((fl.colmask >> s1) & 1) & ok & (d < 10.0);
-                const lds_fp dst = s1 + 1 < RPL ? fl.lray + G * s1 : fl.llast;
-                dst[0] = obs_dist(d);
-                ill_mask &= ill_mask - 1;
-            }
-        }
-    } else
 #pragma unroll
     for (int s0 = 0; s0 < RPL; s0 += NB) {
         SegD sg[NB];
@@ -855,8 +828,7 @@ __device__ __forceinline__ bool env_step_wave(const EnvParams<float>& p, const T
 
 // Developer-only timing ablation of the persistent rollout kernels: a SEPARATE build (make ABLATE=n -> libppocar_ablate.so,
 // never loaded by the product or the tests) compiled with -DPC_ABLATE=n skips the policy MFMAs (1), the env step (2), the draw
-// (4), the gate casts (8), the float64 refinement (16), the sweep's flag minima (32), the whole sweep (64) or the copy-out (256); 512 = the
-// cost model of a float32-observation tier (refinement only for a pseudo-random 1/16 of the slots and the flagged ones).
+// (4), the gate casts (8), the float64 refinement (16), the sweep's flag minima (32), the whole sweep (64) or the copy-out (256).
 // The shipped library is built with PC_ABLATE = 0 (env_math.hpp): there is no run-time switch that makes a kernel do less.
 // K9: the whole rollout (train.py:173-195) as ONE persistent launch.
 // A workgroup (8 waves) owns 256 envs for all T steps: the policy weights stay in LDS, the env state in
@@ -910,6 +882,7 @@ __device__ __forceinline__ EnvParams<float> stage_tables(const EnvParams<float>&
 //         kernel schedules worse without the generic branch -- it spills -- and keeps it).
 //         MODE 5 = 2 for batches whose tracks are all two equal chains of 13 OR of 9 vertices (big_track.json and track.json
 //         mixed: BASELINE configs[4]): the chain-packed sweep for both lengths, chosen per workgroup.
+//         MODE 6 = 1 for a batch of TWO such tracks INTERLEAVED inside the waves (both tracks' tables staged, the env step once per track of a wave).
 //         LIT (the fast modes): the handle is PC_DTYPE_F64 -- env_step_fast's literal form; state with the float64 rotation and
 //         its row of the rotation table (env_load<double>).
 //         LGE = log2 of the lanes per env: 1 (default) = a wave owns 32 envs, two policy column tiles; 2 (round 5, fast modes at 17
@@ -966,7 +939,15 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     EnvParams<float> q = p;
     FastTabs ft = {};
     static_assert(!LIT || FAST, "the literal form: the fast modes (LDS tables)");
-    if constexpr (FAST) ft = stage_fast_tables<false, RPL != 17, LIT>(p, h0, trk_wg, sTab, tid, 512);
+    // MODE 6: a batch of TWO tracks interleaved inside the waves (car_env.py:621-628: every env may sit on its own track; configs[4]'s
+    // `track_id = i & 1` variant).  Both tracks' gather tables are staged, track 1's block TS6 floats behind track 0's (where the other
+    // fast modes keep the 1/den table: the sweep forms 1 / den itself), and the env step runs once per track present in the wave, each
+    // pass with that track's header and tables -- wave-uniform, as in every fast mode.
+    constexpr int TS6 = (ft_floats(false, RPL != 17) + 3) & ~3;
+    if constexpr (MODE == 6) {
+        ft = stage_fast_tables<false, RPL != 17, LIT>(p, cload(p.hdr), 0, sTab, tid, 512);
+        (void)stage_fast_tables<false, RPL != 17, LIT>(p, cload(p.hdr + 1), 1, sTab + TS6, tid, 512);
+    } else if constexpr (FAST) ft = stage_fast_tables<false, RPL != 17, LIT>(p, h0, trk_wg, sTab, tid, 512);
     else q = stage_tables(p, sTab, tid, 512);
     // the track's 1/den table, when the host found room for it (rden_lds != 0; sized for the batch's largest track)
     float* sRden = sTab + (FAST ? ft_floats(false, RPL != 17) : TAB_FLOATS);
@@ -1075,24 +1056,6 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 __builtin_amdgcn_s_setprio(0);
                 if (!(dbg & 1)) policy_pass<KS>(sW1, sB1, sW2, 0, NT, x, out, lc, lk, lane);  // dbg: timing ablations only
                 __builtin_amdgcn_s_setprio(3);
-            } else if constexpr (pol_wide(PREC)) {
-                // fp16 x 2: the wave's 32 envs as ONE column tile of v_mfma_f32_32x32x16_f16 (policy_pass32).  Observation loads are
-                // unconditional (K padding reads a few floats into the next row / the tables behind: inside the workgroup's LDS)
-                constexpr int KSTEPS = pol_ksteps(KB);
-                const float* xrow = sObs + (pbase + (lane & 31)) * LDX;
-                Pieces<2> xs[KSTEPS];
-#pragma unroll
-                for (int st = 0; st < KSTEPS; ++st) xs[st] = obs_pieces32([&](const int f) { return xrow[f]; }, st, lane >> 5, D);
-                f32x16 o32;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) o32[i] = 0.0f;
-                float v32 = 0.0f;
-                __builtin_amdgcn_s_setprio(0);
-                PC_STAMP(1)
-                if (!(dbg & 1)) policy_pass32<KSTEPS, NG>(sW1p, sW2p, sB1, sW2c, xs, o32, v32, lane);
-                PC_STAMP(2)
-                __builtin_amdgcn_s_setprio(3);
-                store_out32<LDO>(myOut, o32, v32, A, lane);
             } else {
                 Pieces<PREC> x[ET][KB];
 #pragma unroll
@@ -1128,10 +1091,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                     if (A >> 2 == lk) out[et][A & 3] += tv;
                 }
             }
-            if constexpr (!(PREC != 0 && pol_wide(PREC))) {
 #pragma unroll
-                for (int et = 0; et < ET; ++et) *reinterpret_cast<f32x4*>(myOut + (16 * et + lc) * LDO + 4 * lk) = out[et];
-            }
+            for (int et = 0; et < ET; ++et) *reinterpret_cast<f32x4*>(myOut + (16 * et + lc) * LDO + 4 * lk) = out[et];
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the tile is written and read by this wave only
             __builtin_amdgcn_wave_barrier();
             const uint64_t o = off0 + (uint64_t)t;
@@ -1195,28 +1156,49 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 // ---------------- E(t)
                 float rw, tf, cf;
                 const int a = e_valid ? act_reg : 8;
-                const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3 || MODE == 5, LGE, 1, (MODE == 5 ? 5 : (MODE >= 3 ? 7 : 0)), RPL != 17, LIT>(
-                    p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, 0, nullptr, true, nullptr, &hcar);
-                rsum += rw;
-                PC_STAMP(6)
-                // gymnasium 0.29.1 same-step auto-reset: a finished env returns its reset observation
-                if (__builtin_amdgcn_ballot_w64(done) != 0) {   // wave-uniform: ~1.5 % of env steps end an episode
-                    if (done) {
-                        // the reset observation's entries f = g, g + 2, ...: all reads issued, then the writes (rolled, every
-                        // entry is an LDS round trip in series -- and some env of a wave finishes in a third of the steps of a
-                        // young policy)
-                        float ro[(DC + GE - 1) / GE];
+                // one env step of the lanes active here, on the track (hh, ff): CarEnv.step, then gymnasium 0.29.1's same-step auto-reset
+                const auto step_on = [&](const TrackHdr& hh, const FastTabs& ff, const FastLane& fll, const int (&gg)[2]) {
+                    const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3 || MODE == 5, LGE, 1, ((MODE == 5 || MODE == 6) ? 5 : (MODE >= 3 ? 7 : 0)), RPL != 17, LIT>(
+                        p, hh, ff, fll, gg, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, 0, nullptr, true, nullptr, &hcar);
+                    rsum += rw;
+                    PC_STAMP(6)
+                    if (__builtin_amdgcn_ballot_w64(done) != 0) {   // wave-uniform: ~1.5 % of env steps end an episode
+                        if (done) {
+                            // the reset observation's entries f = g, g + 2, ...: all reads issued, then the writes (rolled, every
+                            // entry is an LDS round trip in series -- and some env of a wave finishes in a third of the steps of a
+                            // young policy)
+                            float ro[(DC + GE - 1) / GE];
 #pragma unroll
-                        for (int j = 0; j < (DC + GE - 1) / GE; ++j) ro[j] = ft.reset[g + GE * j];     // (the table has 40 slots: in bounds)
+                            for (int j = 0; j < (DC + GE - 1) / GE; ++j) ro[j] = ff.reset[g + GE * j];     // (the table has 40 slots: in bounds)
 #pragma unroll
-                        for (int j = 0; j < (DC + GE - 1) / GE; ++j)
-                            if (g + GE * j < DC) lrow[g + GE * j] = ro[j];
-                        env_reset_fast(h0, st, k72);
-                        if constexpr (LIT) {
-                            const double2 e0 = p.dirtab64[h0.rot_off];      // row 0 = start_rot
-                            hcar = (f64x2){e0.x, e0.y};
+                            for (int j = 0; j < (DC + GE - 1) / GE; ++j)
+                                if (g + GE * j < DC) lrow[g + GE * j] = ro[j];
+                            env_reset_fast(hh, st, k72);
+                            if constexpr (LIT) {
+                                const double2 e0 = p.dirtab64[hh.rot_off];      // row 0 = start_rot
+                                hcar = (f64x2){e0.x, e0.y};
+                            }
                         }
                     }
+                };
+                if constexpr (MODE == 6) {
+                    uint64_t todo = __builtin_amdgcn_ballot_w64(true);      // once per track present in the wave (K1's waterfall)
+                    do {
+                        const int cur = __builtin_amdgcn_readlane(trk, __builtin_ctzll(todo));
+                        const bool match = trk == cur;
+                        if (match) {
+                            const TrackHdr hb = cload(p.hdr + cur);
+                            const int by = 4 * TS6 * cur;                        // (two tracks: cur is 0 or 1)
+                            FastLane flb = fl;
+                            flb.rs0 += by;
+                            flb.rs_last += by;
+                            const int gqb[2] = {gq[0] + by, gq[1] + by};
+                            step_on(hb, ft_shift(ft, TS6 * cur), flb, gqb);
+                        }
+                        todo &= ~__builtin_amdgcn_ballot_w64(match);
+                    } while (todo);
+                } else {
+                    step_on(h0, ft, fl, gq);
                 }
                 if (g == 0 && e_valid) {
                     rew_buf[(int64_t)t * N + e_env] = rw;
@@ -1359,19 +1341,7 @@ __global__ __launch_bounds__(512) void rollout_f64_kernel(const EnvParams<double
         const bool tail = t == T;      // (uniform)
         {
             // ---------------- P(t): Agent.get_action_and_value (model.py:34-41)
-            if constexpr (pol_wide(PREC)) {      // fp16 x 2: one 32-env column tile of the 32x32x16 instruction, as policy_kernel does
-                constexpr int KSTEPS = pol_ksteps(KB);
-                const float* xrow = sObs + (pbase + (lane & 31)) * LDX;
-                Pieces<2> xs[KSTEPS];
-#pragma unroll
-                for (int st = 0; st < KSTEPS; ++st) xs[st] = obs_pieces32([&](const int f) { return xrow[f < LDX ? f : 0]; }, st, lane >> 5, D);
-                f32x16 o32;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) o32[i] = 0.0f;
-                float v32 = 0.0f;
-                policy_pass32<KSTEPS, NG>(sW1p, sW2p, sB1, sW2c, xs, o32, v32, lane);
-                store_out32<LDO>(myOut, o32, v32, A, lane);
-            } else {
+            {
                 f32x4 out[ET];
 #pragma unroll
                 for (int et = 0; et < ET; ++et) out[et] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};

@@ -1294,6 +1294,30 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
             e->last_kernel = PC_KERNEL_K9_LITERAL;
             return PC_OK;
         }
+        // tracks interleaved inside the waves: the two-track fast form of F32 handles (rollout_impl) with the literal env step
+        if (interleaved && prec == 2 && tabs && rays16 && !e->f64_offgrid && e->opt.fast && e->opt.nv28 != 0 && e->n_tracks == 2 && all_loops &&
+            max_G <= TAB_MAX_GATES && max_nV <= FT_VTX_MAX && e->D >= 17) {
+            const int ts6 = (ft_floats(false, true) + 3) & ~3;
+            const size_t lds6 = (size_t)k9_fast_lds_floats(img, 32, e->D, true, ts6) * sizeof(float);
+            if (lds6 <= 160 * 1024) {
+                const int vec6 = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
+                EnvParams<float> prm6 = e->params<float>();
+                prm6.lg = 1;
+#ifndef PC_DEV_MIN
+                static bool attr6[64] = {false};
+                if (e->device >= 64 || !attr6[e->device]) {
+                    HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<6, 9, 2, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    if (e->device < 64) attr6[e->device] = true;
+                }
+#endif
+                PC_FULL(hipLaunchKernelGGL((rollout_kernel<6, 9, 2, 6, true>), dim3(blocks), dim3(512), lds6, st, prm6, image, A, (int)T, reward_scale, seed, offset,
+                                           offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, next_term, next_trunc, 0, epw,
+                                           vec6, last_value, reward_sum));
+                HIPCHK(hipGetLastError());
+                e->last_kernel = PC_KERNEL_K9_LITERAL;
+                return PC_OK;
+            }
+        }
         const bool shape = (rays16 || rays12 || rays33) && prec == 2 && e->D >= 17 && e->D <= 40 && max_G <= TAB_MAX_GATES &&
                            max_nV <= FT_VTX_MAX && e->opt.fast && e->opt.rden != 0 && (!e->track_id || e->track_block >= epw) &&
                            lds_sel <= 160 * 1024;
@@ -1452,6 +1476,42 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
     // large batches: 256 envs per workgroup, every wave independent; small batches: 32 envs per workgroup, hidden tiles and
     // wall-sweep parts split over the waves
     if (interleaved && o.form == 1) return PC_ERR_UNSUPPORTED;
+    // ... and the FAST form of that layout for the reference's own pair of tracks (two tracks, each two equal loops of 13 or 9 chain
+    // vertices, 16 -> 17 rays, fp16 x 2): both tracks' tables in LDS, the table-driven env step once per track of a wave (rollout_kernel<6, 9, 2, 6>)
+    if (interleaved && o.fast && o.nv28 != 0 && e->n_tracks == 2 && policy_ks(e->D) == 6 && e->n_nominal == 16 && A == 9 && policy_prec(prec_request, e->D, A) == 2 &&
+        e->D >= 17 && e->D <= 40) {
+        bool loops2 = true;
+        int mg = 0;
+        for (const TrackHdr& h : e->hdr_host) {
+            loops2 = loops2 && h.vtxp_off >= 0 && (h.brk2 == 13 || h.brk2 == 9) && h.n_chain == 2 * h.brk2 && h.nV == 4 * ((h.brk2 + 1) / 2) && h.nV <= FT_VTX_MAX;
+            mg = std::max(mg, h.G);
+        }
+        const int img6 = polx_image_dwords(2, pol_ng(6));
+        const int ts6 = (ft_floats(false, true) + 3) & ~3;
+        const size_t lds6 = (size_t)k9_fast_lds_floats(img6, 32, e->D, true, ts6) * sizeof(float);
+        if (loops2 && mg <= TAB_MAX_GATES && lds6 <= 160 * 1024) {
+            DeviceGuard guard6(e->device);
+            if (!guard6.ok) return PC_ERR_NO_DEVICE;
+            const int epw6 = o.epw_override >= 128 ? o.epw_override : (e->N <= g_rollout_epw128_max ? 128 : 256);
+            const int blocks6 = (int)((e->N + epw6 - 1) / epw6);
+            const int vec6 = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
+            EnvParams<float> prm6 = e->params<float>();
+            prm6.lg = 1;
+#ifndef PC_DEV_MIN
+            static bool attr6[64] = {false};
+            if (e->device >= 64 || !attr6[e->device]) {
+                HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<6, 9, 2, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                if (e->device < 64) attr6[e->device] = true;
+            }
+#endif
+            PC_FULL(hipLaunchKernelGGL((rollout_kernel<6, 9, 2, 6>), dim3(blocks6), dim3(512), lds6, (hipStream_t)stream, prm6, image, A, (int)T, reward_scale, seed, offset,
+                                       offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, next_term, next_trunc, 0, epw6,
+                                       vec6, last_value, reward_sum));
+            HIPCHK(hipGetLastError());
+            e->last_kernel = PC_KERNEL_K9;
+            return PC_OK;
+        }
+    }
     const bool small = !interleaved && (o.form == 1 || (o.form < 0 && e->N <= PC_SPLIT_MAX_ENVS));
     const int epw = o.epw_override >= 128 ? o.epw_override
                                                   : ((!small && e->N <= g_rollout_epw128_max) ? 128 : 256);   // big form: envs per workgroup

@@ -81,17 +81,20 @@ def test_mixed_tracks_f32_halves_rollout_vs_step_kernels_and_oracle(n_envs, form
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f64"])
-@pytest.mark.parametrize("n_envs", [2048, 20000, 32768])
-def test_mixed_tracks_interleaved_rollout_vs_step_kernels_and_oracle(n_envs, dtype):
+@pytest.mark.parametrize("dtype,fast", [("f32", 1), ("f32", 2), ("f64", 1), ("f64", 2)],
+                         ids=["f32_two_track_fast_form", "f32_generic_mode", "f64_two_track_literal_form", "f64_K9d"])
+@pytest.mark.parametrize("n_envs", [2048, 20000, 32768, 65536])
+def test_mixed_tracks_interleaved_rollout_vs_step_kernels_and_oracle(n_envs, dtype, fast):
     """track_id = i & 1 (SURVEY 8(d) C4's second variant; car_env.py:621-628 lets every env sit on its own track): every wave holds both
-    tracks.  pc_rollout runs it in the BIG form's generic mode (K9 / K9d), the env step once per distinct track id of a wave (K1's
-    waterfall, which the per-step path takes too): every buffer bitwise the per-step kernels' (unsplit policy arithmetic: the big
-    form's), then the oracle per track -- one float32 ulp / events exact for F32 handles, every bit for F64 handles."""
+    tracks.  pc_rollout runs it in the BIG form with the env step once per track present in a wave (K1's waterfall, which the per-step
+    path takes too): F32 handles in the two-track FAST form (rollout_kernel<6, 9, 2, 6>: both tracks' tables in LDS, the table-driven
+    step per pass; F64 handles: its literal form) or, with the fast modes' track layouts switched off, in the generic mode / K9d.  Every buffer bitwise
+    the per-step kernels' (unsplit policy arithmetic: the big form's), then the oracle per track -- one float32 ulp / events exact for
+    F32 handles, every bit for F64 handles."""
     res, first = {}, None
     for mode in ("mega", "steps"):
         cfg = PPOConfig(n_envs=n_envs, n_steps=192, num_rays=16, track=MIXED, track_interleave=True, rollout_kernel=mode,
-                        use_graphs=False, seed=17, env_dtype=dtype, policy_split=0)
+                        use_graphs=False, seed=17, env_dtype=dtype, policy_split=0, rollout_fast=fast)
         tr = Trainer(cfg, device="cuda")
         if first is None:
             first = tr.next_obs.clone()
@@ -101,7 +104,7 @@ def test_mixed_tracks_interleaved_rollout_vs_step_kernels_and_oracle(n_envs, dty
         torch.cuda.synchronize()
         assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
         if mode == "mega":
-            assert tr.envs.last_rollout_kernel() == ("K9" if dtype == "f32" else "K9d-selector")
+            assert tr.envs.last_rollout_kernel() == ("K9" if dtype == "f32" else ("K9-literal" if fast == 1 else "K9d-selector"))
         res[mode] = _snap(tr)
         res[mode + "_state"] = tr.envs.get_state()
         tr.close()

@@ -314,7 +314,7 @@ def test_mixed_track_batches_through_the_persistent_rollout_kernel(n_envs, form)
     tr = Trainer(_cfg(track=tracks, track_interleave=True, rollout_kernel="mega", use_graphs=False, n_envs=512, n_steps=8, num_rays=16),
                  device="cuda")
     tr.rollout()
-    assert tr.rollout_mode == "mega" and tr.envs.last_rollout_kernel() == "K9"      # (round 6: the big form's generic mode, per-wave track waterfall)
+    assert tr.rollout_mode == "mega" and tr.envs.last_rollout_kernel() == "K9"      # (round 6: the two-track fast form, the env step once per track of a wave)
     tr.close()
 
 
