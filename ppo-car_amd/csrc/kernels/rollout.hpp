@@ -1003,11 +1003,14 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
         k72 = Math<float>::mod72(st.k);
     }
     f64x2 hcar = {1.0, 0.0};      // LIT: (cos, sin) of the env's current rotation (row st.k of the rotation table)
+    const int rot_off_l = (LIT && MODE == 6) ? (trk ? cload(p.hdr + 1).rot_off : cload(p.hdr).rot_off) : h0.rot_off;     // the lane's track's rotation table
     if constexpr (LIT) {
         // the lattice index of the heading: rot = start_rot after k turns of +-5.0 (each sum rounded; the quotient is within 1e-10 of k)
-        k72 = Math<float>::mod72((int)__builtin_rint((st.rot - h0.start_rot) / 5.0));
+        // (MODE 6: the lane's own track -- two tracks -- not the workgroup's)
+        const double start_rot_l = MODE == 6 ? (trk ? cload(p.hdr + 1).start_rot : cload(p.hdr).start_rot) : h0.start_rot;
+        k72 = Math<float>::mod72((int)__builtin_rint((st.rot - start_rot_l) / 5.0));
         if (e_valid) {
-            const double2 e0 = p.dirtab64[h0.rot_off + st.k * (p.R + 2)];
+            const double2 e0 = p.dirtab64[rot_off_l + st.k * (p.R + 2)];
             hcar = (f64x2){e0.x, e0.y};
         }
         st.rot = 0.0;     // (not kept: the rotation is the row's last entry, read again when the state is stored)
@@ -1272,7 +1275,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
         __builtin_amdgcn_wave_barrier();
     }
     if (e_valid && g == 0) {
-        if constexpr (LIT) st.rot = p.dirtab64[h0.rot_off + st.k * (p.R + 2) + p.R + 1].x;
+        if constexpr (LIT) st.rot = p.dirtab64[rot_off_l + st.k * (p.R + 2) + p.R + 1].x;
         env_store<StateT>(ps, e_env, st);
         if (rew_sum) rew_sum[e_env] = rsum;
     }

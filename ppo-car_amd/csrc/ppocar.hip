@@ -1299,6 +1299,25 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
             max_G <= TAB_MAX_GATES && max_nV <= FT_VTX_MAX && e->D >= 17) {
             const int ts6 = (ft_floats(false, true) + 3) & ~3;
             const size_t lds6 = (size_t)k9_fast_lds_floats(img, 32, e->D, true, ts6) * sizeof(float);
+            if (lds6 <= 160 * 1024 && (e->opt.form == 4 || (e->opt.form < 0 && e->opt.epw_override == 0 && e->N > PC_SPLIT_MAX_ENVS && e->N <= PC_MEDIUM_MAX_ENVS))) {
+                const int vec6 = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;      // 16 envs per wave
+                const size_t lds6m = (size_t)k9_fast_lds_floats(img, 16, e->D, true, ts6) * sizeof(float);
+                EnvParams<float> prm6 = e->params<float>();
+                prm6.lg = 2;
+#ifndef PC_DEV_MIN
+                static bool attr6m[64] = {false};
+                if (e->device >= 64 || !attr6m[e->device]) {
+                    HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<6, 5, 2, 6, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    if (e->device < 64) attr6m[e->device] = true;
+                }
+#endif
+                PC_FULL(hipLaunchKernelGGL((rollout_kernel<6, 5, 2, 6, true, 2>), dim3((int)((e->N + 127) / 128)), dim3(512), lds6m, st, prm6, image, A, (int)T, reward_scale, seed,
+                                           offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, next_term, next_trunc, 0, 128,
+                                           vec6, last_value, reward_sum));
+                HIPCHK(hipGetLastError());
+                e->last_kernel = PC_KERNEL_K9M_LITERAL;
+                return PC_OK;
+            }
             if (lds6 <= 160 * 1024) {
                 const int vec6 = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
                 EnvParams<float> prm6 = e->params<float>();
@@ -1492,6 +1511,26 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
         if (loops2 && mg <= TAB_MAX_GATES && lds6 <= 160 * 1024) {
             DeviceGuard guard6(e->device);
             if (!guard6.ok) return PC_ERR_NO_DEVICE;
+            if (o.form == 4 || (o.form < 0 && o.epw_override == 0 && e->N > PC_SPLIT_MAX_ENVS && e->N <= PC_MEDIUM_MAX_ENVS)) {
+                // 16 envs per wave (4 lanes per env), as for single-track and block-mixed batches of this size: two waves on every SIMD
+                const int vec6 = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;
+                const size_t lds6m = (size_t)k9_fast_lds_floats(img6, 16, e->D, true, ts6) * sizeof(float);
+                EnvParams<float> prm6 = e->params<float>();
+                prm6.lg = 2;
+#ifndef PC_DEV_MIN
+                static bool attr6m[64] = {false};
+                if (e->device >= 64 || !attr6m[e->device]) {
+                    HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<6, 5, 2, 6, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    if (e->device < 64) attr6m[e->device] = true;
+                }
+#endif
+                PC_FULL(hipLaunchKernelGGL((rollout_kernel<6, 5, 2, 6, false, 2>), dim3((int)((e->N + 127) / 128)), dim3(512), lds6m, (hipStream_t)stream, prm6, image, A, (int)T,
+                                           reward_scale, seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, next_term,
+                                           next_trunc, 0, 128, vec6, last_value, reward_sum));
+                HIPCHK(hipGetLastError());
+                e->last_kernel = PC_KERNEL_K9M;
+                return PC_OK;
+            }
             const int epw6 = o.epw_override >= 128 ? o.epw_override : (e->N <= g_rollout_epw128_max ? 128 : 256);
             const int blocks6 = (int)((e->N + epw6 - 1) / epw6);
             const int vec6 = ((e->N * e->D) % 4 == 0 && (((uintptr_t)obs_buf | (uintptr_t)next_obs) & 15) == 0) ? 1 : 0;

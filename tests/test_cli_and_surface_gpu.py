@@ -371,7 +371,7 @@ def test_bench_default_line_carries_every_baseline_config_and_the_exact_dtype():
         assert v["rollout"] == "mega" and v["value"] > 1e8 and v["ms_per_step"] > 0 and 0 < v["roofline"]["frac"] < 1 and v["roofline"]["flops_per_env_step"] > 0
         x = v["exact_f64"]
         assert "error" not in x, (k, x)
-        assert x["kernel"] == {"cfg1": "K9s-literal", "cfg2": "K9-literal", "cfg4": "K9m-literal", "cfg4i": "K9-literal"}[k] and v["kernel"] == {"cfg1": "K9s", "cfg2": "K9", "cfg4": "K9m", "cfg4i": "K9"}[k] and x["value"] > 0.2 * v["value"]      # (short side measurements on a box that has just started: either can be off by 30 %)
+        assert x["kernel"] == {"cfg1": "K9s-literal", "cfg2": "K9-literal", "cfg4": "K9m-literal", "cfg4i": "K9m-literal"}[k] and v["kernel"] == {"cfg1": "K9s", "cfg2": "K9", "cfg4": "K9m", "cfg4i": "K9m"}[k] and x["value"] > 0.2 * v["value"]      # (short side measurements on a box that has just started: either can be off by 30 %)
     assert "33 actual" in ow["cfg2"]["workload"] and "track.json + big_track.json (halves)" in ow["cfg4"]["workload"] and "interleaved" in ow["cfg4i"]["workload"]
     assert 0.1 < ow["cfg4i"]["ratio_to_halves_layout"] < 1.2
     c = d["cpu_baseline"]

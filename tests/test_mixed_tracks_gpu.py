@@ -104,7 +104,8 @@ def test_mixed_tracks_interleaved_rollout_vs_step_kernels_and_oracle(n_envs, dty
         torch.cuda.synchronize()
         assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
         if mode == "mega":
-            assert tr.envs.last_rollout_kernel() == ("K9" if dtype == "f32" else ("K9-literal" if fast == 1 else "K9d-selector"))
+            m = "m" if (fast == 1 and 8192 < n_envs <= 32768) else ""      # 16 envs per wave between 8193 and 32768 envs, as for every other layout
+            assert tr.envs.last_rollout_kernel() == (f"K9{m}" if dtype == "f32" else (f"K9{m}-literal" if fast == 1 else "K9d-selector"))
         res[mode] = _snap(tr)
         res[mode + "_state"] = tr.envs.get_state()
         tr.close()
