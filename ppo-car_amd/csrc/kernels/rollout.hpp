@@ -1032,6 +1032,17 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     const int TT = last_val ? T + 1 : T;
     float rsum = 0.0f;
     int act_reg = 8;     // the action drawn for this lane pair's env (the pair draw leaves it in both lanes)
+    // FAST: the per-env rows a lane stores every step as per-lane pointers that advance by one buffer row per step, instead of
+    // base + (t N + e) formed from kernel-argument SGPRs the kernel does not have (spilled to vector lanes: a v_readlane pair per use;
+    // rollout_small_kernel: -4 % of its launch; here -1 %, profiles/r6_ab_k9_ptrs.log).  Twelve more registers: the 12- and 17-ray kernels
+    // have them (the target kernel: 238 -> 252 VGPRs, 57 -> 40 spilled SGPRs), the 33-ray kernels do not.
+    constexpr bool PTRS = FAST && RPL <= 9 && MODE != 6;      // (the two-track form spends its registers on the second pass's header)
+    float* pa_act = act_buf + e_env;
+    float* pa_lp = logprob_buf + e_env;
+    float* pa_val = val_buf + e_env;
+    float* pa_rew = rew_buf + e_env;
+    float* pa_term = term_buf + N + e_env;      // flags that precede obs t + 1 (train.py:176-177,195)
+    float* pa_trunc = trunc_buf + N + e_env;
 #pragma unroll 1
     for (int t = 0; t < TT; ++t) {
         const bool tail = t == T;      // (uniform)
@@ -1118,6 +1129,10 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                             int64_t ee = e_env;
                             asm volatile("" : "+v"(ee));
                             last_val[ee] = val;
+                        } else if constexpr (PTRS) {
+                            *pa_act = (float)act_reg;          // stored as float32 like the reference (buffer.py:13)
+                            *pa_lp = lp;
+                            *pa_val = val;
                         } else {
                             const int64_t row = (int64_t)t * N + e_env;
                             act_buf[row] = (float)act_reg;     // stored as float32 like the reference (buffer.py:13)
@@ -1126,6 +1141,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                         }
                     }
                 }
+                if constexpr (PTRS) { pa_act += N; pa_lp += N; pa_val += N; }
             } else {
                 const int64_t e = e_wave + lane;
                 if (lane < 32 && e < N) {
@@ -1203,7 +1219,18 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 } else {
                     step_on(h0, ft, fl, gq);
                 }
-                if (g == 0 && e_valid) {
+                if constexpr (PTRS) {
+                    if (last) {        // (uniform, once per launch)
+                        pa_term = next_term + e_env;
+                        pa_trunc = next_trunc + e_env;
+                    }
+                    if (g == 0 && e_valid) {
+                        *pa_rew = rw;
+                        *pa_term = tf;
+                        *pa_trunc = cf;
+                    }
+                    pa_rew += N; pa_term += N; pa_trunc += N;
+                } else if (g == 0 && e_valid) {
                     rew_buf[(int64_t)t * N + e_env] = rw;
                     float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;    // flags that precede obs t+1
                     float* tc = last ? next_trunc : trunc_buf + (int64_t)(t + 1) * N;  // (train.py:176-177,195)
@@ -1564,6 +1591,7 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
     // The rows a lane stores every step, as per-lane POINTERS that advance by one buffer row per step (a 64-bit add each) instead of
     // base + (t N + e) formed from kernel arguments: those live in SGPRs this kernel does not have (84 are spilled to vector lanes) and
     // every use reloaded a pair with v_readlane before the address arithmetic -- ~50 vector instructions per wave and step.
+    constexpr bool PTRS = RPL <= 5;      // (the 33-ray small forms have no registers for them: they spilled)
     const int64_t e_draw = e_wg + wave * (EPW / 8) + lk;                              // the env this lane draws for (lk < EPW / 8, lc == 0)
     float* pa_act = act_buf + e_draw;
     float* pa_lp = logprob_buf + e_draw;
@@ -1652,16 +1680,23 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 if constexpr (!WOWN) sAct[dl] = act;
                 if (tail) {
                     last_val[e] = val;
-                } else {
+                } else if constexpr (PTRS) {
                     *pa_act = (float)act;
                     *pa_lp = lp;
                     *pa_val = val;
+                } else {
+                    const int64_t row = (int64_t)t * N + e;
+                    act_buf[row] = (float)act;
+                    logprob_buf[row] = lp;
+                    val_buf[row] = val;
                 }
             }
         }
-        pa_act += row_step;
-        pa_lp += row_step;
-        pa_val += row_step;
+        if constexpr (PTRS) {
+            pa_act += row_step;
+            pa_lp += row_step;
+            pa_val += row_step;
+        }
         if constexpr (!WOWN) lds_barrier();   // (WOWN: the wave steps the two envs it drew for -- lanes 0 and 16 hold their actions)
         PC_STAMP(3)
         if (tail) break;
@@ -1708,21 +1743,31 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                         }
                     }
                 }
-                if (last) {        // (uniform, once per launch) the flags and the observation of the final step go to next_*
-                    pa_term = next_term + e_env;
-                    pa_trunc = next_trunc + e_env;
-                    pa_obs = next_obs + e_wg * D + 4 * (lane + 64 * wave);
-                }
-                if (part == 0) {   // (uniform) the row-writing wave: per-env scalars
+                if constexpr (PTRS) {
+                    if (last) {        // (uniform, once per launch) the flags and the observation of the final step go to next_*
+                        pa_term = next_term + e_env;
+                        pa_trunc = next_trunc + e_env;
+                        pa_obs = next_obs + e_wg * D + 4 * (lane + 64 * wave);
+                    }
+                    if (part == 0) {   // (uniform) the row-writing wave: per-env scalars
+                        if (g == 0 && e_valid) {
+                            *pa_rew = rw;
+                            *pa_term = tf;
+                            *pa_trunc = cf;
+                        }
+                    }
+                    pa_rew += row_step;
+                    pa_term += row_step;
+                    pa_trunc += row_step;
+                } else if (part == 0) {   // (uniform) the row-writing wave: per-env scalars
                     if (g == 0 && e_valid) {
-                        *pa_rew = rw;
-                        *pa_term = tf;
-                        *pa_trunc = cf;
+                        rew_buf[(int64_t)t * N + e_env] = rw;
+                        float* tr = last ? next_term : term_buf + (int64_t)(t + 1) * N;
+                        float* tc = last ? next_trunc : trunc_buf + (int64_t)(t + 1) * N;
+                        tr[e_env] = tf;
+                        tc[e_env] = cf;
                     }
                 }
-                pa_rew += row_step;
-                pa_term += row_step;
-                pa_trunc += row_step;
             }
             PC_STAMP(6)
             lds_barrier();    // the workgroup's observation rows are complete
@@ -1734,11 +1779,14 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 const int n_rows = left >= EPW ? EPW : (int)left;
                 if (vec_ok && n_rows == EPW) {
                     const int i = lane + 64 * wave;
-                    if (i < EPW / 4 * DC) *reinterpret_cast<f32x4*>(pa_obs) = reinterpret_cast<const f32x4*>(sObs)[i];
+                    if (i < EPW / 4 * DC) {
+                        if constexpr (PTRS) *reinterpret_cast<f32x4*>(pa_obs) = reinterpret_cast<const f32x4*>(sObs)[i];
+                        else reinterpret_cast<f32x4*>(dstg)[i] = reinterpret_cast<const f32x4*>(sObs)[i];
+                    }
                 } else {
                     for (int i = tid; i < n_rows * D; i += 512) dstg[i] = sObs[i];
                 }
-                pa_obs += obs_step;
+                if constexpr (PTRS) pa_obs += obs_step;
             }
         } else if constexpr (EPW == 32) {
             if (!(dbg & 2)) {
