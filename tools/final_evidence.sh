@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer tool (GPU box): the round's closing evidence in one call -- the full -m gpu suite, the default bench line, rocprofv3 --stats of the
-# bench command (target / cfg1 / cfg2), the PMC passes of the configs[1] kernel, the shipped kernels' soak against the per-step kernels.
+# bench command (target / cfg1 / cfg2), the PMC passes of the target and configs[1] kernels, the shipped kernels' soak against the per-step kernels.
 # Output under gpurun_out/<tag>/ (copy what is cited into profiles/).   usage: tools/final_evidence.sh <tag> [skip-tests]
 TAG=${1:-r6}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -25,6 +25,7 @@ for w in target cfg1 cfg2; do
   cp $(ls $O/prof_$w/*/*kernel_stats.csv | head -1) $O/${w}_kernel_stats.csv; rm -rf $O/prof_$w
   head -3 $O/${w}_kernel_stats.csv | cut -c1-150
 done
+tools/pmc_k9.sh $TAG/k9 2>&1 | tail -1; cp $O/k9/pmc_summary.json $O/k9_pmc_summary.json
 tools/pmc_k9s.sh $TAG/k9s 2>&1 | tail -1
 python tools/pmc_summary.py gpurun_out/$TAG/k9s/pmc ${TAG}_k9s_raw 4096 16 f32 rollout_small_kernel 1024 > $O/k9s_pmc_summary.json 2> $O/k9s_pmc_summary.err; tail -2 $O/k9s_pmc_summary.err
 S="python tools/soak_rollout.py . --out $O/soak_shipped.jsonl"
