@@ -20,6 +20,9 @@ SHAPES = {
     "cfg1": (dict(n_envs=4096, n_steps=1024, num_rays=16, track=TRACKS["big_track"]), "K9s", 200),
     "cfg2": (dict(n_envs=65536, n_steps=128, num_rays=32, track=TRACKS["big_track"]), "K9", 400),
     "cfg4": (dict(n_envs=32768, n_steps=1024, num_rays=16, track=MIXED), "K9m", 200),
+    "cfg4i": (dict(n_envs=32768, n_steps=512, num_rays=16, track=MIXED, track_interleave=True), "K9m", 200),      # the two-track fast form
+    "cfg4i_65536": (dict(n_envs=65536, n_steps=256, num_rays=16, track=MIXED, track_interleave=True), "K9", 200),
+    "cfg4i_f64": (dict(n_envs=32768, n_steps=256, num_rays=16, track=MIXED, track_interleave=True, env_dtype="f64"), "K9m-literal", 200),
     "target_f64": (dict(n_envs=65536, n_steps=256, num_rays=16, track=TRACKS["big_track"], env_dtype="f64"), "K9-literal", 200),
     "cfg2_f64": (dict(n_envs=65536, n_steps=128, num_rays=32, track=TRACKS["big_track"], env_dtype="f64"), "K9-literal", 200),
 }

@@ -32,6 +32,7 @@ ap.add_argument("--rays", type=int, default=32)
 ap.add_argument("--fast", type=int, default=1)
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--mixed", action="store_true", help="track.json + big_track.json in halves (configs[4]'s layout)")
+ap.add_argument("--interleave", action="store_true", help="with --mixed: track_id = i & 1 instead of halves")
 ap.add_argument("--form", type=int, default=-1, help="PPOConfig.rollout_form (2: the big form without the 1/den table in LDS)")
 ap.add_argument("--train-every", type=int, default=25, help="one PPO update every k launches (both sides: the policy moves, identically)")
 ap.add_argument("--repeats", type=int, default=10, help="on an event: repeat the rollout launch this many times from the saved state")
@@ -54,7 +55,7 @@ def bufs(tr):
 
 def make(mode):
     cfg = PPOConfig(n_envs=args.n_envs, n_steps=args.n_steps, num_rays=args.rays, track=([f"{ROOT}/tracks/track.json", f"{ROOT}/tracks/big_track.json"] if args.mixed else f"{ROOT}/tracks/big_track.json"), rollout_kernel=mode,
-                    use_graphs=False, seed=11, env_dtype=args.dtype, rollout_fast=args.fast, rollout_form=args.form, bootstrap_value="fp32", policy_split=1 if args.n_envs <= 8192 else 0)
+                    use_graphs=False, seed=11, env_dtype=args.dtype, rollout_fast=args.fast, rollout_form=args.form, track_interleave=bool(args.interleave), bootstrap_value="fp32", policy_split=1 if args.n_envs <= 8192 else 0)
     return Trainer(cfg, device="cuda")
 
 
@@ -141,7 +142,7 @@ for it in range(args.launches):
     if it % 50 == 49:
         print(f"# {it + 1} launches, {entries:.3e} entries compared, {len(events)} events, {time.time() - t0:.0f} s", flush=True)
 summary = {"summary": True, "pkg": args.pkg, "kernel": A.envs.last_rollout_kernel(), "launches": args.launches, "n_envs": args.n_envs, "n_steps": args.n_steps,
-           "rays": args.rays, "mixed": args.mixed, "fast": args.fast, "dtype": args.dtype, "entries_compared": entries, "events": len(events), "obs_columns_of_primary_differences": {str(k): v for k, v in sorted(cols.items())}, "seconds": time.time() - t0}
+           "rays": args.rays, "mixed": args.mixed, "interleave": bool(args.interleave), "fast": args.fast, "dtype": args.dtype, "entries_compared": entries, "events": len(events), "obs_columns_of_primary_differences": {str(k): v for k, v in sorted(cols.items())}, "seconds": time.time() - t0}
 print(json.dumps(summary), flush=True)
 if out:
     out.write(json.dumps(summary) + "\n")
