@@ -381,3 +381,31 @@ def test_f32_ray_through_a_shared_corner_follows_the_reference():
         env.step(torch.full((1,), 8, dtype=torch.int64, device="cuda"), final_obs=fin)
         assert float(obs[0, 6]) == float(np.float32(0.2)) and float(fin[0, 6]) == float(np.float32(0.2)), (dtype, obs[0, 6], fin[0, 6])
         env.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("n_envs,n_steps,num_rays", [(1, 1, 16), (1, 40, 12), (33, 3, 16), (257, 2, 32), (8193, 1, 16), (32769, 2, 16), (65537, 3, 16)])
+def test_ragged_and_minimal_shapes_through_the_persistent_kernels(n_envs, n_steps, num_rays, dtype):
+    """The smallest and the most ragged launches: one env, one step, env counts one past a workgroup / wave / form boundary (33, 257, 8193 =
+    the first batch of the 16-envs-per-wave form, 32769 and 65537 = a last workgroup with a single env), observation rows whose
+    16-byte alignment the vector stores cannot assume.  pc_rollout with the trainer's 256-env threshold lifted: bitwise the per-step
+    kernels, float64 state included, and the oracle on every env (up to 256) for all steps."""
+    res, first = {}, None
+    for mode in ("mega", "steps"):
+        cfg = PPOConfig(n_envs=n_envs, n_steps=n_steps, num_rays=num_rays, track=TRACKS["big_track"], rollout_kernel=mode, use_graphs=False, seed=41,
+                        env_dtype=dtype, policy_split=1 if (n_envs <= 8192 and not (dtype == "f64" and num_rays == 32)) else 0)
+        tr = Trainer(cfg, device="cuda")
+        if first is None:
+            first = tr.next_obs.clone()
+        for _ in range(2):
+            tr.rollout()
+            tr.buffer.ptr = 0
+        torch.cuda.synchronize()
+        assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager"), tr.rollout_mode
+        res[mode] = _snap(tr)
+        res[mode + "_state"] = tr.envs.get_state()
+        tr.close()
+    for i, (a, b) in enumerate(zip(res["mega"], res["steps"])):
+        assert torch.equal(a, b), f"buffer {i} differs (N={n_envs}, T={n_steps}, rays={num_rays}, {dtype})"
+    for k in res["mega_state"]:
+        assert np.array_equal(res["mega_state"][k], res["steps_state"][k]), k
