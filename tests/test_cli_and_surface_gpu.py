@@ -325,6 +325,28 @@ def test_bench_self_spawned_four_ranks_on_one_device(world, exchange):
     assert c["visible_devices"] >= 1
 
 
+def test_bench_one_rank_rccl_communicator_reports_live_ranks_and_exchange_latency():
+    """`bench.py --force-collective` on ONE rank with backend nccl: the multi-rank update path (K10, K11, RCCL all-reduce, clip + Adam per
+    minibatch, eagerly enqueued) over a real RCCL communicator of size one -- the closest a one-GPU box gets to the N > 1 line's RCCL
+    fields: `rccl_ranks` counted by an all-reduce of ones on the LIVE communicator (1), `exchange_us` from HIP events around every
+    all-reduce of the timed epochs (the transport-free floor of the figure the multi-GPU run will report)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-collective", "--backend", "nccl", "--workload", "cfg1", "--n-envs", "1024",
+                        "--n-steps", "64", "--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    c = json.loads(lines[0])["config"]
+    assert c["backend"] == "nccl" and c["rccl_ranks"] == 1 and c["ranks"] == 1 and "multi-rank" in c["update_path"]
+    ex = c["exchange_us"]
+    assert ex["n"] == 80 and 0 < ex["p50"] <= ex["max"], ex
+    print("one-rank RCCL all-reduce of the 59 KB bucket, HIP events:", {k: round(v, 1) for k, v in ex.items() if isinstance(v, float)})
+
+
 def test_bench_refuses_more_gpus_than_are_visible():
     """`--gpus N` with fewer than N devices visible and no --same-device: a one-line reason on stderr and a non-zero exit code from the
     PARENT, before any rank is started (the first real multi-GPU run must not die somewhere inside a rendezvous for this reason)."""
