@@ -227,7 +227,13 @@ int pc_policy_act(const pc_policy* p, const float* obs, int64_t N, const float* 
  * inside the small form, whose policy arithmetic is the split policy step's) --, else the filter form,
  * which tests every (ray, wall) pair in float64 (any track, any state, bf16 x 3 at 12 rays; not built for 32 rays); tracks of more
  * than 64 chain vertices and rotations set off the table take the generic kernel with the selector step (PC_KERNEL_K9D_SELECTOR).
- * PC_ERR_UNSUPPORTED for mixed-track handles whose track ids change inside an aligned block of 32 envs, ray
+ * With a precision-0 policy handle an F64 handle at 16 rays runs the literal form with the fp32 weight image: every number of the
+ * rollout in the reference's own arithmetic, still one launch.
+ * Mixed-track handles: track ids constant inside aligned blocks of 32 envs (or more: whole workgroups) run the fast modes per block;
+ * track ids that change INSIDE a block (car_env.py:621-628 puts every env on its own track: e.g. track_id = i & 1) run the big form with
+ * the env step once per track present in a wave -- two tracks of the reference's layout (two equal loops of 13 or 9 chain vertices) at
+ * 16 rays in the table-driven two-track form (both tracks' tables in LDS; F32 and F64 handles), anything else in the generic mode.
+ * PC_ERR_UNSUPPORTED for ray
  * counts whose slots per lane are not on the kernel menu (12 / 16 / 32 run the table-driven fast mode; 17 and 18 share the
  * slots of 16 and run the generic mode), shapes whose LDS footprint exceeds 160 KB (33 rays with the fp32 or bf16x3 weight
  * image in the large form), and 33 rays in the GENERIC mode with split operands (a mixed-track batch whose workgroups
