@@ -46,6 +46,8 @@ def parse_args(argv=None):
     p.add_argument("--full-sweep", action="store_true", help="use every sample each train iter instead of train.py:228's loop bound")
     p.add_argument("--policy-arith", default="fp16x2", choices=["fp16x2", "bf16x3", "fp32"],
                    help="arithmetic of the rollout policy step's GEMMs on the matrix cores: fp16x2 / bf16x3 operand splits (fp32-grade) or the exact fp32 chain")
+    p.add_argument("--policy-range", default="fallback", choices=["fallback", "raise"],
+                   help="weights outside the fp16x2 policy arithmetic's numeric domain (checked at every pack): switch to the exact fp32 chain, or raise")
     p.add_argument("--bootstrap-value", default="kernel", choices=["kernel", "fp32"],
                    help="agent.get_value(next_obs) for GAE (train.py:200): from inside the rollout launch, or torch's fp32 Linear")
     p.add_argument("--out-dir", default=".", help="where checkpoints/ and logs/ are created")
@@ -90,7 +92,7 @@ def main(argv=None):
                     learning_rate_decay=args.learning_rate_decay, max_grad_norm=args.max_grad_norm,
                     reward_scaling=args.reward_scaling, track=args.track, num_rays=args.num_rays, env_dtype=args.env_dtype,
                     seed=args.seed, full_sweep=args.full_sweep, bootstrap_value=args.bootstrap_value,
-                    policy_precision={"fp16x2": 2, "bf16x3": 1, "fp32": 0}[args.policy_arith])
+                    policy_precision={"fp16x2": 2, "bf16x3": 1, "fp32": 0}[args.policy_arith], policy_range=args.policy_range)
     trainer = Trainer(cfg, device=torch.device("cuda", local_rank), rank=rank, world_size=world)
     first_epoch = 1
     if args.resume:
