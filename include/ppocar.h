@@ -338,7 +338,8 @@ int pc_ppo_epoch_prepared(int device, const float* prepared, int n_mb, int B, in
  *                                                   (bucket[r] := the rank-ordered sum, for every r): the ranks' workgroups are then
  *                                                   co-resident by construction -- separate launches on separate streams are not (HIP
  *                                                   multiplexes streams onto a few hardware queues) and must not be used with more
- *                                                   ranks per device than hardware queues;
+ *                                                   ranks per device than hardware queues; PC_ERR_UNSUPPORTED when world x
+ *                                                   ceil(n_floats / 1024) workgroups exceed what the device holds at once;
  *   pc_xchg_set_timeout(x, seconds)                 patience of a wait inside the exchange kernel (default 20 s);
  *   pc_xchg_allreduce(x, bucket, stream)            in place, asynchronous on `stream`, capturable into a HIP graph: bucket[0..n)
  *                                                   := sum over ranks (rank order) of their buckets.  Every rank must make the

@@ -2104,6 +2104,15 @@ int pc_xchg_allreduce_group(pc_xchg* const* ranks, float* const* buckets, void* 
     }
     DeviceGuard guard(ranks[0]->device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
+    // a workgroup waits for the same chunk's workgroups of the other ranks: the whole grid must be resident at once
+    int per_cu = 0, cus = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, xchg_allreduce_group_kernel, 256, 0));
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ranks[0]->device));
+    if ((int64_t)ranks[0]->n_chunks * W > (int64_t)per_cu * cus) {
+        g_hip_err = "pc_xchg_allreduce_group: " + std::to_string((int64_t)ranks[0]->n_chunks * W) + " workgroups cannot be co-resident on " +
+                    std::to_string(cus) + " compute units";
+        return PC_ERR_UNSUPPORTED;
+    }
     hipLaunchKernelGGL(xchg_allreduce_group_kernel, dim3(ranks[0]->n_chunks, W), dim3(256), 0, (hipStream_t)stream, g);
     HIPCHK(hipGetLastError());
     return PC_OK;

@@ -559,6 +559,30 @@ def test_one_shot_exchange_eight_ranks_in_one_process(world, n):
         lib.pc_xchg_destroy(h)
 
 
+def test_grouped_exchange_refuses_a_grid_that_cannot_be_resident():
+    """A workgroup of the grouped exchange waits for the same chunk's workgroups of the other ranks: world x ceil(n / 1024) workgroups
+    must be on the device at once.  8 ranks x 1 M floats (8192 workgroups) is refused with PC_ERR_UNSUPPORTED and a reason, not
+    launched into a timeout."""
+    import ctypes as C
+    from ppo_car_amd._capi import check, lib
+    world, n = 8, 1 << 20
+    hs = []
+    for r in range(world):
+        h = C.c_void_p()
+        check(lib.pc_xchg_create(0, r, world, n, C.byref(h)), "pc_xchg_create")
+        hs.append(h)
+    arr = (C.c_void_p * world)(*[h.value for h in hs])
+    for h in hs:
+        check(lib.pc_xchg_connect_local(h, arr), "pc_xchg_connect_local")
+    buckets = [torch.zeros(n, device="cuda") for _ in range(world)]
+    ptrs = (C.c_void_p * world)(*[b.data_ptr() for b in buckets])
+    rc = lib.pc_xchg_allreduce_group(arr, ptrs, torch.cuda.current_stream().cuda_stream)
+    assert rc == -5 and b"co-resident" in lib.pc_last_hip_error()
+    for h in hs:
+        assert lib.pc_xchg_status(h) == 0
+        lib.pc_xchg_destroy(h)
+
+
 @pytest.mark.parametrize("world", [4])
 def test_four_ranks_on_one_gpu_keep_replicas_identical_both_exchanges(tmp_path, world):
     """The trainer at world size 4 (four processes sharing cuda:0, gloo for the rendezvous): env shards and action streams differ per
