@@ -156,9 +156,9 @@ __device__ __forceinline__ FastTabs stage_fast_tables(const EnvParams<float>& p,
 __device__ __forceinline__ FastTabs ft_shift(const FastTabs& a, const int floats) {
     FastTabs b;
     const int by = 4 * floats;
-#define PC_SH(m) b.m = (decltype(b.m))(size_t)((unsigned)(size_t)a.m + (unsigned)by)
-    PC_SH(head); PC_SH(wrap); PC_SH(act); PC_SH(gates); PC_SH(dir); PC_SH(reset); PC_SH(vtx); PC_SH(seg); PC_SH(dir64); PC_SH(rden);
-#undef PC_SH
+#define PC_FT_SH(m) b.m = (decltype(b.m))(size_t)((unsigned)(size_t)a.m + (unsigned)by)
+    PC_FT_SH(head); PC_FT_SH(wrap); PC_FT_SH(act); PC_FT_SH(gates); PC_FT_SH(dir); PC_FT_SH(reset); PC_FT_SH(vtx); PC_FT_SH(seg); PC_FT_SH(dir64); PC_FT_SH(rden);
+#undef PC_FT_SH
     return b;
 }
 
