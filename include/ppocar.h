@@ -110,6 +110,26 @@ int pc_env_reset(pc_env* e, float* obs, void* stream);
 int pc_env_step(pc_env* e, const int64_t* actions, double reward_scale, float* obs, float* reward,
                 float* terminated, float* truncated, int32_t* gates_passed, float* final_obs, void* stream);
 
+/* T successive pc_env_step calls as ONE call -- `for t in range(T): envs.step(actions[t])`, the env alone under pre-generated
+ * actions (SURVEY 8(d)'s level (i)); train.py:185 without the policy in front of it.  actions [T][N] int64; row t of obs [T][N][D],
+ * reward / terminated / truncated [T][N] = what the t-th pc_env_step writes, bit for bit, and the handle's state afterwards is the
+ * state after those T calls.  Where the handle has the table-driven form (below) the T steps are ONE launch with the env state in
+ * registers throughout; otherwise T launches of the per-step kernel, enqueued by this call. */
+int pc_env_step_many(pc_env* e, const int64_t* actions, int64_t T, double reward_scale, float* obs, float* reward,
+                     float* terminated, float* truncated, void* stream);
+/* Which kernel the last pc_env_step / pc_env_step_many on this handle launched (0 before the first; both fill the same outputs bit for bit):
+ *   PC_STEP_K1         env_step_kernel: any ray count 4..360, any track, per-env track ids; 2^k lanes per env chosen from the batch size
+ *   PC_STEP_K1F        env_steps_fast_kernel: the table-driven env step of the persistent rollout kernel -- 12 / 16 / 32 nominal rays, the
+ *                      track's gather tables staged in LDS per launch, 2 lanes per env, the chain-packed / unrolled selector sweep; F64
+ *                      handles: its literal form (tracks inside the selector's limits, rotations on the rotation table).  Taken from
+ *                      16384 envs on (pc_env_step without gates_passed / final_obs; pc_env_step_many from 8192), PC_OPT_STEP_FORM decides otherwise
+ *   PC_STEP_K1F_TABLE  the same with the track's 1/den table staged too (pc_env_step_many, T > 1, when it fits) */
+#define PC_STEP_NONE 0
+#define PC_STEP_K1 1
+#define PC_STEP_K1F 2
+#define PC_STEP_K1F_TABLE 3
+int pc_env_last_step_kernel(const pc_env* e);
+
 /* CarEnv._get_info (car_env.py:599-603) of every env's CURRENT state: info["gates_passed"] and info["time_passed"]
  * as the vector env's `infos` hold them after a step (an env auto-reset in that step reports its reset state, 0 / 0;
  * the finished episode's count is pc_env_step's `gates_passed`).  [N] int32 device arrays, either may be NULL. */
@@ -131,6 +151,9 @@ int pc_env_info(pc_env* e, int32_t* gates_passed, int32_t* time_passed, void* st
 #define PC_OPT_ROLLOUT_FORM 1
 #define PC_OPT_ROLLOUT_EPW 2
 #define PC_OPT_ROLLOUT_FAST 3
+/*   PC_OPT_STEP_FORM     pc_env_step / pc_env_step_many: 0 (default) automatic (PC_STEP_K1F from 16384 / 8192 envs on, where the handle has
+ *                        it), 1 = always PC_STEP_K1, 2 = PC_STEP_K1F wherever the handle has it, at any batch size */
+#define PC_OPT_STEP_FORM 4
 int pc_env_set_option(pc_env* e, int option, int value);
 int pc_env_get_option(const pc_env* e, int option, int* value);
 

@@ -18,6 +18,7 @@ PC_XCHG_HANDLE_BYTES = 128
 PC_DTYPE_F32, PC_DTYPE_F64 = 0, 1
 PC_OPT_ROLLOUT_FORM, PC_OPT_ROLLOUT_EPW, PC_OPT_ROLLOUT_FAST = 1, 2, 3
 PC_KERNEL_NAMES = {0: "none", 1: "K9", 2: "K9s", 3: "K9-literal", 4: "K9d-filter", 5: "K9s-literal", 6: "K9d-selector", 7: "K9m", 8: "K9m-literal"}     # pc_env_last_rollout_kernel
+PC_STEP_NAMES = {0: "none", 1: "K1", 2: "K1f", 3: "K1f-table"}     # pc_env_last_step_kernel
 DTYPES = {"f32": PC_DTYPE_F32, "float32": PC_DTYPE_F32, "f64": PC_DTYPE_F64, "float64": PC_DTYPE_F64}
 
 
@@ -70,6 +71,8 @@ _sig = {
     "pc_env_num_envs": (_i64, [_vp]),
     "pc_env_reset": (_i, [_vp, _vp, _vp]),
     "pc_env_step": (_i, [_vp, _vp, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pc_env_step_many": (_i, [_vp, _vp, C.c_int64, _d, _vp, _vp, _vp, _vp, _vp]),
+    "pc_env_last_step_kernel": (_i, [_vp]),
     "pc_env_info": (_i, [_vp, _vp, _vp, _vp]),
     "pc_build_ablate": (_i, []),
     "pc_env_get_state": (_i, [_vp] * 9),

@@ -300,6 +300,66 @@ __device__ __forceinline__ double lit_careful(const int k, const LoadSeg& segs, 
     }
     return d;
 }
+// ---- the careful path of ONE ray as a job of the WHOLE WAVE (the table-driven env steps, all 64 lanes active) ---------------------
+// refine_careful / lit_careful run on the lane that owns the ray: one or two lanes of a wave at work, the chain scan ~900 instructions
+// deep -- and a third of all wave-steps of the benchmark meet one (4.5e-4 of the rays end within 0.05 px of a corner, 2.5e-4 are flagged:
+// 0.3 careful iterations per wave-step, ~6 % of the persistent kernel's vector instructions).  Here lane j measures chain segment j
+// (nV <= 64: FT_VTX_MAX) for the job's ray (position and direction wave-uniform), and the answer is the minimum over the SAME set of
+// segments the per-lane functions take: {k, its two chain neighbours} if segment k is a hit and not marked PC_SEG_SCAN, else the
+// whole chain (LIT: every wall of the track in the reference's own list, car_env.py:203-207).  Every distance is the same function of
+// the same operands, the minimum of doubles is exact: the same bits (tests: the persistent kernels against env_step_kernel, which
+// keeps the per-lane form).
+__device__ __forceinline__ double wave_min_d(double v) {
+    // rows of 16 lanes by DPP butterflies (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), the four rows through readlane
+    const auto step = [&](auto CTRL) {
+        constexpr int ctrl = decltype(CTRL)::value;
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xf, 0xf, false), hi2 = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xf, 0xf, false);
+        v = __builtin_fmin(v, __hiloint2double(hi2, lo2));
+    };
+    step(std::integral_constant<int, 0xb1>{});
+    step(std::integral_constant<int, 0x4e>{});
+    step(std::integral_constant<int, 0x141>{});
+    step(std::integral_constant<int, 0x140>{});
+    const auto row = [&](const int l) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+    };
+    return __builtin_fmin(__builtin_fmin(row(0), row(16)), __builtin_fmin(row(32), row(48)));
+}
+__device__ __forceinline__ double bcast_d(const double v, const int l) {     // lane l's value in every lane (l wave-uniform)
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+template <bool LIT, typename LoadSeg>
+__device__ __forceinline__ double careful_wave(const int k, const LoadSeg& segs, const int nV, const Seg* walls, const int S, const double px,
+                                               const double py, const double dx, const double dy, const int lane) {
+    const SegD sg = segs(lane < nV ? lane : 0);      // (record 0 is a chain start: a zero edge, never a hit)
+    double dj;
+    bool hit;
+    if constexpr (LIT) {
+        const LitR c = cast_ref_t(sg.x1, sg.y1, sg.ex, sg.ey, px, py, dx, dy);
+        dj = c.d;
+        hit = c.hit;
+    } else {
+        const CastR c = cast_exact(sg, px, py, dx, dy);
+        dj = c.d;
+        hit = c.hit;
+    }
+    const uint64_t hitm = __builtin_amdgcn_ballot_w64(hit & (lane < nV)), scanm = __builtin_amdgcn_ballot_w64((sg.prev_next & PC_SEG_SCAN) != 0);
+    const int pn = __builtin_amdgcn_readlane(sg.prev_next, k);       // (k < nV <= 64)
+    const bool any = (k != 0) & (bool)((hitm >> k) & 1) & !(bool)((scanm >> k) & 1);      // wave-uniform
+    double dm;
+    if (any) {
+        const bool in = (lane == k) | (lane == (pn & 0x7fff)) | (lane == (int)(((unsigned)pn >> 16) & 0x7fff));   // (neighbour index 0 = none: record 0 never hits)
+        dm = (in & (lane < nV)) ? dj : 1000.0;
+    } else if constexpr (LIT) {
+        const Seg w = walls[lane < S ? lane : 0];
+        const double dw = cast_ref_t(w.x1, w.y1, w.x2, w.y2, px, py, dx, dy).d;
+        dm = lane < S ? dw : 1000.0;
+    } else {
+        dm = ((lane >= 1) & (lane < nV)) ? dj : 1000.0;
+    }
+    return wave_min_d(dm);
+}
 // min(1000, d) / 1000 as the observation holds it (Ray.get_distance :198,:210-211; car_env.py:593,:595)
 __device__ __forceinline__ float obs_dist(const double d) { return (float)(__builtin_fmin(d, 1000.0) * 0.001); }
 // one ray against one segment (the reward gates: Car.check_collision(gate), car_env.py:387-390), float64, the reference's verdict

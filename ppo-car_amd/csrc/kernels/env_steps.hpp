@@ -1,0 +1,136 @@
+// env_steps.hpp -- part of the single translation unit ppocar.hip (included there after rollout.hpp; not a stand-alone header).
+// K1f env_steps_fast_kernel: T successive CarEnv.step transitions (car_env.py:693-760, + TransformReward + gymnasium 0.29.1's same-step
+// auto-reset) of every env as ONE launch, the actions read from the caller's [T, N] rows: pc_env_step (T = 1) and pc_env_step_many
+// (SURVEY 8(d)'s level (i): the env alone under pre-generated actions).
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// The table-driven env step of the persistent rollout kernel (env_step_fast, rollout.hpp) without a policy in front of it: a
+// workgroup of 8 waves owns `epw` envs (256; 128: waves 4..7 only help to stage), a WAVE owns 32 of them with 2 lanes per env;
+// the track's gather tables are staged in LDS once per launch (32 KB; with TAB also its 1/den table), the env state lives in
+// registers from the first step to the last, every step's observation rows leave through the wave's 32 dense LDS rows as 16-byte
+// stores.  After staging no barrier.  RPL: ray slots per lane (6 / 9 / 17 = 12 / 17 / 33 rays), SWP: the selector sweep (7: the
+// chain-packed one for two loops of 13 vertices, big_track.json; 0: the generic ones), LIT: PC_DTYPE_F64 handles (the literal form).
+// Every value is env_step_fast's, i.e. bit for bit what env_step_kernel computes (tests/test_env_gpu.py, test_env_steps_gpu.py);
+// an action outside 0..7 is the no-op (car_env.py:721), as there.
+// ------------------------------------------------------------------------------------------
+template <int RPL, int SWP, bool TAB, bool LIT>
+__global__ __launch_bounds__(512) void env_steps_fast_kernel(const EnvParams<float> p, const int64_t* __restrict__ actions, const int T,
+                                                             const double reward_scale, float* __restrict__ obs,
+                                                             float* __restrict__ reward, float* __restrict__ term_out,
+                                                             float* __restrict__ trunc_out, const int epw, const int vec_ok) {
+    constexpr int DC = RPL == 6 ? 18 : (RPL == 9 ? 23 : 39);
+    static_assert(RPL == 6 || RPL == 9 || RPL == 17, "12 / 17 / 33 rays on two lanes per env");
+    static_assert(SWP == 0 || (SWP == 7 && RPL == 9), "the chain-packed sweep: 17 rays");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sObs = lds;                     // [256 envs][DC]: the step's observation rows, dense (the caller's row layout)
+    float* sTab = sObs + 256 * DC;         // the track's gather tables (ft_floats), then its 1/den table (TAB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t N = p.N;
+    // a mixed-track batch: the host checked that every workgroup's envs lie on ONE track, whose tables it stages
+    const int trk_wg = p.track_id ? __builtin_amdgcn_readfirstlane((int)p.track_id[min((int64_t)blockIdx.x * epw, N - 1)]) : 0;
+    const TrackHdr h0 = cload(p.hdr + trk_wg);
+    const FastTabs ft = stage_fast_tables<false, true, LIT>(p, h0, trk_wg, sTab, tid, 512);
+    if constexpr (TAB) {
+        float* sRden = sTab + ft_floats(false, true);
+        const float* src = p.rden + h0.rden_off;
+        const int nv = h0.nV, n = 361 * nv;
+        if constexpr (SWP == 7) {
+            // wall_sweep_loops reads a row in the order (0, L, 1, L + 1, ...): entry 2 i = vertex i, entry 2 i + 1 = vertex L + i
+            const int L = h0.brk2;
+            for (int i = tid; i < n; i += 512) {
+                const int row = i / nv, e = i - nv * row;
+                const int k = e < 2 * L ? (e >> 1) + ((e & 1) ? L : 0) : e;
+                sRden[i] = src[nv * row + k];
+            }
+        } else {
+            for (int i = tid; i < n / 4; i += 512) reinterpret_cast<f32x4*>(sRden)[i] = reinterpret_cast<const f32x4*>(src)[i];   // nV is a multiple of 4
+        }
+    }
+    // this wave's 32 envs: local rows [pbase, pbase + 32), 2 lanes per env
+    const int pbase = wave * 32;
+    const int el = pbase + (lane >> 1), g = lane & 1;
+    const int64_t e_wave = (int64_t)blockIdx.x * epw + pbase;
+    const int64_t e_env = e_wave + (lane >> 1);
+    const bool e_valid = e_env < N;
+    using StateT = std::conditional_t<LIT, double, float>;
+    const EnvParams<StateT> ps = p.template as<StateT>();
+    EnvRegs st = {};
+    if (e_valid) st = env_load<StateT>(ps, e_env);
+    const FastLane fl = fast_lane<RPL, 2>(p, ft, g, sObs + el * DC);
+    const int gq[2] = {(int)(size_t)ft.dir + 16 * g * p.q * p.step_deg,           // Car.get_passed_gate's rays j * (n // 4), j = g and g + 2,
+                       (int)(size_t)ft.dir + 16 * (g + 2) * p.q * p.step_deg};    // as byte addresses into the direction table
+    int k72 = Math<float>::mod72(st.k);
+    f64x2 hcar = {1.0, 0.0};      // LIT: (cos, sin) of the env's current rotation (row st.k of the rotation table)
+    if constexpr (LIT) {
+        k72 = Math<float>::mod72((int)__builtin_rint((st.rot - h0.start_rot) / 5.0));
+        if (e_valid) {
+            const double2 e0 = p.dirtab64[h0.rot_off + st.k * (p.R + 2)];
+            hcar = (f64x2){e0.x, e0.y};
+        }
+        st.rot = 0.0;     // (not kept: the rotation is the row's last entry, read again when the state is stored)
+    }
+    const lds_fp lrow = (lds_fp)(sObs + el * DC);
+    int64_t a_next = e_valid ? actions[e_env] : 8;
+    __syncthreads();      // the tables are in place; from here on the waves never synchronise again
+    if (pbase >= epw) return;
+    asm volatile("" : "+v"(st.px), "+v"(st.py), "+v"(st.vx), "+v"(st.vy), "+v"(st.k), "+v"(st.time), "+v"(st.next), "+v"(st.passed), "+v"(k72));
+    if constexpr (LIT) asm volatile("" : "+v"(hcar));
+    float* pa_rew = reward + e_env;
+    float* pa_term = term_out + e_env;
+    float* pa_trunc = trunc_out + e_env;
+    const int64_t* pa_act = actions + e_env;
+    float* dstg = obs + e_wave * DC;       // the wave's 32 rows are contiguous in the caller's [N, D] rows
+    const int64_t left = N - e_wave;       // valid envs from this wave's first on
+    const int n_rows = left >= 32 ? 32 : (int)left;
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        const int a = (a_next >= 0 && a_next < 8) ? (int)a_next : 8;
+        pa_act += N;
+        if (t + 1 < T && e_valid) a_next = *pa_act;        // the next step's action row, under this step's arithmetic
+        float rw, tf, cf;
+        const bool done = env_step_fast<RPL, TAB, 1, 1, SWP, true, LIT, true>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave,
+                                                                      0, nullptr, true, nullptr, &hcar);
+        if (__builtin_amdgcn_ballot_w64(done) != 0) {   // wave-uniform: a finished env gets its reset observation and CarEnv.reset's state
+            if (done) {
+                float ro[(DC + 1) / 2];
+#pragma unroll
+                for (int j = 0; j < (DC + 1) / 2; ++j) ro[j] = ft.reset[g + 2 * j];     // (the table has 40 slots: in bounds)
+#pragma unroll
+                for (int j = 0; j < (DC + 1) / 2; ++j)
+                    if (g + 2 * j < DC) lrow[g + 2 * j] = ro[j];
+                env_reset_fast(h0, st, k72);
+                if constexpr (LIT) {
+                    const double2 e0 = p.dirtab64[h0.rot_off];      // row 0 = start_rot
+                    hcar = (f64x2){e0.x, e0.y};
+                }
+            }
+        }
+        if (g == 0 && e_valid) {
+            *pa_rew = rw;
+            *pa_term = tf;
+            *pa_trunc = cf;
+        }
+        pa_rew += N; pa_term += N; pa_trunc += N;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the rows are complete (this wave wrote them all)
+        __builtin_amdgcn_wave_barrier();
+        const float* srcl = sObs + pbase * DC;
+        if (vec_ok && n_rows == 32) {
+            constexpr int NF4 = 8 * DC;                         // the wave's rows as float4s
+#pragma unroll
+            for (int j = 0; j < (NF4 + 63) / 64; ++j) {
+                const int i = lane + 64 * j;
+                if (64 * j + 63 < NF4 || i < NF4) reinterpret_cast<f32x4*>(dstg)[i] = reinterpret_cast<const f32x4*>(srcl)[i];
+            }
+        } else {
+            for (int i = lane; i < n_rows * DC; i += 64) dstg[i] = srcl[i];
+        }
+        dstg += N * DC;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the next step overwrites the rows)
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (e_valid && g == 0) {
+        if constexpr (LIT) st.rot = p.dirtab64[h0.rot_off + st.k * (p.R + 2) + p.R + 1].x;
+        env_store<StateT>(ps, e_env, st);
+    }
+}

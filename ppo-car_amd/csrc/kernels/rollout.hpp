@@ -36,6 +36,9 @@ __device__ unsigned long long g_stamps_u[16];    // the minibatch kernel (K10), 
 //     global memory with 16-byte stores (three per lane instead of 23 scattered dword stores), and an env that finished its
 //     episode gets its reset observation in a rarely taken, wave-uniformly skipped fix-up.
 // ------------------------------------------------------------------------------------------
+#ifndef PC_AB_NOCOOP
+#define PC_AB_NOCOOP 0
+#endif
 constexpr int TAB_MAX_GATES = 128;  // reward gates of a track staged in LDS (32 bytes each)
 struct ActLut {          // one per action 0..15 (9..15: no-op, car_env.py:721), 32 bytes
     double thrust;       // acc = heading * thrust: +0.8 forward, -0.8 backward, 0 none (car_env.py:423-438)
@@ -277,7 +280,7 @@ __device__ __forceinline__ void wall_sweep_lds(lds_cd2 vt, const int nV, const i
 // distances are cast_ref's (lit_fast / lit_careful), the observation is normalised by division (Math<double>::norm) -- while
 // the float32 sweep only SELECTS, on the float32 lattice directions, exactly as for F32 handles.  Bit for bit what
 // env_step_core<double> computes (tests/test_rollout_f64_gpu.py).
-template <int RPL, bool TAB, int LG = 1, int PARTS = 1, int SWP = 0, bool TWICE = true, bool LIT = false>
+template <int RPL, bool TAB, int LG = 1, int PARTS = 1, int SWP = 0, bool TWICE = true, bool LIT = false, bool COOP = false>
 __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const TrackHdr& h, const FastTabs& ft, const FastLane& fl,
                                               const int (&gq)[2], const int g,
                                               EnvRegs& st, int& k72, const int a, const double reward_scale, lds_fp lrow,
@@ -529,8 +532,49 @@ __device__ __forceinline__ bool env_step_fast(const EnvParams<float>& p, const T
     }
     wall_hit |= __builtin_amdgcn_inverse_ballot_w64(hit_mask);
     PC_STAMP_E(8)
-    // the rare rest, one slot of one lane at a time through ONE copy of the careful code (a select chain picks the slot's selection)
-    while (__builtin_expect(__builtin_amdgcn_ballot_w64(todo != 0) != 0, 0)) {
+    // the rare rest.  COOP (every lane of the wave is active here: the caller's promise): one slot of ONE lane at a time as a job of the
+    // whole wave (careful_wave, env_math.hpp: lane j measures chain segment j) -- ~100 instructions per slot where the owning lane alone
+    // needs up to ~900
+    if constexpr (COOP) {
+        // (every branch of these loops is on wave-uniform SCALAR values -- the mask of lanes with work, taken once, and the owning lane's
+        // slot bits -- and no ballot sits behind a divergent branch: hipcc threads a `while (ballot(todo))` through an earlier
+        // `if (lane-condition)` and then runs the loop body with part of the wave masked off, which a per-lane body tolerates and a
+        // whole-wave job does not)
+        const int ln = threadIdx.x & 63;
+        uint64_t tm = __builtin_amdgcn_ballot_w64(todo != 0);
+        asm volatile("" : "+s"(tm));
+        while (__builtin_expect(tm != 0, 0)) {
+            const int L = __builtin_ctzll(tm);                       // the job's lane
+            unsigned tl = (unsigned)__builtin_amdgcn_readlane((int)todo, L);      // ... and its careful slots
+            do {
+                const int s0 = __builtin_ctz(tl);
+                unsigned sel = 0;
+#pragma unroll
+                for (int s = 0; s < RPL; ++s) sel = s == s0 ? bb[s] : sel;
+                const int ms = m0 + s0 * fl.rstep;
+                f64x2 dd;
+                if constexpr (LIT) {
+                    const double2 e = rot_row_new[ray_of(s0)];
+                    dd = (f64x2){e.x, e.y};
+                } else {
+                    dd = dir64_at(s0 + 1 < RPL ? ms : min(ms, m_last));
+                }
+                const double d = careful_wave<LIT>(__builtin_amdgcn_readlane((int)(sel & h.idx_mask), L), segs, h.nV, p.segs + h.wall_off, h.S,
+                                                   bcast_d(npx, L), bcast_d(npy, L), bcast_d(dd.x, L), bcast_d(dd.y, L), ln);
+                if (ln == L) {
+                    wall_hit |= (bool)((fl.colmask >> s0) & 1) & (d < 10.0);
+                    if (write_row || PARTS > 1) {
+                        const lds_fp dst = s0 + 1 < RPL ? fl.lray + G * s0 : fl.llast;
+                        dst[0] = LIT ? Math<double>::norm_dist(d < 1000.0 ? d : 1000.0) : obs_dist(d);
+                    }
+                }
+                tl &= tl - 1;
+            } while (tl != 0);
+            tm &= tm - 1;
+        }
+    }
+    // ... else one slot of one lane at a time through ONE copy of the per-lane careful code (a select chain picks the slot's selection)
+    while (!COOP && __builtin_expect(__builtin_amdgcn_ballot_w64(todo != 0) != 0, 0)) {
         const int s0 = todo ? __builtin_ctz(todo) : -1;
         unsigned sel = 0;
 #pragma unroll
@@ -744,19 +788,26 @@ __device__ __forceinline__ bool env_step_wave(const EnvParams<float>& p, const T
     double d = LIT ? lit_fast(sg, npx, npy, d64.x, d64.y, ok) : refine_fast(sg, npx, npy, d64.x, d64.y, ok);
     const auto obs_of = [](const double dd) { return LIT ? Math<double>::norm_dist(dd < 1000.0 ? dd : 1000.0) : obs_dist(dd); };   // :198, :593
     bool todo = active & !ok;
+    // the lanes with a careful job, taken HERE: ahead of every lane-dependent branch (see env_step_fast's whole-wave jobs)
+    uint64_t tm = __builtin_amdgcn_ballot_w64(todo);
+    asm volatile("" : "+s"(tm));
     const bool col = (bool)((fl.colmask >> slot) & 1) & active;
     bool hit = col & ok & (d < 10.0);                                                              // :387-390 on Car.check_collision's rays
     const lds_fp dst = is_last ? fl.llast : fl.lray + G * slot;
     if (active) dst[0] = obs_of(d);
     PC_STAMP(8)
-    while (__builtin_expect(__builtin_amdgcn_ballot_w64(todo) != 0, 0)) {   // the rare rest: the careful path
-        if (todo) {
-            if constexpr (LIT) d = lit_careful((int)(sel & h.idx_mask), segs, p.segs + h.wall_off, h.S, npx, npy, d64.x, d64.y);
-            else d = refine_careful((int)(sel & h.idx_mask), segs, h.nV, npx, npy, d64.x, d64.y);
+    // the rare rest: the careful path, one ray at a time as a job of the whole wave (careful_wave, env_math.hpp; every lane is active here).
+    // The owning lane alone needs up to ~900 instructions for it -- with the workgroup's other seven waves waiting at the step's barrier
+    while (__builtin_expect(tm != 0, 0)) {
+        const int L = __builtin_ctzll(tm);       // the job's lane (wave-uniform)
+        const double dj = careful_wave<LIT>(__builtin_amdgcn_readlane((int)(sel & h.idx_mask), L), segs, h.nV, p.segs + h.wall_off, h.S, bcast_d(npx, L),
+                                            bcast_d(npy, L), bcast_d(d64.x, L), bcast_d(d64.y, L), (int)(threadIdx.x & 63));
+        if ((int)(threadIdx.x & 63) == L) {
+            d = dj;
             hit = col & (d < 10.0);
             dst[0] = obs_of(d);
-            todo = false;
         }
+        tm &= tm - 1;
     }
     PC_STAMP(9)
     const uint64_t hit_mask = __builtin_amdgcn_ballot_w64(hit);
@@ -1177,7 +1228,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 const int a = e_valid ? act_reg : 8;
                 // one env step of the lanes active here, on the track (hh, ff): CarEnv.step, then gymnasium 0.29.1's same-step auto-reset
                 const auto step_on = [&](const TrackHdr& hh, const FastTabs& ff, const FastLane& fll, const int (&gg)[2]) {
-                    const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3 || MODE == 5, LGE, 1, ((MODE == 5 || MODE == 6) ? 5 : (MODE >= 3 ? 7 : 0)), RPL != 17, LIT>(
+                    // (COOP: the careful slots as whole-wave jobs -- every lane is active here; not in the two-track form, whose passes are exec-masked)
+                    const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3 || MODE == 5, LGE, 1, ((MODE == 5 || MODE == 6) ? 5 : (MODE >= 3 ? 7 : 0)), RPL != 17, LIT, MODE != 6 && !PC_AB_NOCOOP>(
                         p, hh, ff, fll, gg, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, 0, nullptr, true, nullptr, &hcar);
                     rsum += rw;
                     PC_STAMP(6)
@@ -1718,8 +1770,8 @@ __global__ __launch_bounds__(512) void rollout_small_kernel(const EnvParams<floa
                 } else {
                     const int a = e_valid ? sAct[el] : 8;
                     done = rden_lds   // (uniform)
-                        ? env_step_fast<RPL, true, 2, PARTS, 0, true, LIT>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0, sHit + el * PARTS, &hcar)
-                        : env_step_fast<RPL, false, 2, PARTS, 0, true, LIT>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0, sHit + el * PARTS, &hcar);
+                        ? env_step_fast<RPL, true, 2, PARTS, 0, true, LIT, true>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0, sHit + el * PARTS, &hcar)
+                        : env_step_fast<RPL, false, 2, PARTS, 0, true, LIT, true>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, part, exch, part == 0, sHit + el * PARTS, &hcar);
                 }
                 rsum += rw;
                 if (__builtin_amdgcn_ballot_w64(done) != 0) {

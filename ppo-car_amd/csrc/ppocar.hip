@@ -69,6 +69,7 @@
 #include "kernels/gae_sample.hpp"
 #include "kernels/policy.hpp"
 #include "kernels/rollout.hpp"
+#include "kernels/env_steps.hpp"
 #include "kernels/update.hpp"
 #include "kernels/exchange.hpp"
 
@@ -132,7 +133,10 @@ struct RolloutOpts {
     int epw_override = 0; // 0 = automatic, 16 / 32 / 128 / 256 = force (test knob)
     int fast = 1;         // the fast modes (LDS tables behind LDS pointers) when the shape allows them (0: never; A/B knob)
     int nv28 = 1;         // kernels compiled for a padded wall chain of 28 vertices (big_track.json) when every track of the batch has one
+    int step_form = 0;    // pc_env_step / pc_env_step_many: 0 = automatic (the table-driven form K1f from PC_STEP_FAST_MIN_ENVS envs on, where the
+                          // shape has one), 1 = always the generic per-step kernel K1, 2 = K1f wherever the shape has one (any batch size)
 };
+constexpr int64_t PC_STEP_FAST_MIN_ENVS = 16384;   // below: K1's 4+ lanes per env fill the device better than K1f's workgroups of 256 envs
 constexpr int kDefaultPolicyPrecision = 2;   // pc_policy_create(precision = -1): 0 = fp32-input MFMA; split forms on the 16-bit matrix cores (need D <= 40, A <= 9): 1 = bf16 x 3, 2 = fp16 x 2
 
 struct pc_env {
@@ -165,6 +169,7 @@ struct pc_env {
     std::vector<std::unordered_map<uint64_t, int>> rot_ids;   // F64, host only: per track, rotation bits -> row of the rotation table (pc_env_set_state)
     std::vector<std::vector<int>> rot_depth;                  // F64, host only: per track and row, how many turns from start_rot reach it
     int last_kernel = 0;           // PC_KERNEL_*: what the last successful pc_rollout launched (pc_env_last_rollout_kernel)
+    int last_step_kernel = 0;      // PC_STEP_*: what the last pc_env_step / pc_env_step_many launched (pc_env_last_step_kernel)
     bool f64_offgrid = false;      // F64: pc_env_set_state left an env whose episode can leave the rotation table (a rotation that is not a
                                    // row, or a row more turns from start_rot than the env's time step): the selector kernel needs rows
     float* reset_obs = nullptr;
@@ -241,6 +246,55 @@ static void launch_step(const pc_env* e, const int64_t* actions, double reward_s
     } else
         hipLaunchKernelGGL((env_step_kernel<T, RPL, false>), dim3(e->blocks), dim3(256), 0, st, e->params<T>(), actions,
                            reward_scale, obs, reward, term, trunc, gates_passed, final_obs);
+}
+
+// K1f (env_steps_fast_kernel): T successive steps as one launch, where the shape has the table-driven form -- 12 / 16 / 32 nominal rays,
+// every track's gather tables inside the LDS limits, a mixed batch in blocks of one track per workgroup; F64 handles: every track inside
+// the selector's limits with its rotation table, every env's rotation on it (the conditions of pc_rollout's literal kernels).
+// PC_ERR_UNSUPPORTED: no such form for this handle (the caller launches K1).  `table`: stage the 1/den table too (worth it for T > 1).
+static int steps_fast_launch(pc_env* e, const int64_t* actions, int64_t T, double reward_scale, float* obs, float* reward, float* term,
+                             float* trunc, bool table, hipStream_t st) {
+    const bool f64 = e->dtype == PC_DTYPE_F64;
+    const bool rays12 = e->n_nominal == 12 && e->R == 12, rays16 = e->n_nominal == 16 && e->R == 17, rays32 = e->n_nominal == 32 && e->R == 33;
+    if (!(rays12 || rays16 || rays32) || !e->opt.fast || T < 1 || T > INT_MAX) return PC_ERR_UNSUPPORTED;
+    int max_G = 0, max_nV = 0;
+    bool all_nv28 = e->opt.nv28 != 0, tabs = true, all_rden = true;
+    for (const TrackHdr& h : e->hdr_host) {
+        max_G = std::max(max_G, h.G);
+        max_nV = std::max(max_nV, h.nV);
+        tabs = tabs && h.lat_off >= 0 && (!f64 || (h.sel_ok && h.rot_off >= 0));
+        all_rden = all_rden && h.rden_off >= 0;
+        all_nv28 = all_nv28 && h.nV == 28 && h.n_chain == 26 && h.brk2 == 13 && h.vtxp_off >= 0;   // big_track's layout: two loops of 12 walls
+    }
+    const int epw = e->N <= 32768 ? 128 : 256;      // (one wave per SIMD on twice the workgroups up to 32768 envs, as pc_rollout's big form)
+    if (!tabs || max_G > TAB_MAX_GATES || max_nV > FT_VTX_MAX || (f64 && e->f64_offgrid) || (e->track_id && e->track_block < epw)) return PC_ERR_UNSUPPORTED;
+    size_t lds = (size_t)(256 * e->D + ft_floats(false, true)) * sizeof(float);
+    const bool tab = table && all_rden && e->opt.rden != 0 && lds + (size_t)361 * max_nV * sizeof(float) <= 160 * 1024;
+    if (tab) lds += (size_t)361 * max_nV * sizeof(float);
+    const int blocks = (int)((e->N + epw - 1) / epw);
+    const int vec_ok = ((e->N * e->D) % 4 == 0 && ((uintptr_t)obs & 15) == 0) ? 1 : 0;
+    EnvParams<float> prm = e->params<float>();
+    prm.lg = 1;
+#define PC_STEPS(RPLV, SWPV, TABV, LITV)                                                                                 \
+    do {                                                                                                                 \
+        static bool attr_set[64] = {false};                                                                              \
+        if (e->device >= 64 || !attr_set[e->device]) {                                                                    \
+            HIPCHK(hipFuncSetAttribute((const void*)env_steps_fast_kernel<RPLV, SWPV, TABV, LITV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            if (e->device < 64) attr_set[e->device] = true;                                                                \
+        }                                                                                                                \
+        hipLaunchKernelGGL((env_steps_fast_kernel<RPLV, SWPV, TABV, LITV>), dim3(blocks), dim3(512), lds, st, prm, actions, (int)T, reward_scale, obs, \
+                           reward, term, trunc, epw, vec_ok);                                                            \
+    } while (0)
+#define PC_STEPS_T(RPLV, SWPV, LITV) do { if (tab) PC_STEPS(RPLV, SWPV, true, LITV); else PC_STEPS(RPLV, SWPV, false, LITV); } while (0)
+    if (rays16 && all_nv28) { if (f64) PC_DEV(3, PC_STEPS_T(9, 7, true)); else PC_DEV(0, PC_STEPS_T(9, 7, false)); }
+    else if (rays16) { PC_FULL(if (f64) PC_STEPS_T(9, 0, true); else PC_STEPS_T(9, 0, false)); }
+    else if (rays12) { PC_FULL(if (f64) PC_STEPS_T(6, 0, true); else PC_STEPS_T(6, 0, false)); }
+    else { PC_FULL(if (f64) PC_STEPS_T(17, 0, true); else PC_STEPS_T(17, 0, false)); }
+#undef PC_STEPS_T
+#undef PC_STEPS
+    HIPCHK(hipGetLastError());
+    e->last_step_kernel = tab ? PC_STEP_K1F_TABLE : PC_STEP_K1F;
+    return PC_OK;
 }
 
 extern "C" {
@@ -808,6 +862,12 @@ int pc_env_step(pc_env* e, const int64_t* actions, double reward_scale, float* o
     DeviceGuard guard(e->device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
     hipStream_t st = (hipStream_t)stream;
+    // the table-driven form (K1f) where the handle has one and nothing but the step's own outputs is asked for
+    if (!gates_passed && !final_obs && (e->opt.step_form == 2 || (e->opt.step_form == 0 && e->N >= PC_STEP_FAST_MIN_ENVS))) {
+        const int rc = steps_fast_launch(e, actions, 1, reward_scale, obs, reward, terminated, truncated, false, st);
+        if (rc != PC_ERR_UNSUPPORTED) return rc;
+    }
+    e->last_step_kernel = PC_STEP_K1;
 #define PC_CASE(T, M)                                                                                        \
     case M:                                                                                                  \
         launch_step<T, M>(e, actions, reward_scale, obs, reward, terminated, truncated, gates_passed, final_obs, st); \
@@ -831,6 +891,31 @@ int pc_env_step(pc_env* e, const int64_t* actions, double reward_scale, float* o
     HIPCHK(hipGetLastError());
     return PC_OK;
 }
+
+int pc_env_step_many(pc_env* e, const int64_t* actions, int64_t T, double reward_scale, float* obs, float* reward, float* terminated,
+                     float* truncated, void* stream) {
+    g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
+    if (!e || !actions || !obs || !reward || !terminated || !truncated || T < 1) return PC_ERR_INVALID_ARG;
+    {
+        DeviceGuard guard(e->device);
+        if (!guard.ok) return PC_ERR_NO_DEVICE;
+        if (e->opt.step_form != 1 && (e->opt.step_form == 2 || e->N >= PC_STEP_FAST_MIN_ENVS / 2)) {
+            const int rc = steps_fast_launch(e, actions, T, reward_scale, obs, reward, terminated, truncated, T > 1, (hipStream_t)stream);
+            if (rc != PC_ERR_UNSUPPORTED) return rc;
+        }
+    }
+    // no table-driven form for this handle: the same T steps as T launches of K1, row by row
+    const int saved = e->opt.step_form;
+    e->opt.step_form = 1;
+    int rc = PC_OK;
+    for (int64_t t = 0; t < T && rc == PC_OK; ++t)
+        rc = pc_env_step(e, actions + t * e->N, reward_scale, obs + t * e->N * e->D, reward + t * e->N, terminated + t * e->N, truncated + t * e->N,
+                         nullptr, nullptr, stream);
+    e->opt.step_form = saved;
+    return rc;
+}
+
+int pc_env_last_step_kernel(const pc_env* e) { return e ? e->last_step_kernel : PC_ERR_INVALID_ARG; }
 
 int pc_env_info(pc_env* e, int32_t* gates_passed, int32_t* time_passed, void* stream) {
     g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
@@ -1054,6 +1139,10 @@ int pc_env_set_option(pc_env* e, int option, int value) {
             e->opt.fast = value != 0;
             e->opt.nv28 = value == 1;
             return PC_OK;
+        case PC_OPT_STEP_FORM:
+            if (value < 0 || value > 2) return PC_ERR_INVALID_ARG;
+            e->opt.step_form = value;
+            return PC_OK;
         default: return PC_ERR_INVALID_ARG;
     }
 }
@@ -1065,6 +1154,7 @@ int pc_env_get_option(const pc_env* e, int option, int* value) {
         case PC_OPT_ROLLOUT_FORM: *value = e->opt.form < 0 ? -1 : e->opt.form + (e->opt.rden ? 0 : 2); return PC_OK;
         case PC_OPT_ROLLOUT_EPW: *value = e->opt.epw_override; return PC_OK;
         case PC_OPT_ROLLOUT_FAST: *value = !e->opt.fast ? 0 : (e->opt.nv28 ? 1 : 2); return PC_OK;
+        case PC_OPT_STEP_FORM: *value = e->opt.step_form; return PC_OK;
         default: return PC_ERR_INVALID_ARG;
     }
 }

@@ -124,6 +124,7 @@ class VecCarEnv:
         self._h = None
         self._tracks = None
         self._track_id = None if track_id is None else np.ascontiguousarray(track_id, np.uint8)
+        self._opts = {}
         self._build(tracks)
 
     # ---- construction ---------------------------------------------------------------------
@@ -162,6 +163,8 @@ class VecCarEnv:
         self.action_space = _Space(shape=(self.num_envs,), dtype=np.int64)
         self.single_observation_space_shape = (self.obs_dim,)     # (round-1 spellings, kept)
         self.single_action_space_n = self.act_dim
+        for name, value in self._opts.items():       # (a rebuilt handle -- reset(options={"track_path": ...}) -- keeps its options)
+            check(lib.pc_env_set_option(self._h, self.OPTIONS[name], value), f"pc_env_set_option({name})")
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -227,6 +230,33 @@ class VecCarEnv:
             infos["final_observation"] = final_obs
         return obs, rew, term, trunc, infos
 
+    def step_many(self, actions, out=None):
+        """`for t in range(T): envs.step(actions[t])` as ONE call (pc_env_step_many): actions [T, N] int64 -> (obs [T, N, D], rewards,
+        terminateds, truncateds [T, N]), row t = what the t-th step() returns, bit for bit; the env state afterwards is the state after
+        those T steps.  Where the handle has the table-driven kernel (last_step_kernel() == "K1f" / "K1f-table") the T steps are one launch."""
+        N, D = self.num_envs, self.obs_dim
+        if actions.dtype != torch.int64 or not actions.is_cuda:
+            actions = actions.to(device=self.device, dtype=torch.int64)
+        actions = actions.contiguous()
+        if actions.dim() != 2 or actions.shape[1] != N:
+            raise ValueError(f"step_many: actions must be [T, {N}], got {tuple(actions.shape)}")
+        T = actions.shape[0]
+        if out is None:
+            out = (self._new(T, N, D), self._new(T, N), self._new(T, N), self._new(T, N))
+        obs, rew, term, trunc = out
+        check(lib.pc_env_step_many(self._h, self._ptr(actions, torch.int64, T * N, "actions"), T, self.reward_scaling,
+                                   self._ptr(obs, torch.float32, T * N * D, "obs"), self._ptr(rew, torch.float32, T * N, "rewards"),
+                                   self._ptr(term, torch.float32, T * N, "terminateds"), self._ptr(trunc, torch.float32, T * N, "truncateds"),
+                                   self._stream()), "pc_env_step_many")
+        return obs, rew, term, trunc
+
+    def last_step_kernel(self):
+        """which kernel the last step() / step_many() launched: "K1" (generic per-step kernel), "K1f" (table-driven), "K1f-table" or "none"."""
+        code = lib.pc_env_last_step_kernel(self._h)
+        if code < 0:
+            check(code, "pc_env_last_step_kernel")
+        return _capi.PC_STEP_NAMES[code]
+
     def close(self):
         h, self._h = self._h, None
         if h:
@@ -276,11 +306,13 @@ class VecCarEnv:
     def set_lanes_per_env(self, lanes):
         check(lib.pc_env_set_lanes_per_env(self._h, int(lanes)), "pc_env_set_lanes_per_env")
 
-    OPTIONS = {"rollout_form": 1, "rollout_epw": 2, "rollout_fast": 3}     # PC_OPT_* (include/ppocar.h)
+    OPTIONS = {"rollout_form": 1, "rollout_epw": 2, "rollout_fast": 3, "step_form": 4}     # PC_OPT_* (include/ppocar.h)
 
     def set_option(self, name, value):
-        """Per-handle launch option of pc_rollout on THIS vector env (other handles keep theirs)."""
+        """Per-handle launch option of pc_rollout / pc_env_step on THIS vector env (other handles keep theirs).  step_form: 0 automatic,
+        1 always the generic per-step kernel K1, 2 the table-driven K1f wherever the handle has it."""
         check(lib.pc_env_set_option(self._h, self.OPTIONS[name], int(value)), f"pc_env_set_option({name})")
+        self._opts[name] = int(value)
 
     def get_option(self, name):
         v = C.c_int()

@@ -1,0 +1,190 @@
+"""K1f (env_steps_fast_kernel): pc_env_step's table-driven form and pc_env_step_many -- CarEnv.step (car_env.py:693-760) as the
+persistent rollout kernel computes it (env_step_fast: gather tables in LDS, two lanes per env, the chain-packed / unrolled selector
+sweep, float64 refinement or the literal cast), with the actions taken from the caller instead of a policy pass.
+
+Bars: every output and the env state afterwards equal the generic per-step kernel K1's bit for bit (K1 is pinned to the reference's
+golden vectors in test_env_gpu.py) -- F32 and F64 handles, 12 / 16 / 32 nominal rays, both reference tracks, ragged batch sizes,
+out-of-range actions, mixed tracks in blocks; F64 handles reproduce the golden vectors themselves; the actions of a trained policy's
+2048-step rollout (laps, time limits) replayed through pc_env_step_many reproduce that rollout's buffers."""
+import numpy as np
+import pytest
+import torch
+
+import ppo_car_amd as pc
+from conftest import GOLDEN, TRACKS
+
+pytestmark = pytest.mark.gpu
+
+STATE = ("px", "py", "vx", "vy", "rot", "time_step", "next_gate", "passed")
+FAST_CONFIGS = [(t, n) for t in ("big_track", "track") for n in (12, 16, 32)]
+
+
+def _env(N, track, n, dtype, form, track_id=None, rs=0.1):
+    e = pc.VecCarEnv(N, track, num_rays=n, reward_scaling=rs, dtype=dtype, track_id=track_id)
+    e.set_option("step_form", form)
+    return e
+
+
+def _actions(T, N, seed, wild=True):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randint(0, 9, (T, N), generator=g)
+    fwd = torch.rand(T, N, generator=g) < 0.35           # biased forward: cars reach gates as well as walls
+    a = torch.where(fwd, torch.zeros_like(a), a)
+    if wild:                                             # anything outside 0..7 is the no-op (car_env.py:721)
+        w = torch.rand(T, N, generator=g) < 0.01
+        a = torch.where(w, torch.randint(-3, 200, (T, N), generator=g), a)
+    return a.cuda()
+
+
+@pytest.mark.parametrize("track,n", FAST_CONFIGS)
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("N", [1, 33, 257, 4099])
+def test_table_driven_step_is_bitwise_the_generic_step(track, n, dtype, N):
+    T = 160
+    acts = _actions(T, N, 1000 * n + N)
+    a, b = _env(N, TRACKS[track], n, dtype, 1), _env(N, TRACKS[track], n, dtype, 2)
+    oa, _ = a.reset()
+    ob, _ = b.reset()
+    assert torch.equal(oa, ob)
+    n_done = 0
+    for t in range(T):
+        ra, rb = a.step(acts[t]), b.step(acts[t])
+        for x, y, what in zip(ra[:4], rb[:4], ("obs", "reward", "terminated", "truncated")):
+            assert torch.equal(x, y), (t, what, int((x != y).sum()))
+        n_done += int(ra[2].sum())
+    assert a.last_step_kernel() == "K1" and b.last_step_kernel() == "K1f"
+    sa, sb = a.get_state(), b.get_state()
+    for k in STATE:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert n_done > 0 or N == 1        # episodes ended and restarted inside the run
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("track,n", FAST_CONFIGS)
+@pytest.mark.parametrize("grp", ["long", "short"])
+def test_table_driven_step_reproduces_the_reference_goldens_f64(track, n, grp):
+    """The reference's own transitions (tests/golden/env_*.npz, recorded from car_env.py), teacher-forced through K1f on an F64 handle:
+    returned observation, scaled reward, flags and the float64 state afterwards, bit for bit."""
+    g = np.load(f"{GOLDEN}/env_{track}_n{n}.npz")
+    T, N = g[f"{grp}_action"].shape
+    M = T * N
+    env = _env(M, TRACKS[track], n, "f64", 2, rs=float(g["reward_scaling"]))
+    env.reset()
+    env.set_state(**{k: g[f"{grp}_pre_{k}"].reshape(-1) for k in STATE})
+    obs, rew, term, trunc, _ = env.step(torch.from_numpy(g[f"{grp}_action"].reshape(-1)).cuda())
+    torch.cuda.synchronize()
+    assert env.last_step_kernel() == "K1f"
+    done = g[f"{grp}_terminated"].reshape(-1) | g[f"{grp}_truncated"].reshape(-1)
+    assert np.array_equal(obs.cpu().numpy(), g[f"{grp}_ret_obs"].reshape(M, -1))
+    assert np.array_equal(rew.cpu().numpy(), g[f"{grp}_reward_scaled"].reshape(-1).astype(np.float32))
+    assert np.array_equal(term.cpu().numpy() != 0, g[f"{grp}_terminated"].reshape(-1))
+    assert np.array_equal(trunc.cpu().numpy() != 0, g[f"{grp}_truncated"].reshape(-1))
+    st = env.get_state()
+    for k in STATE:
+        assert np.array_equal(st[k][~done], g[f"{grp}_post_{k}"].reshape(-1)[~done]), k
+    assert np.all(st["time_step"][done] == 0) and np.all(st["px"][done] == g["reset_state"][0])
+    env.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("N,form,kernel", [(9000, 0, "K1f-table"), (4099, 2, "K1f-table"), (4099, 0, "K1"), (300, 1, "K1")])
+def test_step_many_is_T_steps(dtype, N, form, kernel):
+    """pc_env_step_many == T x pc_env_step: one launch where the handle has the table-driven form (automatic from 8192 envs on, with the
+    1/den table staged for T > 1), T launches of K1 otherwise -- the same rows and the same state either way."""
+    T, n = 96, 16
+    acts = _actions(T, N, 7 + N)
+    a, b = _env(N, TRACKS["big_track"], n, dtype, 1), _env(N, TRACKS["big_track"], n, dtype, form)
+    a.reset()
+    b.reset()
+    rows = [a.step(acts[t])[:4] for t in range(T)]
+    many = b.step_many(acts)
+    assert b.last_step_kernel() == kernel
+    for i, what in enumerate(("obs", "reward", "terminated", "truncated")):
+        want = torch.stack([r[i] for r in rows])
+        assert many[i].shape == want.shape and torch.equal(many[i], want), what
+    sa, sb = a.get_state(), b.get_state()
+    for k in STATE:
+        assert np.array_equal(sa[k], sb[k]), k
+    # ... and on from there: the state the launch left is a state the per-step kernel continues from
+    more = _actions(8, N, 99, wild=False)
+    for t in range(8):
+        ra, rb = a.step(more[t]), b.step(more[t])
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1])
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_mixed_tracks_in_blocks_take_the_table_driven_step_interleaved_ones_do_not(dtype):
+    N, n, T = 1024, 16, 64
+    tracks = [TRACKS["track"], TRACKS["big_track"]]
+    acts = _actions(T, N, 5)
+    halves = (np.arange(N) >= N // 2).astype(np.uint8)
+    inter = (np.arange(N) & 1).astype(np.uint8)
+    for tid, kernel in ((halves, "K1f-table"), (inter, "K1")):
+        a, b = _env(N, tracks, n, dtype, 1, track_id=tid), _env(N, tracks, n, dtype, 2, track_id=tid)
+        a.reset()
+        b.reset()
+        rows = [a.step(acts[t])[:4] for t in range(T)]
+        many = b.step_many(acts)
+        assert b.last_step_kernel() == kernel
+        for i in range(4):
+            assert torch.equal(many[i], torch.stack([r[i] for r in rows])), i
+        for k in STATE:
+            assert np.array_equal(a.get_state()[k], b.get_state()[k]), k
+        a.close()
+        b.close()
+
+
+def test_shapes_without_a_table_driven_form_take_the_generic_kernel():
+    """17 nominal rays (18 actual), a track of 128 walls (oval64), and a step that asks for gates_passed / final_obs: K1, same API."""
+    for kw, trk in ((dict(num_rays=17), "big_track"), (dict(num_rays=16), "oval64")):
+        e = pc.VecCarEnv(512, TRACKS[trk], reward_scaling=0.1, **kw)
+        e.set_option("step_form", 2)
+        e.reset()
+        e.step(torch.zeros(512, dtype=torch.int64, device="cuda"))
+        assert e.last_step_kernel() == "K1", (kw, trk)
+        out = e.step_many(torch.zeros(3, 512, dtype=torch.int64, device="cuda"))
+        assert e.last_step_kernel() == "K1" and out[0].shape == (3, 512, e.obs_dim)
+        e.close()
+    e = pc.VecCarEnv(512, TRACKS["big_track"], num_rays=16, reward_scaling=0.1)
+    e.set_option("step_form", 2)
+    e.reset()
+    e.step(torch.zeros(512, dtype=torch.int64, device="cuda"))
+    assert e.last_step_kernel() == "K1f"
+    e.step(torch.zeros(512, dtype=torch.int64, device="cuda"), gates_passed=torch.empty(512, dtype=torch.int32, device="cuda"))
+    assert e.last_step_kernel() == "K1"
+    assert e.get_option("step_form") == 2
+    e.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_trained_policy_rollout_replayed_through_step_many(dtype):
+    """Laps, time limits and ~100 turns of heading inside K1f: the actions a TRAINED policy drew in a 2048-step persistent rollout
+    (tests/golden/policy_trained.npz: ~3 laps per episode), replayed from reset through pc_env_step_many, reproduce that rollout's
+    observation / reward / flag rows and its final env state bit for bit."""
+    from ppo_car_amd.ppo import PPOConfig, Trainer
+    from oracle.scenarios import load_trained_policy
+    N, T = 16384, 2048
+    tr = Trainer(PPOConfig(n_envs=N, n_steps=T, num_rays=16, track=TRACKS["big_track"], rollout_kernel="mega", use_graphs=False, seed=31,
+                           env_dtype=dtype), device="cuda")
+    load_trained_policy(tr.agent)
+    tr.rollout()
+    torch.cuda.synchronize()
+    b = tr.buffer
+    rew = b.rew_buf.clone()
+    assert float(rew.max()) > 1.05 and float(b.trunc_buf.sum()) > 0           # laps (+1 +10, scaled 0.1) and time limits happened
+    env = _env(N, TRACKS["big_track"], 16, dtype, 0)
+    env.reset()
+    obs, r, te, tc = env.step_many(b.act_buf.to(torch.int64))
+    assert env.last_step_kernel() == "K1f-table"
+    assert torch.equal(obs[:-1], b.obs_buf[1:]) and torch.equal(obs[-1], tr.next_obs)
+    assert torch.equal(r, rew)
+    assert torch.equal(te[:-1], b.term_buf[1:]) and torch.equal(te[-1], tr.next_term)
+    assert torch.equal(tc[:-1], b.trunc_buf[1:]) and torch.equal(tc[-1], tr.next_trunc)
+    sa, sb = tr.envs.get_state(), env.get_state()
+    for k in STATE:
+        assert np.array_equal(sa[k], sb[k]), k
+    env.close()
+    tr.close()
