@@ -523,23 +523,62 @@ def main():
 
     cfg, tr = make_trainer()
     tr.profile_stride = 0
-    # K1 probe: a second env batch of the same size and launch geometry.  When the rollout runs as a replayed HIP
-    # graph its kernels cannot be bracketed one by one, so inside the timed region (same stream) this twin is
-    # stepped PROBE times back to back between two events with the trainer's latest actions.
+    # Env-step probe (SURVEY 8(d)'s level (i): the env alone), after the timed epochs and outside them: a second env batch of the same
+    # size is given the trainer's env STATE as the timed epochs left it (cars spread over the track by the current policy -- a batch
+    # fresh from reset has every car at the start line, where no ray takes the rare paths, and flatters a single step by 2x) and the
+    # ACTIONS the last rollout stored; timed between HIP events on the launch stream: PROBE launches of pc_env_step as a user of the
+    # drop-in boundary gets them (the table-driven kernel K1f from 4096 envs on), the same with the generic kernel K1 forced, and
+    # pc_env_step_many over PROBE_T action rows (one launch).
     from ppo_car_amd.env import VecCarEnv
-    PROBE = 32
+    PROBE, PROBE_T = 32, 256
     probe = VecCarEnv(cfg.n_envs, os.path.join(ROOT, "tracks", "big_track.json"), num_rays=cfg.num_rays, reward_scaling=cfg.reward_scaling, device=dev, dtype=cfg.env_dtype)
     p_obs, _ = probe.reset()
     p_out = (p_obs, torch.empty(cfg.n_envs, device=dev), torch.empty(cfg.n_envs, device=dev), torch.empty(cfg.n_envs, device=dev))
-    probe_events = []
 
     def run_probe():
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(PROBE):
-            probe.step(tr.actions, out=p_out)
-        e1.record()
-        probe_events.append((e0, e1))
+        """-> {"step_us", "step_kernel", "generic_us", "many_us_per_step", "many_kernel", "state"}"""
+        res = {"state": "reset (mixed-track workload: the probe batch is big_track only)"}
+        Tn = min(PROBE_T, cfg.n_steps)
+        acts = tr.buffer.act_buf[:Tn].to(torch.int64).contiguous()          # what the policy drew in the last rollout
+        state = None
+        if not mixed:
+            torch.cuda.synchronize()
+            state = tr.envs.get_state()
+            res["state"] = "the trainer's env state after the timed epochs"
+
+        def fresh():
+            probe.reset()
+            if state is not None:
+                probe.set_state(**state)
+
+        def span(fn, reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(reps):
+                fn(i)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / reps
+        for key, form in (("generic_us", 1), ("step_us", 0)):
+            probe.set_option("step_form", form)
+            best = None
+            for _ in range(3):
+                fresh()
+                us = span(lambda i: probe.step(acts[i % Tn], out=p_out), PROBE)
+                best = us if best is None else min(best, us)
+            res[key] = best
+            if form == 0:
+                res["step_kernel"] = probe.last_step_kernel()
+        outm = (torch.empty(Tn, cfg.n_envs, obs_dim_probe, device=dev), torch.empty(Tn, cfg.n_envs, device=dev),
+                torch.empty(Tn, cfg.n_envs, device=dev), torch.empty(Tn, cfg.n_envs, device=dev))
+        best = None
+        for _ in range(3):
+            fresh()
+            us = span(lambda i: probe.step_many(acts, out=outm), 1) / Tn
+            best = us if best is None else min(best, us)
+        res["many_us_per_step"], res["many_kernel"], res["many_T"] = best, probe.last_step_kernel(), Tn
+        return res
+    obs_dim_probe = probe.obs_dim
 
     def barrier():
         if dist is not None:
@@ -558,8 +597,6 @@ def main():
 
     for _ in range(max(args.warmup, 2 if cfg.use_graphs else 0)):   # graphs: 1 eager epoch, then capture, then replay
         tr.run_epoch(sync=False)
-    run_probe()
-    probe_events.clear()
     if args.eager_rollout:
         tr.profile_stride = args.event_stride
     tr.k1_events = []
@@ -568,8 +605,10 @@ def main():
     if tr.learner.collective and not tr.learner._can_capture_update():
         tr.learner.exchange_events = []      # HIP events around every eagerly enqueued exchange of the timed epochs (a captured one cannot be bracketed)
     dt = timed(tr, args.steps)
-    for _ in range(args.steps):          # the stand-alone K1 probe, outside the timed region (it is not part of the path)
-        run_probe()
+    try:                                 # the stand-alone env-step probe, outside the timed region (it is not part of the path)
+        probe_res = run_probe()
+    except Exception as ex:              # (the probe must never take the benchmark line down with it)
+        probe_res = {"error": repr(ex)}
     # the GAE scan alone (HBM-bound: 24 B per transition), outside the timed region
     gae_events = []
     tr.buffer.ptr = tr.buffer.capacity          # (Buffer.get() rewinds it; the rows of the last epoch are still there)
@@ -616,7 +655,7 @@ def main():
         every = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         replicas_equal = bool(all(torch.equal(every[0], t) for t in every[1:]))
-    k1_us = float(np.mean([a.elapsed_time(b) for a, b in probe_events]) * 1e3 / PROBE)
+    k1_us = probe_res.get("step_us")
     k1_bracketed_us = float(np.mean([a.elapsed_time(b) for a, b in tr.k1_events]) * 1e3) if tr.k1_events else None
     gae_us = float(np.median([a.elapsed_time(b) for a, b in gae_events]) * 1e3)
     probe.close()
@@ -712,10 +751,25 @@ def main():
         nr = cfg.num_rays
         per_step_bytes = step_bytes(obs_dim - 6)                           # algorithmic bytes per env step
         per_step_flops = step_flops(obs_dim - 6, wall_counts(track))       # ... and flops, for this batch's track(s)
-        k1 = {"kernel": "env_step_kernel (K1), stand-alone", "launch_us": k1_us, "achieved": per_step_bytes * cfg.n_envs / (k1_us * 1e-6) / 1e9,
-              "unit": "GB/s", "frac": per_step_bytes * cfg.n_envs / (k1_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-              "launch_us_method": f"{PROBE} back-to-back launches on an identical env batch between two HIP events on the launch stream, "
-                                  "after the timed epochs", "launch_us_bracketed_in_rollout": k1_bracketed_us}
+        step_names = {"K1": "env_step_kernel (K1: the generic per-step kernel)", "K1f": "env_steps_fast_kernel (K1f: the table-driven env step, one launch per step)",
+                      "K1f-table": "env_steps_fast_kernel (K1f, 1/den table staged: T steps in one launch)"}
+        if k1_us:
+            k1 = {"kernel": step_names.get(probe_res.get("step_kernel"), "?") + ", stand-alone (pc_env_step as the drop-in boundary launches it)", "launch_us": k1_us,
+                  "achieved": per_step_bytes * cfg.n_envs / (k1_us * 1e-6) / 1e9, "unit": "GB/s", "frac": per_step_bytes * cfg.n_envs / (k1_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                  "valu_frac": per_step_flops * cfg.n_envs / (k1_us * 1e-6) / 1e12 / VALU_PEAK_TFLOPS, "env_steps_per_s": cfg.n_envs / (k1_us * 1e-6),
+                  "generic_kernel_launch_us": probe_res.get("generic_us"), "state": probe_res.get("state"),
+                  "launch_us_method": f"{PROBE} back-to-back launches (the last rollout's action rows) between two HIP events on the launch stream, best of 3, after the timed epochs",
+                  "launch_us_bracketed_in_rollout": k1_bracketed_us}
+        else:
+            k1 = {"error": probe_res.get("error", "no probe")}
+        env_only = None
+        if probe_res.get("many_us_per_step"):
+            mu = probe_res["many_us_per_step"]
+            env_only = {"kernel": step_names.get(probe_res.get("many_kernel"), "?") + " -- pc_env_step_many: the env alone under pre-generated actions (SURVEY 8(d) level (i))",
+                        "us_per_step": mu, "steps_per_launch": probe_res.get("many_T"), "value": cfg.n_envs / (mu * 1e-6), "unit": "env steps/s",
+                        "valu_frac": per_step_flops * cfg.n_envs / (mu * 1e-6) / 1e12 / VALU_PEAK_TFLOPS,
+                        "hbm_frac": per_step_bytes * cfg.n_envs / (mu * 1e-6) / 1e9 / HBM_PEAK_GBS, "state": probe_res.get("state"),
+                        "method": "one launch between two HIP events on the launch stream, best of 3, after the timed epochs"}
         if mega_us is not None:
             # the timed region's dominant kernel is the persistent rollout kernel: ONE launch does n_steps env steps (+ policy steps)
             # for every env; algorithmic bytes = SURVEY's per-env-step figure x n_envs x n_steps
@@ -725,7 +779,7 @@ def main():
             dom_method = "HIP events on the launch stream around each pc_rollout launch inside the timed epochs"
             units = cfg.n_envs * cfg.n_steps
         else:
-            dom_us, algo_bytes, dom_name, dom_method, units = k1_us, per_step_bytes * cfg.n_envs, k1["kernel"], k1["launch_us_method"], cfg.n_envs
+            dom_us, algo_bytes, dom_name, dom_method, units = k1_us, per_step_bytes * cfg.n_envs, k1.get("kernel"), k1.get("launch_us_method"), cfg.n_envs
         sec = dom_us * 1e-6
         achieved = algo_bytes / sec / 1e9
         D, A = obs_dim, 9
@@ -746,7 +800,7 @@ def main():
                 "valu": {"achieved": per_step_flops * units / sec / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": per_step_flops * units / sec / 1e12 / VALU_PEAK_TFLOPS,
                          "counts": "SURVEY 8(d) env-step flops only"},
-                "k1_standalone": k1,
+                "k1_standalone": k1, "env_only": env_only,
                 "gae": {"kernel": "gae_kernel (K3)", "bound": "hbm", "launch_us": gae_us,
                         "achieved": GAE_BYTES * cfg.n_envs * cfg.n_steps / (gae_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": GAE_BYTES * cfg.n_envs * cfg.n_steps / (gae_us * 1e-6) / 1e9 / HBM_PEAK_GBS,

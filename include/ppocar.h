@@ -121,8 +121,9 @@ int pc_env_step_many(pc_env* e, const int64_t* actions, int64_t T, double reward
  *   PC_STEP_K1         env_step_kernel: any ray count 4..360, any track, per-env track ids; 2^k lanes per env chosen from the batch size
  *   PC_STEP_K1F        env_steps_fast_kernel: the table-driven env step of the persistent rollout kernel -- 12 / 16 / 32 nominal rays, the
  *                      track's gather tables staged in LDS per launch, 2 lanes per env, the chain-packed / unrolled selector sweep; F64
- *                      handles: its literal form (tracks inside the selector's limits, rotations on the rotation table).  Taken from
- *                      16384 envs on (pc_env_step without gates_passed / final_obs; pc_env_step_many from 8192), PC_OPT_STEP_FORM decides otherwise
+ *                      handles: its literal form (tracks inside the selector's limits, rotations on the rotation table).  Taken by
+ *                      pc_env_step from 4096 envs on when neither gates_passed nor final_obs is asked for, by pc_env_step_many at any
+ *                      batch size; PC_OPT_STEP_FORM decides otherwise
  *   PC_STEP_K1F_TABLE  the same with the track's 1/den table staged too (pc_env_step_many, T > 1, when it fits) */
 #define PC_STEP_NONE 0
 #define PC_STEP_K1 1
@@ -151,8 +152,8 @@ int pc_env_info(pc_env* e, int32_t* gates_passed, int32_t* time_passed, void* st
 #define PC_OPT_ROLLOUT_FORM 1
 #define PC_OPT_ROLLOUT_EPW 2
 #define PC_OPT_ROLLOUT_FAST 3
-/*   PC_OPT_STEP_FORM     pc_env_step / pc_env_step_many: 0 (default) automatic (PC_STEP_K1F from 16384 / 8192 envs on, where the handle has
- *                        it), 1 = always PC_STEP_K1, 2 = PC_STEP_K1F wherever the handle has it, at any batch size */
+/*   PC_OPT_STEP_FORM     pc_env_step / pc_env_step_many: 0 (default) automatic (see PC_STEP_K1F), 1 = always PC_STEP_K1, 2 = PC_STEP_K1F
+ *                        wherever the handle has it, at any batch size */
 #define PC_OPT_STEP_FORM 4
 int pc_env_set_option(pc_env* e, int option, int value);
 int pc_env_get_option(const pc_env* e, int option, int* value);

@@ -36,9 +36,6 @@ __device__ unsigned long long g_stamps_u[16];    // the minibatch kernel (K10), 
 //     global memory with 16-byte stores (three per lane instead of 23 scattered dword stores), and an env that finished its
 //     episode gets its reset observation in a rarely taken, wave-uniformly skipped fix-up.
 // ------------------------------------------------------------------------------------------
-#ifndef PC_AB_NOCOOP
-#define PC_AB_NOCOOP 0
-#endif
 constexpr int TAB_MAX_GATES = 128;  // reward gates of a track staged in LDS (32 bytes each)
 struct ActLut {          // one per action 0..15 (9..15: no-op, car_env.py:721), 32 bytes
     double thrust;       // acc = heading * thrust: +0.8 forward, -0.8 backward, 0 none (car_env.py:423-438)
@@ -1229,7 +1226,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 // one env step of the lanes active here, on the track (hh, ff): CarEnv.step, then gymnasium 0.29.1's same-step auto-reset
                 const auto step_on = [&](const TrackHdr& hh, const FastTabs& ff, const FastLane& fll, const int (&gg)[2]) {
                     // (COOP: the careful slots as whole-wave jobs -- every lane is active here; not in the two-track form, whose passes are exec-masked)
-                    const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3 || MODE == 5, LGE, 1, ((MODE == 5 || MODE == 6) ? 5 : (MODE >= 3 ? 7 : 0)), RPL != 17, LIT, MODE != 6 && !PC_AB_NOCOOP>(
+                    const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3 || MODE == 5, LGE, 1, ((MODE == 5 || MODE == 6) ? 5 : (MODE >= 3 ? 7 : 0)), RPL != 17, LIT, MODE != 6>(
                         p, hh, ff, fll, gg, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, 0, nullptr, true, nullptr, &hcar);
                     rsum += rw;
                     PC_STAMP(6)

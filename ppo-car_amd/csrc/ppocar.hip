@@ -133,10 +133,12 @@ struct RolloutOpts {
     int epw_override = 0; // 0 = automatic, 16 / 32 / 128 / 256 = force (test knob)
     int fast = 1;         // the fast modes (LDS tables behind LDS pointers) when the shape allows them (0: never; A/B knob)
     int nv28 = 1;         // kernels compiled for a padded wall chain of 28 vertices (big_track.json) when every track of the batch has one
-    int step_form = 0;    // pc_env_step / pc_env_step_many: 0 = automatic (the table-driven form K1f from PC_STEP_FAST_MIN_ENVS envs on, where the
-                          // shape has one), 1 = always the generic per-step kernel K1, 2 = K1f wherever the shape has one (any batch size)
+    int step_form = 0;    // pc_env_step / pc_env_step_many: 0 = automatic (pc_env_step: the table-driven form K1f from PC_STEP_FAST_MIN_ENVS envs
+                          // on, where the shape has one; pc_env_step_many: wherever the shape has one), 1 = always the generic per-step kernel
+                          // K1, 2 = K1f wherever the shape has one (any batch size)
 };
-constexpr int64_t PC_STEP_FAST_MIN_ENVS = 16384;   // below: K1's 4+ lanes per env fill the device better than K1f's workgroups of 256 envs
+constexpr int64_t PC_STEP_FAST_MIN_ENVS = 4096;   // below: K1's 16+ lanes per env fill the device better than K1f's workgroups of 128 envs
+                                                  // (tools/step_forms_probe.py: kernel time 11.5 against 13.9 us at 4096 envs, 19 against 35 at 65536)
 constexpr int kDefaultPolicyPrecision = 2;   // pc_policy_create(precision = -1): 0 = fp32-input MFMA; split forms on the 16-bit matrix cores (need D <= 40, A <= 9): 1 = bf16 x 3, 2 = fp16 x 2
 
 struct pc_env {
@@ -899,7 +901,7 @@ int pc_env_step_many(pc_env* e, const int64_t* actions, int64_t T, double reward
     {
         DeviceGuard guard(e->device);
         if (!guard.ok) return PC_ERR_NO_DEVICE;
-        if (e->opt.step_form != 1 && (e->opt.step_form == 2 || e->N >= PC_STEP_FAST_MIN_ENVS / 2)) {
+        if (e->opt.step_form != 1) {      // (one launch instead of T: worth it at any batch size)
             const int rc = steps_fast_launch(e, actions, T, reward_scale, obs, reward, terminated, truncated, T > 1, (hipStream_t)stream);
             if (rc != PC_ERR_UNSUPPORTED) return rc;
         }

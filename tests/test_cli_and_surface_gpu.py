@@ -380,6 +380,11 @@ def test_bench_default_line_carries_every_baseline_config_and_the_exact_dtype():
     assert d["config"]["rollout"] == "mega" and d["value"] > 1e9
     rf = d["roofline"]
     assert rf["bound"] == "valu" and 0.1 < rf["frac"] < 1.0 and rf["launch_us"] > 0 and rf["traffic"] is not None
+    # the env alone (SURVEY 8(d) level (i)), on the trainer's env state and the last rollout's actions: pc_env_step as the boundary launches
+    # it (the table-driven kernel at this batch size), the generic kernel beside it, and T steps in one launch
+    k1, eo = rf["k1_standalone"], rf["env_only"]
+    assert "K1f" in k1["kernel"] and 0 < k1["launch_us"] < k1["generic_kernel_launch_us"] and "trainer's env state" in k1["state"], k1
+    assert "K1f" in eo["kernel"] and 0 < eo["us_per_step"] < k1["launch_us"] and eo["value"] > d["value"] and 0 < eo["valu_frac"] < 1, eo
     assert d["parity_check"]["ok"] is True
     rb = d["parity_check"]["rare_branches"]      # the second leg: injected states + the trained policy, the same kernel
     assert rb["ok"] is True and rb["events_replayed"]["laps"] > 0 and rb["events_replayed"]["truncations"] > 0 and rb["events_replayed"]["terminated_at_time_limit"] > 0, rb

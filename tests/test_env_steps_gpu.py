@@ -88,10 +88,10 @@ def test_table_driven_step_reproduces_the_reference_goldens_f64(track, n, grp):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
-@pytest.mark.parametrize("N,form,kernel", [(9000, 0, "K1f-table"), (4099, 2, "K1f-table"), (4099, 0, "K1"), (300, 1, "K1")])
+@pytest.mark.parametrize("N,form,kernel", [(9000, 0, "K1f-table"), (24, 0, "K1f-table"), (4099, 2, "K1f-table"), (300, 1, "K1")])
 def test_step_many_is_T_steps(dtype, N, form, kernel):
-    """pc_env_step_many == T x pc_env_step: one launch where the handle has the table-driven form (automatic from 8192 envs on, with the
-    1/den table staged for T > 1), T launches of K1 otherwise -- the same rows and the same state either way."""
+    """pc_env_step_many == T x pc_env_step: one launch where the handle has the table-driven form (at any batch size, with the 1/den
+    table staged for T > 1), T launches of K1 otherwise -- the same rows and the same state either way."""
     T, n = 96, 16
     acts = _actions(T, N, 7 + N)
     a, b = _env(N, TRACKS["big_track"], n, dtype, 1), _env(N, TRACKS["big_track"], n, dtype, form)
@@ -135,6 +135,15 @@ def test_mixed_tracks_in_blocks_take_the_table_driven_step_interleaved_ones_do_n
             assert np.array_equal(a.get_state()[k], b.get_state()[k]), k
         a.close()
         b.close()
+
+
+def test_automatic_choice_of_the_step_kernel():
+    for N, kernel in ((4095, "K1"), (4096, "K1f")):
+        e = pc.VecCarEnv(N, TRACKS["big_track"], num_rays=16, reward_scaling=0.1)
+        e.reset()
+        e.step(torch.zeros(N, dtype=torch.int64, device="cuda"))
+        assert e.last_step_kernel() == kernel and e.get_option("step_form") == 0
+        e.close()
 
 
 def test_shapes_without_a_table_driven_form_take_the_generic_kernel():
