@@ -18,7 +18,8 @@ template <int RPL, int SWP, bool TAB, bool LIT>
 __global__ __launch_bounds__(512) void env_steps_fast_kernel(const EnvParams<float> p, const int64_t* __restrict__ actions, const int T,
                                                              const double reward_scale, float* __restrict__ obs,
                                                              float* __restrict__ reward, float* __restrict__ term_out,
-                                                             float* __restrict__ trunc_out, const int epw, const int vec_ok) {
+                                                             float* __restrict__ trunc_out, const int epw, const int vec_ok,
+                                                             int32_t* __restrict__ gates_passed, float* __restrict__ final_obs) {
     constexpr int DC = RPL == 6 ? 18 : (RPL == 9 ? 23 : 39);
     static_assert(RPL == 6 || RPL == 9 || RPL == 17, "12 / 17 / 33 rays on two lanes per env");
     static_assert(SWP == 0 || (SWP == 7 && RPL == 9), "the chain-packed sweep: 17 rays");
@@ -91,6 +92,18 @@ __global__ __launch_bounds__(512) void env_steps_fast_kernel(const EnvParams<flo
         float rw, tf, cf;
         const bool done = env_step_fast<RPL, TAB, 1, 1, SWP, true, LIT, true>(p, h0, ft, fl, gq, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave,
                                                                       0, nullptr, true, nullptr, &hcar);
+        // pc_env_step's optional outputs (T = 1 only: the host passes them to no other launch): the finished episode's gate count
+        // (info["gates_passed"] of CarEnv.step itself) and the observation CarEnv.step returned, before the same-step auto-reset
+        if (gates_passed != nullptr && g == 0 && e_valid) gates_passed[e_env] = st.passed;
+        if (final_obs != nullptr) {      // (uniform)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float* fo = final_obs + e_wave * DC;
+            const float* sl = sObs + pbase * DC;
+            for (int i = lane; i < n_rows * DC; i += 64) fo[i] = sl[i];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         if (__builtin_amdgcn_ballot_w64(done) != 0) {   // wave-uniform: a finished env gets its reset observation and CarEnv.reset's state
             if (done) {
                 float ro[(DC + 1) / 2];

@@ -255,10 +255,11 @@ static void launch_step(const pc_env* e, const int64_t* actions, double reward_s
 // the selector's limits with its rotation table, every env's rotation on it (the conditions of pc_rollout's literal kernels).
 // PC_ERR_UNSUPPORTED: no such form for this handle (the caller launches K1).  `table`: stage the 1/den table too (worth it for T > 1).
 static int steps_fast_launch(pc_env* e, const int64_t* actions, int64_t T, double reward_scale, float* obs, float* reward, float* term,
-                             float* trunc, bool table, hipStream_t st) {
+                             float* trunc, bool table, hipStream_t st, int32_t* gates_passed = nullptr, float* final_obs = nullptr) {
     const bool f64 = e->dtype == PC_DTYPE_F64;
     const bool rays12 = e->n_nominal == 12 && e->R == 12, rays16 = e->n_nominal == 16 && e->R == 17, rays32 = e->n_nominal == 32 && e->R == 33;
     if (!(rays12 || rays16 || rays32) || !e->opt.fast || T < 1 || T > INT_MAX) return PC_ERR_UNSUPPORTED;
+    if ((gates_passed || final_obs) && T != 1) return PC_ERR_INVALID_ARG;      // (the optional outputs are pc_env_step's)
     int max_G = 0, max_nV = 0;
     bool all_nv28 = e->opt.nv28 != 0, tabs = true, all_rden = true;
     for (const TrackHdr& h : e->hdr_host) {
@@ -285,7 +286,7 @@ static int steps_fast_launch(pc_env* e, const int64_t* actions, int64_t T, doubl
             if (e->device < 64) attr_set[e->device] = true;                                                                \
         }                                                                                                                \
         hipLaunchKernelGGL((env_steps_fast_kernel<RPLV, SWPV, TABV, LITV>), dim3(blocks), dim3(512), lds, st, prm, actions, (int)T, reward_scale, obs, \
-                           reward, term, trunc, epw, vec_ok);                                                            \
+                           reward, term, trunc, epw, vec_ok, gates_passed, final_obs);                                   \
     } while (0)
 #define PC_STEPS_T(RPLV, SWPV, LITV) do { if (tab) PC_STEPS(RPLV, SWPV, true, LITV); else PC_STEPS(RPLV, SWPV, false, LITV); } while (0)
     if (rays16 && all_nv28) { if (f64) PC_DEV(3, PC_STEPS_T(9, 7, true)); else PC_DEV(0, PC_STEPS_T(9, 7, false)); }
@@ -864,9 +865,9 @@ int pc_env_step(pc_env* e, const int64_t* actions, double reward_scale, float* o
     DeviceGuard guard(e->device);
     if (!guard.ok) return PC_ERR_NO_DEVICE;
     hipStream_t st = (hipStream_t)stream;
-    // the table-driven form (K1f) where the handle has one and nothing but the step's own outputs is asked for
-    if (!gates_passed && !final_obs && (e->opt.step_form == 2 || (e->opt.step_form == 0 && e->N >= PC_STEP_FAST_MIN_ENVS))) {
-        const int rc = steps_fast_launch(e, actions, 1, reward_scale, obs, reward, terminated, truncated, false, st);
+    // the table-driven form (K1f) where the handle has one
+    if (e->opt.step_form == 2 || (e->opt.step_form == 0 && e->N >= PC_STEP_FAST_MIN_ENVS)) {
+        const int rc = steps_fast_launch(e, actions, 1, reward_scale, obs, reward, terminated, truncated, false, st, gates_passed, final_obs);
         if (rc != PC_ERR_UNSUPPORTED) return rc;
     }
     e->last_step_kernel = PC_STEP_K1;

@@ -33,6 +33,16 @@ def _cuda(a, dtype=None):
     return t if dtype is None else t.to(dtype)
 
 
+FORMS = [1, 2]      # PC_OPT_STEP_FORM: the generic per-step kernel K1, the table-driven K1f (where the shape has it: else K1 again)
+
+
+def _form(env, form, track=None, n=None):
+    """Pin pc_env_step's kernel for this env; -> the kernel name its steps must report."""
+    env.set_option("step_form", form)
+    has_fast = n in (12, 16, 32) and track in (None, "big_track", "track")
+    return "K1f" if form == 2 and has_fast else "K1"
+
+
 def _step(env, actions, want_final=True):
     N, D = env.num_envs, env.obs_dim
     fin = torch.empty(N, D, device="cuda") if want_final else None
@@ -68,14 +78,17 @@ def test_reset_obs(track, n, dtype):
 
 @pytest.mark.parametrize("track,n", ENV_CONFIGS)
 @pytest.mark.parametrize("grp", ["long", "short"])
-def test_teacher_forced_f64_bit_exact(track, n, grp):
+@pytest.mark.parametrize("form", FORMS)
+def test_teacher_forced_f64_bit_exact(track, n, grp, form):
     g = _load(track, n)
     T, N = g[f"{grp}_action"].shape
     M = T * N
     env = pc.VecCarEnv(M, TRACKS[track], num_rays=n, reward_scaling=float(g["reward_scaling"]), dtype="f64")
+    kernel = _form(env, form, track, n)
     env.reset()
     env.set_state(**{k: g[f"{grp}_pre_{k}"].reshape(-1) for k in STATE})
     obs, rew, term, trunc, fin, gp = _step(env, g[f"{grp}_action"].reshape(-1))
+    assert env.last_step_kernel() == kernel
     done = g[f"{grp}_terminated"].reshape(-1) | g[f"{grp}_truncated"].reshape(-1)
     assert np.array_equal(fin, g[f"{grp}_step_obs"].reshape(M, -1))            # CarEnv.step's own obs
     assert np.array_equal(obs, g[f"{grp}_ret_obs"].reshape(M, -1))             # after same-step auto-reset
@@ -95,14 +108,17 @@ def test_teacher_forced_f64_bit_exact(track, n, grp):
 
 @pytest.mark.parametrize("track,n", ENV_CONFIGS)
 @pytest.mark.parametrize("grp", ["long", "short"])
-def test_teacher_forced_f32(track, n, grp):
+@pytest.mark.parametrize("form", FORMS)
+def test_teacher_forced_f32(track, n, grp, form):
     g = _load(track, n)
     T, N = g[f"{grp}_action"].shape
     M = T * N
     env = pc.VecCarEnv(M, TRACKS[track], num_rays=n, reward_scaling=float(g["reward_scaling"]), dtype="f32")
+    kernel = _form(env, form, track, n)
     env.reset()
     env.set_state(**{k: g[f"{grp}_pre_{k}"].reshape(-1) for k in STATE})
     obs, rew, term, trunc, fin, gp = _step(env, g[f"{grp}_action"].reshape(-1))
+    assert env.last_step_kernel() == kernel
     assert np.abs(fin - g[f"{grp}_step_obs"].reshape(M, -1)).max() <= OBS_TOL_F32
     # the six header entries (car_env.py:578-584: position, velocity, heading cos / sin) come from the float64 state.  The F32
     # mode forms them as `v * (1 / d)` in float64 and reads the heading from a table of start_rot + 5 k (the reference's rot is
@@ -136,13 +152,15 @@ def test_teacher_forced_f32(track, n, grp):
 
 @pytest.mark.parametrize("track,n", [("big_track", 16), ("big_track", 12), ("track", 32)])
 @pytest.mark.parametrize("grp", ["long", "short"])
-def test_free_running_f64_reproduces_reference_trajectories(track, n, grp):
+@pytest.mark.parametrize("form", FORMS)
+def test_free_running_f64_reproduces_reference_trajectories(track, n, grp, form):
     """Replay the recorded action streams from reset through the vector-env call: every step of every
     episode (crashes, gates, a full lap, the 1000-step truncation, auto-resets) must match the reference."""
     g = _load(track, n)
     act = g[f"{grp}_action"]
     T, N = act.shape
     env = pc.VecCarEnv(N, TRACKS[track], num_rays=n, reward_scaling=float(g["reward_scaling"]), dtype="f64")
+    kernel = _form(env, form, track, n)
     env.reset()
     acts = _cuda(act)
     O = torch.empty(T, N, env.obs_dim, device="cuda")
@@ -151,6 +169,7 @@ def test_free_running_f64_reproduces_reference_trajectories(track, n, grp):
     for t in range(T):
         env.step(acts[t], out=(O[t], R[t], TE[t], TR[t]), final_obs=F[t])
     torch.cuda.synchronize()
+    assert env.last_step_kernel() == kernel
     assert np.array_equal(O.cpu().numpy(), g[f"{grp}_ret_obs"])
     assert np.array_equal(F.cpu().numpy(), g[f"{grp}_step_obs"])
     assert np.array_equal(R.cpu().numpy(), g[f"{grp}_reward_scaled"].astype(np.float32))
@@ -243,7 +262,8 @@ def test_full_size_f64_vs_oracle_and_replication():
 
 
 @pytest.mark.parametrize("n", [12, 16, 32])
-def test_f32_teacher_forced_from_oracle_states(n):
+@pytest.mark.parametrize("form", FORMS)
+def test_f32_teacher_forced_from_oracle_states(n, form):
     """F32 kernel, state re-injected from the float64 oracle at EVERY step of a long seeded rollout: observations within one
     float32 ulp, events and rewards equal."""
     T, N = 300, 512
@@ -252,6 +272,7 @@ def test_f32_teacher_forced_from_oracle_states(n):
     ora = oracle.OracleVecEnv(oracle.Track(TRACKS["big_track"]), N, num_rays=n, reward_scaling=0.1, threads=8)
     ora.reset()
     env = pc.VecCarEnv(N, TRACKS["big_track"], num_rays=n, reward_scaling=0.1, dtype="f32")
+    kernel = _form(env, form, "big_track", n)
     env.reset()
     q = n // 4
     n_ev = n_mis = 0
@@ -266,7 +287,7 @@ def test_f32_teacher_forced_from_oracle_states(n):
         assert not (bad & (wall_margin > MARGIN_PX)).any()
         n_ev += int(TE.sum())
         n_mis += int(bad.sum()) + int(((r != R.astype(np.float32)) & ~bad).sum())
-    assert worst <= OBS_TOL_F32
+    assert worst <= OBS_TOL_F32 and env.last_step_kernel() == kernel
     assert n_ev > 500 and n_mis == 0
 
 

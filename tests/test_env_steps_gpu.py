@@ -147,7 +147,7 @@ def test_automatic_choice_of_the_step_kernel():
 
 
 def test_shapes_without_a_table_driven_form_take_the_generic_kernel():
-    """17 nominal rays (18 actual), a track of 128 walls (oval64), and a step that asks for gates_passed / final_obs: K1, same API."""
+    """17 nominal rays (18 actual), a track of 128 walls (oval64): K1, same API."""
     for kw, trk in ((dict(num_rays=17), "big_track"), (dict(num_rays=16), "oval64")):
         e = pc.VecCarEnv(512, TRACKS[trk], reward_scaling=0.1, **kw)
         e.set_option("step_form", 2)
@@ -162,8 +162,9 @@ def test_shapes_without_a_table_driven_form_take_the_generic_kernel():
     e.reset()
     e.step(torch.zeros(512, dtype=torch.int64, device="cuda"))
     assert e.last_step_kernel() == "K1f"
-    e.step(torch.zeros(512, dtype=torch.int64, device="cuda"), gates_passed=torch.empty(512, dtype=torch.int32, device="cuda"))
-    assert e.last_step_kernel() == "K1"
+    e.step(torch.zeros(512, dtype=torch.int64, device="cuda"), gates_passed=torch.empty(512, dtype=torch.int32, device="cuda"),
+           final_obs=torch.empty(512, e.obs_dim, device="cuda"))
+    assert e.last_step_kernel() == "K1f"       # (the optional outputs are K1f's as well: test_env_gpu.py's goldens run through both kernels)
     assert e.get_option("step_form") == 2
     e.close()
 
