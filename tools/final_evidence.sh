@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer tool (GPU box): the round's closing evidence in one call -- the full -m gpu suite, the default bench line, rocprofv3 --stats of the
-# bench command (target / cfg1 / cfg2), the PMC passes of the target and configs[1] kernels, the shipped kernels' soak against the per-step kernels.
+# bench command (target / cfg1 / cfg2), the PMC passes of the target and configs[1] kernels, the shipped kernels' soak against the per-step kernels, K1f's soak against K1, the step-kernel probe.
 # Output under gpurun_out/<tag>/ (copy what is cited into profiles/).   usage: tools/final_evidence.sh <tag> [skip-tests]
 TAG=${1:-r6}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -31,4 +31,6 @@ python tools/pmc_summary.py gpurun_out/$TAG/k9s/pmc ${TAG}_k9s_raw 4096 16 f32 r
 S="python tools/soak_rollout.py . --out $O/soak_shipped.jsonl"
 $S --launches 110 --rays 16 --n-steps 1024 > /dev/null 2>&1 && $S --launches 400 --rays 16 --n-envs 4096 --n-steps 1024 > /dev/null 2>&1 && $S --launches 600 --rays 32 > /dev/null 2>&1 && \
   $S --launches 150 --rays 16 --n-envs 32768 --n-steps 1024 --mixed > /dev/null 2>&1 && $S --launches 600 --rays 16 --dtype f64 > /dev/null 2>&1
+python tools/soak_steps.py --launches 20 --out $O/soak_shipped.jsonl > /dev/null 2>&1 && python tools/soak_steps.py --launches 20 --dtype f64 --out $O/soak_shipped.jsonl > /dev/null 2>&1
+python tools/step_forms_probe.py 16 2> /dev/null | grep -v amdgpu.ids > $O/step_forms_probe.txt
 cut -c1-260 $O/soak_shipped.jsonl
