@@ -693,9 +693,11 @@ class Trainer:
         for name, default in (("rollout_form", -1), ("rollout_epw", 0), ("rollout_fast", 1)):
             if int(getattr(cfg, name)) != default:
                 self.envs.set_option(name, int(getattr(cfg, name)))
-        # the per-step rollout (rollout_kernel="steps", and what pc_rollout's refusals fall back to) runs the GENERIC env-step kernel K1: it is
-        # the independent implementation the persistent kernels -- and K1f, which shares their env step -- are compared with bit for bit
-        self.envs.set_option("step_form", 1)
+        # rollout_kernel="steps" (asked for by name: the tests' reference path) runs the GENERIC env-step kernel K1 -- the independent
+        # implementation the persistent kernels, and K1f, which shares their env step, are compared with bit for bit.  The per-step rollout
+        # that "auto" / "mega" fall back to (a torch policy, a shape pc_rollout refuses) takes pc_env_step's automatic choice.
+        if cfg.rollout_kernel == "steps":
+            self.envs.set_option("step_form", 1)
         self.learner = PPOLearner(self.agent, cfg, self.device, rank, world_size)
         self.optimizer, self.scheduler = self.learner.optimizer, self.learner.scheduler
         self.buffer = Buffer(self.obs_dim, cfg.n_steps, cfg.n_envs, self.device, cfg.gamma, cfg.gae_lambda)   # :152
