@@ -198,3 +198,15 @@ def test_trained_policy_rollout_replayed_through_step_many(dtype):
         assert np.array_equal(sa[k], sb[k]), k
     env.close()
     tr.close()
+
+
+def test_env_only_example_runs_and_reports_identical_rows():
+    """examples/env_only.py: the env alone step by step and as one call, compared inside the script."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "env_only.py"), "--n-envs", "8192", "--n-steps", "64"], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "identical rows: True" in out.stdout and "(K1f)" in out.stdout and "(K1f-table)" in out.stdout, out.stdout
