@@ -546,16 +546,17 @@ def test_f32_t_junction_and_crossing_walls_match_the_oracle(tmp_path, n):
         env.close()
 
 
-@pytest.mark.parametrize("n_envs", [2048, 20000])
-def test_f32_junction_track_through_the_persistent_rollout_kernel(tmp_path, n_envs):
-    """The same track through pc_rollout (small and big form: the flagged segments sit in the LDS copy of the chain) and the
-    per-step kernels: bitwise each other, and the oracle replayed on the stored actions."""
+@pytest.mark.parametrize("n_envs,epw", [(2048, 0), (2048, 32), (20000, 0)], ids=["2048", "2048-epw32", "20000"])
+def test_f32_junction_track_through_the_persistent_rollout_kernel(tmp_path, n_envs, epw):
+    """The same track through pc_rollout (small form with 16 and with 32 envs per workgroup, big form: the flagged segments sit in the
+    LDS copy of the chain; every ray that selects one of them is a careful job of the whole wave -- four of nine walls here) and the
+    per-step kernels (the per-lane careful path): bitwise each other, and the oracle replayed on the stored actions."""
     from ppo_car_amd.ppo import PPOConfig, Trainer
     from test_rollout_baseline_gpu import _oracle_replay_check, _snap, strided_population
     path = _junction_track_json(str(tmp_path / "junction.json"))
     res, first = {}, None
     for mode in ("mega", "steps"):
-        cfg = PPOConfig(n_envs=n_envs, n_steps=200, num_rays=16, track=path, rollout_kernel=mode, use_graphs=False, seed=19)
+        cfg = PPOConfig(n_envs=n_envs, n_steps=200, num_rays=16, track=path, rollout_kernel=mode, use_graphs=False, seed=19, rollout_epw=epw)
         tr = Trainer(cfg, device="cuda")
         if first is None:
             first = tr.next_obs.clone()

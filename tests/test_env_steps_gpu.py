@@ -137,6 +137,31 @@ def test_mixed_tracks_in_blocks_take_the_table_driven_step_interleaved_ones_do_n
         b.close()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_junction_track_careful_jobs_match_the_generic_kernel(tmp_path, dtype):
+    """A track with a T-junction and crossing walls (4 of 9 walls marked for the float64 scan): every ray that selects one of them is a
+    careful job of the whole wave in K1f and a per-lane chain scan in K1 -- the same rows, the same state."""
+    from test_env_gpu import _junction_track_json
+    import warnings
+    path = _junction_track_json(str(tmp_path / "junction.json"))
+    N, T = 3000, 200
+    acts = _actions(T, N, 3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        a, b = _env(N, path, 16, dtype, 1), _env(N, path, 16, dtype, 2)
+    a.reset()
+    b.reset()
+    rows = [a.step(acts[t])[:4] for t in range(T)]
+    many = b.step_many(acts)
+    assert a.last_step_kernel() == "K1" and b.last_step_kernel().startswith("K1f")
+    for i in range(4):
+        assert torch.equal(many[i], torch.stack([r[i] for r in rows])), i
+    for k in STATE:
+        assert np.array_equal(a.get_state()[k], b.get_state()[k]), k
+    a.close()
+    b.close()
+
+
 def test_automatic_choice_of_the_step_kernel():
     for N, kernel in ((4095, "K1"), (4096, "K1f")):
         e = pc.VecCarEnv(N, TRACKS["big_track"], num_rays=16, reward_scaling=0.1)
