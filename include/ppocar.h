@@ -147,7 +147,9 @@ int pc_env_info(pc_env* e, int32_t* gates_passed, int32_t* time_passed, void* st
  *                        behind LDS pointers -- at 16 (17) rays in the kernels compiled for the chain layout of the reference's tracks
  *                        when every track of the batch has it; 2 = that mode but never those specialised kernels; 0 = always the
  *                        generic mode (what mixed-track batches whose workgroups straddle tracks take).  F64 handles: 1 / 2 = the
- *                        selector form (with / without the specialised sweeps), 0 = the filter form */
+ *                        selector form (with / without the specialised sweeps), 0 = the filter form.  3 = as 1, but two tracks interleaved
+ *                        in evenly split blocks keep the per-track passes inside every wave instead of being de-interleaved by wave
+ *                        (what unevenly interleaved batches take anyway; a test / timing knob) */
 #define PC_OPT_ROLLOUT_FORM 1
 #define PC_OPT_ROLLOUT_EPW 2
 #define PC_OPT_ROLLOUT_FAST 3

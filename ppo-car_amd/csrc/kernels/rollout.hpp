@@ -992,7 +992,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     // fast modes keep the 1/den table: the sweep forms 1 / den itself), and the env step runs once per track present in the wave, each
     // pass with that track's header and tables -- wave-uniform, as in every fast mode.
     constexpr int TS6 = (ft_floats(false, RPL != 17) + 3) & ~3;
-    if constexpr (MODE == 6) {
+    if constexpr (MODE == 6 || MODE == 7) {
         ft = stage_fast_tables<false, RPL != 17, LIT>(p, cload(p.hdr), 0, sTab, tid, 512);
         (void)stage_fast_tables<false, RPL != 17, LIT>(p, cload(p.hdr + 1), 1, sTab + TS6, tid, 512);
     } else if constexpr (FAST) ft = stage_fast_tables<false, RPL != 17, LIT>(p, h0, trk_wg, sTab, tid, 512);
@@ -1024,8 +1024,25 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     // epw = envs per workgroup: 256 (all 8 waves) or 128 (waves 4..7 only help to stage LDS and leave: at <= 32768 envs
     // that doubles the workgroups, one wave per SIMD on all 256 CUs instead of two on half of them)
     const int64_t e_wave = (int64_t)blockIdx.x * epw + pbase;      // first env of this wave
-    const int64_t e_env = e_wave + (lane >> LGE);
-    const bool e_valid = e_env < N;
+    // MODE 7: two tracks interleaved env by env with every aligned block of 2 x EPWV envs split evenly (the host checked; `i & 1` is the
+    // plainest case): the block's two waves DE-INTERLEAVE it -- wave 2k takes its track-0 envs, wave 2k + 1 its track-1 envs, slot s the
+    // s-th of them -- so that every wave steps ONE track: one pass of the table-driven step with that track's header and tables, careful
+    // rays as whole-wave jobs, where mode 6 runs a pass per track with the other track's lanes masked off.  Only the addresses change:
+    // an env's rows, state and Philox counter are the env's (same bits as every other form); the observation rows leave by row.
+    const int wtrk = MODE == 7 ? (wave & 1) : 0;
+    const int64_t e_block = (int64_t)blockIdx.x * epw + (wave >> 1) * (2 * EPWV);
+    int lj = lane >> LGE;      // MODE 7: this lane's env inside the block
+    if constexpr (MODE == 7) {
+        const int64_t ei = e_block + lane;
+        const bool is1 = lane < 2 * EPWV && ei < N && p.track_id[ei] != 0;
+        const bool is0 = lane < 2 * EPWV && ei < N && p.track_id[ei] == 0;
+        uint64_t m = wtrk ? __builtin_amdgcn_ballot_w64(is1) : __builtin_amdgcn_ballot_w64(is0);
+        for (int k = lane >> LGE; k > 0; --k) m &= m - 1;      // drop the slot's predecessors (once per launch)
+        lj = m ? __builtin_ctzll(m) : 2 * EPWV;                // (an unbalanced tail cannot happen: the host's check)
+        if ((lane & (GE - 1)) == 0) sAct[pbase + (lane >> LGE)] = lj;
+    }
+    const int64_t e_env = MODE == 7 ? e_block + lj : e_wave + (lane >> LGE);
+    const bool e_valid = e_env < N && (MODE != 7 || lj < 2 * EPWV);
     using StateT = std::conditional_t<LIT, double, float>;
     const EnvParams<StateT> ps = p.template as<StateT>();
     EnvRegs st = {};
@@ -1049,13 +1066,21 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
         gq[0] = (int)(size_t)ft.dir + 16 * g * p.q * p.step_deg;            // Car.get_passed_gate's rays j * (n // 4), j = g and (two lanes per env) g + 2,
         gq[1] = (int)(size_t)ft.dir + 16 * (g + 2) * p.q * p.step_deg;      // as byte addresses into the direction table
         k72 = Math<float>::mod72(st.k);
+        if constexpr (MODE == 7) {      // the wave's track: its block of tables, TS6 floats behind track 0's
+            const int by = 4 * TS6 * wtrk;
+            fl.rs0 += by;
+            fl.rs_last += by;
+            gq[0] += by;
+            gq[1] += by;
+        }
     }
+    const TrackHdr hw = MODE == 7 ? cload(p.hdr + wtrk) : h0;      // MODE 7: the wave's own track
     f64x2 hcar = {1.0, 0.0};      // LIT: (cos, sin) of the env's current rotation (row st.k of the rotation table)
-    const int rot_off_l = (LIT && MODE == 6) ? (trk ? cload(p.hdr + 1).rot_off : cload(p.hdr).rot_off) : h0.rot_off;     // the lane's track's rotation table
+    const int rot_off_l = (LIT && MODE == 6) ? (trk ? cload(p.hdr + 1).rot_off : cload(p.hdr).rot_off) : hw.rot_off;     // the lane's track's rotation table
     if constexpr (LIT) {
         // the lattice index of the heading: rot = start_rot after k turns of +-5.0 (each sum rounded; the quotient is within 1e-10 of k)
         // (MODE 6: the lane's own track -- two tracks -- not the workgroup's)
-        const double start_rot_l = MODE == 6 ? (trk ? cload(p.hdr + 1).start_rot : cload(p.hdr).start_rot) : h0.start_rot;
+        const double start_rot_l = MODE == 6 ? (trk ? cload(p.hdr + 1).start_rot : cload(p.hdr).start_rot) : hw.start_rot;
         k72 = Math<float>::mod72((int)__builtin_rint((st.rot - start_rot_l) / 5.0));
         if (e_valid) {
             const double2 e0 = p.dirtab64[rot_off_l + st.k * (p.R + 2)];
@@ -1084,7 +1109,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
     // base + (t N + e) formed from kernel-argument SGPRs the kernel does not have (spilled to vector lanes: a v_readlane pair per use;
     // rollout_small_kernel: -4 % of its launch; here -1 %, profiles/r6_ab_k9_ptrs.log).  Twelve more registers: the 12- and 17-ray kernels
     // have them (the target kernel: 238 -> 252 VGPRs, 57 -> 40 spilled SGPRs), the 33-ray kernels do not.
-    constexpr bool PTRS = FAST && RPL <= 9 && MODE != 6;      // (the two-track form spends its registers on the second pass's header)
+    constexpr bool PTRS = FAST && RPL <= 9 && MODE != 6 && MODE != 7;      // (the two-track form spends its registers on the second pass's header; mode 7 addresses by env)
     float* pa_act = act_buf + e_env;
     float* pa_lp = logprob_buf + e_env;
     float* pa_val = val_buf + e_env;
@@ -1226,7 +1251,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 // one env step of the lanes active here, on the track (hh, ff): CarEnv.step, then gymnasium 0.29.1's same-step auto-reset
                 const auto step_on = [&](const TrackHdr& hh, const FastTabs& ff, const FastLane& fll, const int (&gg)[2]) {
                     // (COOP: the careful slots as whole-wave jobs -- every lane is active here; not in the two-track form, whose passes are exec-masked)
-                    const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3 || MODE == 5, LGE, 1, ((MODE == 5 || MODE == 6) ? 5 : (MODE >= 3 ? 7 : 0)), RPL != 17, LIT, MODE != 6>(
+                    const bool done = env_step_fast<RPL, MODE == 2 || MODE == 3 || MODE == 5, LGE, 1, ((MODE == 5 || MODE == 6 || MODE == 7) ? 5 : (MODE >= 3 ? 7 : 0)), RPL != 17, LIT, MODE != 6>(
                         p, hh, ff, fll, gg, g, st, k72, a, reward_scale, lrow, rw, tf, cf, t, lane, wave, 0, nullptr, true, nullptr, &hcar);
                     rsum += rw;
                     PC_STAMP(6)
@@ -1265,6 +1290,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                         }
                         todo &= ~__builtin_amdgcn_ballot_w64(match);
                     } while (todo);
+                } else if constexpr (MODE == 7) {
+                    step_on(hw, ft_shift(ft, TS6 * wtrk), fl, gq);
                 } else {
                     step_on(h0, ft, fl, gq);
                 }
@@ -1294,6 +1321,18 @@ __global__ __launch_bounds__(512) void rollout_kernel(const EnvParams<float> p, 
                 const int n_rows = left >= EPWV ? EPWV : (int)left;
                 const float* srcl = sObs + pbase * LDX;
                 if constexpr (PC_ABLATE & 256) {
+                } else if constexpr (MODE == 7) {
+                    // the wave's rows -> rows e_block + lj(slot) of the buffer (the slots' envs: sAct, written at the kernel's start)
+                    float* bg = (last ? next_obs : obs_buf + (int64_t)(t + 1) * N * D) + e_block * D;
+#pragma unroll
+                    for (int j = 0; j < (EPWV * DC + 63) / 64; ++j) {
+                        const int i = lane + 64 * j;
+                        if (64 * j + 63 < EPWV * DC || i < EPWV * DC) {
+                            const int r = i / DC, c = i - r * DC;
+                            const int lr = sAct[pbase + r];
+                            if (e_block + lr < N && lr < 2 * EPWV) bg[lr * DC + c] = srcl[i];
+                        }
+                    }
                 } else if (vec_ok && n_rows == EPWV) {
                     constexpr int NF4 = EPWV / 4 * DC;                  // the wave's rows as float4s: 8 D (32 envs: 3 or 5 stores per lane) or 4 D
 #pragma unroll

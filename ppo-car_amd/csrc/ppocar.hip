@@ -133,6 +133,7 @@ struct RolloutOpts {
     int epw_override = 0; // 0 = automatic, 16 / 32 / 128 / 256 = force (test knob)
     int fast = 1;         // the fast modes (LDS tables behind LDS pointers) when the shape allows them (0: never; A/B knob)
     int nv28 = 1;         // kernels compiled for a padded wall chain of 28 vertices (big_track.json) when every track of the batch has one
+    int deinterleave = 1; // two tracks interleaved in evenly split blocks: the block's two waves de-interleave it (0: the per-track passes; A/B and test knob)
     int step_form = 0;    // pc_env_step / pc_env_step_many: 0 = automatic (pc_env_step: the table-driven form K1f from PC_STEP_FAST_MIN_ENVS envs
                           // on, where the shape has one; pc_env_step_many: wherever the shape has one), 1 = always the generic per-step kernel
                           // K1, 2 = K1f wherever the shape has one (any batch size)
@@ -158,6 +159,8 @@ struct pc_env {
     bool mixed = false;            // a track_id array was given (known before the geometry is chosen)
     bool track_blocks32 = false;   // mixed tracks: every aligned block of 32 envs holds ONE track (what pc_rollout needs)
     int track_block = 0;           // ... the largest of 256 / 128 / 64 / 32 for which that holds (0: none)
+    bool track_bal64 = false, track_bal32 = false;   // two tracks, interleaved, every aligned block of 64 / 32 envs split evenly between them (and N a
+                                                     // multiple of the block): the block's two waves de-interleave it (rollout_kernel's mode 7)
     TrackHdr* hdr = nullptr;
     Seg* segs = nullptr;
     Vtx* vtx = nullptr;
@@ -717,6 +720,15 @@ static int env_create_impl(pc_env* e, const pc_track* const* tracks, const uint8
             if (ok) e->track_block = blk;
         }
         e->track_blocks32 = e->track_block >= 32;
+        for (int blk = 64; blk >= 32; blk >>= 1) {
+            bool ok = e->n_tracks == 2 && N % blk == 0;
+            for (size_t b = 0; b < N && ok; b += blk) {
+                int ones = 0;
+                for (int i = 0; i < blk; ++i) ones += track_id[b + i] == 1, ok = ok && track_id[b + i] < 2;
+                ok = ok && ones == blk / 2;
+            }
+            (blk == 64 ? e->track_bal64 : e->track_bal32) = ok;
+        }
         HIPCHK(hipMalloc((void**)&e->track_id, N));
         HIPCHK(hipMemcpy(e->track_id, track_id, N, hipMemcpyHostToDevice));
     }
@@ -1138,9 +1150,10 @@ int pc_env_set_option(pc_env* e, int option, int value) {
             e->opt.epw_override = value;
             return PC_OK;
         case PC_OPT_ROLLOUT_FAST:
-            if (value < 0 || value > 2) return PC_ERR_INVALID_ARG;
+            if (value < 0 || value > 3) return PC_ERR_INVALID_ARG;
             e->opt.fast = value != 0;
-            e->opt.nv28 = value == 1;
+            e->opt.nv28 = value == 1 || value == 3;
+            e->opt.deinterleave = value != 3;
             return PC_OK;
         case PC_OPT_STEP_FORM:
             if (value < 0 || value > 2) return PC_ERR_INVALID_ARG;
@@ -1156,7 +1169,7 @@ int pc_env_get_option(const pc_env* e, int option, int* value) {
     switch (option) {
         case PC_OPT_ROLLOUT_FORM: *value = e->opt.form < 0 ? -1 : e->opt.form + (e->opt.rden ? 0 : 2); return PC_OK;
         case PC_OPT_ROLLOUT_EPW: *value = e->opt.epw_override; return PC_OK;
-        case PC_OPT_ROLLOUT_FAST: *value = !e->opt.fast ? 0 : (e->opt.nv28 ? 1 : 2); return PC_OK;
+        case PC_OPT_ROLLOUT_FAST: *value = !e->opt.fast ? 0 : (!e->opt.nv28 ? 2 : (e->opt.deinterleave ? 1 : 3)); return PC_OK;
         case PC_OPT_STEP_FORM: *value = e->opt.step_form; return PC_OK;
         default: return PC_ERR_INVALID_ARG;
     }
@@ -1404,6 +1417,18 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
                     if (e->device < 64) attr6m[e->device] = true;
                 }
 #endif
+                if (e->track_bal32 && e->opt.deinterleave) {
+#ifndef PC_DEV_MIN
+                    static bool attr7m[64] = {false};
+                    if (e->device >= 64 || !attr7m[e->device]) {
+                        HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<6, 5, 2, 7, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                        if (e->device < 64) attr7m[e->device] = true;
+                    }
+#endif
+                    PC_FULL(hipLaunchKernelGGL((rollout_kernel<6, 5, 2, 7, true, 2>), dim3((int)((e->N + 127) / 128)), dim3(512), lds6m, st, prm6, image, A, (int)T, reward_scale, seed,
+                                               offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, next_term, next_trunc, 0, 128,
+                                               vec6, last_value, reward_sum));
+                } else
                 PC_FULL(hipLaunchKernelGGL((rollout_kernel<6, 5, 2, 6, true, 2>), dim3((int)((e->N + 127) / 128)), dim3(512), lds6m, st, prm6, image, A, (int)T, reward_scale, seed,
                                            offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, next_term, next_trunc, 0, 128,
                                            vec6, last_value, reward_sum));
@@ -1422,6 +1447,18 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
                     if (e->device < 64) attr6[e->device] = true;
                 }
 #endif
+                if (e->track_bal64 && e->opt.deinterleave) {
+#ifndef PC_DEV_MIN
+                    static bool attr7[64] = {false};
+                    if (e->device >= 64 || !attr7[e->device]) {
+                        HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<6, 9, 2, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                        if (e->device < 64) attr7[e->device] = true;
+                    }
+#endif
+                    PC_FULL(hipLaunchKernelGGL((rollout_kernel<6, 9, 2, 7, true>), dim3(blocks), dim3(512), lds6, st, prm6, image, A, (int)T, reward_scale, seed, offset,
+                                               offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, next_term, next_trunc, 0, epw,
+                                               vec6, last_value, reward_sum));
+                } else
                 PC_FULL(hipLaunchKernelGGL((rollout_kernel<6, 9, 2, 6, true>), dim3(blocks), dim3(512), lds6, st, prm6, image, A, (int)T, reward_scale, seed, offset,
                                            offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, next_term, next_trunc, 0, epw,
                                            vec6, last_value, reward_sum));
@@ -1617,6 +1654,18 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
                     if (e->device < 64) attr6m[e->device] = true;
                 }
 #endif
+                if (e->track_bal32 && o.deinterleave) {      // every block of 32 envs split evenly: the block's two waves de-interleave it (mode 7)
+#ifndef PC_DEV_MIN
+                    static bool attr7m[64] = {false};
+                    if (e->device >= 64 || !attr7m[e->device]) {
+                        HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<6, 5, 2, 7, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                        if (e->device < 64) attr7m[e->device] = true;
+                    }
+#endif
+                    PC_FULL(hipLaunchKernelGGL((rollout_kernel<6, 5, 2, 7, false, 2>), dim3((int)((e->N + 127) / 128)), dim3(512), lds6m, (hipStream_t)stream, prm6, image, A, (int)T,
+                                               reward_scale, seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, next_term,
+                                               next_trunc, 0, 128, vec6, last_value, reward_sum));
+                } else
                 PC_FULL(hipLaunchKernelGGL((rollout_kernel<6, 5, 2, 6, false, 2>), dim3((int)((e->N + 127) / 128)), dim3(512), lds6m, (hipStream_t)stream, prm6, image, A, (int)T,
                                            reward_scale, seed, offset, offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, next_term,
                                            next_trunc, 0, 128, vec6, last_value, reward_sum));
@@ -1636,6 +1685,18 @@ static int rollout_impl(pc_env* e, int prec_request, const float* image, int A, 
                 if (e->device < 64) attr6[e->device] = true;
             }
 #endif
+            if (e->track_bal64 && o.deinterleave) {
+#ifndef PC_DEV_MIN
+                static bool attr7[64] = {false};
+                if (e->device >= 64 || !attr7[e->device]) {
+                    HIPCHK(hipFuncSetAttribute((const void*)rollout_kernel<6, 9, 2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    if (e->device < 64) attr7[e->device] = true;
+                }
+#endif
+                PC_FULL(hipLaunchKernelGGL((rollout_kernel<6, 9, 2, 7>), dim3(blocks6), dim3(512), lds6, (hipStream_t)stream, prm6, image, A, (int)T, reward_scale, seed, offset,
+                                           offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, next_term, next_trunc, 0, epw6,
+                                           vec6, last_value, reward_sum));
+            } else
             PC_FULL(hipLaunchKernelGGL((rollout_kernel<6, 9, 2, 6>), dim3(blocks6), dim3(512), lds6, (hipStream_t)stream, prm6, image, A, (int)T, reward_scale, seed, offset,
                                        offset_dev, obs_buf, act_buf, rew_buf, val_buf, term_buf, trunc_buf, logprob_buf, next_obs, next_term, next_trunc, 0, epw6,
                                        vec6, last_value, reward_sum));

@@ -81,8 +81,8 @@ def test_mixed_tracks_f32_halves_rollout_vs_step_kernels_and_oracle(n_envs, form
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("dtype,fast", [("f32", 1), ("f32", 2), ("f64", 1), ("f64", 2)],
-                         ids=["f32_two_track_fast_form", "f32_generic_mode", "f64_two_track_literal_form", "f64_K9d"])
+@pytest.mark.parametrize("dtype,fast", [("f32", 1), ("f32", 3), ("f32", 2), ("f64", 1), ("f64", 3), ("f64", 2)],
+                         ids=["f32_deinterleaved_by_wave", "f32_two_track_passes", "f32_generic_mode", "f64_deinterleaved_literal", "f64_two_track_passes_literal", "f64_K9d"])
 @pytest.mark.parametrize("n_envs", [2048, 20000, 32768, 65536])
 def test_mixed_tracks_interleaved_rollout_vs_step_kernels_and_oracle(n_envs, dtype, fast):
     """track_id = i & 1 (SURVEY 8(d) C4's second variant; car_env.py:621-628 lets every env sit on its own track): every wave holds both
@@ -104,8 +104,10 @@ def test_mixed_tracks_interleaved_rollout_vs_step_kernels_and_oracle(n_envs, dty
         torch.cuda.synchronize()
         assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
         if mode == "mega":
-            m = "m" if (fast == 1 and 8192 < n_envs <= 32768) else ""      # 16 envs per wave between 8193 and 32768 envs, as for every other layout
-            assert tr.envs.last_rollout_kernel() == (f"K9{m}" if dtype == "f32" else (f"K9{m}-literal" if fast == 1 else "K9d-selector"))
+            # fast 1: `i & 1` splits every block of 64 / 32 envs evenly -- the block's two waves de-interleave it (rollout_kernel's mode 7: one pass per
+            # wave); 3: the per-track passes inside every wave (mode 6: what an unevenly interleaved batch takes); 2: the generic mode
+            m = "m" if (fast in (1, 3) and 8192 < n_envs <= 32768) else ""      # 16 envs per wave between 8193 and 32768 envs, as for every other layout
+            assert tr.envs.last_rollout_kernel() == (f"K9{m}" if dtype == "f32" else (f"K9{m}-literal" if fast in (1, 3) else "K9d-selector"))
         res[mode] = _snap(tr)
         res[mode + "_state"] = tr.envs.get_state()
         tr.close()
