@@ -258,6 +258,9 @@ int pc_policy_act(const pc_policy* p, const float* obs, int64_t N, const float* 
  * track ids that change INSIDE a block (car_env.py:621-628 puts every env on its own track: e.g. track_id = i & 1) run the big form with
  * the env step once per track present in a wave -- two tracks of the reference's layout (two equal loops of 13 or 9 chain vertices) at
  * 16 rays in the table-driven two-track form (both tracks' tables in LDS; F32 and F64 handles), anything else in the generic mode.
+ * When every aligned block of 64 envs (32 in the 16-envs-per-wave form) is split evenly between the two tracks -- i & 1 is -- the
+ * block's two waves DE-INTERLEAVE it: each wave steps the block's envs of ONE track (one pass; an env's rows, state and random stream stay
+ * the env's own, so the buffers are the same bits).
  * PC_ERR_UNSUPPORTED for ray
  * counts whose slots per lane are not on the kernel menu (12 / 16 / 32 run the table-driven fast mode; 17 and 18 share the
  * slots of 16 and run the generic mode), shapes whose LDS footprint exceeds 160 KB (33 rays with the fp32 or bf16x3 weight
