@@ -218,7 +218,7 @@ def test_both_workgroup_sizes_of_the_big_form_at_small_n(n_envs, epw, fast):
                                use_graphs=False, seed=3, policy_split=0, rollout_form=0, rollout_epw=epw, rollout_fast=fast), device="cuda")
         assert (tr.envs.get_option("rollout_form"), tr.envs.get_option("rollout_epw"), tr.envs.get_option("rollout_fast")) == (0, epw, fast)
         with pytest.raises(pc.PpoCarError):
-            tr.envs.set_option("rollout_fast", 3)
+            tr.envs.set_option("rollout_fast", 4)
         for _ in range(2):
             tr.rollout()
             tr.buffer.ptr = 0

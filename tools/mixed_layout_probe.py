@@ -1,7 +1,7 @@
 """Developer probe (GPU box): the rollout of configs[4]'s shard (32768 envs, track.json + big_track.json) per env layout and kernel path --
-halves through the fast modes (K9m), halves through the generic mode (rollout_fast = 0), interleaved (track_id = i & 1) through the
-two-track fast form (both tracks' tables in LDS, the env step once per track of a wave), through the generic mode's per-wave track
-waterfall, and through the per-step kernels (graph replay).  us per vector step, median of N launches."""
+halves through the fast modes (K9m), halves through the generic mode (rollout_fast = 0), interleaved (track_id = i & 1) de-interleaved by
+wave (mode 7: one pass per wave), through the two-track form's per-track passes (mode 6: both tracks' tables in LDS, the env step once per
+track of a wave), through the generic mode's per-wave track waterfall, and through the per-step kernels (graph replay).  us per vector step, median of N launches."""
 import os
 import sys
 
@@ -14,7 +14,8 @@ from ppo_car_amd.ppo import PPOConfig, Trainer  # noqa: E402
 N, T = int(sys.argv[1]) if len(sys.argv) > 1 else 32768, 256
 tracks = [f"{ROOT}/tracks/track.json", f"{ROOT}/tracks/big_track.json"]
 for name, kw in (("halves, fast modes", dict()), ("halves, generic mode", dict(rollout_fast=0)),
-                 ("interleaved, two-track fast form", dict(track_interleave=True)),
+                 ("interleaved, de-interleaved by wave (mode 7)", dict(track_interleave=True)),
+                 ("interleaved, per-track passes (mode 6)", dict(track_interleave=True, rollout_fast=3)),
                  ("interleaved, generic mode (waterfall)", dict(track_interleave=True, rollout_fast=2)),
                  ("interleaved, per-step kernels (graph)", dict(track_interleave=True, rollout_kernel="steps")),
                  ("single track big_track, generic mode", dict(rollout_fast=0, _single=True))):
