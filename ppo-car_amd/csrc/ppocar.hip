@@ -303,6 +303,34 @@ static int steps_fast_launch(pc_env* e, const int64_t* actions, int64_t T, doubl
     return PC_OK;
 }
 
+// K1 (env_step_kernel): one step of every env, the generic kernel -- any ray count on the menu, any track, per-env track ids
+static int step_generic_launch(pc_env* e, const int64_t* actions, double reward_scale, float* obs, float* reward, float* terminated,
+                               float* truncated, int32_t* gates_passed, float* final_obs, hipStream_t st) {
+    e->last_step_kernel = PC_STEP_K1;
+#define PC_CASE(T, M)                                                                                        \
+    case M:                                                                                                  \
+        launch_step<T, M>(e, actions, reward_scale, obs, reward, terminated, truncated, gates_passed, final_obs, st); \
+        break;
+    if (e->dtype == PC_DTYPE_F64) {
+        switch (e->rpl) {
+#ifndef PC_DEV_MIN
+            PC_CASE(double, 1) PC_CASE(double, 2) PC_CASE(double, 3) PC_CASE(double, 5) PC_CASE(double, 6)
+            PC_CASE(double, 9) PC_CASE(double, 12) PC_CASE(double, 17)
+#endif
+            default: return PC_ERR_UNSUPPORTED;
+        }
+    } else {
+        switch (e->rpl) {
+            PC_CASE(float, 1) PC_CASE(float, 2) PC_CASE(float, 3) PC_CASE(float, 5) PC_CASE(float, 6)
+            PC_CASE(float, 9) PC_CASE(float, 12) PC_CASE(float, 17) PC_CASE(float, 33)
+            default: return PC_ERR_UNSUPPORTED;
+        }
+    }
+#undef PC_CASE
+    HIPCHK(hipGetLastError());
+    return PC_OK;
+}
+
 extern "C" {
 
 const char* pc_strerror(int code) {
@@ -882,51 +910,24 @@ int pc_env_step(pc_env* e, const int64_t* actions, double reward_scale, float* o
         const int rc = steps_fast_launch(e, actions, 1, reward_scale, obs, reward, terminated, truncated, false, st, gates_passed, final_obs);
         if (rc != PC_ERR_UNSUPPORTED) return rc;
     }
-    e->last_step_kernel = PC_STEP_K1;
-#define PC_CASE(T, M)                                                                                        \
-    case M:                                                                                                  \
-        launch_step<T, M>(e, actions, reward_scale, obs, reward, terminated, truncated, gates_passed, final_obs, st); \
-        break;
-    if (e->dtype == PC_DTYPE_F64) {
-        switch (e->rpl) {
-#ifndef PC_DEV_MIN
-            PC_CASE(double, 1) PC_CASE(double, 2) PC_CASE(double, 3) PC_CASE(double, 5) PC_CASE(double, 6)
-            PC_CASE(double, 9) PC_CASE(double, 12) PC_CASE(double, 17)
-#endif
-            default: return PC_ERR_UNSUPPORTED;
-        }
-    } else {
-        switch (e->rpl) {
-            PC_CASE(float, 1) PC_CASE(float, 2) PC_CASE(float, 3) PC_CASE(float, 5) PC_CASE(float, 6)
-            PC_CASE(float, 9) PC_CASE(float, 12) PC_CASE(float, 17) PC_CASE(float, 33)
-            default: return PC_ERR_UNSUPPORTED;
-        }
-    }
-#undef PC_CASE
-    HIPCHK(hipGetLastError());
-    return PC_OK;
+    return step_generic_launch(e, actions, reward_scale, obs, reward, terminated, truncated, gates_passed, final_obs, st);
 }
 
 int pc_env_step_many(pc_env* e, const int64_t* actions, int64_t T, double reward_scale, float* obs, float* reward, float* terminated,
                      float* truncated, void* stream) {
     g_hip_err.clear();   // (pc_last_hip_error speaks of THIS call)
     if (!e || !actions || !obs || !reward || !terminated || !truncated || T < 1) return PC_ERR_INVALID_ARG;
-    {
-        DeviceGuard guard(e->device);
-        if (!guard.ok) return PC_ERR_NO_DEVICE;
-        if (e->opt.step_form != 1) {      // (one launch instead of T: worth it at any batch size)
-            const int rc = steps_fast_launch(e, actions, T, reward_scale, obs, reward, terminated, truncated, T > 1, (hipStream_t)stream);
-            if (rc != PC_ERR_UNSUPPORTED) return rc;
-        }
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return PC_ERR_NO_DEVICE;
+    if (e->opt.step_form != 1) {      // (one launch instead of T: worth it at any batch size)
+        const int rc = steps_fast_launch(e, actions, T, reward_scale, obs, reward, terminated, truncated, T > 1, (hipStream_t)stream);
+        if (rc != PC_ERR_UNSUPPORTED) return rc;
     }
     // no table-driven form for this handle: the same T steps as T launches of K1, row by row
-    const int saved = e->opt.step_form;
-    e->opt.step_form = 1;
     int rc = PC_OK;
     for (int64_t t = 0; t < T && rc == PC_OK; ++t)
-        rc = pc_env_step(e, actions + t * e->N, reward_scale, obs + t * e->N * e->D, reward + t * e->N, terminated + t * e->N, truncated + t * e->N,
-                         nullptr, nullptr, stream);
-    e->opt.step_form = saved;
+        rc = step_generic_launch(e, actions + t * e->N, reward_scale, obs + t * e->N * e->D, reward + t * e->N, terminated + t * e->N, truncated + t * e->N,
+                                 nullptr, nullptr, (hipStream_t)stream);
     return rc;
 }
 
