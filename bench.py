@@ -527,7 +527,7 @@ def main():
     # size is given the trainer's env STATE as the timed epochs left it (cars spread over the track by the current policy -- a batch
     # fresh from reset has every car at the start line, where no ray takes the rare paths, and flatters a single step by 2x) and the
     # ACTIONS the last rollout stored; timed between HIP events on the launch stream: PROBE launches of pc_env_step as a user of the
-    # drop-in boundary gets them (the table-driven kernel K1f from 4096 envs on), the same with the generic kernel K1 forced, and
+    # drop-in boundary gets them (the table-driven kernel K1f from 8192 envs on), the same with the generic kernel K1 forced, and
     # pc_env_step_many over PROBE_T action rows (one launch).
     from ppo_car_amd.env import VecCarEnv
     PROBE, PROBE_T = 32, 256

@@ -122,7 +122,7 @@ int pc_env_step_many(pc_env* e, const int64_t* actions, int64_t T, double reward
  *   PC_STEP_K1F        env_steps_fast_kernel: the table-driven env step of the persistent rollout kernel -- 12 / 16 / 32 nominal rays, the
  *                      track's gather tables staged in LDS per launch, 2 lanes per env, the chain-packed / unrolled selector sweep; F64
  *                      handles: its literal form (tracks inside the selector's limits, rotations on the rotation table).  Taken by
- *                      pc_env_step from 4096 envs on, by pc_env_step_many at any batch size; PC_OPT_STEP_FORM decides otherwise
+ *                      pc_env_step from 8192 envs on, by pc_env_step_many at any batch size; PC_OPT_STEP_FORM decides otherwise
  *   PC_STEP_K1F_TABLE  the same with the track's 1/den table staged too (pc_env_step_many, T > 1, when it fits) */
 #define PC_STEP_NONE 0
 #define PC_STEP_K1 1

@@ -138,8 +138,8 @@ struct RolloutOpts {
                           // on, where the shape has one; pc_env_step_many: wherever the shape has one), 1 = always the generic per-step kernel
                           // K1, 2 = K1f wherever the shape has one (any batch size)
 };
-constexpr int64_t PC_STEP_FAST_MIN_ENVS = 4096;   // below: K1's 16+ lanes per env fill the device better than K1f's workgroups of 128 envs
-                                                  // (tools/step_forms_probe.py: kernel time 11.5 against 13.9 us at 4096 envs, 19 against 35 at 65536)
+constexpr int64_t PC_STEP_FAST_MIN_ENVS = 8192;   // below: K1's 8+ lanes per env fill the device as well as K1f's workgroups of 128 envs (call to call,
+                                                  // tools/step_forms_probe.py: 11.2 against 12.5 us at 4096 envs, 13.6 = 13.6 at 8192, 21 against 15 at 16384, 34 against 21 at 65536)
 constexpr int kDefaultPolicyPrecision = 2;   // pc_policy_create(precision = -1): 0 = fp32-input MFMA; split forms on the 16-bit matrix cores (need D <= 40, A <= 9): 1 = bf16 x 3, 2 = fp16 x 2
 
 struct pc_env {

@@ -163,7 +163,7 @@ def test_junction_track_careful_jobs_match_the_generic_kernel(tmp_path, dtype):
 
 
 def test_automatic_choice_of_the_step_kernel():
-    for N, kernel in ((4095, "K1"), (4096, "K1f")):
+    for N, kernel in ((8191, "K1"), (8192, "K1f")):
         e = pc.VecCarEnv(N, TRACKS["big_track"], num_rays=16, reward_scaling=0.1)
         e.reset()
         e.step(torch.zeros(N, dtype=torch.int64, device="cuda"))
