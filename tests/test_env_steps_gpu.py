@@ -235,3 +235,41 @@ def test_env_only_example_runs_and_reports_identical_rows():
                          text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "identical rows: True" in out.stdout and "(K1f)" in out.stdout and "(K1f-table)" in out.stdout, out.stdout
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_table_driven_step_inside_a_hip_graph(dtype):
+    """pc_env_step / pc_env_step_many never synchronise: a loop of steps (K1f) and a step_many launch captured into ONE HIP graph -- the
+    very first launches of their kernels on this handle happen inside the capture -- and replayed twice give what the eager calls give."""
+    N, T = 8192, 24
+    acts = _actions(3 * T, N, 21, wild=False)
+    a, b = _env(N, TRACKS["big_track"], 16, dtype, 0), _env(N, TRACKS["big_track"], 16, dtype, 0)
+    a.reset()
+    b.reset()
+    torch.cuda.synchronize()
+    D = a.obs_dim
+    cur = torch.zeros(T, N, dtype=torch.int64, device="cuda")
+    rows = (torch.empty(T, N, D, device="cuda"), torch.empty(T, N, device="cuda"), torch.empty(T, N, device="cuda"), torch.empty(T, N, device="cuda"))
+    many = tuple(torch.empty(T // 2, *r.shape[1:], device="cuda") for r in rows)
+    s_ = torch.cuda.Stream()
+    with torch.cuda.stream(s_):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for t in range(T // 2):
+                b.step(cur[t], out=tuple(r[t] for r in rows))
+            b.step_many(cur[T // 2:], out=many)
+    torch.cuda.synchronize()
+    b.reset()
+    for rep in range(2):
+        chunk = acts[rep * T:(rep + 1) * T]
+        want = [a.step(chunk[t])[:4] for t in range(T)]
+        cur.copy_(chunk)
+        g.replay()
+        torch.cuda.synchronize()
+        for i in range(4):
+            assert torch.equal(rows[i][:T // 2], torch.stack([w[i] for w in want[:T // 2]])), (rep, i)
+            assert torch.equal(many[i], torch.stack([w[i] for w in want[T // 2:]])), (rep, i)
+    for k in STATE:
+        assert np.array_equal(a.get_state()[k], b.get_state()[k]), k
+    a.close()
+    b.close()
