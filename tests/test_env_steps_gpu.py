@@ -162,6 +162,60 @@ def test_junction_track_careful_jobs_match_the_generic_kernel(tmp_path, dtype):
     b.close()
 
 
+def _oval_track(tmp_path, n_points):
+    import json
+    from ppo_car_amd.track_tool import make_oval
+    path = str(tmp_path / f"oval{n_points}.json")
+    with open(path, "w") as f:
+        json.dump(make_oval(n_points=n_points, n_gates=24, wobble=0.06, seed=5), f)
+    return path
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("n_points,nv", [(30, 64), (20, 44)])
+def test_long_chains_fill_the_wave_of_a_careful_job(tmp_path, dtype, n_points, nv):
+    """The whole-wave careful jobs put chain segment j on lane j: the reference's tracks (28 / 20 padded vertices) only ever use the
+    first two rows of 16 lanes.  Synthetic circuits of 2 x 30 walls (62 -> 64 chain vertices: EVERY lane, all four rows of the reduction)
+    and 2 x 20 walls (44: three rows), irregular, random actions: K1f's rows and state equal the generic kernel's, whose careful path is
+    per lane; the persistent kernel (big form) equals the per-step kernels."""
+    from ppo_car_amd.ppo import PPOConfig, Trainer
+    path = _oval_track(tmp_path, n_points)
+    N, T = 3000, 160
+    acts = _actions(T, N, n_points)
+    a, b = _env(N, path, 16, dtype, 1), _env(N, path, 16, dtype, 2)
+    assert a.track_info[0]["n_chain_vertices"] + (-a.track_info[0]["n_chain_vertices"]) % 4 == nv
+    a.reset()
+    b.reset()
+    rows = [a.step(acts[t])[:4] for t in range(T)]
+    many = b.step_many(acts)
+    assert a.last_step_kernel() == "K1" and b.last_step_kernel().startswith("K1f")
+    for i in range(4):
+        assert torch.equal(many[i], torch.stack([r[i] for r in rows])), i
+    for k in STATE:
+        assert np.array_equal(a.get_state()[k], b.get_state()[k]), k
+    assert float(many[2].sum()) > 0        # episodes ended: cars reached walls
+    a.close()
+    b.close()
+    res = {}
+    for mode in ("mega", "steps"):
+        tr = Trainer(PPOConfig(n_envs=20000, n_steps=96, num_rays=16, track=path, rollout_kernel=mode, use_graphs=False, seed=23, env_dtype=dtype),
+                     device="cuda")
+        for _ in range(2):
+            tr.rollout()
+            tr.buffer.ptr = 0
+        torch.cuda.synchronize()
+        assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
+        if mode == "mega":
+            # (F64: K9's literal form wants the 1/den table of a 16-ray track in LDS -- 92 / 63 KB here: the generic kernel's selector step takes
+            # these tracks; the literal whole-wave jobs on 64 lanes are K1f's above)
+            assert tr.envs.last_rollout_kernel() == ("K9" if dtype == "f32" else "K9d-selector"), tr.envs.last_rollout_kernel()
+        bf = tr.buffer
+        res[mode] = [x.clone() for x in (bf.obs_buf, bf.act_buf, bf.rew_buf, bf.val_buf, bf.logprob_buf, bf.term_buf, bf.trunc_buf, tr.next_obs)]
+        tr.close()
+    for i, (x, y) in enumerate(zip(res["mega"], res["steps"])):
+        assert torch.equal(x, y), i
+
+
 def test_automatic_choice_of_the_step_kernel():
     for N, kernel in ((8191, "K1"), (8192, "K1f")):
         e = pc.VecCarEnv(N, TRACKS["big_track"], num_rays=16, reward_scaling=0.1)
