@@ -120,7 +120,8 @@ int pc_env_step_many(pc_env* e, const int64_t* actions, int64_t T, double reward
 /* Which kernel the last pc_env_step / pc_env_step_many on this handle launched (0 before the first; both fill the same outputs bit for bit):
  *   PC_STEP_K1         env_step_kernel: any ray count 4..360, any track, per-env track ids; 2^k lanes per env chosen from the batch size
  *   PC_STEP_K1F        env_steps_fast_kernel: the table-driven env step of the persistent rollout kernel -- 12 / 16 / 32 nominal rays, the
- *                      track's gather tables staged in LDS per launch, 2 lanes per env, the chain-packed / unrolled selector sweep; F64
+ *                      track's gather tables staged in LDS per launch (mixed batches: one track per workgroup, or two tracks interleaved in
+ *                      evenly split blocks of 64 envs, de-interleaved by wave), 2 lanes per env, the chain-packed / unrolled selector sweep; F64
  *                      handles: its literal form (tracks inside the selector's limits, rotations on the rotation table).  Taken by
  *                      pc_env_step from 8192 envs on, by pc_env_step_many at any batch size; PC_OPT_STEP_FORM decides otherwise
  *   PC_STEP_K1F_TABLE  the same with the track's 1/den table staged too (pc_env_step_many, T > 1, when it fits) */

@@ -264,19 +264,26 @@ static int steps_fast_launch(pc_env* e, const int64_t* actions, int64_t T, doubl
     if (!(rays12 || rays16 || rays32) || !e->opt.fast || T < 1 || T > INT_MAX) return PC_ERR_UNSUPPORTED;
     if ((gates_passed || final_obs) && T != 1) return PC_ERR_INVALID_ARG;      // (the optional outputs are pc_env_step's)
     int max_G = 0, max_nV = 0;
-    bool all_nv28 = e->opt.nv28 != 0, tabs = true, all_rden = true;
+    bool all_nv28 = e->opt.nv28 != 0, all_loops = e->opt.nv28 != 0, tabs = true, all_rden = true;
+    int sum_nV = 0;
     for (const TrackHdr& h : e->hdr_host) {
         max_G = std::max(max_G, h.G);
         max_nV = std::max(max_nV, h.nV);
+        sum_nV += h.nV;
         tabs = tabs && h.lat_off >= 0 && (!f64 || (h.sel_ok && h.rot_off >= 0));
         all_rden = all_rden && h.rden_off >= 0;
         all_nv28 = all_nv28 && h.nV == 28 && h.n_chain == 26 && h.brk2 == 13 && h.vtxp_off >= 0;   // big_track's layout: two loops of 12 walls
+        all_loops = all_loops && h.vtxp_off >= 0 && (h.brk2 == 13 || h.brk2 == 9) && h.n_chain == 2 * h.brk2 && h.nV == 4 * ((h.brk2 + 1) / 2);
     }
     const int epw = e->N <= 32768 ? 128 : 256;      // (one wave per SIMD on twice the workgroups up to 32768 envs, as pc_rollout's big form)
-    if (!tabs || max_G > TAB_MAX_GATES || max_nV > FT_VTX_MAX || (f64 && e->f64_offgrid) || (e->track_id && e->track_block < epw)) return PC_ERR_UNSUPPORTED;
-    size_t lds = (size_t)(256 * e->D + ft_floats(false, true)) * sizeof(float);
-    const bool tab = table && all_rden && e->opt.rden != 0 && lds + (size_t)361 * max_nV * sizeof(float) <= 160 * 1024;
-    if (tab) lds += (size_t)361 * max_nV * sizeof(float);
+    // two tracks interleaved in evenly split blocks of 64 envs: de-interleaved by wave (the kernel's TWO form: 16 rays, the reference's track layouts)
+    const bool two = e->track_id && e->track_block < epw && e->n_tracks == 2 && e->track_bal64 && all_loops && rays16 && e->opt.deinterleave;
+    if (!tabs || max_G > TAB_MAX_GATES || max_nV > FT_VTX_MAX || (f64 && e->f64_offgrid) || (e->track_id && e->track_block < epw && !two)) return PC_ERR_UNSUPPORTED;
+    size_t lds = (size_t)(256 * e->D + (two ? 256 + 2 * ft_floats(false, true) : ft_floats(false, true))) * sizeof(float);
+    const int rden_all = 361 * (two ? sum_nV : max_nV);
+    const bool tab = table && all_rden && e->opt.rden != 0 && lds + (size_t)rden_all * sizeof(float) <= 160 * 1024;
+    if (tab) lds += (size_t)rden_all * sizeof(float);
+    const int ts_floats = two ? ((ft_floats(false, true) + (tab ? 361 * e->hdr_host[0].nV : 0) + 3) & ~3) : 0;
     const int blocks = (int)((e->N + epw - 1) / epw);
     const int vec_ok = ((e->N * e->D) % 4 == 0 && ((uintptr_t)obs & 15) == 0) ? 1 : 0;
     EnvParams<float> prm = e->params<float>();
@@ -289,13 +296,25 @@ static int steps_fast_launch(pc_env* e, const int64_t* actions, int64_t T, doubl
             if (e->device < 64) attr_set[e->device] = true;                                                                \
         }                                                                                                                \
         hipLaunchKernelGGL((env_steps_fast_kernel<RPLV, SWPV, TABV, LITV>), dim3(blocks), dim3(512), lds, st, prm, actions, (int)T, reward_scale, obs, \
-                           reward, term, trunc, epw, vec_ok, gates_passed, final_obs);                                   \
+                           reward, term, trunc, epw, vec_ok, gates_passed, final_obs, ts_floats);                        \
     } while (0)
 #define PC_STEPS_T(RPLV, SWPV, LITV) do { if (tab) PC_STEPS(RPLV, SWPV, true, LITV); else PC_STEPS(RPLV, SWPV, false, LITV); } while (0)
-    if (rays16 && all_nv28) { if (f64) PC_DEV(3, PC_STEPS_T(9, 7, true)); else PC_DEV(0, PC_STEPS_T(9, 7, false)); }
+#define PC_STEPS2(TABV, LITV)                                                                                            \
+    do {                                                                                                                 \
+        static bool attr_set[64] = {false};                                                                              \
+        if (e->device >= 64 || !attr_set[e->device]) {                                                                    \
+            HIPCHK(hipFuncSetAttribute((const void*)env_steps_fast_kernel<9, 5, TABV, LITV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            if (e->device < 64) attr_set[e->device] = true;                                                                \
+        }                                                                                                                \
+        hipLaunchKernelGGL((env_steps_fast_kernel<9, 5, TABV, LITV, true>), dim3(blocks), dim3(512), lds, st, prm, actions, (int)T, reward_scale, obs, \
+                           reward, term, trunc, epw, vec_ok, gates_passed, final_obs, ts_floats);                        \
+    } while (0)
+    if (two) { PC_FULL(if (f64) { if (tab) PC_STEPS2(true, true); else PC_STEPS2(false, true); } else { if (tab) PC_STEPS2(true, false); else PC_STEPS2(false, false); }); }
+    else if (rays16 && all_nv28) { if (f64) PC_DEV(3, PC_STEPS_T(9, 7, true)); else PC_DEV(0, PC_STEPS_T(9, 7, false)); }
     else if (rays16) { PC_FULL(if (f64) PC_STEPS_T(9, 0, true); else PC_STEPS_T(9, 0, false)); }
     else if (rays12) { PC_FULL(if (f64) PC_STEPS_T(6, 0, true); else PC_STEPS_T(6, 0, false)); }
     else { PC_FULL(if (f64) PC_STEPS_T(17, 0, true); else PC_STEPS_T(17, 0, false)); }
+#undef PC_STEPS2
 #undef PC_STEPS_T
 #undef PC_STEPS
     HIPCHK(hipGetLastError());

@@ -116,50 +116,36 @@ def test_step_many_is_T_steps(dtype, N, form, kernel):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
-def test_mixed_tracks_in_blocks_take_the_table_driven_step_interleaved_ones_do_not(dtype):
-    N, n, T = 1024, 16, 64
+@pytest.mark.parametrize("N", [1024, 4160])
+def test_mixed_tracks_in_blocks_and_evenly_interleaved_take_the_table_driven_step(dtype, N):
+    """Two tracks in halves: a workgroup stages its own track.  Interleaved i & 1 (every block of 64 envs split evenly): both tracks staged,
+    the block's two waves de-interleave it (K1f's TWO form, as rollout_kernel's mode 7) -- with gates_passed / final_obs as well.  An
+    uneven interleave (i % 3 == 0) has no table-driven form: K1.  All the generic kernel's rows and state."""
+    n, T = 16, 64
     tracks = [TRACKS["track"], TRACKS["big_track"]]
     acts = _actions(T, N, 5)
-    halves = (np.arange(N) >= N // 2).astype(np.uint8)
+    halves = (np.arange(N) >= N // 2 // 256 * 256).astype(np.uint8)
     inter = (np.arange(N) & 1).astype(np.uint8)
-    for tid, kernel in ((halves, "K1f-table"), (inter, "K1")):
+    uneven = (np.arange(N) % 3 == 0).astype(np.uint8)
+    for tid, kernel in ((halves, "K1f-table"), (inter, "K1f-table"), (uneven, "K1")):
         a, b = _env(N, tracks, n, dtype, 1, track_id=tid), _env(N, tracks, n, dtype, 2, track_id=tid)
         a.reset()
         b.reset()
         rows = [a.step(acts[t])[:4] for t in range(T)]
         many = b.step_many(acts)
-        assert b.last_step_kernel() == kernel
+        assert b.last_step_kernel() == kernel, (kernel, b.last_step_kernel())
         for i in range(4):
             assert torch.equal(many[i], torch.stack([r[i] for r in rows])), i
         for k in STATE:
             assert np.array_equal(a.get_state()[k], b.get_state()[k]), k
+        # one more step with the optional outputs
+        ga, gb = torch.empty(N, dtype=torch.int32, device="cuda"), torch.empty(N, dtype=torch.int32, device="cuda")
+        fa, fb = torch.empty(N, a.obs_dim, device="cuda"), torch.empty(N, a.obs_dim, device="cuda")
+        ra, rb = a.step(acts[0], gates_passed=ga, final_obs=fa), b.step(acts[0], gates_passed=gb, final_obs=fb)
+        assert b.last_step_kernel() == ("K1f" if kernel != "K1" else "K1")
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and torch.equal(ga, gb) and torch.equal(fa, fb)
         a.close()
         b.close()
-
-
-@pytest.mark.parametrize("dtype", ["f32", "f64"])
-def test_junction_track_careful_jobs_match_the_generic_kernel(tmp_path, dtype):
-    """A track with a T-junction and crossing walls (4 of 9 walls marked for the float64 scan): every ray that selects one of them is a
-    careful job of the whole wave in K1f and a per-lane chain scan in K1 -- the same rows, the same state."""
-    from test_env_gpu import _junction_track_json
-    import warnings
-    path = _junction_track_json(str(tmp_path / "junction.json"))
-    N, T = 3000, 200
-    acts = _actions(T, N, 3)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore", RuntimeWarning)
-        a, b = _env(N, path, 16, dtype, 1), _env(N, path, 16, dtype, 2)
-    a.reset()
-    b.reset()
-    rows = [a.step(acts[t])[:4] for t in range(T)]
-    many = b.step_many(acts)
-    assert a.last_step_kernel() == "K1" and b.last_step_kernel().startswith("K1f")
-    for i in range(4):
-        assert torch.equal(many[i], torch.stack([r[i] for r in rows])), i
-    for k in STATE:
-        assert np.array_equal(a.get_state()[k], b.get_state()[k]), k
-    a.close()
-    b.close()
 
 
 def _oval_track(tmp_path, n_points):
