@@ -1391,8 +1391,12 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
         const int img = polx_image_dwords(prec, pol_ng(KS));
         const bool rays16 = KS == 6 && rpl == 9 && e->n_nominal == 16, rays12 = KS == 5 && rpl == 6 && e->n_nominal == 12;
         const bool rays33 = KS == 10 && rpl == 17 && e->n_nominal == 32;
-        const int rden_lds = rays33 ? 0 : 361 * max_nV;      // (33 rays: no room for the table -- the sweep forms 1/den itself, as for F32 handles)
-        const size_t lds_sel = (size_t)k9_fast_lds_floats(img, 32, e->D, !rays33, rden_lds) * sizeof(float);
+        int rden_lds = rays33 ? 0 : 361 * max_nV;      // (33 rays: no room for the table -- the sweep forms 1/den itself, as for F32 handles)
+        size_t lds_sel = (size_t)k9_fast_lds_floats(img, 32, e->D, !rays33, rden_lds) * sizeof(float);
+        if (rden_lds && lds_sel > 160 * 1024) {        // ... and so does a 12 / 16-ray track whose table does not fit (more than ~36 chain vertices)
+            rden_lds = 0;
+            lds_sel = (size_t)k9_fast_lds_floats(img, 32, e->D, true, 0) * sizeof(float);
+        }
         if (prec == 0) {
             // THE STRICTEST CELL: float64 env (the literal form) AND the policy GEMMs as the exact fp32 chain (v_mfma_f32_16x16x4_f32) -- every
             // number of the rollout in the reference's own arithmetic -- as one persistent launch: K9's literal form with the fp32 weight
@@ -1575,9 +1579,9 @@ static int rollout_f64_impl(pc_env* e, int prec_request, const float* image, int
     } while (0)
             if (rays16 && all_nv28) PC_DEV(3, PC_ROLL_LIT(6, 9, 3));            // big_track.json's layout
             else if (rays16 && all_loops) PC_FULL(PC_ROLL_LIT(6, 9, 5));        // ... mixed with track.json's
-            else if (rays16) PC_FULL(PC_ROLL_LIT(6, 9, 2));                     // any other track: the generic sweeps
+            else if (rays16) { PC_FULL(if (rden_lds) PC_ROLL_LIT(6, 9, 2); else PC_ROLL_LIT(6, 9, 1)); }     // any other track: the generic sweeps
             else if (rays33) PC_DEV(5, PC_ROLL_LIT(10, 17, 1));                 // 32 -> 33 rays: no room for the 1/den table
-            else PC_FULL(PC_ROLL_LIT(5, 6, 2));                                 // 12 rays
+            else { PC_FULL(if (rden_lds) PC_ROLL_LIT(5, 6, 2); else PC_ROLL_LIT(5, 6, 1)); }                // 12 rays
 #undef PC_ROLL_LIT
             HIPCHK(hipGetLastError());
             e->last_kernel = PC_KERNEL_K9_LITERAL;

@@ -192,9 +192,8 @@ def test_long_chains_fill_the_wave_of_a_careful_job(tmp_path, dtype, n_points, n
         torch.cuda.synchronize()
         assert tr.rollout_mode == ("mega" if mode == "mega" else "steps-eager")
         if mode == "mega":
-            # (F64: K9's literal form wants the 1/den table of a 16-ray track in LDS -- 92 / 63 KB here: the generic kernel's selector step takes
-            # these tracks; the literal whole-wave jobs on 64 lanes are K1f's above)
-            assert tr.envs.last_rollout_kernel() == ("K9" if dtype == "f32" else "K9d-selector"), tr.envs.last_rollout_kernel()
+            # (the 1/den table of these tracks -- 92 / 63 KB -- does not fit beside the weight image: both dtypes form 1/den arithmetically)
+            assert tr.envs.last_rollout_kernel() == ("K9" if dtype == "f32" else "K9-literal"), tr.envs.last_rollout_kernel()
         bf = tr.buffer
         res[mode] = [x.clone() for x in (bf.obs_buf, bf.act_buf, bf.rew_buf, bf.val_buf, bf.logprob_buf, bf.term_buf, bf.trunc_buf, tr.next_obs)]
         tr.close()
