@@ -840,7 +840,10 @@ class Trainer:
         self._aux_valid = False     # the in-kernel bootstrap values belong to THAT rollout and THOSE parameters only
 
     def run_epoch(self, sync=True):
-        """One epoch = rollout + update.  Returns the reference's scalars (train.py:286-292) when sync."""
+        """One epoch = rollout + update.  Returns the reference's scalars (train.py:286-292) when sync.
+        sync="lazy" (one rank): the epoch is only ENQUEUED; its scalars travel to pinned host memory behind it, and the call returns the
+        scalars of the epoch BEFORE (None on the first call) -- the host never waits for the epoch it has just launched, so the device
+        runs epoch after epoch back to back while train.py prints and logs one epoch late (flush_scalars() hands over the last one)."""
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if self.phase_events is not None else None
         if ev:
             ev[0].record()
@@ -856,6 +859,21 @@ class Trainer:
         self.epoch += 1
         if not sync:
             return None
+        if sync == "lazy" and self.world_size == 1 and self.device.type == "cuda":
+            prev = self.flush_scalars()
+            L = self.learner
+            with torch.no_grad():
+                lr = L.lr_dev.reshape(1).to(torch.float32) if L.fused else torch.full((1,), float(L.current_lr()), device=self.device)
+                rng = getattr(self.agent, "_range_dev", None)      # the fp16x2 domain's status word of the last pack (it may have run inside a graph)
+                rng = rng.to(torch.float32) if rng is not None else torch.zeros(1, device=self.device)
+                dev = torch.cat([L.metrics / self.cfg.train_iters, rew_mean.reshape(1).to(torch.float32), lr, rng])
+            host = torch.empty(7, dtype=torch.float32, pin_memory=True)
+            host.copy_(dev, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            self._pending_scalars = (host, done, self.global_step_idx)
+            return prev
+        self.flush_scalars()        # (a switch from lazy to synchronous calls drops nothing silently: the pending epoch is waited for)
         self.check_exchange()       # (synchronises; the scalars below are fetched anyway) a timed-out exchange stops the job HERE
         if self.device.type == "cuda":
             self.agent.check_policy_range(sync=True)    # weights outside the policy arithmetic's domain: precision 0 from the next rollout on (or PolicyRangeError)
@@ -872,6 +890,22 @@ class Trainer:
                 "charts/avg_reward": avg_reward, "charts/learning_rate": self.learner.current_lr(),
                 "charts/SPS": self.global_step_idx / max(elapsed, 1e-9), "global_step": self.global_step_idx,
                 "elapsed": elapsed}
+
+    def flush_scalars(self):
+        """The scalars of the last epoch run with sync="lazy" (waits for THAT epoch only), or None."""
+        pend, self._pending_scalars = getattr(self, "_pending_scalars", None), None
+        if pend is None:
+            return None
+        host, done, gstep = pend
+        done.synchronize()
+        m = host.tolist()
+        lr = m[5]
+        if m[6] != 0.0 and self.device.type == "cuda":
+            self.agent.check_policy_range(sync=True)    # weights outside the policy arithmetic's domain: precision 0 from the next rollout on (or PolicyRangeError)
+        elapsed = time.time() - self.start_time
+        return {"losses/policy_loss": m[0], "losses/value_loss": m[1], "losses/entropy": m[2], "losses/total_loss": m[3],
+                "charts/avg_reward": m[4] / self.cfg.reward_scaling, "charts/learning_rate": lr,
+                "charts/SPS": gstep / max(elapsed, 1e-9), "global_step": gstep, "elapsed": elapsed}
 
     # ---- checkpoint / resume (SURVEY 8(f) row 1: the reference only saves agent.state_dict(), train.py:283,301) ----
     def state_dict(self):

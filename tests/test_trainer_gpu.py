@@ -777,3 +777,25 @@ def test_deferred_adam_epoch_chain_is_bitwise_the_three_launch_steps(num_rays, b
     for a, b in zip(res[False][1], res[True][1]):
         for k in ("losses/policy_loss", "losses/value_loss", "losses/entropy", "losses/total_loss", "charts/avg_reward"):
             assert a[k] == b[k], k
+
+
+def test_lazy_scalars_are_the_synchronous_scalars_one_epoch_late():
+    """Trainer.run_epoch(sync="lazy") (train.py's default on one rank): the epoch is only enqueued, the call hands back the scalars of the
+    epoch before -- the same numbers the synchronous call returns, the learning rate and the policy-range word riding along -- and
+    flush_scalars() the last one."""
+    keys = ("losses/policy_loss", "losses/value_loss", "losses/entropy", "losses/total_loss", "charts/avg_reward", "charts/learning_rate", "global_step")
+    a, b = Trainer(_cfg(n_envs=512, n_steps=64), device="cuda"), Trainer(_cfg(n_envs=512, n_steps=64), device="cuda")
+    want = [a.run_epoch(sync=True) for _ in range(6)]
+    got = [b.run_epoch(sync="lazy") for _ in range(6)]
+    assert got[0] is None
+    got = got[1:] + [b.flush_scalars()]
+    assert b.flush_scalars() is None
+    for w, g_ in zip(want, got):
+        for k in keys:
+            assert w[k] == pytest.approx(g_[k], rel=1e-6, abs=1e-9), k
+    # a synchronous call after lazy ones waits for the pending epoch instead of dropping it
+    b.run_epoch(sync="lazy")
+    s7 = b.run_epoch(sync=True)
+    assert s7["global_step"] == 8 * 512 * 64 and b.flush_scalars() is None
+    a.close()
+    b.close()

@@ -51,6 +51,8 @@ def parse_args(argv=None):
     p.add_argument("--bootstrap-value", default="kernel", choices=["kernel", "fp32"],
                    help="agent.get_value(next_obs) for GAE (train.py:200): from inside the rollout launch, or torch's fp32 Linear")
     p.add_argument("--out-dir", default=".", help="where checkpoints/ and logs/ are created")
+    p.add_argument("--sync-logging", action="store_true", help="fetch every epoch's scalars before the next epoch is launched (the reference's order; "
+                   "default on one rank: print and log one epoch behind the device)")
     p.add_argument("--resume", default=None, help="trainer_<epoch>.pt written by an earlier run: continue it exactly")
     return p.parse_args(argv)
 
@@ -104,19 +106,28 @@ def main(argv=None):
         print(trainer.agent.critic)
     start = time.time()
     try:
+        def report(ep, scalars):
+            print(f"Epoch {ep} done in {time.time() - start:.2f}s. Avg reward: {scalars['charts/avg_reward']:.4f}. ", flush=True)   # train.py:275-276
+            log.write(json.dumps(scalars) + "\n")
+            log.flush()
+        # one rank: the host runs one epoch AHEAD of what it prints (Trainer.run_epoch(sync="lazy")) -- the device never idles while an
+        # epoch's scalars are fetched, printed and logged; several ranks: the synchronous form (the scalars are all-reduced)
+        lazy = world == 1 and not args.sync_logging
         for epoch in range(first_epoch, args.n_epochs + 1):
-            scalars = trainer.run_epoch(sync=True)
+            scalars = trainer.run_epoch(sync="lazy" if lazy else True)
             if rank == 0:
-                print(f"Epoch {epoch} done in {time.time() - start:.2f}s. Avg reward: {scalars['charts/avg_reward']:.4f}. ",
-                      flush=True)                                                                  # train.py:275-276
-                log.write(json.dumps(scalars) + "\n")
-                log.flush()
+                if scalars is not None:
+                    report(epoch - 1 if lazy else epoch, scalars)
                 if epoch % 10 == 0:                                                                # train.py:280-283
                     torch.save(trainer.agent.state_dict(), os.path.join(ckpt_dir, f"checkpoint_{epoch}.dat"))
             if epoch % 10 == 0:   # full resumable state next to the reference-format file (every rank: env shards differ)
                 os.makedirs(ckpt_dir, exist_ok=True)
                 name = f"trainer_{epoch}.pt" if world == 1 else f"trainer_{epoch}.rank{rank}.pt"
                 torch.save(trainer.state_dict(), os.path.join(ckpt_dir, name))
+        if lazy and rank == 0:
+            last = trainer.flush_scalars()
+            if last is not None:
+                report(args.n_epochs, last)
     finally:
         trainer.close()                                                                            # train.py:296
         if rank == 0:
