@@ -843,7 +843,8 @@ class Trainer:
         """One epoch = rollout + update.  Returns the reference's scalars (train.py:286-292) when sync.
         sync="lazy" (one rank): the epoch is only ENQUEUED; its scalars travel to pinned host memory behind it, and the call returns the
         scalars of the epoch BEFORE (None on the first call) -- the host never waits for the epoch it has just launched, so the device
-        runs epoch after epoch back to back while train.py prints and logs one epoch late (flush_scalars() hands over the last one)."""
+        runs epoch after epoch back to back while the caller prints and logs one epoch late (flush_scalars() hands over the last one;
+        train.py --lazy-logging.  Worth ~1 % at 65536 envs: the synchronous fetch of five floats per 17 ms epoch was never the cost)."""
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if self.phase_events is not None else None
         if ev:
             ev[0].record()

@@ -780,7 +780,7 @@ def test_deferred_adam_epoch_chain_is_bitwise_the_three_launch_steps(num_rays, b
 
 
 def test_lazy_scalars_are_the_synchronous_scalars_one_epoch_late():
-    """Trainer.run_epoch(sync="lazy") (train.py's default on one rank): the epoch is only enqueued, the call hands back the scalars of the
+    """Trainer.run_epoch(sync="lazy") (train.py --lazy-logging): the epoch is only enqueued, the call hands back the scalars of the
     epoch before -- the same numbers the synchronous call returns, the learning rate and the policy-range word riding along -- and
     flush_scalars() the last one."""
     keys = ("losses/policy_loss", "losses/value_loss", "losses/entropy", "losses/total_loss", "charts/avg_reward", "charts/learning_rate", "global_step")

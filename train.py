@@ -51,8 +51,8 @@ def parse_args(argv=None):
     p.add_argument("--bootstrap-value", default="kernel", choices=["kernel", "fp32"],
                    help="agent.get_value(next_obs) for GAE (train.py:200): from inside the rollout launch, or torch's fp32 Linear")
     p.add_argument("--out-dir", default=".", help="where checkpoints/ and logs/ are created")
-    p.add_argument("--sync-logging", action="store_true", help="fetch every epoch's scalars before the next epoch is launched (the reference's order; "
-                   "default on one rank: print and log one epoch behind the device)")
+    p.add_argument("--lazy-logging", action="store_true", help="one rank: print and log one epoch behind the device (Trainer.run_epoch(sync=\"lazy\")) instead of "
+                   "fetching every epoch's scalars before the next epoch is launched (the reference's order, the default: it costs ~1 %% at 65536 envs)")
     p.add_argument("--resume", default=None, help="trainer_<epoch>.pt written by an earlier run: continue it exactly")
     return p.parse_args(argv)
 
@@ -110,9 +110,9 @@ def main(argv=None):
             print(f"Epoch {ep} done in {time.time() - start:.2f}s. Avg reward: {scalars['charts/avg_reward']:.4f}. ", flush=True)   # train.py:275-276
             log.write(json.dumps(scalars) + "\n")
             log.flush()
-        # one rank: the host runs one epoch AHEAD of what it prints (Trainer.run_epoch(sync="lazy")) -- the device never idles while an
-        # epoch's scalars are fetched, printed and logged; several ranks: the synchronous form (the scalars are all-reduced)
-        lazy = world == 1 and not args.sync_logging
+        # --lazy-logging (one rank): the host runs one epoch AHEAD of what it prints (Trainer.run_epoch(sync="lazy")) -- the device never idles
+        # while an epoch's scalars are fetched, printed and logged.  Measured at 65536 envs: 17.16 against 17.34 ms per epoch: off by default
+        lazy = world == 1 and args.lazy_logging
         for epoch in range(first_epoch, args.n_epochs + 1):
             scalars = trainer.run_epoch(sync="lazy" if lazy else True)
             if rank == 0:
