@@ -26,6 +26,22 @@ def _run_dirs(out_dir):
     return ck, lg
 
 
+def test_train_cli_lazy_logging_writes_the_same_rows(tmp_path):
+    """--lazy-logging prints and logs one epoch behind the device: the same rows as the default order (same seed), every epoch present."""
+    import train
+    rows = {}
+    for name, extra in (("sync", []), ("lazy", ["--lazy-logging"])):
+        out = str(tmp_path / name)
+        train.main(["--run-name", name, "--n-epochs", "6", "--cuda", "--track", TRACKS["big_track"], "--n-envs", "256", "--n-steps", "64", "--batch-size", "64",
+                    "--train-iters", "2", "--num-rays", "16", "--out-dir", out] + extra)
+        _, lg = _run_dirs(out)
+        rows[name] = [json.loads(l) for l in open(os.path.join(out, "logs", lg[0], "scalars.jsonl"))]
+    assert len(rows["sync"]) == len(rows["lazy"]) == 6
+    for a, b in zip(rows["sync"], rows["lazy"]):
+        for k in ("losses/total_loss", "charts/avg_reward", "charts/learning_rate", "global_step"):
+            assert a[k] == pytest.approx(b[k], rel=1e-6, abs=1e-9), k
+
+
 def test_train_cli_end_to_end_and_resume(tmp_path):
     import train
     out = str(tmp_path)
